@@ -1,0 +1,176 @@
+"""ctypes wrapper around oracle/liboracle.so -- TEST INFRASTRUCTURE ONLY.
+
+Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import this
+module; the product package must never do so (see sdmesh_oracle.c header).
+
+The wrapper re-enacts the host half of the reference's CudaHandler
+(src/cuda/mod.rs:105-122 create, :124-202 refine + retain, :204-346 mesh + weld) on top
+of the C restatement of the kernels.
+"""
+import ctypes
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB = None
+
+SCENES = {"sdobj": 0, "sphere": 1, "csg3": 2, "anim": 3}
+
+POINT = np.dtype([("x", "<f4"), ("y", "<f4"), ("z", "<f4")])
+VERTEX = np.dtype([("position", POINT), ("normal", POINT)])
+TRIANGLE = np.dtype([("vertices", VERTEX, (3,))])
+assert POINT.itemsize == 12 and VERTEX.itemsize == 24 and TRIANGLE.itemsize == 72
+
+
+def build(force=False):
+    so = os.path.join(_HERE, "liboracle.so")
+    src = os.path.join(_HERE, "sdmesh_oracle.c")
+    if force or not os.path.exists(so) or os.path.getmtime(so) < os.path.getmtime(src):
+        subprocess.check_call(["make", "-C", _HERE, "-B", "liboracle.so"], stdout=subprocess.DEVNULL)
+    return so
+
+
+def lib():
+    global _LIB
+    if _LIB is None:
+        so = os.path.join(_HERE, "liboracle.so")
+        if not os.path.exists(so):
+            build()
+        L = ctypes.CDLL(so)
+        vp, u32, u64, sz, fp = ctypes.c_void_p, ctypes.c_uint32, ctypes.c_uint64, ctypes.c_size_t, ctypes.c_float
+        L.orc_sdf.restype = fp
+        L.orc_sdf.argtypes = [ctypes.c_int, vp, fp, fp, fp]
+        L.orc_eval_count.restype = u64
+        L.orc_eval_count.argtypes = [ctypes.c_int]
+        L.orc_set_threads.argtypes = [ctypes.c_int]
+        L.orc_max_threads.restype = ctypes.c_int
+        L.orc_create_voxel_field.argtypes = [vp, vp]
+        L.orc_refine_raw.argtypes = [ctypes.c_int, vp, vp, u32, _PointC, vp]
+        L.orc_retain_finite.restype = sz
+        L.orc_retain_finite.argtypes = [vp, sz]
+        L.orc_triangles_raw.argtypes = [ctypes.c_int, vp, vp, u32, _PointC, vp, vp]
+        L.orc_weld.restype = sz
+        L.orc_weld.argtypes = [vp, sz, vp, vp, vp, ctypes.POINTER(sz)]
+        L.orc_fnv1a64.restype = u64
+        L.orc_fnv1a64.argtypes = [vp, sz]
+        L.orc_dense_mc_count.restype = u64
+        L.orc_dense_mc_count.argtypes = [ctypes.c_int, vp, u32]
+        _LIB = L
+    return _LIB
+
+
+class _PointC(ctypes.Structure):
+    _fields_ = [("x", ctypes.c_float), ("y", ctypes.c_float), ("z", ctypes.c_float)]
+
+
+def _params(params):
+    p = np.zeros(4, dtype=np.float32)
+    if params is not None:
+        a = np.asarray(params, dtype=np.float32).ravel()
+        p[: a.size] = a
+    return p
+
+
+def _pt(a):
+    return _PointC(float(a[0]), float(a[1]), float(a[2]))
+
+
+def set_threads(n):
+    lib().orc_set_threads(int(n))
+
+
+def max_threads():
+    return lib().orc_max_threads()
+
+
+def eval_count(reset=False):
+    return int(lib().orc_eval_count(1 if reset else 0))
+
+
+def fnv1a64(arr):
+    a = np.ascontiguousarray(arr)
+    return int(lib().orc_fnv1a64(a.ctypes.data, a.nbytes))
+
+
+def sdf(scene, pts, params=None):
+    p = _params(params)
+    pts = np.asarray(pts, dtype=np.float32).reshape(-1, 3)
+    L = lib()
+    return np.array([L.orc_sdf(SCENES[scene], p.ctypes.data, *map(float, q)) for q in pts], dtype=np.float32)
+
+
+def create_voxel_field():
+    """-> (voxels float32 [32768,3], voxel_size float32 [3])   src/cuda/mod.rs:105-122"""
+    vox = np.empty((32 ** 3, 3), dtype=np.float32)
+    size = np.empty(3, dtype=np.float32)
+    lib().orc_create_voxel_field(vox.ctypes.data, size.ctypes.data)
+    return vox, size
+
+
+def refine_raw(scene, voxels, voxel_size, params=None):
+    """Kernel only: raw 8n float32 [8n,3] layout, INF for non-border children."""
+    p = _params(params)
+    vox = np.ascontiguousarray(voxels, dtype=np.float32).reshape(-1, 3)
+    out = np.empty((vox.shape[0] * 8, 3), dtype=np.float32)
+    lib().orc_refine_raw(SCENES[scene], p.ctypes.data, vox.ctypes.data, vox.shape[0], _pt(voxel_size), out.ctypes.data)
+    return out
+
+
+def refine(scene, voxels, voxel_size, params=None):
+    """CudaHandler::refine_voxel_field (src/cuda/mod.rs:124-202): -> (voxels', voxel_size/2)."""
+    vox = np.ascontiguousarray(voxels, dtype=np.float32).reshape(-1, 3)
+    size = np.asarray(voxel_size, dtype=np.float32)
+    if vox.shape[0] == 0:                       # mod.rs:137 -- nothing changes, not even the size
+        return vox, size
+    raw = refine_raw(scene, vox, size, params)
+    n = lib().orc_retain_finite(raw.ctypes.data, raw.shape[0])
+    return raw[:n].copy(), (size / np.float32(2.0)).astype(np.float32)
+
+
+def triangles_raw(scene, voxels, voxel_size, params=None, iter_hist=None):
+    """Kernel only: raw 5n Triangle slots (float32 [5n,3,2,3]), NaN/zero padded."""
+    p = _params(params)
+    vox = np.ascontiguousarray(voxels, dtype=np.float32).reshape(-1, 3)
+    out = np.empty((vox.shape[0] * 5, 3, 2, 3), dtype=np.float32)
+    hp = iter_hist.ctypes.data if iter_hist is not None else None
+    lib().orc_triangles_raw(SCENES[scene], p.ctypes.data, vox.ctypes.data, vox.shape[0], _pt(voxel_size),
+                            out.ctypes.data, hp)
+    return out
+
+
+def weld(raw_triangles):
+    """Host weld (src/cuda/mod.rs:263-296) -> (pos [V,3] f32, nrm [V,3] f32, idx [T,3] u32)."""
+    raw = np.ascontiguousarray(raw_triangles, dtype=np.float32).reshape(-1, 3, 2, 3)
+    n = raw.shape[0]
+    pos = np.empty((max(n, 1) * 3, 3), dtype=np.float32)
+    nrm = np.empty((max(n, 1) * 3, 3), dtype=np.float32)
+    idx = np.empty((max(n, 1), 3), dtype=np.uint32)
+    nt = ctypes.c_size_t(0)
+    nv = lib().orc_weld(raw.ctypes.data, n, pos.ctypes.data, nrm.ctypes.data, idx.ctypes.data, ctypes.byref(nt))
+    return pos[:nv].copy(), nrm[:nv].copy(), idx[: nt.value].copy()
+
+
+def voxel_field_to_mesh(scene, voxels, voxel_size, params=None):
+    """CudaHandler::voxel_field_to_mesh (src/cuda/mod.rs:204-346) -> (pos, nrm, idx)."""
+    vox = np.ascontiguousarray(voxels, dtype=np.float32).reshape(-1, 3)
+    if vox.shape[0] == 0:
+        z = np.zeros((0, 3), dtype=np.float32)
+        return z, z.copy(), np.zeros((0, 3), dtype=np.uint32)
+    return weld(triangles_raw(scene, vox, voxel_size, params))
+
+
+def regen(scene, levels, params=None):
+    """Level-0 field -> `levels` refines -> mesh; the reference's user-visible flow
+    (src/renderer/mod.rs:162-225).  Returns dict with voxels, voxel_size, pos, nrm, idx."""
+    vox, size = create_voxel_field()
+    for _ in range(levels):
+        vox, size = refine(scene, vox, size, params)
+    pos, nrm, idx = voxel_field_to_mesh(scene, vox, size, params)
+    return {"voxels": vox, "voxel_size": size, "pos": pos, "nrm": nrm, "idx": idx}
+
+
+def dense_mc_count(scene, N, params=None):
+    p = _params(params)
+    return int(lib().orc_dense_mc_count(SCENES[scene], p.ctypes.data, int(N)))
