@@ -1,0 +1,775 @@
+// api.hip -- C ABI of libsdmesh.so (include/sdmesh.h): the host half of the reference's
+// CudaHandler (src/cuda/mod.rs:25-346) re-designed around device-resident data.
+//
+// Memory model: every device buffer is grow-only and owned by the handle, like the reference's
+// DynamicCudaSlice (src/cuda/mod.rs:10-23), but results stay in HBM until asked for.  The
+// device chain of a regen is a fixed sequence of grid-stride launches that read their item
+// counts from a device counter block, so once capacities are known there is exactly one host
+// synchronisation per regen (the final read-back of counters + status).
+#include <hip/hip_runtime.h>
+
+#include <math.h>
+#include <stdarg.h>
+#include <stdio.h>
+#include <string.h>
+
+#include <algorithm>
+#include <vector>
+
+#include "../../include/sdmesh.h"
+#include "kernels.hpp"
+
+using namespace sdm;
+
+namespace {
+
+struct DevBuf {
+    void *p = nullptr;
+    size_t cap = 0;
+};
+
+enum {
+    CTR_LEVEL0 = 0,     // .. CTR_LEVEL0 + SDMESH_MAX_LEVELS : voxel count entering level i
+    CTR_NUNIQ = 16,
+    CTR_NTRI = 17,
+    CTR_NVERT = 18,
+    CTR_NSLOTS = 19,
+    CTR_SCRATCH = 20,
+    CTR_WORDS = 32
+};
+
+}  // namespace
+
+struct sdmesh_handle {
+    int device = 0;
+    hipStream_t own_stream = nullptr;
+    hipStream_t stream = nullptr;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    int scene = SDMESH_SCENE_SDOBJ;
+    SceneParams sp{};
+    int grid = 1024;           // workgroups per grid-stride launch (4 per CU)
+    int force_direct = 0;
+    uint32_t min_chunk = 128;  // unique edges per wave queue in k_project
+    char err[512] = {0};
+
+    // voxel lists (ping-pong), refine scratch
+    DevBuf vox[2];
+    int cur = 0;
+    DevBuf mask, tilecnt;
+    // counters / status
+    uint32_t *d_ctr = nullptr;     // CTR_WORDS
+    uint32_t *d_status = nullptr;  // ST_WORDS
+    uint32_t *h_pinned = nullptr;  // CTR_WORDS + ST_WORDS, pinned
+    // mesh stage
+    DevBuf cubeidx, trioff, trilist, ff_arena, hids, ukeys, uverts, tri_e, vslot, bitmap, wordpre, wvidx;
+    DevBuf vertices, indices, raw, compact, staging;
+    // capacities the device chain was laid out for
+    uint32_t cap_vox = 0, hsize = 0, ucap = 0, tcap = 0, wsize = 0;
+    uint64_t *hkeys = nullptr, *wkeys = nullptr;
+    uint32_t *first_ord = nullptr, *wmin = nullptr;
+
+    // last results (host view)
+    uint32_t n_vox = 0, n_tris = 0, n_verts = 0, n_unique = 0;
+    Point voxel_size{0, 0, 0};
+    bool mesh_valid = false, vox_valid = false, last_direct = false;
+
+    // capacity plan learnt from the last synchronous run (async path)
+    bool plan_valid = false;
+    int plan_scene = -1, plan_levels = -1, plan_mode = 0, plan_part = 0, plan_nparts = 1;
+    uint32_t plan_counts[SDMESH_MAX_LEVELS + 1] = {0};
+    uint32_t plan_uniq = 0;
+};
+
+namespace {
+
+int fail(sdmesh_handle *h, int code, const char *fmt, ...) {
+    if (h) {
+        va_list ap;
+        va_start(ap, fmt);
+        vsnprintf(h->err, sizeof h->err, fmt, ap);
+        va_end(ap);
+    }
+    return code;
+}
+
+#define HIPCHK(expr)                                                                                   \
+    do {                                                                                               \
+        hipError_t e_ = (expr);                                                                        \
+        if (e_ != hipSuccess)                                                                          \
+            return fail(h, SDMESH_ERR_HIP, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_), __FILE__, __LINE__); \
+    } while (0)
+
+#define SDCHK(expr)                  \
+    do {                             \
+        int r_ = (expr);             \
+        if (r_ != SDMESH_OK) return r_; \
+    } while (0)
+
+int ensure(sdmesh_handle *h, DevBuf &b, size_t bytes) {
+    if (bytes == 0) bytes = 16;
+    if (b.p && b.cap >= bytes) return SDMESH_OK;
+    if (b.p) {
+        HIPCHK(hipStreamSynchronize(h->stream));
+        HIPCHK(hipFree(b.p));
+        b.p = nullptr;
+        b.cap = 0;
+    }
+    HIPCHK(hipMalloc(&b.p, bytes));
+    b.cap = bytes;
+    return SDMESH_OK;
+}
+
+void release(DevBuf &b) {
+    if (b.p) (void) hipFree(b.p);
+    b.p = nullptr;
+    b.cap = 0;
+}
+
+inline uint32_t tiles(uint32_t n) { return (n + 255u) / 256u; }
+inline size_t align256(size_t v) { return (v + 255) & ~(size_t) 255; }
+
+Point half_size(Point p) { return Point{p.x / 2.0f, p.y / 2.0f, p.z / 2.0f}; }   // src/cuda/mod.rs:126-130
+
+// Lay out the mesh-stage buffers for up to n_cap voxels / u_cap unique edges.
+int layout_mesh(sdmesh_handle *h, uint32_t n_cap, uint32_t u_cap_hint) {
+    if (n_cap < 64) n_cap = 64;
+    const uint32_t ucap = std::max<uint32_t>(u_cap_hint, 2u * n_cap + 1024u);
+    const uint32_t tcap = 5u * n_cap;
+    const uint32_t hsize = 2u * ucap + 64u;           // load factor <= 0.5
+    const uint32_t wsize = 2u * ucap + 64u;
+    SDCHK(ensure(h, h->cubeidx, n_cap));
+    SDCHK(ensure(h, h->trioff, 4ull * n_cap));
+    SDCHK(ensure(h, h->tilecnt, 4ull * std::max(tiles(n_cap), tiles(5u * n_cap)) + 64));
+    SDCHK(ensure(h, h->trilist, 4ull * tcap));
+    SDCHK(ensure(h, h->hids, 4ull * hsize));
+    SDCHK(ensure(h, h->ukeys, 8ull * ucap));
+    SDCHK(ensure(h, h->uverts, sizeof(Vertex) * (size_t) ucap));
+    SDCHK(ensure(h, h->tri_e, 12ull * tcap));
+    SDCHK(ensure(h, h->vslot, 4ull * ucap));
+    SDCHK(ensure(h, h->bitmap, 4ull * ((3ull * tcap + 31) / 32 + 1)));
+    SDCHK(ensure(h, h->wordpre, 4ull * ((3ull * tcap + 31) / 32 + 1)));
+    SDCHK(ensure(h, h->wvidx, 4ull * wsize));
+    SDCHK(ensure(h, h->vertices, sizeof(Vertex) * (size_t) ucap));
+    SDCHK(ensure(h, h->indices, 12ull * tcap));
+    // one arena for everything that must start as 0xFF: a single memset per regen
+    const size_t o_hkeys = 0, o_wkeys = align256(o_hkeys + 8ull * hsize), o_first = align256(o_wkeys + 8ull * wsize),
+                 o_wmin = align256(o_first + 4ull * ucap), total = align256(o_wmin + 4ull * wsize);
+    SDCHK(ensure(h, h->ff_arena, total));
+    char *base = (char *) h->ff_arena.p;
+    h->hkeys = (uint64_t *) (base + o_hkeys);
+    h->wkeys = (uint64_t *) (base + o_wkeys);
+    h->first_ord = (uint32_t *) (base + o_first);
+    h->wmin = (uint32_t *) (base + o_wmin);
+    h->hsize = hsize; h->wsize = wsize; h->ucap = ucap; h->tcap = tcap; h->cap_vox = n_cap;
+    return SDMESH_OK;
+}
+
+size_t ff_bytes(const sdmesh_handle *h) {
+    return (size_t) ((char *) h->wmin - (char *) h->ff_arena.p) + 4ull * h->wsize;
+}
+
+// classify .. tri_orient for the voxel list d_vox (count at *n_ptr, at most n_cap)
+int mesh_front(sdmesh_handle *h, const Point *d_vox, const uint32_t *n_ptr, Point vs) {
+    hipStream_t st = h->stream;
+    HIPCHK(hipMemsetAsync(h->ff_arena.p, 0xFF, ff_bytes(h), st));
+    HIPCHK(hipMemsetAsync(h->d_ctr + CTR_NUNIQ, 0, 4 * sizeof(uint32_t), st));
+    HIPCHK(launch_classify(st, h->grid, h->scene, h->sp, d_vox, n_ptr, vs, (uint8_t *) h->cubeidx.p, (uint32_t *) h->tilecnt.p,
+                           h->hkeys, (uint32_t *) h->hids.p, h->hsize, (uint64_t *) h->ukeys.p, h->ucap,
+                           h->d_ctr + CTR_NUNIQ, h->d_status));
+    HIPCHK(launch_scan_tiles(st, (uint32_t *) h->tilecnt.p, n_ptr, 256, h->d_ctr + CTR_NTRI, h->tcap, h->d_status));
+    HIPCHK(launch_emit_trilist(st, h->grid, (const uint8_t *) h->cubeidx.p, n_ptr, (const uint32_t *) h->tilecnt.p,
+                               (uint32_t *) h->trioff.p, (uint32_t *) h->trilist.p, h->tcap));
+    HIPCHK(launch_project(st, h->grid, h->scene, h->sp, (const uint64_t *) h->ukeys.p, h->d_ctr + CTR_NUNIQ, h->ucap,
+                          h->min_chunk, vs, (Vertex *) h->uverts.p, h->d_status));
+    HIPCHK(launch_tri_orient(st, h->grid, h->scene, h->sp, d_vox, vs, (const uint8_t *) h->cubeidx.p,
+                             (const uint32_t *) h->trilist.p, h->d_ctr + CTR_NTRI, h->hkeys, (const uint32_t *) h->hids.p,
+                             h->hsize, (const Vertex *) h->uverts.p, (uint32_t *) h->tri_e.p, h->first_ord, h->d_status));
+    return SDMESH_OK;
+}
+
+// weld of (uverts[0..*nu), tri_e[0..3*ntri)) -> vertices / indices
+int mesh_weld(sdmesh_handle *h, const Vertex *uverts, const uint32_t *nu_ptr, uint32_t ucap, const uint32_t *tri_e) {
+    hipStream_t st = h->stream;
+    HIPCHK(hipMemsetAsync(h->bitmap.p, 0, h->bitmap.cap, st));
+    HIPCHK(launch_weld(st, h->grid, uverts, nu_ptr, ucap, tri_e, h->d_ctr + CTR_NTRI, h->first_ord, h->wkeys, h->wmin,
+                       h->wsize, (uint32_t *) h->vslot.p, (uint32_t *) h->bitmap.p, (uint32_t *) h->wordpre.p,
+                       (uint32_t *) h->wvidx.p, (Vertex *) h->vertices.p, (uint32_t) (h->vertices.cap / sizeof(Vertex)),
+                       h->d_ctr + CTR_NVERT, (uint32_t *) h->indices.p, h->d_status));
+    return SDMESH_OK;
+}
+
+// read counters + status back (the one synchronisation point of a device chain)
+int read_back(sdmesh_handle *h) {
+    HIPCHK(hipMemcpyAsync(h->h_pinned, h->d_ctr, CTR_WORDS * 4, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(hipMemcpyAsync(h->h_pinned + CTR_WORDS, h->d_status, ST_WORDS * 4, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    return SDMESH_OK;
+}
+
+int status_to_error(sdmesh_handle *h) {
+    const uint32_t *s = h->h_pinned + CTR_WORDS;
+    if (s[ST_INTERNAL]) return fail(h, SDMESH_ERR_INTERNAL, "device invariant violated (status %u)", s[ST_INTERNAL]);
+    if (s[ST_WELD_RANGE]) return fail(h, SDMESH_ERR_WELD_RANGE, "vertex outside the +-10.48 unit weld key range");
+    return SDMESH_OK;
+}
+
+int zero_status(sdmesh_handle *h) {
+    HIPCHK(hipMemsetAsync(h->d_status, 0, ST_WORDS * 4, h->stream));
+    return SDMESH_OK;
+}
+
+// Weld a raw / compact slot list on the device: ordered compaction of the valid slots, then the
+// generic weld with every triangle corner as its own "unique vertex".
+int weld_raw_device(sdmesh_handle *h, const Triangle *d_raw, uint32_t nslots) {
+    hipStream_t st = h->stream;
+    if (nslots == 0) {
+        h->n_tris = h->n_verts = 0;
+        h->mesh_valid = true;
+        return SDMESH_OK;
+    }
+    const uint32_t vcap = 3u * nslots;
+    SDCHK(layout_mesh(h, (nslots + 4) / 5, vcap + 64));
+    if (h->tcap < nslots) return fail(h, SDMESH_ERR_INTERNAL, "weld layout too small");
+    SDCHK(ensure(h, h->compact, sizeof(Triangle) * (size_t) nslots));
+    HIPCHK(hipMemsetAsync(h->ff_arena.p, 0xFF, ff_bytes(h), st));
+    HIPCHK(launch_set_u32(st, h->d_ctr + CTR_NSLOTS, nslots));
+    HIPCHK(launch_raw_count(st, h->grid, d_raw, h->d_ctr + CTR_NSLOTS, (uint32_t *) h->tilecnt.p));
+    HIPCHK(launch_scan_tiles(st, (uint32_t *) h->tilecnt.p, h->d_ctr + CTR_NSLOTS, 256, h->d_ctr + CTR_NTRI, nslots, h->d_status));
+    HIPCHK(launch_raw_compact(st, h->grid, d_raw, h->d_ctr + CTR_NSLOTS, (const uint32_t *) h->tilecnt.p,
+                              (Triangle *) h->compact.p, (uint32_t *) h->tri_e.p, nslots));
+    HIPCHK(launch_mul3_u32(st, h->d_ctr + CTR_NTRI, h->d_ctr + CTR_NUNIQ));
+    HIPCHK(launch_first_ord(st, h->grid, (const uint32_t *) h->tri_e.p, h->d_ctr + CTR_NTRI, h->first_ord));
+    SDCHK(mesh_weld(h, (const Vertex *) h->compact.p, h->d_ctr + CTR_NUNIQ, vcap, (const uint32_t *) h->tri_e.p));
+    return SDMESH_OK;
+}
+
+void fill_info(sdmesh_handle *h, sdmesh_regen_info *info, int levels, bool direct, float ms) {
+    if (!info) return;
+    memset(info, 0, sizeof *info);
+    info->levels = (uint32_t) levels;
+    for (int i = 0; i <= levels && i <= SDMESH_MAX_LEVELS; i++) info->voxel_count[i] = h->h_pinned[CTR_LEVEL0 + i];
+    info->unique_edges = h->n_unique;
+    info->triangles = h->n_tris;
+    info->vertices = h->n_verts;
+    info->voxel_size = h->voxel_size;
+    memcpy(info->status, h->h_pinned + CTR_WORDS, sizeof info->status);
+    info->used_direct_path = direct ? 1u : 0u;
+    info->device_ms = ms;
+}
+
+// One refine level on the device: src list (count at ctr[L]) -> dst list (count to ctr[L+1]).
+// If out_cap == 0 the output size is discovered with a host sync after the scan (exact
+// allocation); otherwise everything is enqueued without synchronisation.
+int refine_level(sdmesh_handle *h, int L, uint32_t n_cap_in, uint32_t out_cap, Point cs, uint32_t *count_out) {
+    hipStream_t st = h->stream;
+    const int src = h->cur, dst = 1 - h->cur;
+    SDCHK(ensure(h, h->mask, n_cap_in));
+    SDCHK(ensure(h, h->tilecnt, 4ull * tiles(n_cap_in) + 64));
+    const uint32_t *n_in = h->d_ctr + CTR_LEVEL0 + L;
+    uint32_t *n_out = h->d_ctr + CTR_LEVEL0 + L + 1;
+    HIPCHK(launch_refine_mask(st, h->grid, h->scene, h->sp, (const Point *) h->vox[src].p, n_in, cs, (uint8_t *) h->mask.p,
+                              (uint32_t *) h->tilecnt.p));
+    uint32_t cap = out_cap;
+    if (out_cap == 0) {
+        HIPCHK(launch_scan_tiles(st, (uint32_t *) h->tilecnt.p, n_in, 256, n_out, 0xFFFFFFFFu, h->d_status));
+        uint32_t cnt = 0;
+        HIPCHK(hipMemcpyAsync(&cnt, n_out, 4, hipMemcpyDeviceToHost, st));
+        HIPCHK(hipStreamSynchronize(st));
+        cap = cnt;
+        if (count_out) *count_out = cnt;
+        SDCHK(ensure(h, h->vox[dst], sizeof(Point) * (size_t) std::max<uint32_t>(cap, 64)));
+    } else {
+        SDCHK(ensure(h, h->vox[dst], sizeof(Point) * (size_t) cap));
+        HIPCHK(launch_scan_tiles(st, (uint32_t *) h->tilecnt.p, n_in, 256, n_out, cap, h->d_status));
+    }
+    HIPCHK(launch_refine_emit(st, h->grid, (const Point *) h->vox[src].p, n_in, cs, (const uint8_t *) h->mask.p,
+                              (const uint32_t *) h->tilecnt.p, (Point *) h->vox[dst].p, cap));
+    h->cur = dst;
+    return SDMESH_OK;
+}
+
+uint32_t padded(uint32_t n) { return n + n / 4 + 4096; }
+
+int regen_impl(sdmesh_handle *h, int levels, int mode, int part, int nparts, sdmesh_regen_info *info) {
+    if (!h) return SDMESH_ERR_INVALID;
+    if (levels < 0 || levels > SDMESH_MAX_LEVELS) return fail(h, SDMESH_ERR_INVALID, "levels must be 0..%d", SDMESH_MAX_LEVELS);
+    if (mode != SDMESH_PART_NONE && mode != SDMESH_PART_ZSLAB) return fail(h, SDMESH_ERR_INVALID, "bad partition mode");
+    if (mode == SDMESH_PART_NONE) { part = 0; nparts = 1; }
+    if (nparts < 1 || nparts > 32 || part < 0 || part >= nparts) return fail(h, SDMESH_ERR_INVALID, "bad partition %d/%d", part, nparts);
+    HIPCHK(hipSetDevice(h->device));
+    hipStream_t st = h->stream;
+    const uint32_t F = MESH_GENERATION_INIT_FACTOR;
+    const uint32_t z0 = F * (uint32_t) part / (uint32_t) nparts, z1 = F * (uint32_t) (part + 1) / (uint32_t) nparts;
+    const uint32_t n0 = F * F * (z1 - z0);
+
+    for (int attempt = 0; attempt < 2; attempt++) {
+        const bool async = h->plan_valid && h->plan_scene == h->scene && h->plan_levels == levels && h->plan_mode == mode &&
+                           h->plan_part == part && h->plan_nparts == nparts && attempt == 0;
+        h->mesh_valid = h->vox_valid = false;
+        h->cur = 0;
+        SDCHK(ensure(h, h->vox[0], sizeof(Point) * (size_t) std::max<uint32_t>(n0, 64)));
+        if (async) SDCHK(layout_mesh(h, padded(h->plan_counts[levels]), padded(h->plan_uniq)));
+
+        HIPCHK(hipEventRecord(h->ev0, st));
+        SDCHK(zero_status(h));
+        HIPCHK(hipMemsetAsync(h->d_ctr, 0, CTR_WORDS * 4, st));
+        Point vs;
+        vs.x = vs.y = vs.z = MESH_GENERATION_BB_SIZE / (float) MESH_GENERATION_INIT_FACTOR;
+        if (n0) HIPCHK(launch_create_field(st, (Point *) h->vox[0].p, z0, z1, h->d_ctr + CTR_LEVEL0));
+        uint32_t n_cap = n0;
+        for (int L = 0; L < levels; L++) {
+            const Point cs = half_size(vs);
+            const uint32_t out_cap = async ? padded(h->plan_counts[L + 1]) : 0u;
+            uint32_t cnt = out_cap;
+            SDCHK(refine_level(h, L, std::max<uint32_t>(n_cap, 64), out_cap, cs, &cnt));
+            vs = cs;
+            n_cap = cnt;
+        }
+        if (!async) SDCHK(layout_mesh(h, n_cap, 0));
+        const Point *d_vox = (const Point *) h->vox[h->cur].p;
+        const uint32_t *n_ptr = h->d_ctr + CTR_LEVEL0 + levels;
+        bool direct = h->force_direct != 0;
+        if (!direct) {
+            SDCHK(mesh_front(h, d_vox, n_ptr, vs));
+            SDCHK(mesh_weld(h, (const Vertex *) h->uverts.p, h->d_ctr + CTR_NUNIQ, h->ucap, (const uint32_t *) h->tri_e.p));
+        }
+        HIPCHK(hipEventRecord(h->ev1, st));
+        SDCHK(read_back(h));
+        const uint32_t *c = h->h_pinned, *s = h->h_pinned + CTR_WORDS;
+        if (!direct && s[ST_OVERFLOW]) {
+            if (async) { h->plan_valid = false; continue; }   // capacities were too tight: redo synchronously
+            // synchronous path: voxel buffers are exact, so only the unique-edge estimate can be too
+            // small -- lay out for the observed count and run the mesh stage again
+            h->plan_valid = false;
+            SDCHK(layout_mesh(h, n_cap, c[CTR_NUNIQ] + 1024));
+            SDCHK(zero_status(h));
+            SDCHK(mesh_front(h, d_vox, n_ptr, vs));
+            SDCHK(mesh_weld(h, (const Vertex *) h->uverts.p, h->d_ctr + CTR_NUNIQ, h->ucap, (const uint32_t *) h->tri_e.p));
+            HIPCHK(hipEventRecord(h->ev1, st));
+            SDCHK(read_back(h));
+            if (s[ST_OVERFLOW]) return fail(h, SDMESH_ERR_INTERNAL, "capacity overflow persists (status %u)", s[ST_OVERFLOW]);
+        }
+        if (!direct && s[ST_NOT_LATTICE]) direct = true;   // cannot happen for create+refine fields; handled anyway
+        const uint32_t n = c[CTR_LEVEL0 + levels];
+        if (direct) {
+            SDCHK(ensure(h, h->raw, sizeof(Triangle) * 5ull * std::max<uint32_t>(n, 1)));
+            SDCHK(zero_status(h));
+            HIPCHK(launch_triangles_direct(st, h->scene, h->sp, d_vox, n, vs, (Triangle *) h->raw.p));
+            SDCHK(weld_raw_device(h, (const Triangle *) h->raw.p, 5u * n));
+            HIPCHK(hipEventRecord(h->ev1, st));
+            // keep the level counters: weld_raw_device only touches the mesh counters
+            SDCHK(read_back(h));
+        }
+        SDCHK(status_to_error(h));
+        float ms = 0.0f;
+        HIPCHK(hipEventElapsedTime(&ms, h->ev0, h->ev1));
+        h->n_vox = n;
+        h->n_unique = c[CTR_NUNIQ];
+        h->n_tris = c[CTR_NTRI];
+        h->n_verts = c[CTR_NVERT];
+        h->voxel_size = vs;
+        h->mesh_valid = h->vox_valid = true;
+        h->last_direct = direct;
+        if (!direct) {
+            h->plan_valid = true;
+            h->plan_scene = h->scene; h->plan_levels = levels; h->plan_mode = mode; h->plan_part = part; h->plan_nparts = nparts;
+            for (int i = 0; i <= levels; i++) h->plan_counts[i] = std::max(h->plan_counts[i] * (async ? 1u : 0u), c[CTR_LEVEL0 + i]);
+            h->plan_uniq = std::max(async ? h->plan_uniq : 0u, c[CTR_NUNIQ]);
+        }
+        fill_info(h, info, levels, direct, ms);
+        return SDMESH_OK;
+    }
+    return fail(h, SDMESH_ERR_INTERNAL, "regen did not converge on a capacity plan");
+}
+
+// shared front half of the host-buffer mesh calls: upload, lattice path, fall back to direct
+// when the field is not a lattice field (or when forced).  On return either (uverts, tri_e) are
+// valid (direct == false) or h->raw holds the 5n raw slots (direct == true).
+int host_mesh_front(sdmesh_handle *h, const Point *voxels, uint32_t n, Point vs, bool &direct) {
+    hipStream_t st = h->stream;
+    SDCHK(ensure(h, h->vox[0], sizeof(Point) * (size_t) n));
+    h->cur = 0;
+    h->vox_valid = false;
+    h->mesh_valid = false;
+    HIPCHK(hipMemcpyAsync(h->vox[0].p, voxels, sizeof(Point) * (size_t) n, hipMemcpyHostToDevice, st));
+    SDCHK(zero_status(h));
+    HIPCHK(hipMemsetAsync(h->d_ctr, 0, CTR_WORDS * 4, st));
+    HIPCHK(launch_set_u32(st, h->d_ctr + CTR_LEVEL0, n));
+    direct = h->force_direct != 0;
+    if (!direct) {
+        SDCHK(layout_mesh(h, n, 0));
+        for (int attempt = 0; attempt < 2; attempt++) {
+            SDCHK(mesh_front(h, (const Point *) h->vox[0].p, h->d_ctr + CTR_LEVEL0, vs));
+            SDCHK(read_back(h));
+            const uint32_t *s = h->h_pinned + CTR_WORDS;
+            if (s[ST_NOT_LATTICE]) { direct = true; break; }
+            if (!s[ST_OVERFLOW]) break;
+            if (attempt == 1) return fail(h, SDMESH_ERR_INTERNAL, "capacity overflow persists");
+            SDCHK(layout_mesh(h, n, h->h_pinned[CTR_NUNIQ] + 1024));
+            SDCHK(zero_status(h));
+        }
+    }
+    if (direct) {
+        SDCHK(ensure(h, h->raw, sizeof(Triangle) * 5ull * n));
+        SDCHK(zero_status(h));
+        HIPCHK(launch_triangles_direct(st, h->scene, h->sp, (const Point *) h->vox[0].p, n, vs, (Triangle *) h->raw.p));
+    }
+    h->n_vox = n;
+    h->voxel_size = vs;
+    return SDMESH_OK;
+}
+
+}  // namespace
+
+// ================================================================================================
+extern "C" {
+
+int sdmesh_create(int device, sdmesh_handle **out) {
+    if (!out) return SDMESH_ERR_INVALID;
+    *out = nullptr;
+    int count = 0;
+    if (hipGetDeviceCount(&count) != hipSuccess || count <= 0 || device < 0 || device >= count) return SDMESH_ERR_NO_DEVICE;
+    sdmesh_handle *h = new sdmesh_handle();
+    h->device = device;
+    auto bail = [&](hipError_t e, const char *what) {
+        fprintf(stderr, "sdmesh_create: %s failed: %s\n", what, hipGetErrorString(e));
+        sdmesh_destroy(h);
+        return SDMESH_ERR_HIP;
+    };
+    hipError_t e;
+    if ((e = hipSetDevice(device)) != hipSuccess) return bail(e, "hipSetDevice");
+    hipDeviceProp_t prop;
+    if ((e = hipGetDeviceProperties(&prop, device)) != hipSuccess) return bail(e, "hipGetDeviceProperties");
+    if (strncmp(prop.gcnArchName, "gfx950", 6) != 0) {
+        fprintf(stderr, "sdmesh_create: device %d is %s; this library carries gfx950 code only\n", device, prop.gcnArchName);
+        sdmesh_destroy(h);
+        return SDMESH_ERR_NO_DEVICE;
+    }
+    h->grid = 4 * prop.multiProcessorCount;
+    if ((e = hipStreamCreateWithFlags(&h->own_stream, hipStreamNonBlocking)) != hipSuccess) return bail(e, "hipStreamCreate");
+    h->stream = h->own_stream;
+    if ((e = hipEventCreate(&h->ev0)) != hipSuccess) return bail(e, "hipEventCreate");
+    if ((e = hipEventCreate(&h->ev1)) != hipSuccess) return bail(e, "hipEventCreate");
+    if ((e = hipMalloc((void **) &h->d_ctr, CTR_WORDS * 4)) != hipSuccess) return bail(e, "hipMalloc");
+    if ((e = hipMalloc((void **) &h->d_status, ST_WORDS * 4)) != hipSuccess) return bail(e, "hipMalloc");
+    if ((e = hipHostMalloc((void **) &h->h_pinned, (CTR_WORDS + ST_WORDS) * 4, hipHostMallocDefault)) != hipSuccess)
+        return bail(e, "hipHostMalloc");
+    memset(h->h_pinned, 0, (CTR_WORDS + ST_WORDS) * 4);
+    *out = h;
+    return SDMESH_OK;
+}
+
+void sdmesh_destroy(sdmesh_handle *h) {
+    if (!h) return;
+    (void) hipSetDevice(h->device);
+    if (h->stream) (void) hipStreamSynchronize(h->stream);
+    DevBuf *bufs[] = {&h->vox[0], &h->vox[1], &h->mask, &h->tilecnt, &h->cubeidx, &h->trioff, &h->trilist, &h->ff_arena,
+                      &h->hids, &h->ukeys, &h->uverts, &h->tri_e, &h->vslot, &h->bitmap, &h->wordpre, &h->wvidx,
+                      &h->vertices, &h->indices, &h->raw, &h->compact, &h->staging};
+    for (DevBuf *b : bufs) release(*b);
+    if (h->d_ctr) (void) hipFree(h->d_ctr);
+    if (h->d_status) (void) hipFree(h->d_status);
+    if (h->h_pinned) (void) hipHostFree(h->h_pinned);
+    if (h->ev0) (void) hipEventDestroy(h->ev0);
+    if (h->ev1) (void) hipEventDestroy(h->ev1);
+    if (h->own_stream) (void) hipStreamDestroy(h->own_stream);
+    delete h;
+}
+
+const char *sdmesh_last_error(const sdmesh_handle *h) { return h ? h->err : "null handle"; }
+
+int sdmesh_set_scene(sdmesh_handle *h, int scene, const float *params, int nparams) {
+    if (!h) return SDMESH_ERR_INVALID;
+    if (scene < 0 || scene >= SCENE_COUNT) return fail(h, SDMESH_ERR_INVALID, "unknown scene %d", scene);
+    if (nparams < 0 || nparams > 4 || (nparams > 0 && !params)) return fail(h, SDMESH_ERR_INVALID, "bad scene params");
+    h->scene = scene;
+    for (int i = 0; i < 4; i++) h->sp.p[i] = i < nparams ? params[i] : 0.0f;
+    return SDMESH_OK;
+}
+
+int sdmesh_set_stream(sdmesh_handle *h, void *hip_stream) {
+    if (!h) return SDMESH_ERR_INVALID;
+    HIPCHK(hipStreamSynchronize(h->stream));
+    h->stream = hip_stream ? (hipStream_t) hip_stream : h->own_stream;
+    return SDMESH_OK;
+}
+
+int sdmesh_set_option(sdmesh_handle *h, const char *name, int value) {
+    if (!h || !name) return SDMESH_ERR_INVALID;
+    if (!strcmp(name, "direct")) { h->force_direct = value ? 1 : 0; h->plan_valid = false; return SDMESH_OK; }
+    if (!strcmp(name, "grid")) {
+        if (value < 1 || value > 65535) return fail(h, SDMESH_ERR_INVALID, "grid out of range");
+        h->grid = value;
+        return SDMESH_OK;
+    }
+    if (!strcmp(name, "min_chunk")) {
+        if (value < 1) return fail(h, SDMESH_ERR_INVALID, "min_chunk out of range");
+        h->min_chunk = (uint32_t) value;
+        return SDMESH_OK;
+    }
+    if (!strcmp(name, "forget_plan")) { h->plan_valid = false; return SDMESH_OK; }
+    return fail(h, SDMESH_ERR_INVALID, "unknown option %s", name);
+}
+
+int sdmesh_create_voxel_field(struct Point *voxels, struct Point *voxel_size) {
+    if (!voxels || !voxel_size) return SDMESH_ERR_INVALID;
+    const float SIZE = MESH_GENERATION_BB_SIZE / (float) MESH_GENERATION_INIT_FACTOR;
+    voxel_size->x = voxel_size->y = voxel_size->z = SIZE;
+    size_t o = 0;
+    for (int x = 0; x < MESH_GENERATION_INIT_FACTOR; x++)
+        for (int y = 0; y < MESH_GENERATION_INIT_FACTOR; y++)
+            for (int z = 0; z < MESH_GENERATION_INIT_FACTOR; z++, o++) {
+                voxels[o].x = (float) x * SIZE - MESH_GENERATION_BB_SIZE / 2.0f;
+                voxels[o].y = (float) y * SIZE - MESH_GENERATION_BB_SIZE / 2.0f;
+                voxels[o].z = (float) z * SIZE - MESH_GENERATION_BB_SIZE / 2.0f;
+            }
+    return SDMESH_OK;
+}
+
+static int refine_host_common(sdmesh_handle *h, const Point *in, size_t n, Point voxel_size) {
+    hipStream_t st = h->stream;
+    HIPCHK(hipSetDevice(h->device));
+    SDCHK(ensure(h, h->vox[0], sizeof(Point) * n));
+    SDCHK(ensure(h, h->mask, n));
+    SDCHK(ensure(h, h->tilecnt, 4ull * tiles((uint32_t) n) + 64));
+    h->cur = 0;
+    h->vox_valid = h->mesh_valid = false;
+    HIPCHK(hipMemcpyAsync(h->vox[0].p, in, sizeof(Point) * n, hipMemcpyHostToDevice, st));
+    SDCHK(zero_status(h));
+    HIPCHK(hipMemsetAsync(h->d_ctr, 0, CTR_WORDS * 4, st));
+    HIPCHK(launch_set_u32(st, h->d_ctr + CTR_LEVEL0, (uint32_t) n));
+    HIPCHK(launch_refine_mask(st, h->grid, h->scene, h->sp, (const Point *) h->vox[0].p, h->d_ctr + CTR_LEVEL0, half_size(voxel_size),
+                              (uint8_t *) h->mask.p, (uint32_t *) h->tilecnt.p));
+    return SDMESH_OK;
+}
+
+int sdmesh_refine_voxel_field(sdmesh_handle *h, const struct Point *in, size_t n, struct Point voxel_size,
+                              struct Point *out, size_t out_cap, size_t *n_out, struct Point *size_out) {
+    if (!h || !n_out || !size_out || (n && (!in || !out))) return SDMESH_ERR_INVALID;
+    if (n == 0) {                      // src/cuda/mod.rs:137: nothing happens, not even the size halves
+        *n_out = 0;
+        *size_out = voxel_size;
+        return SDMESH_OK;
+    }
+    if (n > 0x1FFFFFFFu) return fail(h, SDMESH_ERR_INVALID, "too many voxels");
+    hipStream_t st = h->stream;
+    SDCHK(refine_host_common(h, in, n, voxel_size));
+    HIPCHK(launch_scan_tiles(st, (uint32_t *) h->tilecnt.p, h->d_ctr + CTR_LEVEL0, 256, h->d_ctr + CTR_LEVEL0 + 1, 0xFFFFFFFFu,
+                             h->d_status));
+    SDCHK(read_back(h));
+    const uint32_t cnt = h->h_pinned[CTR_LEVEL0 + 1];
+    if (cnt > out_cap) return fail(h, SDMESH_ERR_CAPACITY, "refine output needs %u points, caller gave %zu", cnt, out_cap);
+    SDCHK(ensure(h, h->vox[1], sizeof(Point) * (size_t) std::max<uint32_t>(cnt, 64)));
+    HIPCHK(launch_refine_emit(st, h->grid, (const Point *) h->vox[0].p, h->d_ctr + CTR_LEVEL0, half_size(voxel_size),
+                              (const uint8_t *) h->mask.p, (const uint32_t *) h->tilecnt.p, (Point *) h->vox[1].p, cnt));
+    if (cnt) HIPCHK(hipMemcpyAsync(out, h->vox[1].p, sizeof(Point) * (size_t) cnt, hipMemcpyDeviceToHost, st));
+    HIPCHK(hipStreamSynchronize(st));
+    h->cur = 1;
+    h->n_vox = cnt;
+    h->voxel_size = half_size(voxel_size);
+    h->vox_valid = true;
+    *n_out = cnt;
+    *size_out = h->voxel_size;
+    return SDMESH_OK;
+}
+
+int sdmesh_refine_voxel_field_raw(sdmesh_handle *h, const struct Point *in, size_t n, struct Point voxel_size,
+                                  struct Point *out8n) {
+    if (!h || (n && (!in || !out8n))) return SDMESH_ERR_INVALID;
+    if (n == 0) return SDMESH_OK;
+    if (n > 0x0FFFFFFFu) return fail(h, SDMESH_ERR_INVALID, "too many voxels");
+    hipStream_t st = h->stream;
+    SDCHK(refine_host_common(h, in, n, voxel_size));
+    SDCHK(ensure(h, h->vox[1], sizeof(Point) * 8 * n));
+    HIPCHK(launch_refine_expand_raw(st, h->grid, (const Point *) h->vox[0].p, (uint32_t) n, half_size(voxel_size),
+                                    (const uint8_t *) h->mask.p, (Point *) h->vox[1].p));
+    HIPCHK(hipMemcpyAsync(out8n, h->vox[1].p, sizeof(Point) * 8 * n, hipMemcpyDeviceToHost, st));
+    HIPCHK(hipStreamSynchronize(st));
+    return SDMESH_OK;
+}
+
+int sdmesh_voxel_field_to_triangles_raw(sdmesh_handle *h, const struct Point *voxels, size_t n, struct Point voxel_size,
+                                        struct Triangle *out5n) {
+    if (!h || (n && (!voxels || !out5n))) return SDMESH_ERR_INVALID;
+    if (n == 0) return SDMESH_OK;
+    if (n > 0x0FFFFFFFu) return fail(h, SDMESH_ERR_INVALID, "too many voxels");
+    HIPCHK(hipSetDevice(h->device));
+    hipStream_t st = h->stream;
+    bool direct = false;
+    SDCHK(host_mesh_front(h, voxels, (uint32_t) n, voxel_size, direct));
+    SDCHK(ensure(h, h->raw, sizeof(Triangle) * 5ull * n));
+    if (!direct)
+        HIPCHK(launch_expand_raw(st, h->grid, (const Vertex *) h->uverts.p, (const uint32_t *) h->tri_e.p,
+                                 (const uint8_t *) h->cubeidx.p, (const uint32_t *) h->trioff.p, (uint32_t) n, (Triangle *) h->raw.p));
+    HIPCHK(hipMemcpyAsync(out5n, h->raw.p, sizeof(Triangle) * 5ull * n, hipMemcpyDeviceToHost, st));
+    SDCHK(read_back(h));
+    return status_to_error(h);
+}
+
+int sdmesh_voxel_field_to_mesh(sdmesh_handle *h, const struct Point *voxels, size_t n, struct Point voxel_size,
+                               struct Vertex *verts, size_t vert_cap, size_t *n_verts, struct IndexTriangle *tris,
+                               size_t tri_cap, size_t *n_tris) {
+    if (!h || !n_verts || !n_tris || (n && !voxels)) return SDMESH_ERR_INVALID;
+    *n_verts = *n_tris = 0;
+    if (n == 0) {                                  // src/cuda/mod.rs:327-344: empty mesh
+        h->n_tris = h->n_verts = 0;
+        h->mesh_valid = true;
+        return SDMESH_OK;
+    }
+    if (n > 0x0FFFFFFFu) return fail(h, SDMESH_ERR_INVALID, "too many voxels");
+    HIPCHK(hipSetDevice(h->device));
+    bool direct = false;
+    SDCHK(host_mesh_front(h, voxels, (uint32_t) n, voxel_size, direct));
+    if (direct) SDCHK(weld_raw_device(h, (const Triangle *) h->raw.p, 5u * (uint32_t) n));
+    else SDCHK(mesh_weld(h, (const Vertex *) h->uverts.p, h->d_ctr + CTR_NUNIQ, h->ucap, (const uint32_t *) h->tri_e.p));
+    SDCHK(read_back(h));
+    SDCHK(status_to_error(h));
+    h->n_unique = h->h_pinned[CTR_NUNIQ];
+    h->n_tris = h->h_pinned[CTR_NTRI];
+    h->n_verts = h->h_pinned[CTR_NVERT];
+    h->mesh_valid = true;
+    *n_verts = h->n_verts;
+    *n_tris = h->n_tris;
+    if (verts || tris) {
+        if ((verts && h->n_verts > vert_cap) || (tris && h->n_tris > tri_cap))
+            return fail(h, SDMESH_ERR_CAPACITY, "mesh needs %u vertices / %u triangles", h->n_verts, h->n_tris);
+        return sdmesh_download_mesh(h, verts, tris);
+    }
+    return SDMESH_OK;
+}
+
+int sdmesh_weld_triangles(sdmesh_handle *h, const struct Triangle *raw, size_t nslots, struct Vertex *verts, size_t vert_cap,
+                          size_t *n_verts, struct IndexTriangle *tris, size_t tri_cap, size_t *n_tris) {
+    if (!h || !n_verts || !n_tris || (nslots && !raw)) return SDMESH_ERR_INVALID;
+    *n_verts = *n_tris = 0;
+    if (nslots > 0x0FFFFFFFu) return fail(h, SDMESH_ERR_INVALID, "too many slots");
+    HIPCHK(hipSetDevice(h->device));
+    if (nslots) {
+        SDCHK(ensure(h, h->staging, sizeof(Triangle) * nslots));
+        HIPCHK(hipMemcpyAsync(h->staging.p, raw, sizeof(Triangle) * nslots, hipMemcpyHostToDevice, h->stream));
+    }
+    SDCHK(sdmesh_weld_device_triangles(h, (const Triangle *) h->staging.p, nslots, nullptr));
+    *n_verts = h->n_verts;
+    *n_tris = h->n_tris;
+    if (verts || tris) {
+        if ((verts && h->n_verts > vert_cap) || (tris && h->n_tris > tri_cap))
+            return fail(h, SDMESH_ERR_CAPACITY, "mesh needs %u vertices / %u triangles", h->n_verts, h->n_tris);
+        return sdmesh_download_mesh(h, verts, tris);
+    }
+    return SDMESH_OK;
+}
+
+int sdmesh_weld_device_triangles(sdmesh_handle *h, const struct Triangle *d_raw, size_t nslots, sdmesh_regen_info *info) {
+    if (!h || (nslots && !d_raw)) return SDMESH_ERR_INVALID;
+    if (nslots > 0x0FFFFFFFu) return fail(h, SDMESH_ERR_INVALID, "too many slots");
+    HIPCHK(hipSetDevice(h->device));
+    h->mesh_valid = false;
+    HIPCHK(hipEventRecord(h->ev0, h->stream));
+    SDCHK(zero_status(h));
+    HIPCHK(hipMemsetAsync(h->d_ctr + CTR_NUNIQ, 0, 4 * sizeof(uint32_t), h->stream));
+    SDCHK(weld_raw_device(h, d_raw, (uint32_t) nslots));
+    HIPCHK(hipEventRecord(h->ev1, h->stream));
+    SDCHK(read_back(h));
+    SDCHK(status_to_error(h));
+    if (h->h_pinned[CTR_WORDS + ST_OVERFLOW]) return fail(h, SDMESH_ERR_INTERNAL, "weld overflow (status %u)", h->h_pinned[CTR_WORDS + ST_OVERFLOW]);
+    h->n_unique = nslots ? h->h_pinned[CTR_NUNIQ] : 0;
+    h->n_tris = nslots ? h->h_pinned[CTR_NTRI] : 0;
+    h->n_verts = nslots ? h->h_pinned[CTR_NVERT] : 0;
+    h->mesh_valid = true;
+    float ms = 0.0f;
+    HIPCHK(hipEventElapsedTime(&ms, h->ev0, h->ev1));
+    fill_info(h, info, 0, true, ms);
+    return SDMESH_OK;
+}
+
+int sdmesh_regen(sdmesh_handle *h, int levels, sdmesh_regen_info *info) {
+    return regen_impl(h, levels, SDMESH_PART_NONE, 0, 1, info);
+}
+
+int sdmesh_regen_part(sdmesh_handle *h, int levels, int mode, int part, int nparts, sdmesh_regen_info *info) {
+    return regen_impl(h, levels, mode, part, nparts, info);
+}
+
+int sdmesh_device_mesh(sdmesh_handle *h, struct Mesh *mesh, uint32_t *n_tris) {
+    if (!h || !mesh) return SDMESH_ERR_INVALID;
+    if (!h->mesh_valid) return fail(h, SDMESH_ERR_INVALID, "no mesh on the device");
+    mesh->vertices = (Vertex *) h->vertices.p;
+    mesh->vertex_count = h->n_verts;
+    mesh->triangles = (IndexTriangle *) h->indices.p;
+    if (n_tris) *n_tris = h->n_tris;
+    return SDMESH_OK;
+}
+
+int sdmesh_device_voxels(sdmesh_handle *h, struct VoxelField *field) {
+    if (!h || !field) return SDMESH_ERR_INVALID;
+    if (!h->vox_valid) return fail(h, SDMESH_ERR_INVALID, "no voxel field on the device");
+    field->voxel_size = h->voxel_size;
+    field->voxels = (Point *) h->vox[h->cur].p;
+    field->voxel_count = h->n_vox;
+    return SDMESH_OK;
+}
+
+int sdmesh_device_triangles(sdmesh_handle *h, struct Triangle *d_out, size_t cap, size_t *n_tris) {
+    if (!h || !n_tris) return SDMESH_ERR_INVALID;
+    if (!h->mesh_valid || !h->vox_valid) return fail(h, SDMESH_ERR_INVALID, "no regen result on the device");
+    *n_tris = h->n_tris;
+    if (!d_out) return SDMESH_OK;
+    if (cap < h->n_tris) return fail(h, SDMESH_ERR_CAPACITY, "need room for %u triangles", h->n_tris);
+    if (h->n_tris == 0) return SDMESH_OK;
+    const bool have_compact = h->last_direct;   // the direct path left the compact list in h->compact
+    if (have_compact) {
+        HIPCHK(hipMemcpyAsync(d_out, h->compact.p, sizeof(Triangle) * (size_t) h->n_tris, hipMemcpyDeviceToDevice, h->stream));
+    } else {
+        HIPCHK(launch_expand_compact(h->stream, h->grid, (const Vertex *) h->uverts.p, (const uint32_t *) h->tri_e.p,
+                                     h->d_ctr + CTR_NTRI, d_out, (uint32_t) std::min<size_t>(cap, 0xFFFFFFFFu)));
+    }
+    HIPCHK(hipStreamSynchronize(h->stream));
+    return SDMESH_OK;
+}
+
+int sdmesh_download_mesh(sdmesh_handle *h, struct Vertex *verts, struct IndexTriangle *tris) {
+    if (!h) return SDMESH_ERR_INVALID;
+    if (!h->mesh_valid) return fail(h, SDMESH_ERR_INVALID, "no mesh on the device");
+    if (verts && h->n_verts)
+        HIPCHK(hipMemcpyAsync(verts, h->vertices.p, sizeof(Vertex) * (size_t) h->n_verts, hipMemcpyDeviceToHost, h->stream));
+    if (tris && h->n_tris)
+        HIPCHK(hipMemcpyAsync(tris, h->indices.p, sizeof(IndexTriangle) * (size_t) h->n_tris, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    return SDMESH_OK;
+}
+
+int sdmesh_download_voxels(sdmesh_handle *h, struct Point *voxels) {
+    if (!h || !voxels) return SDMESH_ERR_INVALID;
+    if (!h->vox_valid) return fail(h, SDMESH_ERR_INVALID, "no voxel field on the device");
+    if (h->n_vox)
+        HIPCHK(hipMemcpyAsync(voxels, h->vox[h->cur].p, sizeof(Point) * (size_t) h->n_vox, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    return SDMESH_OK;
+}
+
+int sdmesh_sample_dense(sdmesh_handle *h, uint32_t N, float *d_out, float *kernel_ms) {
+    if (!h || !d_out || N == 0 || N > 4096) return SDMESH_ERR_INVALID;
+    HIPCHK(hipSetDevice(h->device));
+    HIPCHK(hipEventRecord(h->ev0, h->stream));
+    HIPCHK(launch_sample_dense(h->stream, 8 * h->grid, h->scene, h->sp, d_out, N));
+    HIPCHK(hipEventRecord(h->ev1, h->stream));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    if (kernel_ms) HIPCHK(hipEventElapsedTime(kernel_ms, h->ev0, h->ev1));
+    return SDMESH_OK;
+}
+
+int sdmesh_time_kernel(sdmesh_handle *h, int which, uint32_t N, float *d_buf, int iters, float *avg_ms) {
+    if (!h || !avg_ms || iters < 1 || which != 0 || !d_buf || N == 0 || N > 4096) return SDMESH_ERR_INVALID;
+    HIPCHK(hipSetDevice(h->device));
+    HIPCHK(launch_sample_dense(h->stream, 8 * h->grid, h->scene, h->sp, d_buf, N));   // warm-up
+    HIPCHK(hipEventRecord(h->ev0, h->stream));
+    for (int i = 0; i < iters; i++) HIPCHK(launch_sample_dense(h->stream, 8 * h->grid, h->scene, h->sp, d_buf, N));
+    HIPCHK(hipEventRecord(h->ev1, h->stream));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    float ms = 0.0f;
+    HIPCHK(hipEventElapsedTime(&ms, h->ev0, h->ev1));
+    *avg_ms = ms / (float) iters;
+    return SDMESH_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,188 @@
+// sdf.hpp -- scene signed-distance functions and the per-point numerics of the mesh path,
+// written for gfx950 (also host-callable so the CPU test-suite can check the formulation).
+//
+// Semantics follow the reference bit for bit under strict IEEE f32 (no FMA contraction,
+// correctly rounded div/sqrt):
+//   sd_obj              cuda/modules/common.cu:222-226
+//   sd_box_skeleton     cuda/includes/signed_distance.cu:93-113 (incl. the `% 2` bug at :101)
+//   sd_line / sd_ray    signed_distance.cu:77-80 / :65-75
+//   smooth_min          signed_distance.cu:20-23
+//   sd_box              signed_distance.cu:86-91
+//   empirical_normal    signed_distance.cu:179-202
+//   closest_surface_point signed_distance.cu:227-240 (one Newton round = newton_round())
+// GLM arithmetic as fixed in SURVEY.md 8(c): dot = (x+y)+z, length = sqrt(dot),
+// normalize = v * (1/sqrt(dot)), min(a,b) = (b<a)?b:a, max(a,b) = (a<b)?b:a.
+//
+// This is NOT a transliteration.  sd_obj is restructured for the VALU:
+//  * all 12 bars of the skeleton are axis-aligned with compile-time end points, so
+//    dot(p - b0, dir) is exactly one coordinate difference, the clamp is a select, and the
+//    perpendicular squared offsets are shared between bars (11 squares + 20 adds for 12 bars);
+//  * min_i (sqrt(d2_i) - lw) == sqrt(min_i d2_i) - lw exactly (correctly rounded sqrt and the
+//    subtraction are monotone non-decreasing), so one sqrt replaces twelve.
+// Both rewrites are value-preserving for finite inputs; tests/test_host_numerics.py checks the
+// result bit-for-bit against the oracle's literal 12-bar loop.
+#pragma once
+
+#include <math.h>
+#include <stdint.h>
+
+#if defined(__HIPCC__)
+#define SDM_HD __host__ __device__ __forceinline__
+#else
+#define SDM_HD static inline
+#endif
+
+#pragma clang fp contract(off)
+
+namespace sdm {
+
+enum Scene : int { SCENE_SDOBJ = 0, SCENE_SPHERE = 1, SCENE_CSG3 = 2, SCENE_ANIM = 3, SCENE_COUNT = 4 };
+
+struct SceneParams {
+    float p[4];
+};
+
+struct f3 {
+    float x, y, z;
+};
+
+SDM_HD f3 mk(float x, float y, float z) { f3 r; r.x = x; r.y = y; r.z = z; return r; }
+SDM_HD float gmin(float a, float b) { return (b < a) ? b : a; }
+SDM_HD float gmax(float a, float b) { return (a < b) ? b : a; }
+SDM_HD float dot3(f3 a, f3 b) { return (a.x * b.x + a.y * b.y) + a.z * b.z; }
+SDM_HD f3 sub3(f3 a, f3 b) { return mk(a.x - b.x, a.y - b.y, a.z - b.z); }
+SDM_HD f3 add3(f3 a, f3 b) { return mk(a.x + b.x, a.y + b.y, a.z + b.z); }
+SDM_HD f3 scale3(f3 a, float s) { return mk(a.x * s, a.y * s, a.z * s); }
+SDM_HD f3 normalize3(f3 a) { return scale3(a, 1.0f / sqrtf(dot3(a, a))); }
+SDM_HD f3 cross3(f3 x, f3 y) {
+    return mk(x.y * y.z - y.y * x.z, x.z * y.x - y.z * x.x, x.x * y.y - y.x * x.y);
+}
+
+SDM_HD float smooth_min(float a, float b, float k) {
+    float h = gmax(k - fabsf(a - b), 0.0f) / k;
+    return gmin(a, b) - h * h * h * k * (1.0f / 6.0f);
+}
+
+// Squared residual along a bar's own axis: t = p - b0 (b0 = lo), bar length len.
+//   t < 0   -> closest point b0            -> e = p - lo
+//   t > len -> closest point b0 + len      -> e = p - (lo + len)   (lo + len is exact)
+//   else    -> closest point b0 + t        -> e = p - (lo + t)     (rounding residue, kept)
+SDM_HD float along_sq(float p, float lo, float len) {
+    float t = p - lo;
+    float q = (t < 0.0f) ? lo : ((t > len) ? (lo + len) : (lo + t));
+    float e = p - q;
+    return e * e;
+}
+
+SDM_HD float sq(float v) { return v * v; }
+
+// sd_box_skeleton(p, 0, (3, 1, 0.5), 0.1) with the reference's indexing bug:
+//   x-bars: y in {-0.5, +0.5},  z in {-0.25, +0.25}, x from -1.5, len 3
+//   y-bars: z in {-0.25, +2.75}, x in {-1.5, +1.5},  y from -0.5, len 1    (z offset uses bs[0]=3)
+//   z-bars: x in {-1.5, -0.5},  y in {-0.5, +0.5},   z from -0.25, len 0.5 (x offset uses bs[1]=1)
+SDM_HD float skeleton_min_d2(float px, float py, float pz) {
+    const float ax = along_sq(px, -1.5f, 3.0f);
+    const float ay = along_sq(py, -0.5f, 1.0f);
+    const float az = along_sq(pz, -0.25f, 0.5f);
+    const float xm15 = sq(px - (-1.5f)), xp15 = sq(px - 1.5f), xm05 = sq(px - (-0.5f));
+    const float ym05 = sq(py - (-0.5f)), yp05 = sq(py - 0.5f);
+    const float zm025 = sq(pz - (-0.25f)), zp025 = sq(pz - 0.25f), zp275 = sq(pz - 2.75f);
+
+    // each d2 is (ex^2 + ey^2) + ez^2 in x, y, z order, as glm::dot evaluates it
+    const float x0 = ax + ym05, x1 = ax + yp05;
+    float m = gmin(x0 + zm025, x0 + zp025);
+    m = gmin(m, gmin(x1 + zm025, x1 + zp025));
+    const float y0 = xm15 + ay, y1 = xp15 + ay;
+    m = gmin(m, gmin(y0 + zm025, y0 + zp275));
+    m = gmin(m, gmin(y1 + zm025, y1 + zp275));
+    m = gmin(m, gmin((xm15 + ym05) + az, (xm15 + yp05) + az));
+    m = gmin(m, gmin((xm05 + ym05) + az, (xm05 + yp05) + az));
+    return m;
+}
+
+SDM_HD float sd_box(f3 p, f3 bp, f3 bs) {
+    f3 d = sub3(p, bp);
+    f3 hs = mk(bs.x / 2.0f, bs.y / 2.0f, bs.z / 2.0f);
+    f3 q = mk(fabsf(d.x) - hs.x, fabsf(d.y) - hs.y, fabsf(d.z) - hs.z);
+    f3 u = mk(gmax(q.x, 0.0f), gmax(q.y, 0.0f), gmax(q.z, 0.0f));
+    float udst = sqrtf(dot3(u, u));
+    f3 m = mk(gmin(q.x, 0.0f), gmin(q.y, 0.0f), gmin(q.z, 0.0f));
+    float idst = gmax(gmax(m.x, m.y), m.z);
+    return udst + idst;
+}
+
+template <int SCENE>
+SDM_HD float sdf(float px, float py, float pz, const SceneParams &sp) {
+    if (SCENE == SCENE_SPHERE) {
+        return sqrtf((px * px + py * py) + pz * pz) - 1.0f;
+    } else if (SCENE == SCENE_CSG3) {
+        // build-defined scene; mirrors oracle sdf_eval SCENE_CSG3
+        float a = sqrtf((px * px + py * py) + pz * pz) - 1.0f;
+        float b = sd_box(mk(px, py, pz), mk(1.2f, 0.0f, 0.0f), mk(1.2f, 1.2f, 1.2f));
+        float qx = sqrtf(px * px + pz * pz) - 1.5f;
+        float c = sqrtf(qx * qx + py * py) - 0.25f;
+        return smooth_min(smooth_min(a, b, 0.3f), c, 0.3f);
+    } else {
+        const float a1 = sqrtf(skeleton_min_d2(px, py, pz)) - 0.1f;
+        float sy = py;
+        if (SCENE == SCENE_ANIM) sy = py - sp.p[0];
+        const float a2 = sqrtf((px * px + sy * sy) + pz * pz) - 1.0f;
+        return smooth_min(a1, a2, 0.5f);
+    }
+}
+
+#define SDM_NORMAL_EPS 0.001f
+
+// 4th-order central stencil, un-normalised weights, then normalize (signed_distance.cu:179-202)
+template <int SCENE>
+SDM_HD f3 empirical_normal(f3 p, const SceneParams &sp) {
+    const float e1 = SDM_NORMAL_EPS, e2 = 2.0f * SDM_NORMAL_EPS;
+    float dx = (-sdf<SCENE>(p.x + e2, p.y, p.z, sp) + 8.0f * sdf<SCENE>(p.x + e1, p.y, p.z, sp) -
+                8.0f * sdf<SCENE>(p.x + (-e1), p.y, p.z, sp) + sdf<SCENE>(p.x + (-e2), p.y, p.z, sp));
+    float dy = (-sdf<SCENE>(p.x, p.y + e2, p.z, sp) + 8.0f * sdf<SCENE>(p.x, p.y + e1, p.z, sp) -
+                8.0f * sdf<SCENE>(p.x, p.y + (-e1), p.z, sp) + sdf<SCENE>(p.x, p.y + (-e2), p.z, sp));
+    float dz = (-sdf<SCENE>(p.x, p.y, p.z + e2, sp) + 8.0f * sdf<SCENE>(p.x, p.y, p.z + e1, sp) -
+                8.0f * sdf<SCENE>(p.x, p.y, p.z + (-e1), sp) + sdf<SCENE>(p.x, p.y, p.z + (-e2), sp));
+    return normalize3(mk(dx, dy, dz));
+}
+
+// One iteration of closest_surface_point: g <- g - sd(g) * n(g); returns true when the
+// PRE-step |sd| <= 1e-5 (the step is applied on the converging iteration too).
+template <int SCENE>
+SDM_HD bool newton_round(f3 &g, const SceneParams &sp) {
+    float sd = sdf<SCENE>(g.x, g.y, g.z, sp);
+    f3 n = empirical_normal<SCENE>(g, sp);
+    g = sub3(g, scale3(n, sd));
+    return fabsf(sd) <= 0.00001f;
+}
+
+#define SDM_MAX_NEWTON 10000
+
+template <int SCENE>
+SDM_HD f3 closest_surface_point(f3 p, const SceneParams &sp) {
+    f3 g = p;
+    bool collision = false;
+    for (int i = 0; !collision && i < SDM_MAX_NEWTON; i++) collision = newton_round<SCENE>(g, sp);
+    return g;
+}
+
+// Triangle orientation test of compute_mesh_generation.cu:102-105
+template <int SCENE>
+SDM_HD bool change_orientation(f3 v0, f3 v1, f3 v2, const SceneParams &sp) {
+    f3 tn = normalize3(cross3(sub3(v1, v0), sub3(v2, v0)));
+    f3 s = add3(add3(v0, v1), v2);
+    f3 c = mk(s.x / 3.0f, s.y / 3.0f, s.z / 3.0f);
+    f3 an = empirical_normal<SCENE>(c, sp);
+    return dot3(tn, an) <= 0.0f;
+}
+
+// Weld quantisation of src/cuda/mod.rs:270: (x * 10e4f32).round() as i64
+SDM_HD long long weld_quant(float x) {
+    float r = roundf(x * 100000.0f);
+    if (!(r == r)) return 0;
+    if (r >= 9.2233720368547758e18f) return 0x7fffffffffffffffLL;
+    if (r <= -9.2233720368547758e18f) return (long long) 0x8000000000000000ULL;
+    return (long long) r;
+}
+
+}  // namespace sdm

@@ -1,0 +1,226 @@
+"""Host-side mirror of the reference's `CudaHandler` / `CudaVoxelField` (src/cuda/mod.rs:25-346)
+on top of the C ABI (include/sdmesh.h).  Same method names, argument meaning and behaviour:
+
+    CudaHandler()                              CudaHandler::new                 mod.rs:49
+    CudaHandler.create_cuda_voxel_field()      assoc. fn, no device needed      mod.rs:105
+    handler.refine_voxel_field(field)          in place: voxels <- kept children, size <- size/2   mod.rs:124
+    handler.voxel_field_to_mesh(field)         -> ObjData (positions, normals, index triples)       mod.rs:204
+
+The reference panics on any driver failure; here failures raise SdMeshError.  There is no CPU
+fallback: constructing a handler without a gfx950 GPU raises.
+"""
+import ctypes
+import dataclasses
+import math
+
+import numpy as np
+
+from . import _abi
+from ._abi import MAX_LEVELS, PART_NONE, PART_ZSLAB, SCENES, Mesh, Point, RegenInfo, VoxelField  # noqa: F401
+
+
+class SdMeshError(RuntimeError):
+    def __init__(self, code, text):
+        super().__init__(f"sdmesh error {code} ({_abi.ERRORS.get(code, '?')}): {text}")
+        self.code = code
+
+
+@dataclasses.dataclass
+class CudaVoxelField:
+    """`pub struct CudaVoxelField { pub voxels: Vec<Point>, pub voxel_size: Point }` (mod.rs:41-46).
+    voxels: float32 [n, 3]; voxel_size: float32 [3]."""
+    voxels: np.ndarray
+    voxel_size: np.ndarray
+
+
+@dataclasses.dataclass
+class ObjData:
+    """What the reference packs into obj::ObjData (mod.rs:303-326): `position`, `normal`, one texture
+    coordinate [0, 0], and per polygon the IndexTuple (i, Some(0), Some(i)) -- position index ==
+    normal index (asserted by obj_to_bevy_mesh, src/renderer/mod.rs:110-128)."""
+    position: np.ndarray            # float32 [V, 3]
+    normal: np.ndarray              # float32 [V, 3]
+    indices: np.ndarray             # uint32  [T, 3]
+    texture: np.ndarray = dataclasses.field(default_factory=lambda: np.zeros((1, 2), np.float32))
+
+    def save(self, path):
+        """Wavefront OBJ in the layout obj-rs writes for the reference (`v`, `vt 0 0`, `vn`, then
+        `f i/1/i` with 1-based indices; src/renderer/mod.rs:204)."""
+        with open(path, "w") as f:
+            f.write("o default\ng default\n")
+            for p in self.position:
+                f.write("v %s %s %s\n" % (repr(float(p[0])), repr(float(p[1])), repr(float(p[2]))))
+            f.write("vt 0 0\n")
+            for n in self.normal:
+                f.write("vn %s %s %s\n" % (repr(float(n[0])), repr(float(n[1])), repr(float(n[2]))))
+            for t in self.indices:
+                a, b, c = int(t[0]) + 1, int(t[1]) + 1, int(t[2]) + 1
+                f.write(f"f {a}/1/{a} {b}/1/{b} {c}/1/{c}\n")
+
+
+def _pt(a):
+    return Point(float(a[0]), float(a[1]), float(a[2]))
+
+
+class CudaHandler:
+    def __init__(self, device=0, scene="sdobj", params=None):
+        self._lib = _abi.load()
+        hp = ctypes.c_void_p()
+        rc = self._lib.sdmesh_create(int(device), ctypes.byref(hp))
+        if rc != 0:
+            raise SdMeshError(rc, "sdmesh_create failed (is a gfx950 GPU visible?)")
+        self._h = hp
+        self.device = int(device)
+        self.set_scene(scene, params)
+
+    # -- lifetime ------------------------------------------------------------------------------
+    def close(self):
+        if getattr(self, "_h", None):
+            self._lib.sdmesh_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _chk(self, rc):
+        if rc != 0:
+            raise SdMeshError(rc, self._lib.sdmesh_last_error(self._h).decode(errors="replace"))
+
+    # -- configuration -------------------------------------------------------------------------
+    def set_scene(self, scene, params=None):
+        p = np.zeros(4, np.float32)
+        n = 0
+        if params is not None:
+            a = np.asarray(params, np.float32).ravel()
+            n = a.size
+            p[:n] = a
+        self.scene = scene
+        self._chk(self._lib.sdmesh_set_scene(self._h, SCENES[scene] if isinstance(scene, str) else int(scene),
+                                              p.ctypes.data, n))
+
+    def set_animation_time(self, t):
+        """sphere centre (0, 0.5*sin t, 0); sin is evaluated on the host."""
+        self.set_scene("anim", [np.float32(0.5) * np.float32(math.sin(t))])
+
+    def set_stream(self, hip_stream):
+        self._chk(self._lib.sdmesh_set_stream(self._h, ctypes.c_void_p(hip_stream or 0)))
+
+    def set_option(self, name, value):
+        self._chk(self._lib.sdmesh_set_option(self._h, name.encode(), int(value)))
+
+    # -- the reference's methods ---------------------------------------------------------------
+    @staticmethod
+    def create_cuda_voxel_field():
+        lib = _abi.load()
+        vox = np.empty((_abi.MESH_GENERATION_INIT_FACTOR ** 3, 3), np.float32)
+        size = np.empty(3, np.float32)
+        rc = lib.sdmesh_create_voxel_field(vox.ctypes.data, size.ctypes.data)
+        if rc != 0:
+            raise SdMeshError(rc, "sdmesh_create_voxel_field")
+        return CudaVoxelField(vox, size)
+
+    def refine_voxel_field(self, field):
+        vox = np.ascontiguousarray(field.voxels, np.float32).reshape(-1, 3)
+        n = vox.shape[0]
+        out = np.empty((max(8 * n, 1), 3), np.float32)
+        n_out = ctypes.c_size_t(0)
+        size_out = Point()
+        self._chk(self._lib.sdmesh_refine_voxel_field(self._h, vox.ctypes.data, n, _pt(field.voxel_size),
+                                                       out.ctypes.data, 8 * n, ctypes.byref(n_out),
+                                                       ctypes.byref(size_out)))
+        field.voxels = out[: n_out.value].copy()
+        field.voxel_size = np.array([size_out.x, size_out.y, size_out.z], np.float32)
+
+    def voxel_field_to_mesh(self, field):
+        vox = np.ascontiguousarray(field.voxels, np.float32).reshape(-1, 3)
+        nv, nt = ctypes.c_size_t(0), ctypes.c_size_t(0)
+        self._chk(self._lib.sdmesh_voxel_field_to_mesh(self._h, vox.ctypes.data, vox.shape[0], _pt(field.voxel_size),
+                                                        None, 0, ctypes.byref(nv), None, 0, ctypes.byref(nt)))
+        return self._download_obj(nv.value, nt.value)
+
+    # -- kernel-level layouts ------------------------------------------------------------------
+    def refine_voxel_field_raw(self, field):
+        vox = np.ascontiguousarray(field.voxels, np.float32).reshape(-1, 3)
+        out = np.empty((8 * vox.shape[0], 3), np.float32)
+        self._chk(self._lib.sdmesh_refine_voxel_field_raw(self._h, vox.ctypes.data, vox.shape[0], _pt(field.voxel_size),
+                                                           out.ctypes.data))
+        return out
+
+    def voxel_field_to_triangles_raw(self, field):
+        vox = np.ascontiguousarray(field.voxels, np.float32).reshape(-1, 3)
+        out = np.empty((5 * vox.shape[0], 3, 2, 3), np.float32)
+        self._chk(self._lib.sdmesh_voxel_field_to_triangles_raw(self._h, vox.ctypes.data, vox.shape[0],
+                                                                 _pt(field.voxel_size), out.ctypes.data))
+        return out
+
+    def weld_triangles(self, raw):
+        raw = np.ascontiguousarray(raw, np.float32).reshape(-1, 3, 2, 3)
+        nv, nt = ctypes.c_size_t(0), ctypes.c_size_t(0)
+        self._chk(self._lib.sdmesh_weld_triangles(self._h, raw.ctypes.data, raw.shape[0], None, 0, ctypes.byref(nv),
+                                                   None, 0, ctypes.byref(nt)))
+        return self._download_obj(nv.value, nt.value)
+
+    # -- device-resident path ------------------------------------------------------------------
+    def regen(self, levels, mode=PART_NONE, part=0, nparts=1):
+        """create -> `levels` x refine -> mesh -> weld without leaving HBM.  Returns RegenInfo."""
+        info = RegenInfo()
+        self._chk(self._lib.sdmesh_regen_part(self._h, int(levels), int(mode), int(part), int(nparts),
+                                               ctypes.byref(info)))
+        return info
+
+    def download_mesh(self, info=None):
+        m = Mesh()
+        nt = ctypes.c_uint32(0)
+        self._chk(self._lib.sdmesh_device_mesh(self._h, ctypes.byref(m), ctypes.byref(nt)))
+        return self._download_obj(m.vertex_count, nt.value)
+
+    def download_voxels(self):
+        f = VoxelField()
+        self._chk(self._lib.sdmesh_device_voxels(self._h, ctypes.byref(f)))
+        vox = np.empty((f.voxel_count, 3), np.float32)
+        if f.voxel_count:
+            self._chk(self._lib.sdmesh_download_voxels(self._h, vox.ctypes.data))
+        return CudaVoxelField(vox, np.array([f.voxel_size.x, f.voxel_size.y, f.voxel_size.z], np.float32))
+
+    def device_mesh(self):
+        m = Mesh()
+        nt = ctypes.c_uint32(0)
+        self._chk(self._lib.sdmesh_device_mesh(self._h, ctypes.byref(m), ctypes.byref(nt)))
+        return m, nt.value
+
+    def device_triangles_into(self, dev_ptr, cap):
+        n = ctypes.c_size_t(0)
+        self._chk(self._lib.sdmesh_device_triangles(self._h, ctypes.c_void_p(dev_ptr), cap, ctypes.byref(n)))
+        return n.value
+
+    def triangle_count(self):
+        n = ctypes.c_size_t(0)
+        self._chk(self._lib.sdmesh_device_triangles(self._h, None, 0, ctypes.byref(n)))
+        return n.value
+
+    def weld_device_triangles(self, dev_ptr, nslots):
+        info = RegenInfo()
+        self._chk(self._lib.sdmesh_weld_device_triangles(self._h, ctypes.c_void_p(dev_ptr), int(nslots),
+                                                          ctypes.byref(info)))
+        return info
+
+    def sample_dense(self, N, dev_ptr):
+        ms = ctypes.c_float(0)
+        self._chk(self._lib.sdmesh_sample_dense(self._h, int(N), ctypes.c_void_p(dev_ptr), ctypes.byref(ms)))
+        return ms.value
+
+    def time_kernel(self, which, N, dev_ptr, iters):
+        ms = ctypes.c_float(0)
+        self._chk(self._lib.sdmesh_time_kernel(self._h, int(which), int(N), ctypes.c_void_p(dev_ptr), int(iters),
+                                                ctypes.byref(ms)))
+        return ms.value
+
+    def _download_obj(self, nv, nt):
+        verts = np.empty((max(nv, 1), 2, 3), np.float32)
+        idx = np.empty((max(nt, 1), 3), np.uint32)
+        if nv or nt:
+            self._chk(self._lib.sdmesh_download_mesh(self._h, verts.ctypes.data, idx.ctypes.data))
+        return ObjData(verts[:nv, 0].copy(), verts[:nv, 1].copy(), idx[:nt].copy())

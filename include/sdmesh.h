@@ -1,0 +1,153 @@
+/*
+ * sdmesh.h -- C ABI of libsdmesh.so, the MI355X (gfx950) replacement for the mesh-generation
+ * half of the reference's `CudaHandler` (src/cuda/mod.rs:25-346).
+ *
+ * Every entry point names the reference interface it replaces.  Plain pointers and sizes only;
+ * all functions return 0 (SDMESH_OK) or an SDMESH_ERR_* code and never abort (the reference
+ * `.unwrap()`s every driver call -- SURVEY.md section 5).  A handle is single-threaded, like the
+ * reference handler that lives in a Bevy NonSend resource (src/renderer/mod.rs:159,233).
+ *
+ * Two families:
+ *   host-buffer calls   1:1 with the reference methods: host vectors in, host vectors out,
+ *                       fully synchronous (src/cuda/mod.rs:142-190, :219-261).
+ *   device-resident     the whole level-0 -> refine^k -> mesh -> weld chain without leaving
+ *                       HBM; results are read back (or handed to a renderer / RCCL) afterwards.
+ */
+#ifndef SDMESH_H
+#define SDMESH_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#include "sdmesh/bindings.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+enum {
+    SDMESH_OK = 0,
+    SDMESH_ERR_INVALID = 1,      /* bad argument */
+    SDMESH_ERR_HIP = 2,          /* a HIP runtime call failed (sdmesh_last_error has the text) */
+    SDMESH_ERR_NO_DEVICE = 3,    /* no usable gfx950 device */
+    SDMESH_ERR_CAPACITY = 4,     /* caller-provided output buffer too small */
+    SDMESH_ERR_WELD_RANGE = 5,   /* a vertex outside +-10.48 units: not representable in the weld key */
+    SDMESH_ERR_INTERNAL = 6      /* invariant violated on the device (bug) */
+};
+
+/* Scenes.  The reference hard-codes one SDF, sd_obj (cuda/modules/common.cu:222-226) = SDOBJ.
+ * SPHERE is its a2 term alone; CSG3 and ANIM are build-defined. */
+enum {
+    SDMESH_SCENE_SDOBJ = 0,
+    SDMESH_SCENE_SPHERE = 1,
+    SDMESH_SCENE_CSG3 = 2,
+    SDMESH_SCENE_ANIM = 3        /* params[0] = y of the sphere centre (host passes 0.5*sin(t)) */
+};
+
+/* Multi-GPU partition of the level-0 field. */
+enum {
+    SDMESH_PART_NONE = 0,
+    SDMESH_PART_ZSLAB = 1        /* level-0 z layers [32*part/nparts, 32*(part+1)/nparts) */
+};
+
+typedef struct sdmesh_handle sdmesh_handle;
+
+#define SDMESH_MAX_LEVELS 15
+
+typedef struct sdmesh_regen_info {
+    uint32_t levels;                                   /* refines performed */
+    uint32_t voxel_count[SDMESH_MAX_LEVELS + 1];       /* active voxels entering level i */
+    uint32_t unique_edges;                             /* projected vertices before the weld */
+    uint32_t triangles;
+    uint32_t vertices;                                 /* welded */
+    struct Point voxel_size;                           /* of the final level */
+    uint32_t status[8];                                /* device status block (all 0 = healthy) */
+    uint32_t used_direct_path;                         /* 1 if the non-lattice fallback ran */
+    float device_ms;                                   /* HIP-event time of the device chain */
+} sdmesh_regen_info;
+
+/* ---- lifetime ----------------------------------------------------------------------------- */
+
+/* CudaHandler::new (src/cuda/mod.rs:49-103): picks the device, loads the kernels, creates the
+ * grow-only device buffers (DynamicCudaSlice, :10-23). */
+int sdmesh_create(int device, sdmesh_handle **out);
+void sdmesh_destroy(sdmesh_handle *h);
+const char *sdmesh_last_error(const sdmesh_handle *h);
+
+/* The reference compiles its scene in; here it is a runtime choice. */
+int sdmesh_set_scene(sdmesh_handle *h, int scene, const float *params, int nparams);
+/* Run on a caller-owned hipStream_t (e.g. torch's current stream); NULL = the handle's own. */
+int sdmesh_set_stream(sdmesh_handle *h, void *hip_stream);
+/* Options: "direct" = 1 forces the per-corner projection path (no edge sharing) for A/B runs;
+ * "grid" = workgroups per grid-stride launch. */
+int sdmesh_set_option(sdmesh_handle *h, const char *name, int value);
+
+/* ---- host-buffer API (B2) ----------------------------------------------------------------- */
+
+/* CudaHandler::create_cuda_voxel_field (src/cuda/mod.rs:105-122).  voxels: 32^3 = 32768 Points,
+ * x outer / z inner.  Pure host function, needs no handle and no GPU. */
+int sdmesh_create_voxel_field(struct Point *voxels, struct Point *voxel_size);
+
+/* CudaHandler::refine_voxel_field (src/cuda/mod.rs:124-202): kernel + order-preserving retain.
+ * out needs room for up to 8*n Points (out_cap); *n_out receives the kept count, *size_out the
+ * halved voxel size.  n == 0 leaves everything untouched, as the reference does (:137). */
+int sdmesh_refine_voxel_field(sdmesh_handle *h, const struct Point *in, size_t n, struct Point voxel_size,
+                              struct Point *out, size_t out_cap, size_t *n_out, struct Point *size_out);
+
+/* The refine kernel's own output (compute_mesh_generation.cu:12-62): 8*n Points, INFINITY where a
+ * child is not a border voxel. */
+int sdmesh_refine_voxel_field_raw(sdmesh_handle *h, const struct Point *in, size_t n, struct Point voxel_size,
+                                  struct Point *out8n);
+
+/* The triangle kernel's own output (compute_mesh_generation.cu:64-120): 5*n Triangle slots,
+ * unused slots = {NaN,NaN} in vertex 0 and zeros in vertices 1..2. */
+int sdmesh_voxel_field_to_triangles_raw(sdmesh_handle *h, const struct Point *voxels, size_t n,
+                                        struct Point voxel_size, struct Triangle *out5n);
+
+/* CudaHandler::voxel_field_to_mesh (src/cuda/mod.rs:204-346) without the obj::ObjData wrapping:
+ * welded vertices (first-seen position AND normal) and u32 index triples in emission order.
+ * Worst case 15*n vertices / 5*n triangles; pass verts == NULL / tris == NULL to get the counts
+ * only and fetch the data with sdmesh_download_mesh. */
+int sdmesh_voxel_field_to_mesh(sdmesh_handle *h, const struct Point *voxels, size_t n, struct Point voxel_size,
+                               struct Vertex *verts, size_t vert_cap, size_t *n_verts,
+                               struct IndexTriangle *tris, size_t tri_cap, size_t *n_tris);
+
+/* The host weld alone (src/cuda/mod.rs:263-296) on a raw slot list that lives on the HOST. */
+int sdmesh_weld_triangles(sdmesh_handle *h, const struct Triangle *raw, size_t nslots, struct Vertex *verts,
+                          size_t vert_cap, size_t *n_verts, struct IndexTriangle *tris, size_t tri_cap,
+                          size_t *n_tris);
+
+/* ---- device-resident API ------------------------------------------------------------------- */
+
+/* One user-visible regen (src/renderer/mod.rs:162-225: create, `levels` x refine, mesh) entirely on
+ * the device.  part/nparts/mode select this rank's share of the level-0 field. */
+int sdmesh_regen(sdmesh_handle *h, int levels, sdmesh_regen_info *info);
+int sdmesh_regen_part(sdmesh_handle *h, int levels, int mode, int part, int nparts, sdmesh_regen_info *info);
+
+/* Borrow the results of the last regen / mesh call (device pointers owned by the handle, valid
+ * until the next call).  Fills the reference's otherwise unused `struct Mesh` (bindings.h:70-75). */
+int sdmesh_device_mesh(sdmesh_handle *h, struct Mesh *mesh, uint32_t *n_tris);
+int sdmesh_device_voxels(sdmesh_handle *h, struct VoxelField *field);
+/* Compact (un-welded) triangle list of the last regen in emission order, 72 B each: written into a
+ * caller-provided DEVICE buffer (e.g. a torch tensor that RCCL then gathers). */
+int sdmesh_device_triangles(sdmesh_handle *h, struct Triangle *d_out, size_t cap, size_t *n_tris);
+/* Weld a compact/raw slot list that already lives on the DEVICE (root of the multi-GPU gather). */
+int sdmesh_weld_device_triangles(sdmesh_handle *h, const struct Triangle *d_raw, size_t nslots,
+                                 sdmesh_regen_info *info);
+
+int sdmesh_download_mesh(sdmesh_handle *h, struct Vertex *verts, struct IndexTriangle *tris);
+int sdmesh_download_voxels(sdmesh_handle *h, struct Point *voxels);
+
+/* P1: dense (N+1)^3 f32 sample of the scene SDF into a DEVICE buffer, x outer /
+ * z inner, sample m at (float)m * (5/N) - 2.5.  *kernel_ms (optional) = HIP-event time. */
+int sdmesh_sample_dense(sdmesh_handle *h, uint32_t N, float *d_out, float *kernel_ms);
+
+/* Time `iters` back-to-back launches of one internal kernel with HIP events on the handle's stream
+ * (bench.py's live roofline measurement).  which: 0 = sample_dense(N) into d_buf. */
+int sdmesh_time_kernel(sdmesh_handle *h, int which, uint32_t N, float *d_buf, int iters, float *avg_ms);
+
+#ifdef __cplusplus
+}
+#endif
+
+#endif /* SDMESH_H */

@@ -55,6 +55,9 @@ def lib():
         L.orc_weld.argtypes = [vp, sz, vp, vp, vp, ctypes.POINTER(sz)]
         L.orc_fnv1a64.restype = u64
         L.orc_fnv1a64.argtypes = [vp, sz]
+        L.orc_eval_points.argtypes = [ctypes.c_int, vp, vp, ctypes.c_long, vp, vp, vp, vp]
+        L.orc_weld_quant.restype = ctypes.c_longlong
+        L.orc_weld_quant.argtypes = [fp]
         L.orc_dense_mc_count.restype = u64
         L.orc_dense_mc_count.argtypes = [ctypes.c_int, vp, u32]
         _LIB = L
@@ -99,6 +102,21 @@ def sdf(scene, pts, params=None):
     pts = np.asarray(pts, dtype=np.float32).reshape(-1, 3)
     L = lib()
     return np.array([L.orc_sdf(SCENES[scene], p.ctypes.data, *map(float, q)) for q in pts], dtype=np.float32)
+
+
+def eval_points(scene, pts, params=None, normals=True, project=True, flips=True):
+    """-> dict(sd [n], nrm [n,3], proj [n,3], flip [n//3]) at arbitrary points (numerics tests)."""
+    p = _params(params)
+    pts = np.ascontiguousarray(pts, dtype=np.float32).reshape(-1, 3)
+    n = pts.shape[0]
+    sd = np.empty(n, np.float32)
+    nrm = np.empty((n, 3), np.float32) if normals else None
+    proj = np.empty((n, 3), np.float32) if project else None
+    flip = np.empty(n // 3, np.int32) if flips else None
+    lib().orc_eval_points(SCENES[scene], p.ctypes.data, pts.ctypes.data, n, sd.ctypes.data,
+                          nrm.ctypes.data if normals else None, proj.ctypes.data if project else None,
+                          flip.ctypes.data if flips else None)
+    return {"sd": sd, "nrm": nrm, "proj": proj, "flip": flip}
 
 
 def create_voxel_field():

@@ -12,9 +12,12 @@
  * fixtures or golden vectors for this path, and it cannot be built here (needs nvcc,
  * the CUDA headers and GLM 1.0.1, none of which are in the image or vendored in the
  * reference; building it behind stand-in headers is not allowed).  What pins this file
- * instead: (1) the counts and FNV-1a hashes recorded in SURVEY.md section 8(c) during
- * the survey phase (tests/golden/survey_8c.json) -- this oracle reproduces every row;
- * (2) closed-mesh invariants (V - T/2 = chi, 6.0 raw refs per welded vertex).
+ * instead: (1) the counts recorded in SURVEY.md section 8(c) during the survey phase
+ * (tests/golden/survey_8c.json: voxels, emitting voxels, triangles, welded vertices and the
+ * tris/voxel histogram for sd_obj k=0..5 and the sphere k=0..4) -- this oracle reproduces
+ * every row; the FNV hash columns of that table could not be reproduced by any FNV variant
+ * (not even for the scene-independent level-0 field) and are not used;
+ * (2) closed-mesh invariants (V - T/2 = chi, every edge shared by exactly two triangles).
  *
  * Arithmetic model: GLM 1.0.1 generic scalar paths, no FMA
  * contraction (compile with -ffp-contract=off), IEEE division and sqrt:
@@ -495,3 +498,32 @@ uint64_t orc_dense_mc_count(int scene, const float *params, uint32_t N) {
     free(sign);
     return tris;
 }
+
+/* ---- point-wise probes for the numerics tests (sd, normal, projection, orientation) ---- */
+void orc_eval_points(int scene, const float *params, const float *pts, long n, float *sd, float *nrm,
+                     float *proj, int *flip) {
+    for (long i = 0; i < n; i++) {
+        v3 p = V(pts[3 * i], pts[3 * i + 1], pts[3 * i + 2]);
+        sd[i] = sdf_eval(scene, params, p);
+        if (nrm) {
+            v3 nn = empirical_normal(scene, params, p);
+            nrm[3 * i] = nn.x; nrm[3 * i + 1] = nn.y; nrm[3 * i + 2] = nn.z;
+        }
+        if (proj) {
+            v3 g = closest_surface_point(scene, params, p, NULL);
+            proj[3 * i] = g.x; proj[3 * i + 1] = g.y; proj[3 * i + 2] = g.z;
+        }
+    }
+    if (flip) {
+        for (long i = 0; i + 2 < n; i += 3) {
+            v3 v0 = V(pts[3 * i], pts[3 * i + 1], pts[3 * i + 2]);
+            v3 v1 = V(pts[3 * i + 3], pts[3 * i + 4], pts[3 * i + 5]);
+            v3 v2 = V(pts[3 * i + 6], pts[3 * i + 7], pts[3 * i + 8]);
+            v3 tn = normalize3(cross3(vsub(v1, v0), vsub(v2, v0)));
+            v3 an = empirical_normal(scene, params, vdivs(vadd(vadd(v0, v1), v2), 3.0f));
+            flip[i / 3] = dot3(tn, an) <= 0.0f;
+        }
+    }
+}
+
+long long orc_weld_quant(float x) { return (long long) f32_discrete(x); }
