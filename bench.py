@@ -1,0 +1,174 @@
+#!/usr/bin/env python3
+"""bench.py -- headline benchmark: SDF mesh extraction of the reference scene at 512^3 on MI355X.
+
+    python bench.py --gpus N --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+        --master-port P bench.py --gpus N --steps K --warmup W
+
+One "step" = one full regen of the workload on the device: level-0 field -> 4 hierarchical refines
+-> marching cubes -> Newton projection + normals -> orientation -> vertex weld, ending with the indexed
+mesh resident in HBM (SURVEY.md 8(d) t_regen).  Nothing is uploaded: the SDF is the input.
+
+metric   Mvoxels/s = N_grid^3 * steps * n_gpus / wall  (BASELINE.json: "Mvoxels/s + Mtris/s for 512^3 SDF
+         mesh extract"); Mtris/s rides along in "mtris_per_s".
+N > 1    every rank regenerates the same workload independently (the path shards by object/frame with no
+         data-path exchange) -> "scaling": "weak".  The single-mesh z-slab + RCCL-gather + root-weld path is
+         exercised and timed separately under "sharded" (strong scaling of ONE mesh, reported, not `value`).
+roofline the north-star HBM pass P1 = dense (N+1)^3 f32 SDF sample, timed live with HIP events on the
+         stream the kernel runs on: algorithmic bytes 4*(N+1)^3 per launch / average launch time, vs 8 TB/s.
+cpu_baseline  the CPU oracle (oracle/, a port of the reference algorithm) on the host cores of this box,
+         same workload, whole regen, all cores ("port").  Reported, not a target.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
+
+import sdmesh_pkg  # noqa: E402
+
+HBM_PEAK_GBPS = 8000.0          # MI355X_MICROARCH.md "HBM3E peak BW 8.0 TB/s spec"
+
+
+def host_cores():
+    """CPU threads this job may actually use: affinity mask capped by the cgroup CPU quota."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        q, p = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if q != "max":
+            n = min(n, max(1, int(int(q) / int(p))))
+    except Exception:
+        try:
+            q = int(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+            p = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            if q > 0:
+                n = min(n, max(1, q // p))
+        except Exception:
+            pass
+    return min(n, 64)
+
+
+def cpu_baseline(scene, levels, params):
+    """The oracle (CPU port of the reference algorithm) on all host cores: one whole regen of the same
+    workload.  ~20-30 s of CPU work at 512^3 sd_obj."""
+    from oracle import oracle as O
+    O.build()
+    cores = host_cores()
+    O.set_threads(cores)
+    t0 = time.perf_counter()
+    r = O.regen(scene, levels, params)
+    dt = time.perf_counter() - t0
+    n = 32 << levels
+    return {"value": round(n ** 3 / dt / 1e6, 3), "unit": "Mvoxels/s", "cores": cores, "kind": "port",
+            "sample": f"one full regen of {scene} {n}^3 (refine x{levels} + triangles + weld), OpenMP over voxels, "
+                      f"{dt:.2f} s wall, {len(r['idx'])} triangles",
+            "mtris_per_s": round(len(r["idx"]) / dt / 1e6, 4), "seconds": round(dt, 3)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--scene", default="sdobj")
+    ap.add_argument("--levels", type=int, default=4)          # N = 32 * 2^levels = 512
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-sharded", action="store_true")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            sys.exit("bench.py: --gpus N > 1 must be launched with torch.distributed.run (one rank per GPU)")
+        args.gpus = world
+    if not torch.cuda.is_available():
+        sys.exit("bench.py: no GPU visible -- the product path has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    pkg = sdmesh_pkg.load()
+    params = [0.25] if args.scene == "anim" else None
+    h = pkg.CudaHandler(local_rank, args.scene, params)
+    n_grid = 32 << args.levels
+
+    def sync_all():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    info = h.regen(args.levels)                      # capacity discovery pass (synchronous, untimed)
+    for _ in range(args.warmup):
+        info = h.regen(args.levels)
+    sync_all()
+    t0 = time.perf_counter()
+    dev_ms = []
+    for _ in range(args.steps):
+        info = h.regen(args.levels)
+        dev_ms.append(info.device_ms)
+    sync_all()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+
+    ms_per_step = dt / args.steps * 1e3
+    value = n_grid ** 3 * args.steps * world / dt / 1e6
+    out = {
+        "metric": "Mvoxels/s (512^3 SDF mesh extract: N^3 grid cells per full regen, whole job)",
+        "value": round(value, 1), "unit": "Mvoxels/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": "f32", "data": "synthetic",
+        "config": {"workload": f"{args.scene} {n_grid}^3 (BASELINE configs[2]: reference scene sd_obj, 32^3 level-0 "
+                               f"cells refined x{args.levels}), device-resident regen, indexed mesh left in HBM",
+                   "levels": args.levels, "grid": n_grid,
+                   "parallelism": "1 GPU" if world == 1 else f"{world} independent regens (one per GPU, no exchange)"},
+        "mtris_per_s": round(info.triangles * args.steps * world / dt / 1e6, 2),
+        "triangles": int(info.triangles), "vertices": int(info.vertices), "active_voxels": int(info.voxel_count[args.levels]),
+        "device_ms_per_step": round(float(np.median(dev_ms)), 4),
+    }
+
+    if rank == 0:
+        # --- roofline of the north-star HBM pass (P1 dense SDF sample), HIP-event timed on the handle's stream
+        buf = torch.empty((n_grid + 1) ** 3, dtype=torch.float32, device="cuda")
+        alg_bytes = 4.0 * (n_grid + 1) ** 3
+        roofs = {}
+        for sc in ("sphere", args.scene):
+            h.set_scene(sc, [0.25] if sc == "anim" else None)
+            ms = h.time_kernel(0, n_grid, buf.data_ptr(), 50)
+            gbps = alg_bytes / (ms * 1e-3) / 1e9
+            roofs[sc] = {"bound": "hbm", "kernel": f"k_sample_dense<{sc}>", "achieved": round(gbps, 1), "peak": HBM_PEAK_GBPS,
+                         "unit": "GB/s", "frac": round(gbps / HBM_PEAK_GBPS, 4), "traffic": None,
+                         "bytes_per_launch": alg_bytes, "avg_launch_ms": round(ms, 5),
+                         "gsamples_per_s": round((n_grid + 1) ** 3 / (ms * 1e-3) / 1e9, 1)}
+        h.set_scene(args.scene, params)
+        del buf
+        out["roofline"] = roofs["sphere"]
+        out["roofline"]["note"] = ("P1 dense (N+1)^3 f32 SDF-sample pass, the HBM pass the north star names; claimed on the "
+                                   "sphere scene (SURVEY 8(d) caveat i); the regen itself is O(surface) and VALU/atomic "
+                                   "bound, see DESIGN.md")
+        if args.scene != "sphere":
+            out["roofline_workload_scene"] = roofs[args.scene]
+        if not args.no_cpu_baseline and world == 1:
+            out["cpu_baseline"] = cpu_baseline(args.scene, args.levels, params)
+        print(json.dumps(out), flush=True)
+
+    h.close()
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -85,6 +85,15 @@ def load():
     missing -- the product has no fallback path."""
     global _LIB
     if _LIB is None:
+        # One HIP runtime per process: PyTorch-ROCm wheels bundle their own libamdhip64 with the same
+        # SONAME (libamdhip64.so.7) as the system ROCm one libsdmesh.so is linked against.  Importing
+        # torch first makes the dynamic linker resolve our NEEDED entry to the copy torch already
+        # loaded, so torch tensors, RCCL buffers and our kernels share one runtime and one context.
+        # (Loading ours first would bring in a second runtime and torch.cuda would then fail to init.)
+        try:
+            import torch  # noqa: F401
+        except ImportError:
+            pass
         if not os.path.exists(LIB_PATH):
             raise RuntimeError(f"{LIB_PATH} is missing: build it with __graft_entry__.build() "
                                "(make -C bevy-signed-distance-mesh-generation_amd/csrc)")

@@ -50,6 +50,8 @@ struct sdmesh_handle {
     int grid = 1024;           // workgroups per grid-stride launch (4 per CU)
     int force_direct = 0;
     uint32_t min_chunk = 128;  // unique edges per wave queue in k_project
+    int dense_grid = 16384;    // workgroups for k_sample_dense
+    int dense_nt = 1;          // nontemporal stores in k_sample_dense
     char err[512] = {0};
 
     // voxel lists (ping-pong), refine scratch
@@ -61,11 +63,11 @@ struct sdmesh_handle {
     uint32_t *d_status = nullptr;  // ST_WORDS
     uint32_t *h_pinned = nullptr;  // CTR_WORDS + ST_WORDS, pinned
     // mesh stage
-    DevBuf cubeidx, trioff, trilist, ff_arena, hids, ukeys, uverts, tri_e, vslot, bitmap, wordpre, wvidx;
+    DevBuf cubeidx, trioff, ff_arena, first_ord_buf, wfirst, uverts, tri_e, vslot, bitmap, wordpre, wvidx;
     DevBuf vertices, indices, raw, compact, staging;
     // capacities the device chain was laid out for
-    uint32_t cap_vox = 0, hsize = 0, ucap = 0, tcap = 0, wsize = 0;
-    uint64_t *hkeys = nullptr, *wkeys = nullptr;
+    uint32_t cap_vox = 0, ucap = 0, tcap = 0, wsize = 0;
+    uint64_t *wkeys = nullptr;
     uint32_t *first_ord = nullptr, *wmin = nullptr;
 
     // last results (host view)
@@ -130,37 +132,33 @@ inline size_t align256(size_t v) { return (v + 255) & ~(size_t) 255; }
 
 Point half_size(Point p) { return Point{p.x / 2.0f, p.y / 2.0f, p.z / 2.0f}; }   // src/cuda/mod.rs:126-130
 
-// Lay out the mesh-stage buffers for up to n_cap voxels / u_cap unique edges.
+// Lay out the mesh-stage buffers for up to n_cap voxels / u_cap unique (pre-weld) vertices.
 int layout_mesh(sdmesh_handle *h, uint32_t n_cap, uint32_t u_cap_hint) {
     if (n_cap < 64) n_cap = 64;
-    const uint32_t ucap = std::max<uint32_t>(u_cap_hint, 2u * n_cap + 1024u);
+    const uint32_t ucap = std::max<uint32_t>(u_cap_hint, 2u * n_cap + 4096u);
     const uint32_t tcap = 5u * n_cap;
-    const uint32_t hsize = 2u * ucap + 64u;           // load factor <= 0.5
-    const uint32_t wsize = 2u * ucap + 64u;
+    const uint32_t wsize = 2u * ucap + 64u;           // load factor <= 0.5
     SDCHK(ensure(h, h->cubeidx, n_cap));
     SDCHK(ensure(h, h->trioff, 4ull * n_cap));
     SDCHK(ensure(h, h->tilecnt, 4ull * std::max(tiles(n_cap), tiles(5u * n_cap)) + 64));
-    SDCHK(ensure(h, h->trilist, 4ull * tcap));
-    SDCHK(ensure(h, h->hids, 4ull * hsize));
-    SDCHK(ensure(h, h->ukeys, 8ull * ucap));
     SDCHK(ensure(h, h->uverts, sizeof(Vertex) * (size_t) ucap));
+    SDCHK(ensure(h, h->first_ord_buf, 4ull * ucap));
     SDCHK(ensure(h, h->tri_e, 12ull * tcap));
     SDCHK(ensure(h, h->vslot, 4ull * ucap));
     SDCHK(ensure(h, h->bitmap, 4ull * ((3ull * tcap + 31) / 32 + 1)));
     SDCHK(ensure(h, h->wordpre, 4ull * ((3ull * tcap + 31) / 32 + 1)));
     SDCHK(ensure(h, h->wvidx, 4ull * wsize));
+    SDCHK(ensure(h, h->wfirst, 4ull * wsize));
     SDCHK(ensure(h, h->vertices, sizeof(Vertex) * (size_t) ucap));
     SDCHK(ensure(h, h->indices, 12ull * tcap));
-    // one arena for everything that must start as 0xFF: a single memset per regen
-    const size_t o_hkeys = 0, o_wkeys = align256(o_hkeys + 8ull * hsize), o_first = align256(o_wkeys + 8ull * wsize),
-                 o_wmin = align256(o_first + 4ull * ucap), total = align256(o_wmin + 4ull * wsize);
+    // one arena for everything that must start as 0xFF (weld keys + loser minima): one memset per regen
+    const size_t o_wkeys = 0, o_wmin = align256(o_wkeys + 8ull * wsize), total = align256(o_wmin + 4ull * wsize);
     SDCHK(ensure(h, h->ff_arena, total));
     char *base = (char *) h->ff_arena.p;
-    h->hkeys = (uint64_t *) (base + o_hkeys);
     h->wkeys = (uint64_t *) (base + o_wkeys);
-    h->first_ord = (uint32_t *) (base + o_first);
     h->wmin = (uint32_t *) (base + o_wmin);
-    h->hsize = hsize; h->wsize = wsize; h->ucap = ucap; h->tcap = tcap; h->cap_vox = n_cap;
+    h->first_ord = (uint32_t *) h->first_ord_buf.p;
+    h->wsize = wsize; h->ucap = ucap; h->tcap = tcap; h->cap_vox = n_cap;
     return SDMESH_OK;
 }
 
@@ -168,22 +166,17 @@ size_t ff_bytes(const sdmesh_handle *h) {
     return (size_t) ((char *) h->wmin - (char *) h->ff_arena.p) + 4ull * h->wsize;
 }
 
-// classify .. tri_orient for the voxel list d_vox (count at *n_ptr, at most n_cap)
+// classify + fused tile kernel for the voxel list d_vox (count at *n_ptr, at most cap_vox):
+// leaves (uverts, first_ord, tri_e, trioff) and the counters NUNIQ / NTRI on the device
 int mesh_front(sdmesh_handle *h, const Point *d_vox, const uint32_t *n_ptr, Point vs) {
     hipStream_t st = h->stream;
     HIPCHK(hipMemsetAsync(h->ff_arena.p, 0xFF, ff_bytes(h), st));
     HIPCHK(hipMemsetAsync(h->d_ctr + CTR_NUNIQ, 0, 4 * sizeof(uint32_t), st));
-    HIPCHK(launch_classify(st, h->grid, h->scene, h->sp, d_vox, n_ptr, vs, (uint8_t *) h->cubeidx.p, (uint32_t *) h->tilecnt.p,
-                           h->hkeys, (uint32_t *) h->hids.p, h->hsize, (uint64_t *) h->ukeys.p, h->ucap,
-                           h->d_ctr + CTR_NUNIQ, h->d_status));
-    HIPCHK(launch_scan_tiles(st, (uint32_t *) h->tilecnt.p, n_ptr, 256, h->d_ctr + CTR_NTRI, h->tcap, h->d_status));
-    HIPCHK(launch_emit_trilist(st, h->grid, (const uint8_t *) h->cubeidx.p, n_ptr, (const uint32_t *) h->tilecnt.p,
-                               (uint32_t *) h->trioff.p, (uint32_t *) h->trilist.p, h->tcap));
-    HIPCHK(launch_project(st, h->grid, h->scene, h->sp, (const uint64_t *) h->ukeys.p, h->d_ctr + CTR_NUNIQ, h->ucap,
-                          h->min_chunk, vs, (Vertex *) h->uverts.p, h->d_status));
-    HIPCHK(launch_tri_orient(st, h->grid, h->scene, h->sp, d_vox, vs, (const uint8_t *) h->cubeidx.p,
-                             (const uint32_t *) h->trilist.p, h->d_ctr + CTR_NTRI, h->hkeys, (const uint32_t *) h->hids.p,
-                             h->hsize, (const Vertex *) h->uverts.p, (uint32_t *) h->tri_e.p, h->first_ord, h->d_status));
+    HIPCHK(launch_classify(st, h->grid, h->scene, h->sp, d_vox, n_ptr, vs, (uint8_t *) h->cubeidx.p, (uint32_t *) h->tilecnt.p));
+    HIPCHK(launch_mesh_tile(st, h->grid, h->scene, h->sp, d_vox, n_ptr, vs, (const uint8_t *) h->cubeidx.p,
+                            (const uint32_t *) h->tilecnt.p, (uint32_t *) h->trioff.p, (uint32_t *) h->tri_e.p,
+                            (Vertex *) h->uverts.p, h->first_ord, h->ucap, h->tcap, h->d_ctr + CTR_NUNIQ, h->d_ctr + CTR_NTRI,
+                            h->d_status));
     return SDMESH_OK;
 }
 
@@ -192,7 +185,7 @@ int mesh_weld(sdmesh_handle *h, const Vertex *uverts, const uint32_t *nu_ptr, ui
     hipStream_t st = h->stream;
     HIPCHK(hipMemsetAsync(h->bitmap.p, 0, h->bitmap.cap, st));
     HIPCHK(launch_weld(st, h->grid, uverts, nu_ptr, ucap, tri_e, h->d_ctr + CTR_NTRI, h->first_ord, h->wkeys, h->wmin,
-                       h->wsize, (uint32_t *) h->vslot.p, (uint32_t *) h->bitmap.p, (uint32_t *) h->wordpre.p,
+                       (uint32_t *) h->wfirst.p, h->wsize, (uint32_t *) h->vslot.p, (uint32_t *) h->bitmap.p, (uint32_t *) h->wordpre.p,
                        (uint32_t *) h->wvidx.p, (Vertex *) h->vertices.p, (uint32_t) (h->vertices.cap / sizeof(Vertex)),
                        h->d_ctr + CTR_NVERT, (uint32_t *) h->indices.p, h->d_status));
     return SDMESH_OK;
@@ -232,6 +225,7 @@ int weld_raw_device(sdmesh_handle *h, const Triangle *d_raw, uint32_t nslots) {
     if (h->tcap < nslots) return fail(h, SDMESH_ERR_INTERNAL, "weld layout too small");
     SDCHK(ensure(h, h->compact, sizeof(Triangle) * (size_t) nslots));
     HIPCHK(hipMemsetAsync(h->ff_arena.p, 0xFF, ff_bytes(h), st));
+    HIPCHK(hipMemsetAsync(h->first_ord, 0xFF, 4ull * vcap, st));
     HIPCHK(launch_set_u32(st, h->d_ctr + CTR_NSLOTS, nslots));
     HIPCHK(launch_raw_count(st, h->grid, d_raw, h->d_ctr + CTR_NSLOTS, (uint32_t *) h->tilecnt.p));
     HIPCHK(launch_scan_tiles(st, (uint32_t *) h->tilecnt.p, h->d_ctr + CTR_NSLOTS, 256, h->d_ctr + CTR_NTRI, nslots, h->d_status));
@@ -349,7 +343,7 @@ int regen_impl(sdmesh_handle *h, int levels, int mode, int part, int nparts, sdm
             SDCHK(read_back(h));
             if (s[ST_OVERFLOW]) return fail(h, SDMESH_ERR_INTERNAL, "capacity overflow persists (status %u)", s[ST_OVERFLOW]);
         }
-        if (!direct && s[ST_NOT_LATTICE]) direct = true;   // cannot happen for create+refine fields; handled anyway
+        if (!direct && (s[ST_NOT_LATTICE] || s[ST_TILE_OVERFLOW])) direct = true;   // not expected for create+refine fields; handled anyway
         const uint32_t n = c[CTR_LEVEL0 + levels];
         if (direct) {
             SDCHK(ensure(h, h->raw, sizeof(Triangle) * 5ull * std::max<uint32_t>(n, 1)));
@@ -402,7 +396,7 @@ int host_mesh_front(sdmesh_handle *h, const Point *voxels, uint32_t n, Point vs,
             SDCHK(mesh_front(h, (const Point *) h->vox[0].p, h->d_ctr + CTR_LEVEL0, vs));
             SDCHK(read_back(h));
             const uint32_t *s = h->h_pinned + CTR_WORDS;
-            if (s[ST_NOT_LATTICE]) { direct = true; break; }
+            if (s[ST_NOT_LATTICE] || s[ST_TILE_OVERFLOW]) { direct = true; break; }
             if (!s[ST_OVERFLOW]) break;
             if (attempt == 1) return fail(h, SDMESH_ERR_INTERNAL, "capacity overflow persists");
             SDCHK(layout_mesh(h, n, h->h_pinned[CTR_NUNIQ] + 1024));
@@ -446,6 +440,7 @@ int sdmesh_create(int device, sdmesh_handle **out) {
         return SDMESH_ERR_NO_DEVICE;
     }
     h->grid = 4 * prop.multiProcessorCount;
+    h->dense_grid = 64 * prop.multiProcessorCount;   // measured best for the write-only P1 stream
     if ((e = hipStreamCreateWithFlags(&h->own_stream, hipStreamNonBlocking)) != hipSuccess) return bail(e, "hipStreamCreate");
     h->stream = h->own_stream;
     if ((e = hipEventCreate(&h->ev0)) != hipSuccess) return bail(e, "hipEventCreate");
@@ -463,8 +458,8 @@ void sdmesh_destroy(sdmesh_handle *h) {
     if (!h) return;
     (void) hipSetDevice(h->device);
     if (h->stream) (void) hipStreamSynchronize(h->stream);
-    DevBuf *bufs[] = {&h->vox[0], &h->vox[1], &h->mask, &h->tilecnt, &h->cubeidx, &h->trioff, &h->trilist, &h->ff_arena,
-                      &h->hids, &h->ukeys, &h->uverts, &h->tri_e, &h->vslot, &h->bitmap, &h->wordpre, &h->wvidx,
+    DevBuf *bufs[] = {&h->vox[0], &h->vox[1], &h->mask, &h->tilecnt, &h->cubeidx, &h->trioff, &h->ff_arena,
+                      &h->first_ord_buf, &h->wfirst, &h->uverts, &h->tri_e, &h->vslot, &h->bitmap, &h->wordpre, &h->wvidx,
                       &h->vertices, &h->indices, &h->raw, &h->compact, &h->staging};
     for (DevBuf *b : bufs) release(*b);
     if (h->d_ctr) (void) hipFree(h->d_ctr);
@@ -507,6 +502,8 @@ int sdmesh_set_option(sdmesh_handle *h, const char *name, int value) {
         h->min_chunk = (uint32_t) value;
         return SDMESH_OK;
     }
+    if (!strcmp(name, "dense_grid")) { h->dense_grid = value; return SDMESH_OK; }
+    if (!strcmp(name, "dense_nt")) { h->dense_nt = value ? 1 : 0; return SDMESH_OK; }
     if (!strcmp(name, "forget_plan")) { h->plan_valid = false; return SDMESH_OK; }
     return fail(h, SDMESH_ERR_INVALID, "unknown option %s", name);
 }
@@ -751,7 +748,7 @@ int sdmesh_sample_dense(sdmesh_handle *h, uint32_t N, float *d_out, float *kerne
     if (!h || !d_out || N == 0 || N > 4096) return SDMESH_ERR_INVALID;
     HIPCHK(hipSetDevice(h->device));
     HIPCHK(hipEventRecord(h->ev0, h->stream));
-    HIPCHK(launch_sample_dense(h->stream, 8 * h->grid, h->scene, h->sp, d_out, N));
+    HIPCHK(launch_sample_dense(h->stream, h->dense_grid > 0 ? h->dense_grid : 8 * h->grid, h->scene, h->sp, d_out, N, h->dense_nt != 0));
     HIPCHK(hipEventRecord(h->ev1, h->stream));
     HIPCHK(hipStreamSynchronize(h->stream));
     if (kernel_ms) HIPCHK(hipEventElapsedTime(kernel_ms, h->ev0, h->ev1));
@@ -761,9 +758,9 @@ int sdmesh_sample_dense(sdmesh_handle *h, uint32_t N, float *d_out, float *kerne
 int sdmesh_time_kernel(sdmesh_handle *h, int which, uint32_t N, float *d_buf, int iters, float *avg_ms) {
     if (!h || !avg_ms || iters < 1 || which != 0 || !d_buf || N == 0 || N > 4096) return SDMESH_ERR_INVALID;
     HIPCHK(hipSetDevice(h->device));
-    HIPCHK(launch_sample_dense(h->stream, 8 * h->grid, h->scene, h->sp, d_buf, N));   // warm-up
+    HIPCHK(launch_sample_dense(h->stream, h->dense_grid > 0 ? h->dense_grid : 8 * h->grid, h->scene, h->sp, d_buf, N, h->dense_nt != 0));   // warm-up
     HIPCHK(hipEventRecord(h->ev0, h->stream));
-    for (int i = 0; i < iters; i++) HIPCHK(launch_sample_dense(h->stream, 8 * h->grid, h->scene, h->sp, d_buf, N));
+    for (int i = 0; i < iters; i++) HIPCHK(launch_sample_dense(h->stream, h->dense_grid > 0 ? h->dense_grid : 8 * h->grid, h->scene, h->sp, d_buf, N, h->dense_nt != 0));
     HIPCHK(hipEventRecord(h->ev1, h->stream));
     HIPCHK(hipStreamSynchronize(h->stream));
     float ms = 0.0f;

@@ -225,15 +225,12 @@ __global__ __launch_bounds__(256) void k_refine_expand_raw(const Point *__restri
 }
 
 // ------------------------------------------------------------------------------------------
-// A4/A7 mesh stage 1: cube index per voxel, triangle count per tile, unique-edge hash insert
+// A4 mesh stage 1: cube index per voxel + triangle count per 256-voxel tile (no atomics)
 // ------------------------------------------------------------------------------------------
 template <int SCENE>
 __global__ __launch_bounds__(256) void k_classify(const Point *__restrict__ vox, const uint32_t *__restrict__ n_ptr,
                                                    Point vs, SceneParams sp, uint8_t *__restrict__ cubeidx,
-                                                   uint32_t *__restrict__ tilecnt, uint64_t *__restrict__ hkeys,
-                                                   uint32_t *__restrict__ hids, uint32_t hsize,
-                                                   uint64_t *__restrict__ ukeys, uint32_t ucap,
-                                                   uint32_t *__restrict__ n_unique, uint32_t *__restrict__ status) {
+                                                   uint32_t *__restrict__ tilecnt) {
     __shared__ uint32_t s_cnt;
     const uint32_t n = *n_ptr;
     const uint32_t ntiles = (n + TILE - 1) / TILE;
@@ -257,38 +254,6 @@ __global__ __launch_bounds__(256) void k_classify(const Point *__restrict__ vox,
             }
             cubeidx[v] = (uint8_t) ci;
             ntri = MC_TRI_COUNT[ci];
-            uint32_t em = MC_EDGE_MASK[ci];
-            if (em) {
-                int mx, my, mz;
-                const bool okx = lattice_coord(b.x, vs.x, mx), oky = lattice_coord(b.y, vs.y, my), okz = lattice_coord(b.z, vs.z, mz);
-                const bool ok = okx && oky && okz;
-                if (!ok) {
-                    atomicOr(&status[ST_NOT_LATTICE], 1u);
-                } else {
-                    while (em) {
-                        const int e = __ffs(em) - 1;
-                        em &= em - 1;
-                        const uint64_t key = edge_key(mx, my, mz, e);
-                        uint32_t s = hash_home(key, hsize);
-                        bool done = false;
-                        for (uint32_t probe = 0; probe < hsize && !done; probe++) {
-                            const uint64_t prev = atomicCAS((unsigned long long *) &hkeys[s], (unsigned long long) KEY_EMPTY,
-                                                            (unsigned long long) key);
-                            if (prev == KEY_EMPTY) {
-                                const uint32_t id = atomicAdd(n_unique, 1u);
-                                if (id < ucap) ukeys[id] = key; else atomicOr(&status[ST_OVERFLOW], 2u);
-                                hids[s] = id;
-                                done = true;
-                            } else if (prev == key) {
-                                done = true;
-                            } else {
-                                s = hash_next(s, hsize);
-                            }
-                        }
-                        if (!done) atomicOr(&status[ST_OVERFLOW], 4u);
-                    }
-                }
-            }
         }
         const uint32_t ws = wave_sum(ntri);
         if (lane_id() == 0 && ws) atomicAdd(&s_cnt, ws);
@@ -298,122 +263,237 @@ __global__ __launch_bounds__(256) void k_classify(const Point *__restrict__ vox,
     }
 }
 
-// mesh stage 1b: per-voxel triangle offset + (voxel, slot) list in emission order
-__global__ __launch_bounds__(256) void k_emit_trilist(const uint8_t *__restrict__ cubeidx, const uint32_t *__restrict__ n_ptr,
-                                                       const uint32_t *__restrict__ tileoff, uint32_t *__restrict__ trioff,
-                                                       uint32_t *__restrict__ trilist, uint32_t cap) {
-    __shared__ uint32_t lds[17];
+// ------------------------------------------------------------------------------------------
+// A4-A7 mesh stage 2, fused per tile of 256 consecutive voxels (one workgroup, ~57 KB LDS):
+//   B  unique lattice edges of the tile via an LDS hash (consecutive voxels are spatial
+//      neighbours, so most of the <=4 cubes sharing an edge sit in the same tile);
+//   C  ONE Newton projection + vertex normal per tile-unique edge; 4 lanes co-operate on an
+//      edge (lane a<3 evaluates the 4-point stencil of axis a, lane 3 the centre sample), items
+//      are pulled from an LDS queue so lanes never idle behind a slow-converging neighbour;
+//   D  per triangle the centroid normal + orientation test, same 4-lane scheme;
+//   E  tile-unique vertices, per-vertex first-seen ordinal and the (flipped) corner->vertex
+//      table go to HBM with plain coalesced stores; one global atomic per tile reserves the
+//      vertex range.
+// Cross-tile duplicates of an edge carry bit-identical positions and are merged by the weld.
+// ------------------------------------------------------------------------------------------
+static constexpr uint32_t T_UCAP = 1024;     // tile-unique edges held in LDS
+static constexpr uint32_t T_HASH = 2048;     // LDS hash slots (load <= 0.5)
+static constexpr uint32_t T_TRI = 1280;      // 5 triangles x 256 voxels
+
+template <int SCENE>
+__device__ __forceinline__ float stencil_lane(const f3 g, uint32_t sub, const SceneParams &sp, float &centre) {
+    // lane sub<3: ((-f(+2e) + 8 f(+e)) - 8 f(-e)) + f(-2e) along axis `sub`; lane 3: f(g) in `centre`
+    const float e1 = SDM_NORMAL_EPS, e2 = 2.0f * SDM_NORMAL_EPS;
+    float f[4];
+#pragma unroll 1
+    for (int k = 0; k < 4; k++) {
+        const float off = k == 0 ? e2 : (k == 1 ? e1 : (k == 2 ? -e1 : -e2));
+        const float x = sub == 0 ? g.x + off : g.x;
+        const float y = sub == 1 ? g.y + off : g.y;
+        const float z = sub == 2 ? g.z + off : g.z;
+        f[k] = sdf<SCENE>(x, y, z, sp);
+        if (sub == 3) { f[1] = f[2] = f[3] = f[0]; break; }
+    }
+    centre = f[0];
+    return (-f[0] + 8.0f * f[1] - 8.0f * f[2] + f[3]);
+}
+
+template <int SCENE>
+__global__ __launch_bounds__(256) void k_mesh_tile(const Point *__restrict__ vox, const uint32_t *__restrict__ n_ptr, Point vs,
+                                                    SceneParams sp, const uint8_t *__restrict__ cubeidx,
+                                                    const uint32_t *__restrict__ tilecnt, uint32_t *__restrict__ trioff,
+                                                    uint32_t *__restrict__ tri_e, Vertex *__restrict__ uverts,
+                                                    uint32_t *__restrict__ first_ord, uint32_t ucap, uint32_t tcap,
+                                                    uint32_t *__restrict__ n_unique, uint32_t *__restrict__ ntri_out,
+                                                    uint32_t *__restrict__ status) {
+    __shared__ uint64_t s_keys[T_HASH];
+    __shared__ uint16_t s_lid[T_HASH];
+    __shared__ float s_pos[T_UCAP * 3];
+    __shared__ float s_nrm[T_UCAP * 3];
+    __shared__ uint32_t s_first[T_UCAP];
+    __shared__ uint16_t s_tri[T_TRI * 3];
+    __shared__ uint8_t s_flip[T_TRI];
+    __shared__ uint32_t s_scan[17];
+    __shared__ uint32_t s_q, s_vbase, s_bad;
+
     const uint32_t n = *n_ptr;
     const uint32_t ntiles = (n + TILE - 1) / TILE;
+    const uint32_t tid = threadIdx.x, lane = lane_id(), sub = tid & 3u, gbase = lane & ~3u;
+
     for (uint32_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
-        const uint32_t v = tile * TILE + threadIdx.x;
-        const uint32_t ntri = v < n ? MC_TRI_COUNT[cubeidx[v]] : 0u;
-        uint32_t total;
-        const uint32_t o = tileoff[tile] + block_excl_scan(ntri, total, lds);
-        if (v < n) trioff[v] = o;
-        for (uint32_t j = 0; j < ntri; j++)
-            if (o + j < cap) trilist[o + j] = (v << 3) | j;
-    }
-}
+        // ---- 0: triangle base of this tile = sum of the preceding tile counts
+        uint32_t part = 0;
+        for (uint32_t i = tid; i < tile; i += 256) part += tilecnt[i];
+        uint32_t tbase;
+        (void) block_excl_scan(part, tbase, s_scan);
 
-// ------------------------------------------------------------------------------------------
-// A5/A6 mesh stage 2: one Newton projection + vertex normal per UNIQUE edge, lane refill
-// ------------------------------------------------------------------------------------------
-template <int SCENE>
-__global__ __launch_bounds__(256) void k_project(const uint64_t *__restrict__ ukeys, const uint32_t *__restrict__ n_unique_ptr,
-                                                  uint32_t ucap, uint32_t min_chunk, Point vs, SceneParams sp,
-                                                  Vertex *__restrict__ uverts, uint32_t *__restrict__ status) {
-    uint32_t U = *n_unique_ptr;
-    if (U > ucap) U = ucap;
-    const uint32_t nwaves = gridDim.x * (blockDim.x >> 6);
-    const uint32_t wave = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
-    uint32_t chunk = (U + nwaves - 1) / nwaves;
-    if (chunk < min_chunk) chunk = min_chunk;                         // keep the refill queue deep
-    const uint64_t q0 = (uint64_t) wave * chunk;
-    uint32_t qhead = q0 < U ? (uint32_t) q0 : U;                      // wave-uniform work queue
-    const uint32_t qend = q0 + chunk < U ? (uint32_t) (q0 + chunk) : U;
-    const uint32_t lane = lane_id();
-    const uint64_t lt = (1ull << lane) - 1ull;
-
-    bool active = false, finalize = false;
-    uint32_t id = 0;
-    int it = 0;
-    f3 g = mk(0.0f, 0.0f, 0.0f);
-    for (;;) {
-        const uint64_t need = __ballot(!active);
-        const uint32_t avail = qend - qhead;
-        if (need != 0ull && avail != 0u) {
-            const uint32_t rank = __popcll(need & lt);
-            if (!active && rank < avail) {
-                id = qhead + rank;
-                const uint64_t key = ukeys[id];
-                const int kx = (int) (key & 0x1FFFFF), ky = (int) ((key >> 21) & 0x1FFFFF), kz = (int) ((key >> 42) & 0x1FFFFF);
-                // midpoint = a*0.5 + b*0.5 of the two lattice corners (marching_cubes.cu:13-16)
-                g.x = lat(kx >> 1, vs.x) * 0.5f + lat((kx + 1) >> 1, vs.x) * 0.5f;
-                g.y = lat(ky >> 1, vs.y) * 0.5f + lat((ky + 1) >> 1, vs.y) * 0.5f;
-                g.z = lat(kz >> 1, vs.z) * 0.5f + lat((kz + 1) >> 1, vs.z) * 0.5f;
-                active = true; finalize = false; it = 0;
-            }
-            const uint32_t want = __popcll(need);
-            qhead += want < avail ? want : avail;
-        }
-        if (__ballot(active) == 0ull) break;      // queue drained and every lane idle
-        if (active) {
-            const f3 nn = empirical_normal<SCENE>(g, sp);
-            if (!finalize) {
-                const float sd = sdf<SCENE>(g.x, g.y, g.z, sp);
-                g = sub3(g, scale3(nn, sd));
-                it++;
-                if (fabsf(sd) <= 0.00001f) finalize = true;
-                else if (it >= SDM_MAX_NEWTON) { finalize = true; atomicOr(&status[ST_NEWTON_CAPPED], 1u); }
-            } else {
-                Vertex o;
-                o.position.x = g.x; o.position.y = g.y; o.position.z = g.z;
-                o.normal.x = nn.x; o.normal.y = nn.y; o.normal.z = nn.z;
-                uverts[id] = o;
-                active = false;
+        // ---- A: per-voxel triangle offsets, lattice coordinates, LDS init
+        const uint32_t v = tile * TILE + tid;
+        uint32_t ci = 0, ntri = 0;
+        int mx = 0, my = 0, mz = 0;
+        bool lat_ok = true;
+        if (v < n) {
+            ci = cubeidx[v];
+            ntri = MC_TRI_COUNT[ci];
+            if (ntri) {
+                const Point b = vox[v];
+                const bool okx = lattice_coord(b.x, vs.x, mx), oky = lattice_coord(b.y, vs.y, my), okz = lattice_coord(b.z, vs.z, mz);
+                lat_ok = okx && oky && okz;
             }
         }
-    }
-}
+        uint32_t ttri;
+        const uint32_t lo = block_excl_scan(ntri, ttri, s_scan);
+        if (v < n) trioff[v] = tbase + lo;
+        if (tile == ntiles - 1 && tid == 0) {
+            uint32_t tot = tbase + ttri;
+            if (tot > tcap) { atomicOr(&status[ST_OVERFLOW], 1u); tot = tcap; }
+            *ntri_out = tot;
+        }
+        for (uint32_t i = tid; i < T_HASH; i += 256) s_keys[i] = KEY_EMPTY;
+        for (uint32_t i = tid; i < T_UCAP; i += 256) s_first[i] = U32_NONE;
+        if (tid == 0) { s_q = 0; s_bad = 0; }
+        __syncthreads();
+        if (!lat_ok) { s_bad = 1; atomicOr(&status[ST_NOT_LATTICE], 1u); }
 
-// ------------------------------------------------------------------------------------------
-// A7 mesh stage 3: per triangle -- gather its 3 unique-edge ids, orientation test, first-seen
-// ordinal per unique edge (atomicMin: order independent)
-// ------------------------------------------------------------------------------------------
-template <int SCENE>
-__global__ __launch_bounds__(256) void k_tri_orient(const Point *__restrict__ vox, Point vs, const uint8_t *__restrict__ cubeidx,
-                                                     const uint32_t *__restrict__ trilist, const uint32_t *__restrict__ ntri_ptr,
-                                                     const uint64_t *__restrict__ hkeys, const uint32_t *__restrict__ hids,
-                                                     uint32_t hsize, const Vertex *__restrict__ uverts, SceneParams sp,
-                                                     uint32_t *__restrict__ tri_e, uint32_t *__restrict__ first_ord,
-                                                     uint32_t *__restrict__ status) {
-    const uint32_t T = *ntri_ptr;
-    for (uint32_t t = blockIdx.x * blockDim.x + threadIdx.x; t < T; t += gridDim.x * blockDim.x) {
-        const uint32_t tv = trilist[t], v = tv >> 3, j = tv & 7u;
-        const uint32_t ci = cubeidx[v];
-        const Point b = vox[v];
-        int mx, my, mz;
-        lattice_coord(b.x, vs.x, mx); lattice_coord(b.y, vs.y, my); lattice_coord(b.z, vs.z, mz);
-        const uint32_t row = (uint32_t) (MC_TRI_PACKED[ci] >> (12 * j)) & 0xFFFu;
-        uint32_t e[3];
-        f3 pv[3];
-        bool ok = true;
+        // ---- B1: insert every triangle corner's edge key; remember the slot per corner
+        if (ntri && lat_ok) {
+            uint64_t row = MC_TRI_PACKED[ci];
+            for (uint32_t c = 0; c < 3 * ntri; c++) {
+                const uint64_t key = edge_key(mx, my, mz, (int) (row & 0xF));
+                row >>= 4;
+                uint32_t s = hash_home(key, T_HASH);
+                for (uint32_t probe = 0; probe < T_HASH; probe++) {
+                    const uint64_t prev = atomicCAS((unsigned long long *) &s_keys[s], (unsigned long long) KEY_EMPTY,
+                                                    (unsigned long long) key);
+                    if (prev == KEY_EMPTY || prev == key) break;
+                    s = hash_next(s, T_HASH);
+                }
+                s_tri[3 * lo + c] = (uint16_t) s;
+            }
+        }
+        __syncthreads();
+        // ---- B2: dense local ids in slot order (deterministic), midpoints into s_pos
+        uint32_t occ = 0;
 #pragma unroll
-        for (int q = 0; q < 3; q++) {
-            const uint32_t s = hash_find(hkeys, hsize, edge_key(mx, my, mz, (int) ((row >> (4 * q)) & 0xFu)));
-            ok = ok && (s != U32_NONE);
-            e[q] = ok ? hids[s] : 0u;
-            const Vertex u = uverts[e[q]];
-            pv[q] = mk(u.position.x, u.position.y, u.position.z);
+        for (uint32_t k = 0; k < T_HASH / 256; k++) occ += s_keys[tid * (T_HASH / 256) + k] != KEY_EMPTY ? 1u : 0u;
+        uint32_t nu;
+        uint32_t lid = block_excl_scan(occ, nu, s_scan);
+        const bool tile_ok = (nu <= T_UCAP) && (s_bad == 0);
+        if (!tile_ok && nu > T_UCAP && tid == 0) atomicOr(&status[ST_TILE_OVERFLOW], 1u);
+        if (tile_ok) {
+#pragma unroll
+            for (uint32_t k = 0; k < T_HASH / 256; k++) {
+                const uint32_t s = tid * (T_HASH / 256) + k;
+                const uint64_t key = s_keys[s];
+                if (key != KEY_EMPTY) {
+                    const int kx = (int) (key & 0x1FFFFF), ky = (int) ((key >> 21) & 0x1FFFFF), kz = (int) ((key >> 42) & 0x1FFFFF);
+                    // midpoint = a*0.5 + b*0.5 of the two lattice corners (marching_cubes.cu:13-16)
+                    s_pos[3 * lid + 0] = lat(kx >> 1, vs.x) * 0.5f + lat((kx + 1) >> 1, vs.x) * 0.5f;
+                    s_pos[3 * lid + 1] = lat(ky >> 1, vs.y) * 0.5f + lat((ky + 1) >> 1, vs.y) * 0.5f;
+                    s_pos[3 * lid + 2] = lat(kz >> 1, vs.z) * 0.5f + lat((kz + 1) >> 1, vs.z) * 0.5f;
+                    s_lid[s] = (uint16_t) lid;
+                    lid++;
+                }
+            }
         }
-        if (!ok) atomicOr(&status[ST_INTERNAL], 1u);
-        const bool flip = change_orientation<SCENE>(pv[0], pv[1], pv[2], sp);
-        const uint32_t e0 = flip ? e[2] : e[0], e2 = flip ? e[0] : e[2];
-        tri_e[3 * t + 0] = e0; tri_e[3 * t + 1] = e[1]; tri_e[3 * t + 2] = e2;
-        atomicMin(&first_ord[e0], 3 * t + 0);
-        atomicMin(&first_ord[e[1]], 3 * t + 1);
-        atomicMin(&first_ord[e2], 3 * t + 2);
+        __syncthreads();
+        if (tile_ok) {
+            // ---- B3: corner slot -> local vertex id
+            for (uint32_t i = tid; i < 3 * ttri; i += 256) s_tri[i] = s_lid[s_tri[i]];
+
+            // ---- C: Newton projection + vertex normal, one item per tile-unique edge, 4 lanes per item
+            {
+                bool have = false, finalize = false, done = false;
+                uint32_t item = 0;
+                int it = 0;
+                f3 g = mk(0.0f, 0.0f, 0.0f);
+                for (;;) {
+                    if (!have && !done) {
+                        uint32_t t = 0;
+                        if (sub == 0) t = atomicAdd(&s_q, 1u);
+                        item = __shfl(t, (int) gbase, 64);
+                        if (item < nu) {
+                            g = mk(s_pos[3 * item], s_pos[3 * item + 1], s_pos[3 * item + 2]);
+                            have = true; finalize = false; it = 0;
+                        } else {
+                            done = true;
+                        }
+                    }
+                    if (__ballot(have) == 0ull) break;
+                    if (have) {
+                        float centre;
+                        const float d = stencil_lane<SCENE>(g, sub, sp, centre);
+                        const float dx = __shfl(d, (int) gbase, 64), dy = __shfl(d, (int) gbase + 1, 64), dz = __shfl(d, (int) gbase + 2, 64);
+                        const float sd = __shfl(centre, (int) gbase + 3, 64);
+                        const f3 nn = normalize3(mk(dx, dy, dz));
+                        if (!finalize) {
+                            g = sub3(g, scale3(nn, sd));
+                            it++;
+                            if (fabsf(sd) <= 0.00001f) finalize = true;
+                            else if (it >= SDM_MAX_NEWTON) { finalize = true; if (sub == 0) atomicOr(&status[ST_NEWTON_CAPPED], 1u); }
+                        } else {
+                            if (sub == 0) {
+                                s_pos[3 * item] = g.x; s_pos[3 * item + 1] = g.y; s_pos[3 * item + 2] = g.z;
+                                s_nrm[3 * item] = nn.x; s_nrm[3 * item + 1] = nn.y; s_nrm[3 * item + 2] = nn.z;
+                            }
+                            have = false;
+                        }
+                    }
+                }
+            }
+            __syncthreads();
+
+            // ---- D: orientation test per triangle (compute_mesh_generation.cu:102-105), 4 lanes per triangle
+            for (uint32_t tl = tid >> 2; tl < ((ttri + 63u) & ~63u); tl += 64) {
+                const bool act = tl < ttri;
+                f3 v0 = mk(0, 0, 0), v1 = v0, v2 = v0, c = v0;
+                uint32_t l0 = 0, l1 = 0, l2 = 0;
+                if (act) {
+                    l0 = s_tri[3 * tl]; l1 = s_tri[3 * tl + 1]; l2 = s_tri[3 * tl + 2];
+                    v0 = mk(s_pos[3 * l0], s_pos[3 * l0 + 1], s_pos[3 * l0 + 2]);
+                    v1 = mk(s_pos[3 * l1], s_pos[3 * l1 + 1], s_pos[3 * l1 + 2]);
+                    v2 = mk(s_pos[3 * l2], s_pos[3 * l2 + 1], s_pos[3 * l2 + 2]);
+                    const f3 s = add3(add3(v0, v1), v2);
+                    c = mk(s.x / 3.0f, s.y / 3.0f, s.z / 3.0f);
+                }
+                float centre;
+                const float d = (act && sub < 3) ? stencil_lane<SCENE>(c, sub, sp, centre) : 0.0f;
+                const float dx = __shfl(d, (int) gbase, 64), dy = __shfl(d, (int) gbase + 1, 64), dz = __shfl(d, (int) gbase + 2, 64);
+                if (act && sub == 0) {
+                    const f3 an = normalize3(mk(dx, dy, dz));
+                    const f3 tn = normalize3(cross3(sub3(v1, v0), sub3(v2, v0)));
+                    const bool flip = dot3(tn, an) <= 0.0f;
+                    s_flip[tl] = flip ? 1 : 0;
+                    atomicMin(&s_first[flip ? l2 : l0], 3 * tl + 0);
+                    atomicMin(&s_first[l1], 3 * tl + 1);
+                    atomicMin(&s_first[flip ? l0 : l2], 3 * tl + 2);
+                }
+            }
+            __syncthreads();
+
+            // ---- E: publish
+            if (tid == 0) s_vbase = atomicAdd(n_unique, nu);
+            __syncthreads();
+            const uint32_t vbase = s_vbase;
+            if (vbase + nu > ucap) {
+                if (tid == 0) atomicOr(&status[ST_OVERFLOW], 2u);
+            } else {
+                for (uint32_t i = tid; i < nu; i += 256) {
+                    Vertex o;
+                    o.position.x = s_pos[3 * i]; o.position.y = s_pos[3 * i + 1]; o.position.z = s_pos[3 * i + 2];
+                    o.normal.x = s_nrm[3 * i]; o.normal.y = s_nrm[3 * i + 1]; o.normal.z = s_nrm[3 * i + 2];
+                    uverts[vbase + i] = o;
+                    const uint32_t f = s_first[i];
+                    first_ord[vbase + i] = f == U32_NONE ? U32_NONE : 3u * tbase + f;
+                }
+                for (uint32_t i = tid; i < 3 * ttri; i += 256) {
+                    const uint32_t tl = i / 3u, q = i - 3u * tl;
+                    const uint32_t qq = s_flip[tl] ? 2u - q : q;
+                    if (tbase + tl < tcap) tri_e[3u * (tbase + tl) + q] = vbase + s_tri[3 * tl + qq];
+                }
+            }
+        }
+        __syncthreads();
     }
 }
 
@@ -428,11 +508,14 @@ __global__ __launch_bounds__(256) void k_first_ord(const uint32_t *__restrict__ 
 // ------------------------------------------------------------------------------------------
 // A8 weld (src/cuda/mod.rs:263-296) on the unique-vertex list.
 //   key   = 3 x 21-bit biased round(x * 1e5)  (covers +-10.48 units; bounding cube is +-2.5)
-//   value = smallest first-seen ordinal among the unique vertices that share the key
+//   The vertex that claims a slot records its first-seen ordinal with a plain store (wfirst);
+//   only vertices that find the key already present pay an atomicMin (wmin).  The first-seen
+//   ordinal of a key is min(wfirst, wmin): order independent.
 // ------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void k_weld_insert(const Vertex *__restrict__ uverts, const uint32_t *__restrict__ nu_ptr,
                                                       uint32_t ucap, const uint32_t *__restrict__ first_ord,
-                                                      uint64_t *__restrict__ wkeys, uint32_t *__restrict__ wmin, uint32_t wsize,
+                                                      uint64_t *__restrict__ wkeys, uint32_t *__restrict__ wmin,
+                                                      uint32_t *__restrict__ wfirst, uint32_t wsize,
                                                       uint32_t *__restrict__ vslot, uint32_t *__restrict__ status) {
     uint32_t U = *nu_ptr;
     if (U > ucap) U = ucap;
@@ -450,11 +533,11 @@ __global__ __launch_bounds__(256) void k_weld_insert(const Vertex *__restrict__ 
                 for (uint32_t probe = 0; probe < wsize; probe++) {
                     const uint64_t prev = atomicCAS((unsigned long long *) &wkeys[s], (unsigned long long) KEY_EMPTY,
                                                     (unsigned long long) key);
-                    if (prev == KEY_EMPTY || prev == key) { slot = s; break; }
+                    if (prev == KEY_EMPTY) { slot = s; wfirst[s] = fo; break; }
+                    if (prev == key) { slot = s; atomicMin(&wmin[s], fo); break; }
                     s = hash_next(s, wsize);
                 }
                 if (slot == U32_NONE) atomicOr(&status[ST_OVERFLOW], 8u);
-                else atomicMin(&wmin[slot], fo);
             }
         }
         vslot[e] = slot;
@@ -463,47 +546,52 @@ __global__ __launch_bounds__(256) void k_weld_insert(const Vertex *__restrict__ 
 
 __global__ __launch_bounds__(256) void k_weld_mark(const uint32_t *__restrict__ nu_ptr, uint32_t ucap,
                                                     const uint32_t *__restrict__ first_ord, const uint32_t *__restrict__ wmin,
-                                                    const uint32_t *__restrict__ vslot, uint32_t *__restrict__ bitmap) {
+                                                    const uint32_t *__restrict__ wfirst, const uint32_t *__restrict__ vslot,
+                                                    uint32_t *__restrict__ bitmap) {
     uint32_t U = *nu_ptr;
     if (U > ucap) U = ucap;
     for (uint32_t e = blockIdx.x * blockDim.x + threadIdx.x; e < U; e += gridDim.x * blockDim.x) {
         const uint32_t s = vslot[e];
         if (s == U32_NONE) continue;
         const uint32_t fo = first_ord[e];
-        if (wmin[s] == fo) atomicOr(&bitmap[fo >> 5], 1u << (fo & 31u));
+        const uint32_t a = wfirst[s], b = wmin[s];
+        if ((a < b ? a : b) == fo) atomicOr(&bitmap[fo >> 5], 1u << (fo & 31u));
     }
 }
 
-// exclusive scan of popcounts over the first-seen bitmap (3T bits); total -> n_verts
+// exclusive scan of popcounts over the first-seen bitmap (3T bits); total -> n_verts.
+// Single workgroup; every thread owns a contiguous run of words (sum, block scan, rewrite).
 __global__ __launch_bounds__(1024) void k_scan_bitmap(const uint32_t *__restrict__ bitmap, const uint32_t *__restrict__ ntri_ptr,
                                                        uint32_t *__restrict__ wordpre, uint32_t *__restrict__ nverts_out) {
     __shared__ uint32_t lds[17];
     const uint32_t nwords = (3u * *ntri_ptr + 31u) >> 5;
-    uint32_t carry = 0;
-    for (uint32_t base = 0; base < nwords; base += blockDim.x) {
-        const uint32_t i = base + threadIdx.x;
-        const uint32_t v = i < nwords ? __popc(bitmap[i]) : 0u;
-        uint32_t total;
-        const uint32_t ex = block_excl_scan(v, total, lds);
-        if (i < nwords) wordpre[i] = carry + ex;
-        carry += total;
+    const uint32_t per = (nwords + blockDim.x - 1) / blockDim.x;
+    const uint32_t lo = threadIdx.x * per, hi = lo + per < nwords ? lo + per : nwords;
+    uint32_t sum = 0;
+    for (uint32_t i = lo; i < hi; i++) sum += __popc(bitmap[i]);
+    uint32_t total;
+    uint32_t run = block_excl_scan(sum, total, lds);
+    for (uint32_t i = lo; i < hi; i++) {
+        wordpre[i] = run;
+        run += __popc(bitmap[i]);
     }
-    if (threadIdx.x == 0) *nverts_out = carry;
+    if (threadIdx.x == 0) *nverts_out = total;
 }
 
 __global__ __launch_bounds__(256) void k_weld_assign(const Vertex *__restrict__ uverts, const uint32_t *__restrict__ nu_ptr,
                                                       uint32_t ucap, const uint32_t *__restrict__ first_ord,
-                                                      const uint32_t *__restrict__ wmin, const uint32_t *__restrict__ vslot,
-                                                      const uint32_t *__restrict__ bitmap, const uint32_t *__restrict__ wordpre,
-                                                      uint32_t *__restrict__ wvidx, Vertex *__restrict__ vertices, uint32_t vcap,
-                                                      uint32_t *__restrict__ status) {
+                                                      const uint32_t *__restrict__ wmin, const uint32_t *__restrict__ wfirst,
+                                                      const uint32_t *__restrict__ vslot, const uint32_t *__restrict__ bitmap,
+                                                      const uint32_t *__restrict__ wordpre, uint32_t *__restrict__ wvidx,
+                                                      Vertex *__restrict__ vertices, uint32_t vcap, uint32_t *__restrict__ status) {
     uint32_t U = *nu_ptr;
     if (U > ucap) U = ucap;
     for (uint32_t e = blockIdx.x * blockDim.x + threadIdx.x; e < U; e += gridDim.x * blockDim.x) {
         const uint32_t s = vslot[e];
         if (s == U32_NONE) continue;
         const uint32_t fo = first_ord[e];
-        if (wmin[s] != fo) continue;
+        const uint32_t a = wfirst[s], b = wmin[s];
+        if ((a < b ? a : b) != fo) continue;
         const uint32_t vi = wordpre[fo >> 5] + __popc(bitmap[fo >> 5] & ((1u << (fo & 31u)) - 1u));
         wvidx[s] = vi;
         if (vi < vcap) vertices[vi] = uverts[e]; else atomicOr(&status[ST_OVERFLOW], 16u);
@@ -632,27 +720,50 @@ __global__ void k_mul3_u32(const uint32_t *a, uint32_t *out) { *out = 3u * *a; }
 // ------------------------------------------------------------------------------------------
 // P1: dense SDF sample pass, (N+1)^3 f32, x outer / z inner, one float4 store per thread
 // ------------------------------------------------------------------------------------------
-template <int SCENE>
+template <int SCENE, bool NT>
 __global__ __launch_bounds__(256) void k_sample_dense(float *__restrict__ out, uint32_t N, uint64_t total, SceneParams sp) {
+    // Flat quads (4 consecutive samples, 16-B aligned float4 store) over the x-outer / z-inner volume.
+    // (x, y, z) of a thread's first quad comes from one division; every further grid-stride step adds
+    // the stride decomposed in base S, so the loop body has no division.  The (x, y)-only part of the
+    // SDF is hoisted into a RowCtx and rebuilt only when a quad crosses a row end (1 quad in ~S/4).
     const float h = 5.0f / (float) N;
     const uint32_t S = N + 1u;
     const uint64_t nquads = (total + 3ull) >> 2;
-    for (uint64_t qd = (uint64_t) blockIdx.x * blockDim.x + threadIdx.x; qd < nquads; qd += (uint64_t) gridDim.x * blockDim.x) {
-        const uint64_t i0 = qd << 2;
-        uint32_t z = (uint32_t) (i0 % S);
-        const uint64_t r = i0 / S;
-        uint32_t y = (uint32_t) (r % S), x = (uint32_t) (r / S);
+    const uint64_t stride = (uint64_t) gridDim.x * blockDim.x;
+    uint64_t qd = (uint64_t) blockIdx.x * blockDim.x + threadIdx.x;
+    if (qd >= nquads) return;
+    uint64_t i0 = qd << 2;
+    uint32_t z = (uint32_t) (i0 % S);
+    uint64_t r = i0 / S;
+    uint32_t y = (uint32_t) (r % S), x = (uint32_t) (r / S);
+    const uint64_t st4 = stride << 2;
+    const uint32_t sz = (uint32_t) (st4 % S), sy = (uint32_t) ((st4 / S) % S), sx = (uint32_t) (st4 / S / S);
+    for (; qd < nquads; qd += stride) {
+        uint32_t cx = x, cy = y, cz = z;
+        RowCtx<SCENE> row;
+        row.init((float) cx * h - 2.5f, (float) cy * h - 2.5f, sp);
         float v[4];
 #pragma unroll
         for (int k = 0; k < 4; k++) {
-            v[k] = sdf<SCENE>((float) x * h - 2.5f, (float) y * h - 2.5f, (float) z * h - 2.5f, sp);
-            if (++z == S) { z = 0; if (++y == S) { y = 0; ++x; } }
+            v[k] = row.eval((float) cz * h - 2.5f, sp);
+            if (++cz == S) {
+                cz = 0;
+                if (++cy == S) { cy = 0; ++cx; }
+                row.init((float) cx * h - 2.5f, (float) cy * h - 2.5f, sp);
+            }
         }
         if (i0 + 3 < total) {
-            *reinterpret_cast<float4 *>(out + i0) = make_float4(v[0], v[1], v[2], v[3]);
+            typedef float v4f __attribute__((ext_vector_type(4)));
+            v4f q = {v[0], v[1], v[2], v[3]};
+            if (NT) __builtin_nontemporal_store(q, reinterpret_cast<v4f *>(out + i0));   // write-once stream
+            else *reinterpret_cast<v4f *>(out + i0) = q;
         } else {
             for (int k = 0; k < 4 && i0 + k < total; k++) out[i0 + k] = v[k];
         }
+        i0 += st4;
+        z += sz; if (z >= S) { z -= S; y++; }
+        y += sy; if (y >= S) { y -= S; x++; }
+        x += sx;
     }
 }
 
@@ -693,34 +804,17 @@ hipError_t launch_refine_expand_raw(hipStream_t st, int grid, const Point *vox, 
 }
 
 hipError_t launch_classify(hipStream_t st, int grid, int scene, const SceneParams &sp, const Point *vox,
-                           const uint32_t *n_ptr, Point vs, uint8_t *cubeidx, uint32_t *tilecnt, uint64_t *hkeys,
-                           uint32_t *hids, uint32_t hsize, uint64_t *ukeys, uint32_t ucap, uint32_t *n_unique,
-                           uint32_t *status) {
-    SDM_DISPATCH(scene, hipLaunchKernelGGL(k_classify<S>, dim3(grid), dim3(256), 0, st, vox, n_ptr, vs, sp, cubeidx, tilecnt,
-                                           hkeys, hids, hsize, ukeys, ucap, n_unique, status));
+                           const uint32_t *n_ptr, Point vs, uint8_t *cubeidx, uint32_t *tilecnt) {
+    SDM_DISPATCH(scene, hipLaunchKernelGGL(k_classify<S>, dim3(grid), dim3(256), 0, st, vox, n_ptr, vs, sp, cubeidx, tilecnt));
     return hipGetLastError();
 }
 
-hipError_t launch_emit_trilist(hipStream_t st, int grid, const uint8_t *cubeidx, const uint32_t *n_ptr,
-                               const uint32_t *tileoff, uint32_t *trioff, uint32_t *trilist, uint32_t cap) {
-    hipLaunchKernelGGL(k_emit_trilist, dim3(grid), dim3(256), 0, st, cubeidx, n_ptr, tileoff, trioff, trilist, cap);
-    return hipGetLastError();
-}
-
-hipError_t launch_project(hipStream_t st, int grid, int scene, const SceneParams &sp, const uint64_t *ukeys,
-                          const uint32_t *n_unique_ptr, uint32_t ucap, uint32_t min_chunk, Point vs, Vertex *uverts,
-                          uint32_t *status) {
-    SDM_DISPATCH(scene, hipLaunchKernelGGL(k_project<S>, dim3(grid), dim3(256), 0, st, ukeys, n_unique_ptr, ucap, min_chunk, vs, sp,
-                                           uverts, status));
-    return hipGetLastError();
-}
-
-hipError_t launch_tri_orient(hipStream_t st, int grid, int scene, const SceneParams &sp, const Point *vox, Point vs,
-                             const uint8_t *cubeidx, const uint32_t *trilist, const uint32_t *ntri_ptr,
-                             const uint64_t *hkeys, const uint32_t *hids, uint32_t hsize, const Vertex *uverts,
-                             uint32_t *tri_e, uint32_t *first_ord, uint32_t *status) {
-    SDM_DISPATCH(scene, hipLaunchKernelGGL(k_tri_orient<S>, dim3(grid), dim3(256), 0, st, vox, vs, cubeidx, trilist, ntri_ptr,
-                                           hkeys, hids, hsize, uverts, sp, tri_e, first_ord, status));
+hipError_t launch_mesh_tile(hipStream_t st, int grid, int scene, const SceneParams &sp, const Point *vox,
+                            const uint32_t *n_ptr, Point vs, const uint8_t *cubeidx, const uint32_t *tilecnt,
+                            uint32_t *trioff, uint32_t *tri_e, Vertex *uverts, uint32_t *first_ord, uint32_t ucap,
+                            uint32_t tcap, uint32_t *n_unique, uint32_t *ntri_out, uint32_t *status) {
+    SDM_DISPATCH(scene, hipLaunchKernelGGL(k_mesh_tile<S>, dim3(grid), dim3(256), 0, st, vox, n_ptr, vs, sp, cubeidx, tilecnt,
+                                           trioff, tri_e, uverts, first_ord, ucap, tcap, n_unique, ntri_out, status));
     return hipGetLastError();
 }
 
@@ -731,15 +825,15 @@ hipError_t launch_first_ord(hipStream_t st, int grid, const uint32_t *tri_e, con
 
 hipError_t launch_weld(hipStream_t st, int grid, const Vertex *uverts, const uint32_t *nu_ptr, uint32_t ucap,
                        const uint32_t *tri_e, const uint32_t *ntri_ptr, const uint32_t *first_ord, uint64_t *wkeys,
-                       uint32_t *wmin, uint32_t wsize, uint32_t *vslot, uint32_t *bitmap, uint32_t *wordpre,
-                       uint32_t *wvidx, Vertex *vertices, uint32_t vcap, uint32_t *nverts_out, uint32_t *indices,
-                       uint32_t *status) {
-    hipLaunchKernelGGL(k_weld_insert, dim3(grid), dim3(256), 0, st, uverts, nu_ptr, ucap, first_ord, wkeys, wmin, wsize, vslot,
-                       status);
-    hipLaunchKernelGGL(k_weld_mark, dim3(grid), dim3(256), 0, st, nu_ptr, ucap, first_ord, wmin, vslot, bitmap);
+                       uint32_t *wmin, uint32_t *wfirst, uint32_t wsize, uint32_t *vslot, uint32_t *bitmap,
+                       uint32_t *wordpre, uint32_t *wvidx, Vertex *vertices, uint32_t vcap, uint32_t *nverts_out,
+                       uint32_t *indices, uint32_t *status) {
+    hipLaunchKernelGGL(k_weld_insert, dim3(grid), dim3(256), 0, st, uverts, nu_ptr, ucap, first_ord, wkeys, wmin, wfirst, wsize,
+                       vslot, status);
+    hipLaunchKernelGGL(k_weld_mark, dim3(grid), dim3(256), 0, st, nu_ptr, ucap, first_ord, wmin, wfirst, vslot, bitmap);
     hipLaunchKernelGGL(k_scan_bitmap, dim3(1), dim3(1024), 0, st, bitmap, ntri_ptr, wordpre, nverts_out);
-    hipLaunchKernelGGL(k_weld_assign, dim3(grid), dim3(256), 0, st, uverts, nu_ptr, ucap, first_ord, wmin, vslot, bitmap, wordpre,
-                       wvidx, vertices, vcap, status);
+    hipLaunchKernelGGL(k_weld_assign, dim3(grid), dim3(256), 0, st, uverts, nu_ptr, ucap, first_ord, wmin, wfirst, vslot, bitmap,
+                       wordpre, wvidx, vertices, vcap, status);
     hipLaunchKernelGGL(k_weld_index, dim3(grid), dim3(256), 0, st, tri_e, ntri_ptr, vslot, wvidx, indices);
     return hipGetLastError();
 }
@@ -764,9 +858,10 @@ hipError_t launch_triangles_direct(hipStream_t st, int scene, const SceneParams 
     return hipGetLastError();
 }
 
-hipError_t launch_sample_dense(hipStream_t st, int grid, int scene, const SceneParams &sp, float *out, uint32_t N) {
+hipError_t launch_sample_dense(hipStream_t st, int grid, int scene, const SceneParams &sp, float *out, uint32_t N, bool nt) {
     const uint64_t total = (uint64_t) (N + 1) * (N + 1) * (N + 1);
-    SDM_DISPATCH(scene, hipLaunchKernelGGL(k_sample_dense<S>, dim3(grid), dim3(256), 0, st, out, N, total, sp));
+    if (nt) { SDM_DISPATCH(scene, hipLaunchKernelGGL((k_sample_dense<S, true>), dim3(grid), dim3(256), 0, st, out, N, total, sp)); }
+    else { SDM_DISPATCH(scene, hipLaunchKernelGGL((k_sample_dense<S, false>), dim3(grid), dim3(256), 0, st, out, N, total, sp)); }
     return hipGetLastError();
 }
 

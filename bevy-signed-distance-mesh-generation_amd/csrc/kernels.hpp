@@ -15,7 +15,8 @@ enum StatusWord : int {
     ST_NOT_LATTICE = 1,     // input field is not a lattice field -> host takes the direct path
     ST_WELD_RANGE = 2,      // a vertex lies outside +-10.48 units (21-bit weld key)
     ST_NEWTON_CAPPED = 3,   // informational: closest_surface_point hit the 10 000-iteration cap
-    ST_INTERNAL = 4,        // invariant violated (edge missing from the hash)
+    ST_INTERNAL = 4,        // invariant violated
+    ST_TILE_OVERFLOW = 5,   // a 256-voxel tile has > 1024 unique edges -> host takes the direct path
     ST_WORDS = 8
 };
 
@@ -28,31 +29,24 @@ hipError_t launch_refine_emit(hipStream_t st, int grid, const Point *vox, const 
 hipError_t launch_refine_expand_raw(hipStream_t st, int grid, const Point *vox, uint32_t n, Point cs, const uint8_t *mask,
                                     Point *out);
 hipError_t launch_classify(hipStream_t st, int grid, int scene, const SceneParams &sp, const Point *vox,
-                           const uint32_t *n_ptr, Point vs, uint8_t *cubeidx, uint32_t *tilecnt, uint64_t *hkeys,
-                           uint32_t *hids, uint32_t hsize, uint64_t *ukeys, uint32_t ucap, uint32_t *n_unique,
-                           uint32_t *status);
-hipError_t launch_emit_trilist(hipStream_t st, int grid, const uint8_t *cubeidx, const uint32_t *n_ptr,
-                               const uint32_t *tileoff, uint32_t *trioff, uint32_t *trilist, uint32_t cap);
-hipError_t launch_project(hipStream_t st, int grid, int scene, const SceneParams &sp, const uint64_t *ukeys,
-                          const uint32_t *n_unique_ptr, uint32_t ucap, uint32_t min_chunk, Point vs, Vertex *uverts,
-                          uint32_t *status);
-hipError_t launch_tri_orient(hipStream_t st, int grid, int scene, const SceneParams &sp, const Point *vox, Point vs,
-                             const uint8_t *cubeidx, const uint32_t *trilist, const uint32_t *ntri_ptr,
-                             const uint64_t *hkeys, const uint32_t *hids, uint32_t hsize, const Vertex *uverts,
-                             uint32_t *tri_e, uint32_t *first_ord, uint32_t *status);
+                           const uint32_t *n_ptr, Point vs, uint8_t *cubeidx, uint32_t *tilecnt);
+hipError_t launch_mesh_tile(hipStream_t st, int grid, int scene, const SceneParams &sp, const Point *vox,
+                            const uint32_t *n_ptr, Point vs, const uint8_t *cubeidx, const uint32_t *tilecnt,
+                            uint32_t *trioff, uint32_t *tri_e, Vertex *uverts, uint32_t *first_ord, uint32_t ucap,
+                            uint32_t tcap, uint32_t *n_unique, uint32_t *ntri_out, uint32_t *status);
 hipError_t launch_first_ord(hipStream_t st, int grid, const uint32_t *tri_e, const uint32_t *ntri_ptr, uint32_t *first_ord);
 hipError_t launch_weld(hipStream_t st, int grid, const Vertex *uverts, const uint32_t *nu_ptr, uint32_t ucap,
                        const uint32_t *tri_e, const uint32_t *ntri_ptr, const uint32_t *first_ord, uint64_t *wkeys,
-                       uint32_t *wmin, uint32_t wsize, uint32_t *vslot, uint32_t *bitmap, uint32_t *wordpre,
-                       uint32_t *wvidx, Vertex *vertices, uint32_t vcap, uint32_t *nverts_out, uint32_t *indices,
-                       uint32_t *status);
+                       uint32_t *wmin, uint32_t *wfirst, uint32_t wsize, uint32_t *vslot, uint32_t *bitmap,
+                       uint32_t *wordpre, uint32_t *wvidx, Vertex *vertices, uint32_t vcap, uint32_t *nverts_out,
+                       uint32_t *indices, uint32_t *status);
 hipError_t launch_expand_compact(hipStream_t st, int grid, const Vertex *uverts, const uint32_t *tri_e,
                                  const uint32_t *ntri_ptr, Triangle *out, uint32_t cap);
 hipError_t launch_expand_raw(hipStream_t st, int grid, const Vertex *uverts, const uint32_t *tri_e, const uint8_t *cubeidx,
                              const uint32_t *trioff, uint32_t n, Triangle *out);
 hipError_t launch_triangles_direct(hipStream_t st, int scene, const SceneParams &sp, const Point *vox, uint32_t n, Point vs,
                                    Triangle *out);
-hipError_t launch_sample_dense(hipStream_t st, int grid, int scene, const SceneParams &sp, float *out, uint32_t N);
+hipError_t launch_sample_dense(hipStream_t st, int grid, int scene, const SceneParams &sp, float *out, uint32_t N, bool nt);
 hipError_t launch_create_field(hipStream_t st, Point *vox, uint32_t z0, uint32_t z1, uint32_t *n_out);
 hipError_t launch_raw_count(hipStream_t st, int grid, const Triangle *raw, const uint32_t *n_ptr, uint32_t *tilecnt);
 hipError_t launch_raw_compact(hipStream_t st, int grid, const Triangle *raw, const uint32_t *n_ptr, const uint32_t *tileoff,

@@ -28,8 +28,10 @@
 
 #if defined(__HIPCC__)
 #define SDM_HD __host__ __device__ __forceinline__
+#define SDM_HDM __host__ __device__ __forceinline__
 #else
 #define SDM_HD static inline
+#define SDM_HDM inline
 #endif
 
 #pragma clang fp contract(off)
@@ -130,6 +132,52 @@ SDM_HD float sdf(float px, float py, float pz, const SceneParams &sp) {
         return smooth_min(a1, a2, 0.5f);
     }
 }
+
+// ---------------------------------------------------------------------------------------------
+// Row context for dense sampling along z (k_sample_dense): everything that depends only on
+// (x, y) is computed once per row; eval(z) performs the remaining operations in exactly the
+// order sdf<SCENE>() does, so the values are bit-identical.
+// ---------------------------------------------------------------------------------------------
+template <int SCENE>
+struct RowCtx {
+    float px, py;
+    float a[8];
+    SDM_HDM void init(float x, float y, const SceneParams &sp) {
+        px = x; py = y;
+        if (SCENE == SCENE_SPHERE) {
+            a[0] = px * px + py * py;
+        } else if (SCENE == SCENE_SDOBJ || SCENE == SCENE_ANIM) {
+            const float ax = along_sq(px, -1.5f, 3.0f), ay = along_sq(py, -0.5f, 1.0f);
+            const float xm15 = sq(px - (-1.5f)), xp15 = sq(px - 1.5f), xm05 = sq(px - (-0.5f));
+            const float ym05 = sq(py - (-0.5f)), yp05 = sq(py - 0.5f);
+            a[0] = ax + ym05; a[1] = ax + yp05;          // x-bars, before + z^2
+            a[2] = xm15 + ay; a[3] = xp15 + ay;          // y-bars, before + z^2
+            a[4] = xm15 + ym05; a[5] = xm15 + yp05;      // z-bars, before + az
+            a[6] = xm05 + ym05; a[7] = xm05 + yp05;
+        }
+    }
+    SDM_HDM float eval(float pz, const SceneParams &sp) const {
+        if (SCENE == SCENE_SPHERE) {
+            return sqrtf(a[0] + pz * pz) - 1.0f;
+        } else if (SCENE == SCENE_SDOBJ || SCENE == SCENE_ANIM) {
+            const float az = along_sq(pz, -0.25f, 0.5f);
+            const float zm025 = sq(pz - (-0.25f)), zp025 = sq(pz - 0.25f), zp275 = sq(pz - 2.75f);
+            float m = gmin(a[0] + zm025, a[0] + zp025);
+            m = gmin(m, gmin(a[1] + zm025, a[1] + zp025));
+            m = gmin(m, gmin(a[2] + zm025, a[2] + zp275));
+            m = gmin(m, gmin(a[3] + zm025, a[3] + zp275));
+            m = gmin(m, gmin(a[4] + az, a[5] + az));
+            m = gmin(m, gmin(a[6] + az, a[7] + az));
+            const float a1 = sqrtf(m) - 0.1f;
+            float sy = py;
+            if (SCENE == SCENE_ANIM) sy = py - sp.p[0];
+            const float a2 = sqrtf((px * px + sy * sy) + pz * pz) - 1.0f;
+            return smooth_min(a1, a2, 0.5f);
+        } else {
+            return sdf<SCENE>(px, py, pz, sp);
+        }
+    }
+};
 
 #define SDM_NORMAL_EPS 0.001f
 
