@@ -35,7 +35,9 @@ enum {
     CTR_NVERT = 18,
     CTR_NSLOTS = 19,
     CTR_SCRATCH = 20,
-    CTR_WORDS = 32
+    CTR_NTILES = 21,
+    CTR_WORDS = 32,
+    CTL_LVL0 = 64          // control block: [counters 32 | status 8 | pad | per-level tile counters ...]
 };
 
 }  // namespace
@@ -57,13 +59,14 @@ struct sdmesh_handle {
     // voxel lists (ping-pong), refine scratch
     DevBuf vox[2];
     int cur = 0;
-    DevBuf mask, tilecnt;
+    DevBuf mask, tilecnt, ctl;             // ctl: counters + status + pre-zeroed per-level tile counters
+    uint32_t lvl_off[SDMESH_MAX_LEVELS + 2] = {0};
     // counters / status
     uint32_t *d_ctr = nullptr;     // CTR_WORDS
     uint32_t *d_status = nullptr;  // ST_WORDS
     uint32_t *h_pinned = nullptr;  // CTR_WORDS + ST_WORDS, pinned
     // mesh stage
-    DevBuf cubeidx, trioff, ff_arena, first_ord_buf, wfirst, uverts, tri_e, vslot, bitmap, wordpre, wvidx;
+    DevBuf cubeidx, trioff, ff_arena, first_ord_buf, wfirst, uverts, tri_e, vslot, tdesc, tfirst, tpre, flip, wvidx;
     DevBuf vertices, indices, raw, compact, staging;
     // capacities the device chain was laid out for
     uint32_t cap_vox = 0, ucap = 0, tcap = 0, wsize = 0;
@@ -135,9 +138,10 @@ Point half_size(Point p) { return Point{p.x / 2.0f, p.y / 2.0f, p.z / 2.0f}; }  
 // Lay out the mesh-stage buffers for up to n_cap voxels / u_cap unique (pre-weld) vertices.
 int layout_mesh(sdmesh_handle *h, uint32_t n_cap, uint32_t u_cap_hint) {
     if (n_cap < 64) n_cap = 64;
-    const uint32_t ucap = std::max<uint32_t>(u_cap_hint, 2u * n_cap + 4096u);
     const uint32_t tcap = 5u * n_cap;
-    const uint32_t wsize = 2u * ucap + 64u;           // load factor <= 0.5
+    const uint32_t ucap = 3u * tcap;                  // vertex slots live in corner-ordinal space (sparse)
+    const uint32_t uexp = std::max<uint32_t>(u_cap_hint, 2u * n_cap + 4096u);   // expected pre-weld vertices
+    const uint32_t wsize = 2u * uexp + 64u;           // load factor <= 0.5; a full table raises ST_OVERFLOW
     SDCHK(ensure(h, h->cubeidx, n_cap));
     SDCHK(ensure(h, h->trioff, 4ull * n_cap));
     SDCHK(ensure(h, h->tilecnt, 4ull * std::max(tiles(n_cap), tiles(5u * n_cap)) + 64));
@@ -145,11 +149,13 @@ int layout_mesh(sdmesh_handle *h, uint32_t n_cap, uint32_t u_cap_hint) {
     SDCHK(ensure(h, h->first_ord_buf, 4ull * ucap));
     SDCHK(ensure(h, h->tri_e, 12ull * tcap));
     SDCHK(ensure(h, h->vslot, 4ull * ucap));
-    SDCHK(ensure(h, h->bitmap, 4ull * ((3ull * tcap + 31) / 32 + 1)));
-    SDCHK(ensure(h, h->wordpre, 4ull * ((3ull * tcap + 31) / 32 + 1)));
+    SDCHK(ensure(h, h->tdesc, 16ull * (tiles(n_cap) + tiles(tcap) + 16)));
+    SDCHK(ensure(h, h->tfirst, 4ull * (tiles(n_cap) + tiles(tcap) + 16)));
+    SDCHK(ensure(h, h->tpre, 4ull * (tiles(n_cap) + tiles(tcap) + 16)));
+    SDCHK(ensure(h, h->flip, (size_t) tcap + 64));
     SDCHK(ensure(h, h->wvidx, 4ull * wsize));
     SDCHK(ensure(h, h->wfirst, 4ull * wsize));
-    SDCHK(ensure(h, h->vertices, sizeof(Vertex) * (size_t) ucap));
+    SDCHK(ensure(h, h->vertices, sizeof(Vertex) * (size_t) uexp));
     SDCHK(ensure(h, h->indices, 12ull * tcap));
     // one arena for everything that must start as 0xFF (weld keys + loser minima): one memset per regen
     const size_t o_wkeys = 0, o_wmin = align256(o_wkeys + 8ull * wsize), total = align256(o_wmin + 4ull * wsize);
@@ -166,35 +172,37 @@ size_t ff_bytes(const sdmesh_handle *h) {
     return (size_t) ((char *) h->wmin - (char *) h->ff_arena.p) + 4ull * h->wsize;
 }
 
-// classify + fused tile kernel for the voxel list d_vox (count at *n_ptr, at most cap_vox):
-// leaves (uverts, first_ord, tri_e, trioff) and the counters NUNIQ / NTRI on the device
-int mesh_front(sdmesh_handle *h, const Point *d_vox, const uint32_t *n_ptr, Point vs) {
+// classify -> tile dedupe -> project -> flip for the voxel list d_vox (count at *n_ptr, at most cap_vox):
+// leaves (uverts, tri_e, flip, trioff, tdesc) and the counters NUNIQ / NTRI / NTILES on the device
+int mesh_front(sdmesh_handle *h, const Point *d_vox, const uint32_t *n_ptr, Point vs, bool zero_counters) {
     hipStream_t st = h->stream;
     HIPCHK(hipMemsetAsync(h->ff_arena.p, 0xFF, ff_bytes(h), st));
-    HIPCHK(hipMemsetAsync(h->d_ctr + CTR_NUNIQ, 0, 4 * sizeof(uint32_t), st));
+    if (zero_counters) HIPCHK(hipMemsetAsync(h->d_ctr + CTR_NUNIQ, 0, 4 * sizeof(uint32_t), st));
     HIPCHK(launch_classify(st, h->grid, h->scene, h->sp, d_vox, n_ptr, vs, (uint8_t *) h->cubeidx.p, (uint32_t *) h->tilecnt.p));
-    HIPCHK(launch_mesh_tile(st, h->grid, h->scene, h->sp, d_vox, n_ptr, vs, (const uint8_t *) h->cubeidx.p,
-                            (const uint32_t *) h->tilecnt.p, (uint32_t *) h->trioff.p, (uint32_t *) h->tri_e.p,
-                            (Vertex *) h->uverts.p, h->first_ord, h->ucap, h->tcap, h->d_ctr + CTR_NUNIQ, h->d_ctr + CTR_NTRI,
-                            h->d_status));
+    HIPCHK(launch_tile_dedupe(st, h->grid, d_vox, n_ptr, vs, (const uint8_t *) h->cubeidx.p, (const uint32_t *) h->tilecnt.p,
+                              (uint32_t *) h->trioff.p, (uint32_t *) h->tri_e.p, (Vertex *) h->uverts.p, (uint4 *) h->tdesc.p,
+                              h->ucap, h->tcap, h->d_ctr + CTR_NTRI, h->d_ctr + CTR_NTILES, h->d_status));
+    HIPCHK(launch_tile_prefix(st, (const uint4 *) h->tdesc.p, h->d_ctr + CTR_NTILES, (uint32_t *) h->tpre.p, h->d_ctr + CTR_NUNIQ));
+    HIPCHK(launch_project(st, h->grid, h->scene, h->sp, (Vertex *) h->uverts.p, (const uint4 *) h->tdesc.p,
+                          (const uint32_t *) h->tpre.p, h->d_ctr + CTR_NTILES, h->d_status));
+    HIPCHK(launch_flip(st, h->grid, h->scene, h->sp, (const Vertex *) h->uverts.p, (const uint32_t *) h->tri_e.p,
+                       h->d_ctr + CTR_NTRI, (uint8_t *) h->flip.p));
     return SDMESH_OK;
 }
 
-// weld of (uverts[0..*nu), tri_e[0..3*ntri)) -> vertices / indices
-int mesh_weld(sdmesh_handle *h, const Vertex *uverts, const uint32_t *nu_ptr, uint32_t ucap, const uint32_t *tri_e) {
+// per-tile weld of (uverts, tri_e, flip) described by tdesc[0..*NTILES) -> vertices / indices
+int mesh_weld(sdmesh_handle *h, const Vertex *uverts) {
     hipStream_t st = h->stream;
-    HIPCHK(hipMemsetAsync(h->bitmap.p, 0, h->bitmap.cap, st));
-    HIPCHK(launch_weld(st, h->grid, uverts, nu_ptr, ucap, tri_e, h->d_ctr + CTR_NTRI, h->first_ord, h->wkeys, h->wmin,
-                       (uint32_t *) h->wfirst.p, h->wsize, (uint32_t *) h->vslot.p, (uint32_t *) h->bitmap.p, (uint32_t *) h->wordpre.p,
-                       (uint32_t *) h->wvidx.p, (Vertex *) h->vertices.p, (uint32_t) (h->vertices.cap / sizeof(Vertex)),
-                       h->d_ctr + CTR_NVERT, (uint32_t *) h->indices.p, h->d_status));
+    HIPCHK(launch_weld(st, h->grid, uverts, (const uint4 *) h->tdesc.p, h->d_ctr + CTR_NTILES, (uint32_t *) h->tri_e.p,
+                       (const uint8_t *) h->flip.p, h->d_ctr + CTR_NTRI, h->first_ord, h->wkeys, h->wmin, (uint32_t *) h->wfirst.p,
+                       h->wsize, (uint32_t *) h->vslot.p, (uint32_t *) h->tfirst.p, (uint32_t *) h->wvidx.p, (Vertex *) h->vertices.p,
+                       (uint32_t) (h->vertices.cap / sizeof(Vertex)), h->d_ctr + CTR_NVERT, (uint32_t *) h->indices.p, h->d_status));
     return SDMESH_OK;
 }
 
 // read counters + status back (the one synchronisation point of a device chain)
 int read_back(sdmesh_handle *h) {
-    HIPCHK(hipMemcpyAsync(h->h_pinned, h->d_ctr, CTR_WORDS * 4, hipMemcpyDeviceToHost, h->stream));
-    HIPCHK(hipMemcpyAsync(h->h_pinned + CTR_WORDS, h->d_status, ST_WORDS * 4, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(hipMemcpyAsync(h->h_pinned, h->d_ctr, (CTR_WORDS + ST_WORDS) * 4, hipMemcpyDeviceToHost, h->stream));
     HIPCHK(hipStreamSynchronize(h->stream));
     return SDMESH_OK;
 }
@@ -208,6 +216,29 @@ int status_to_error(sdmesh_handle *h) {
 
 int zero_status(sdmesh_handle *h) {
     HIPCHK(hipMemsetAsync(h->d_status, 0, ST_WORDS * 4, h->stream));
+    return SDMESH_OK;
+}
+
+// Control block = [counters | status | per-level tile counters]; grown on demand, counters preserved.
+int ensure_ctl(sdmesh_handle *h, size_t lvl_words) {
+    const size_t need = 4ull * (CTL_LVL0 + lvl_words + 64);
+    if (h->ctl.cap >= need) return SDMESH_OK;
+    HIPCHK(hipStreamSynchronize(h->stream));
+    void *p = nullptr;
+    HIPCHK(hipMalloc(&p, need * 2));
+    HIPCHK(hipMemset(p, 0, need * 2));
+    HIPCHK(hipMemcpy(p, h->ctl.p, 4ull * CTL_LVL0, hipMemcpyDeviceToDevice));
+    HIPCHK(hipFree(h->ctl.p));
+    h->ctl.p = p;
+    h->ctl.cap = need * 2;
+    h->d_ctr = (uint32_t *) p;
+    h->d_status = h->d_ctr + CTR_WORDS;
+    return SDMESH_OK;
+}
+
+// one memset: counters, status and the first lvl_words per-level tile counters
+int zero_ctl(sdmesh_handle *h, size_t lvl_words) {
+    HIPCHK(hipMemsetAsync(h->ctl.p, 0, 4ull * (CTL_LVL0 + lvl_words), h->stream));
     return SDMESH_OK;
 }
 
@@ -225,15 +256,14 @@ int weld_raw_device(sdmesh_handle *h, const Triangle *d_raw, uint32_t nslots) {
     if (h->tcap < nslots) return fail(h, SDMESH_ERR_INTERNAL, "weld layout too small");
     SDCHK(ensure(h, h->compact, sizeof(Triangle) * (size_t) nslots));
     HIPCHK(hipMemsetAsync(h->ff_arena.p, 0xFF, ff_bytes(h), st));
-    HIPCHK(hipMemsetAsync(h->first_ord, 0xFF, 4ull * vcap, st));
     HIPCHK(launch_set_u32(st, h->d_ctr + CTR_NSLOTS, nslots));
     HIPCHK(launch_raw_count(st, h->grid, d_raw, h->d_ctr + CTR_NSLOTS, (uint32_t *) h->tilecnt.p));
     HIPCHK(launch_scan_tiles(st, (uint32_t *) h->tilecnt.p, h->d_ctr + CTR_NSLOTS, 256, h->d_ctr + CTR_NTRI, nslots, h->d_status));
     HIPCHK(launch_raw_compact(st, h->grid, d_raw, h->d_ctr + CTR_NSLOTS, (const uint32_t *) h->tilecnt.p,
                               (Triangle *) h->compact.p, (uint32_t *) h->tri_e.p, nslots));
-    HIPCHK(launch_mul3_u32(st, h->d_ctr + CTR_NTRI, h->d_ctr + CTR_NUNIQ));
-    HIPCHK(launch_first_ord(st, h->grid, (const uint32_t *) h->tri_e.p, h->d_ctr + CTR_NTRI, h->first_ord));
-    SDCHK(mesh_weld(h, (const Vertex *) h->compact.p, h->d_ctr + CTR_NUNIQ, vcap, (const uint32_t *) h->tri_e.p));
+    HIPCHK(launch_raw_desc(st, h->grid, h->d_ctr + CTR_NTRI, (uint4 *) h->tdesc.p, (uint8_t *) h->flip.p, h->d_ctr + CTR_NTILES,
+                           h->d_ctr + CTR_NUNIQ));
+    SDCHK(mesh_weld(h, (const Vertex *) h->compact.p));
     return SDMESH_OK;
 }
 
@@ -252,32 +282,29 @@ void fill_info(sdmesh_handle *h, sdmesh_regen_info *info, int levels, bool direc
 }
 
 // One refine level on the device: src list (count at ctr[L]) -> dst list (count to ctr[L+1]).
-// If out_cap == 0 the output size is discovered with a host sync after the scan (exact
-// allocation); otherwise everything is enqueued without synchronisation.
-int refine_level(sdmesh_handle *h, int L, uint32_t n_cap_in, uint32_t out_cap, Point cs, uint32_t *count_out) {
+// cnt_region = this level's pre-zeroed tile counters.  If out_cap == 0 the output size is discovered
+// with a host sync between the two kernels (exact allocation); otherwise nothing synchronises.
+int refine_level(sdmesh_handle *h, int L, uint32_t n_cap_in, uint32_t out_cap, Point cs, uint32_t *cnt_region,
+                 uint32_t *count_out) {
     hipStream_t st = h->stream;
     const int src = h->cur, dst = 1 - h->cur;
     SDCHK(ensure(h, h->mask, n_cap_in));
-    SDCHK(ensure(h, h->tilecnt, 4ull * tiles(n_cap_in) + 64));
     const uint32_t *n_in = h->d_ctr + CTR_LEVEL0 + L;
     uint32_t *n_out = h->d_ctr + CTR_LEVEL0 + L + 1;
     HIPCHK(launch_refine_mask(st, h->grid, h->scene, h->sp, (const Point *) h->vox[src].p, n_in, cs, (uint8_t *) h->mask.p,
-                              (uint32_t *) h->tilecnt.p));
+                              cnt_region));
     uint32_t cap = out_cap;
     if (out_cap == 0) {
-        HIPCHK(launch_scan_tiles(st, (uint32_t *) h->tilecnt.p, n_in, 256, n_out, 0xFFFFFFFFu, h->d_status));
+        HIPCHK(launch_sum_tiles(st, cnt_region, n_in, h->d_ctr + CTR_SCRATCH));
         uint32_t cnt = 0;
-        HIPCHK(hipMemcpyAsync(&cnt, n_out, 4, hipMemcpyDeviceToHost, st));
+        HIPCHK(hipMemcpyAsync(&cnt, h->d_ctr + CTR_SCRATCH, 4, hipMemcpyDeviceToHost, st));
         HIPCHK(hipStreamSynchronize(st));
         cap = cnt;
         if (count_out) *count_out = cnt;
-        SDCHK(ensure(h, h->vox[dst], sizeof(Point) * (size_t) std::max<uint32_t>(cap, 64)));
-    } else {
-        SDCHK(ensure(h, h->vox[dst], sizeof(Point) * (size_t) cap));
-        HIPCHK(launch_scan_tiles(st, (uint32_t *) h->tilecnt.p, n_in, 256, n_out, cap, h->d_status));
     }
-    HIPCHK(launch_refine_emit(st, h->grid, (const Point *) h->vox[src].p, n_in, cs, (const uint8_t *) h->mask.p,
-                              (const uint32_t *) h->tilecnt.p, (Point *) h->vox[dst].p, cap));
+    SDCHK(ensure(h, h->vox[dst], sizeof(Point) * (size_t) std::max<uint32_t>(cap, 64)));
+    HIPCHK(launch_refine_emit(st, h->grid, (const Point *) h->vox[src].p, n_in, cs, (const uint8_t *) h->mask.p, cnt_region,
+                              (Point *) h->vox[dst].p, cap, n_out, h->d_status));
     h->cur = dst;
     return SDMESH_OK;
 }
@@ -304,9 +331,18 @@ int regen_impl(sdmesh_handle *h, int levels, int mode, int part, int nparts, sdm
         SDCHK(ensure(h, h->vox[0], sizeof(Point) * (size_t) std::max<uint32_t>(n0, 64)));
         if (async) SDCHK(layout_mesh(h, padded(h->plan_counts[levels]), padded(h->plan_uniq)));
 
+        // per-level tile counters live behind the counters in the control block; with a capacity plan
+        // the whole block is zeroed by ONE memset, otherwise level by level as the sizes become known
+        uint32_t lvl_words = 0;
+        if (async) {
+            for (int L = 0; L < levels; L++) {
+                h->lvl_off[L] = lvl_words;
+                lvl_words += tiles(L == 0 ? n0 : padded(h->plan_counts[L])) + 16;
+            }
+            SDCHK(ensure_ctl(h, lvl_words));
+        }
         HIPCHK(hipEventRecord(h->ev0, st));
-        SDCHK(zero_status(h));
-        HIPCHK(hipMemsetAsync(h->d_ctr, 0, CTR_WORDS * 4, st));
+        SDCHK(zero_ctl(h, lvl_words));
         Point vs;
         vs.x = vs.y = vs.z = MESH_GENERATION_BB_SIZE / (float) MESH_GENERATION_INIT_FACTOR;
         if (n0) HIPCHK(launch_create_field(st, (Point *) h->vox[0].p, z0, z1, h->d_ctr + CTR_LEVEL0));
@@ -315,7 +351,12 @@ int regen_impl(sdmesh_handle *h, int levels, int mode, int part, int nparts, sdm
             const Point cs = half_size(vs);
             const uint32_t out_cap = async ? padded(h->plan_counts[L + 1]) : 0u;
             uint32_t cnt = out_cap;
-            SDCHK(refine_level(h, L, std::max<uint32_t>(n_cap, 64), out_cap, cs, &cnt));
+            if (!async) {
+                h->lvl_off[L] = 0;
+                SDCHK(ensure_ctl(h, tiles(n_cap) + 16));
+                HIPCHK(hipMemsetAsync(h->d_ctr + CTL_LVL0, 0, 4ull * (tiles(n_cap) + 16), st));
+            }
+            SDCHK(refine_level(h, L, std::max<uint32_t>(n_cap, 64), out_cap, cs, h->d_ctr + CTL_LVL0 + h->lvl_off[L], &cnt));
             vs = cs;
             n_cap = cnt;
         }
@@ -324,8 +365,8 @@ int regen_impl(sdmesh_handle *h, int levels, int mode, int part, int nparts, sdm
         const uint32_t *n_ptr = h->d_ctr + CTR_LEVEL0 + levels;
         bool direct = h->force_direct != 0;
         if (!direct) {
-            SDCHK(mesh_front(h, d_vox, n_ptr, vs));
-            SDCHK(mesh_weld(h, (const Vertex *) h->uverts.p, h->d_ctr + CTR_NUNIQ, h->ucap, (const uint32_t *) h->tri_e.p));
+            SDCHK(mesh_front(h, d_vox, n_ptr, vs, false));
+            SDCHK(mesh_weld(h, (const Vertex *) h->uverts.p));
         }
         HIPCHK(hipEventRecord(h->ev1, st));
         SDCHK(read_back(h));
@@ -337,8 +378,8 @@ int regen_impl(sdmesh_handle *h, int levels, int mode, int part, int nparts, sdm
             h->plan_valid = false;
             SDCHK(layout_mesh(h, n_cap, c[CTR_NUNIQ] + 1024));
             SDCHK(zero_status(h));
-            SDCHK(mesh_front(h, d_vox, n_ptr, vs));
-            SDCHK(mesh_weld(h, (const Vertex *) h->uverts.p, h->d_ctr + CTR_NUNIQ, h->ucap, (const uint32_t *) h->tri_e.p));
+            SDCHK(mesh_front(h, d_vox, n_ptr, vs, true));
+            SDCHK(mesh_weld(h, (const Vertex *) h->uverts.p));
             HIPCHK(hipEventRecord(h->ev1, st));
             SDCHK(read_back(h));
             if (s[ST_OVERFLOW]) return fail(h, SDMESH_ERR_INTERNAL, "capacity overflow persists (status %u)", s[ST_OVERFLOW]);
@@ -386,14 +427,13 @@ int host_mesh_front(sdmesh_handle *h, const Point *voxels, uint32_t n, Point vs,
     h->vox_valid = false;
     h->mesh_valid = false;
     HIPCHK(hipMemcpyAsync(h->vox[0].p, voxels, sizeof(Point) * (size_t) n, hipMemcpyHostToDevice, st));
-    SDCHK(zero_status(h));
-    HIPCHK(hipMemsetAsync(h->d_ctr, 0, CTR_WORDS * 4, st));
+    SDCHK(zero_ctl(h, 0));
     HIPCHK(launch_set_u32(st, h->d_ctr + CTR_LEVEL0, n));
     direct = h->force_direct != 0;
     if (!direct) {
         SDCHK(layout_mesh(h, n, 0));
         for (int attempt = 0; attempt < 2; attempt++) {
-            SDCHK(mesh_front(h, (const Point *) h->vox[0].p, h->d_ctr + CTR_LEVEL0, vs));
+            SDCHK(mesh_front(h, (const Point *) h->vox[0].p, h->d_ctr + CTR_LEVEL0, vs, true));
             SDCHK(read_back(h));
             const uint32_t *s = h->h_pinned + CTR_WORDS;
             if (s[ST_NOT_LATTICE] || s[ST_TILE_OVERFLOW]) { direct = true; break; }
@@ -445,8 +485,11 @@ int sdmesh_create(int device, sdmesh_handle **out) {
     h->stream = h->own_stream;
     if ((e = hipEventCreate(&h->ev0)) != hipSuccess) return bail(e, "hipEventCreate");
     if ((e = hipEventCreate(&h->ev1)) != hipSuccess) return bail(e, "hipEventCreate");
-    if ((e = hipMalloc((void **) &h->d_ctr, CTR_WORDS * 4)) != hipSuccess) return bail(e, "hipMalloc");
-    if ((e = hipMalloc((void **) &h->d_status, ST_WORDS * 4)) != hipSuccess) return bail(e, "hipMalloc");
+    if ((e = hipMalloc(&h->ctl.p, 4ull * (CTL_LVL0 + 65536))) != hipSuccess) return bail(e, "hipMalloc");
+    h->ctl.cap = 4ull * (CTL_LVL0 + 65536);
+    h->d_ctr = (uint32_t *) h->ctl.p;
+    h->d_status = h->d_ctr + CTR_WORDS;
+    if ((e = hipMemset(h->ctl.p, 0, h->ctl.cap)) != hipSuccess) return bail(e, "hipMemset");
     if ((e = hipHostMalloc((void **) &h->h_pinned, (CTR_WORDS + ST_WORDS) * 4, hipHostMallocDefault)) != hipSuccess)
         return bail(e, "hipHostMalloc");
     memset(h->h_pinned, 0, (CTR_WORDS + ST_WORDS) * 4);
@@ -458,12 +501,10 @@ void sdmesh_destroy(sdmesh_handle *h) {
     if (!h) return;
     (void) hipSetDevice(h->device);
     if (h->stream) (void) hipStreamSynchronize(h->stream);
-    DevBuf *bufs[] = {&h->vox[0], &h->vox[1], &h->mask, &h->tilecnt, &h->cubeidx, &h->trioff, &h->ff_arena,
-                      &h->first_ord_buf, &h->wfirst, &h->uverts, &h->tri_e, &h->vslot, &h->bitmap, &h->wordpre, &h->wvidx,
+    DevBuf *bufs[] = {&h->vox[0], &h->vox[1], &h->mask, &h->tilecnt, &h->ctl, &h->cubeidx, &h->trioff, &h->ff_arena,
+                      &h->first_ord_buf, &h->wfirst, &h->uverts, &h->tri_e, &h->vslot, &h->tdesc, &h->tfirst, &h->tpre, &h->flip, &h->wvidx,
                       &h->vertices, &h->indices, &h->raw, &h->compact, &h->staging};
     for (DevBuf *b : bufs) release(*b);
-    if (h->d_ctr) (void) hipFree(h->d_ctr);
-    if (h->d_status) (void) hipFree(h->d_status);
     if (h->h_pinned) (void) hipHostFree(h->h_pinned);
     if (h->ev0) (void) hipEventDestroy(h->ev0);
     if (h->ev1) (void) hipEventDestroy(h->ev1);
@@ -528,15 +569,14 @@ static int refine_host_common(sdmesh_handle *h, const Point *in, size_t n, Point
     HIPCHK(hipSetDevice(h->device));
     SDCHK(ensure(h, h->vox[0], sizeof(Point) * n));
     SDCHK(ensure(h, h->mask, n));
-    SDCHK(ensure(h, h->tilecnt, 4ull * tiles((uint32_t) n) + 64));
+    SDCHK(ensure_ctl(h, tiles((uint32_t) n) + 16));
     h->cur = 0;
     h->vox_valid = h->mesh_valid = false;
     HIPCHK(hipMemcpyAsync(h->vox[0].p, in, sizeof(Point) * n, hipMemcpyHostToDevice, st));
-    SDCHK(zero_status(h));
-    HIPCHK(hipMemsetAsync(h->d_ctr, 0, CTR_WORDS * 4, st));
+    SDCHK(zero_ctl(h, tiles((uint32_t) n) + 16));
     HIPCHK(launch_set_u32(st, h->d_ctr + CTR_LEVEL0, (uint32_t) n));
     HIPCHK(launch_refine_mask(st, h->grid, h->scene, h->sp, (const Point *) h->vox[0].p, h->d_ctr + CTR_LEVEL0, half_size(voxel_size),
-                              (uint8_t *) h->mask.p, (uint32_t *) h->tilecnt.p));
+                              (uint8_t *) h->mask.p, h->d_ctr + CTL_LVL0));
     return SDMESH_OK;
 }
 
@@ -551,14 +591,14 @@ int sdmesh_refine_voxel_field(sdmesh_handle *h, const struct Point *in, size_t n
     if (n > 0x1FFFFFFFu) return fail(h, SDMESH_ERR_INVALID, "too many voxels");
     hipStream_t st = h->stream;
     SDCHK(refine_host_common(h, in, n, voxel_size));
-    HIPCHK(launch_scan_tiles(st, (uint32_t *) h->tilecnt.p, h->d_ctr + CTR_LEVEL0, 256, h->d_ctr + CTR_LEVEL0 + 1, 0xFFFFFFFFu,
-                             h->d_status));
+    HIPCHK(launch_sum_tiles(st, h->d_ctr + CTL_LVL0, h->d_ctr + CTR_LEVEL0, h->d_ctr + CTR_SCRATCH));
     SDCHK(read_back(h));
-    const uint32_t cnt = h->h_pinned[CTR_LEVEL0 + 1];
+    const uint32_t cnt = h->h_pinned[CTR_SCRATCH];
     if (cnt > out_cap) return fail(h, SDMESH_ERR_CAPACITY, "refine output needs %u points, caller gave %zu", cnt, out_cap);
     SDCHK(ensure(h, h->vox[1], sizeof(Point) * (size_t) std::max<uint32_t>(cnt, 64)));
     HIPCHK(launch_refine_emit(st, h->grid, (const Point *) h->vox[0].p, h->d_ctr + CTR_LEVEL0, half_size(voxel_size),
-                              (const uint8_t *) h->mask.p, (const uint32_t *) h->tilecnt.p, (Point *) h->vox[1].p, cnt));
+                              (const uint8_t *) h->mask.p, h->d_ctr + CTL_LVL0, (Point *) h->vox[1].p, cnt,
+                              h->d_ctr + CTR_LEVEL0 + 1, h->d_status));
     if (cnt) HIPCHK(hipMemcpyAsync(out, h->vox[1].p, sizeof(Point) * (size_t) cnt, hipMemcpyDeviceToHost, st));
     HIPCHK(hipStreamSynchronize(st));
     h->cur = 1;
@@ -597,7 +637,7 @@ int sdmesh_voxel_field_to_triangles_raw(sdmesh_handle *h, const struct Point *vo
     SDCHK(ensure(h, h->raw, sizeof(Triangle) * 5ull * n));
     if (!direct)
         HIPCHK(launch_expand_raw(st, h->grid, (const Vertex *) h->uverts.p, (const uint32_t *) h->tri_e.p,
-                                 (const uint8_t *) h->cubeidx.p, (const uint32_t *) h->trioff.p, (uint32_t) n, (Triangle *) h->raw.p));
+                                 (const uint8_t *) h->flip.p /* weld has not run: apply flips here */, (const uint8_t *) h->cubeidx.p, (const uint32_t *) h->trioff.p, (uint32_t) n, (Triangle *) h->raw.p));
     HIPCHK(hipMemcpyAsync(out5n, h->raw.p, sizeof(Triangle) * 5ull * n, hipMemcpyDeviceToHost, st));
     SDCHK(read_back(h));
     return status_to_error(h);
@@ -618,7 +658,7 @@ int sdmesh_voxel_field_to_mesh(sdmesh_handle *h, const struct Point *voxels, siz
     bool direct = false;
     SDCHK(host_mesh_front(h, voxels, (uint32_t) n, voxel_size, direct));
     if (direct) SDCHK(weld_raw_device(h, (const Triangle *) h->raw.p, 5u * (uint32_t) n));
-    else SDCHK(mesh_weld(h, (const Vertex *) h->uverts.p, h->d_ctr + CTR_NUNIQ, h->ucap, (const uint32_t *) h->tri_e.p));
+    else SDCHK(mesh_weld(h, (const Vertex *) h->uverts.p));
     SDCHK(read_back(h));
     SDCHK(status_to_error(h));
     h->n_unique = h->h_pinned[CTR_NUNIQ];
@@ -718,7 +758,7 @@ int sdmesh_device_triangles(sdmesh_handle *h, struct Triangle *d_out, size_t cap
         HIPCHK(hipMemcpyAsync(d_out, h->compact.p, sizeof(Triangle) * (size_t) h->n_tris, hipMemcpyDeviceToDevice, h->stream));
     } else {
         HIPCHK(launch_expand_compact(h->stream, h->grid, (const Vertex *) h->uverts.p, (const uint32_t *) h->tri_e.p,
-                                     h->d_ctr + CTR_NTRI, d_out, (uint32_t) std::min<size_t>(cap, 0xFFFFFFFFu)));
+                                     nullptr /* tri_e already flipped by the weld */, h->d_ctr + CTR_NTRI, d_out, (uint32_t) std::min<size_t>(cap, 0xFFFFFFFFu)));
     }
     HIPCHK(hipStreamSynchronize(h->stream));
     return SDMESH_OK;

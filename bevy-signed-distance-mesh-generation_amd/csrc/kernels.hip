@@ -124,29 +124,57 @@ __device__ __forceinline__ uint32_t hash_find(const uint64_t *__restrict__ keys,
 }
 
 // ------------------------------------------------------------------------------------------
-// A2 refine, pass 1: 27 shared lattice samples per parent -> 8-bit child mask + per-tile count
+// A2 refine, pass 1: child masks.  One lane per (parent, lattice sample): 32 lanes per parent
+// (27 active), sign bits gathered with one wave64 ballot (2 parents per wave).  A workgroup owns
+// chunks of 32 consecutive parents (all inside one 256-parent tile) and adds the chunk's kept-child
+// count to tilecnt[tile] with a single global atomic (order independent; tilecnt is pre-zeroed).
 // ------------------------------------------------------------------------------------------
+static constexpr uint32_t MASK_CHUNK = 32;
+
 template <int SCENE>
 __global__ __launch_bounds__(256) void k_refine_mask(const Point *__restrict__ vox, const uint32_t *__restrict__ n_ptr,
                                                       Point cs /* child size = parent size / 2 */, SceneParams sp,
                                                       uint8_t *__restrict__ mask, uint32_t *__restrict__ tilecnt) {
     __shared__ uint32_t s_cnt;
     const uint32_t n = *n_ptr;
-    const uint32_t ntiles = (n + TILE - 1) / TILE;
-    for (uint32_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+    const uint32_t nchunks = (n + MASK_CHUNK - 1) / MASK_CHUNK;
+    const uint32_t grp = threadIdx.x >> 5, s = threadIdx.x & 31u;     // 8 parents per pass, sample id
+    const int ix = (int) (s / 9u), iy = (int) ((s / 3u) % 3u), iz = (int) (s % 3u);
+    for (uint32_t chunk = blockIdx.x; chunk < nchunks; chunk += gridDim.x) {
         if (threadIdx.x == 0) s_cnt = 0;
         __syncthreads();
-        const uint32_t p = tile * TILE + threadIdx.x;
-        uint32_t m = 0;
-        if (p < n) {
-            const Point b = vox[p];
-            m = refine_child_mask<SCENE>(b, cs, sp);
-            mask[p] = (uint8_t) m;
+        uint32_t local = 0;
+        Point pb[MASK_CHUNK / 8];
+#pragma unroll
+        for (uint32_t it = 0; it < MASK_CHUNK / 8; it++) {        // all loads in flight before the first eval
+            const uint32_t p = chunk * MASK_CHUNK + it * 8 + grp;
+            pb[it] = vox[p < n ? p : (n - 1)];
         }
-        const uint32_t ws = wave_sum(__popc(m));
-        if (lane_id() == 0 && ws) atomicAdd(&s_cnt, ws);
+#pragma unroll
+        for (uint32_t it = 0; it < MASK_CHUNK / 8; it++) {
+            const uint32_t p = chunk * MASK_CHUNK + it * 8 + grp;
+            bool in = false;
+            if (p < n && s < 27) {
+                const Point b = pb[it];
+                in = sdf<SCENE>(b.x + (float) ix * cs.x, b.y + (float) iy * cs.y, b.z + (float) iz * cs.z, sp) <= 0.0f;
+            }
+            const uint64_t bal = __ballot(in);
+            if (s == 0 && p < n) {
+                const uint32_t bits = (uint32_t) (bal >> (threadIdx.x & 32u)) & 0x7FFFFFFu;   // bit ix*9 + iy*3 + iz
+                uint32_t m = 0;
+#pragma unroll
+                for (int c = 0; c < 8; c++) {
+                    const int i = c >> 2, j = (c >> 1) & 1, k = c & 1;
+                    const uint32_t cnt = __popc(bits & (0x361Bu << (i * 9 + j * 3 + k)));
+                    if (cnt != 0 && cnt != 8) m |= 1u << c;
+                }
+                mask[p] = (uint8_t) m;
+                local += __popc(m);
+            }
+        }
+        if (local) atomicAdd(&s_cnt, local);
         __syncthreads();
-        if (threadIdx.x == 0) tilecnt[tile] = s_cnt;
+        if (threadIdx.x == 0 && s_cnt) atomicAdd(&tilecnt[(chunk * MASK_CHUNK) / TILE], s_cnt);
         __syncthreads();
     }
 }
@@ -173,19 +201,31 @@ __global__ __launch_bounds__(1024) void k_scan_tiles(uint32_t *__restrict__ cnt,
     }
 }
 
-// A2 refine, pass 2: ordered emit of the border children (slot order id*8 + i*4 + j*2 + k)
+// A2 refine, pass 2: ordered emit of the border children (slot order id*8 + i*4 + j*2 + k).
+// Each workgroup derives its tile's output offset from the per-tile counts itself (no scan kernel);
+// the last tile publishes the total.
 __global__ __launch_bounds__(256) void k_refine_emit(const Point *__restrict__ vox, const uint32_t *__restrict__ n_ptr,
                                                       Point cs, const uint8_t *__restrict__ mask,
-                                                      const uint32_t *__restrict__ tileoff, Point *__restrict__ out,
-                                                      uint32_t cap) {
+                                                      const uint32_t *__restrict__ tilecnt, Point *__restrict__ out,
+                                                      uint32_t cap, uint32_t *__restrict__ n_out, uint32_t *__restrict__ status) {
     __shared__ uint32_t lds[17];
     const uint32_t n = *n_ptr;
     const uint32_t ntiles = (n + TILE - 1) / TILE;
+    if (n == 0 && blockIdx.x == 0 && threadIdx.x == 0) *n_out = 0;
     for (uint32_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        uint32_t part = 0;
+        for (uint32_t i = threadIdx.x; i < tile; i += 256) part += tilecnt[i];
+        uint32_t tbase;
+        (void) block_excl_scan(part, tbase, lds);
         const uint32_t p = tile * TILE + threadIdx.x;
         const uint32_t m = p < n ? mask[p] : 0u;
         uint32_t total;
-        uint32_t o = tileoff[tile] + block_excl_scan(__popc(m), total, lds);
+        uint32_t o = tbase + block_excl_scan(__popc(m), total, lds);
+        if (tile == ntiles - 1 && threadIdx.x == 0) {
+            uint32_t tot = tbase + total;
+            if (tot > cap) { atomicOr(&status[ST_OVERFLOW], 1u); tot = cap; }
+            *n_out = tot;
+        }
         if (m) {
             const Point b = vox[p];
 #pragma unroll
@@ -203,6 +243,18 @@ __global__ __launch_bounds__(256) void k_refine_emit(const Point *__restrict__ v
             }
         }
     }
+}
+
+// total kept children = sum of the per-tile counts (single workgroup; host-API sizing pass)
+__global__ __launch_bounds__(1024) void k_sum_tiles(const uint32_t *__restrict__ tilecnt, const uint32_t *__restrict__ n_ptr,
+                                                     uint32_t *__restrict__ total_out) {
+    __shared__ uint32_t lds[17];
+    const uint32_t ntiles = (*n_ptr + TILE - 1) / TILE;
+    uint32_t part = 0;
+    for (uint32_t i = threadIdx.x; i < ntiles; i += blockDim.x) part += tilecnt[i];
+    uint32_t total;
+    (void) block_excl_scan(part, total, lds);
+    if (threadIdx.x == 0) *total_out = total;
 }
 
 // Raw 8n layout of the reference kernel (INFINITY for non-border children)
@@ -264,20 +316,19 @@ __global__ __launch_bounds__(256) void k_classify(const Point *__restrict__ vox,
 }
 
 // ------------------------------------------------------------------------------------------
-// A4-A7 mesh stage 2, fused per tile of 256 consecutive voxels (one workgroup, ~57 KB LDS):
-//   B  unique lattice edges of the tile via an LDS hash (consecutive voxels are spatial
-//      neighbours, so most of the <=4 cubes sharing an edge sit in the same tile);
-//   C  ONE Newton projection + vertex normal per tile-unique edge; 4 lanes co-operate on an
-//      edge (lane a<3 evaluates the 4-point stencil of axis a, lane 3 the centre sample), items
-//      are pulled from an LDS queue so lanes never idle behind a slow-converging neighbour;
-//   D  per triangle the centroid normal + orientation test, same 4-lane scheme;
-//   E  tile-unique vertices, per-vertex first-seen ordinal and the (flipped) corner->vertex
-//      table go to HBM with plain coalesced stores; one global atomic per tile reserves the
-//      vertex range.
-// Cross-tile duplicates of an edge carry bit-identical positions and are merged by the weld.
+// A4-A7 mesh stage 2.  Work is split by what bounds it:
+//   k_tile_dedupe   per 256-voxel tile, LDS hash: tile-unique lattice edges, corner->vertex table
+//                   (consecutive voxels are spatial neighbours, so most of the <=4 cubes sharing
+//                   an edge sit in one tile; the remaining cross-tile duplicates carry bit-identical
+//                   positions and are merged by the weld).  No SDF evaluation.
+//   k_project       all tile-unique edges of the whole field, globally balanced: 4 lanes per edge
+//                   (lane a<3 = 4-point stencil of axis a, lane 3 = centre sample), 16 edges in
+//                   flight per wave, finished groups refill from the wave's queue.
+//   k_flip          all triangles, 4 lanes each: centroid normal + orientation test.
+//   k_tile_weld_*   per tile again: first-seen ordinals in LDS, weld insert, rank, assign.
 // ------------------------------------------------------------------------------------------
-static constexpr uint32_t T_UCAP = 1024;     // tile-unique edges held in LDS
-static constexpr uint32_t T_HASH = 2048;     // LDS hash slots (load <= 0.5)
+static constexpr uint32_t T_HASH = 2048;     // LDS hash slots; a tile with more than T_UMAX unique edges takes the direct path
+static constexpr uint32_t T_UMAX = 1536;     // (a 256-voxel surface patch has ~300; 3072 is the theoretical maximum)
 static constexpr uint32_t T_TRI = 1280;      // 5 triangles x 256 voxels
 
 template <int SCENE>
@@ -285,49 +336,44 @@ __device__ __forceinline__ float stencil_lane(const f3 g, uint32_t sub, const Sc
     // lane sub<3: ((-f(+2e) + 8 f(+e)) - 8 f(-e)) + f(-2e) along axis `sub`; lane 3: f(g) in `centre`
     const float e1 = SDM_NORMAL_EPS, e2 = 2.0f * SDM_NORMAL_EPS;
     float f[4];
-#pragma unroll 1
+#pragma unroll
     for (int k = 0; k < 4; k++) {
         const float off = k == 0 ? e2 : (k == 1 ? e1 : (k == 2 ? -e1 : -e2));
         const float x = sub == 0 ? g.x + off : g.x;
         const float y = sub == 1 ? g.y + off : g.y;
         const float z = sub == 2 ? g.z + off : g.z;
         f[k] = sdf<SCENE>(x, y, z, sp);
-        if (sub == 3) { f[1] = f[2] = f[3] = f[0]; break; }
     }
     centre = f[0];
     return (-f[0] + 8.0f * f[1] - 8.0f * f[2] + f[3]);
 }
 
-template <int SCENE>
-__global__ __launch_bounds__(256) void k_mesh_tile(const Point *__restrict__ vox, const uint32_t *__restrict__ n_ptr, Point vs,
-                                                    SceneParams sp, const uint8_t *__restrict__ cubeidx,
-                                                    const uint32_t *__restrict__ tilecnt, uint32_t *__restrict__ trioff,
-                                                    uint32_t *__restrict__ tri_e, Vertex *__restrict__ uverts,
-                                                    uint32_t *__restrict__ first_ord, uint32_t ucap, uint32_t tcap,
-                                                    uint32_t *__restrict__ n_unique, uint32_t *__restrict__ ntri_out,
-                                                    uint32_t *__restrict__ status) {
+// tile descriptor: x = first vertex id, y = vertex count, z = first triangle, w = triangle count
+__global__ __launch_bounds__(256) void k_tile_dedupe(const Point *__restrict__ vox, const uint32_t *__restrict__ n_ptr, Point vs,
+                                                      const uint8_t *__restrict__ cubeidx, const uint32_t *__restrict__ tilecnt,
+                                                      uint32_t *__restrict__ trioff, uint32_t *__restrict__ tri_e,
+                                                      Vertex *__restrict__ uverts, uint4 *__restrict__ tdesc, uint32_t ucap,
+                                                      uint32_t tcap, uint32_t *__restrict__ ntri_out,
+                                                      uint32_t *__restrict__ ntiles_out, uint32_t *__restrict__ status) {
     __shared__ uint64_t s_keys[T_HASH];
     __shared__ uint16_t s_lid[T_HASH];
-    __shared__ float s_pos[T_UCAP * 3];
-    __shared__ float s_nrm[T_UCAP * 3];
-    __shared__ uint32_t s_first[T_UCAP];
     __shared__ uint16_t s_tri[T_TRI * 3];
-    __shared__ uint8_t s_flip[T_TRI];
     __shared__ uint32_t s_scan[17];
-    __shared__ uint32_t s_q, s_vbase, s_bad;
+    __shared__ uint32_t s_bad, s_full;
 
     const uint32_t n = *n_ptr;
     const uint32_t ntiles = (n + TILE - 1) / TILE;
-    const uint32_t tid = threadIdx.x, lane = lane_id(), sub = tid & 3u, gbase = lane & ~3u;
-
+    const uint32_t tid = threadIdx.x;
+    if (blockIdx.x == 0 && tid == 0) {
+        *ntiles_out = ntiles;
+        if (n == 0) *ntri_out = 0;
+    }
     for (uint32_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
-        // ---- 0: triangle base of this tile = sum of the preceding tile counts
         uint32_t part = 0;
         for (uint32_t i = tid; i < tile; i += 256) part += tilecnt[i];
         uint32_t tbase;
         (void) block_excl_scan(part, tbase, s_scan);
 
-        // ---- A: per-voxel triangle offsets, lattice coordinates, LDS init
         const uint32_t v = tile * TILE + tid;
         uint32_t ci = 0, ntri = 0;
         int mx = 0, my = 0, mz = 0;
@@ -350,37 +396,44 @@ __global__ __launch_bounds__(256) void k_mesh_tile(const Point *__restrict__ vox
             *ntri_out = tot;
         }
         for (uint32_t i = tid; i < T_HASH; i += 256) s_keys[i] = KEY_EMPTY;
-        for (uint32_t i = tid; i < T_UCAP; i += 256) s_first[i] = U32_NONE;
-        if (tid == 0) { s_q = 0; s_bad = 0; }
+        if (tid == 0) { s_bad = 0; s_full = 0; }
         __syncthreads();
         if (!lat_ok) { s_bad = 1; atomicOr(&status[ST_NOT_LATTICE], 1u); }
 
-        // ---- B1: insert every triangle corner's edge key; remember the slot per corner
+        // insert every triangle corner's edge key; remember the slot per corner
         if (ntri && lat_ok) {
             uint64_t row = MC_TRI_PACKED[ci];
             for (uint32_t c = 0; c < 3 * ntri; c++) {
                 const uint64_t key = edge_key(mx, my, mz, (int) (row & 0xF));
                 row >>= 4;
                 uint32_t s = hash_home(key, T_HASH);
-                for (uint32_t probe = 0; probe < T_HASH; probe++) {
+                bool placed = false;
+                for (uint32_t probe = 0; probe < T_HASH && !placed; probe++) {
                     const uint64_t prev = atomicCAS((unsigned long long *) &s_keys[s], (unsigned long long) KEY_EMPTY,
                                                     (unsigned long long) key);
-                    if (prev == KEY_EMPTY || prev == key) break;
-                    s = hash_next(s, T_HASH);
+                    if (prev == KEY_EMPTY || prev == key) placed = true;
+                    else s = hash_next(s, T_HASH);
                 }
+                if (!placed) s_full = 1;
                 s_tri[3 * lo + c] = (uint16_t) s;
             }
         }
         __syncthreads();
-        // ---- B2: dense local ids in slot order (deterministic), midpoints into s_pos
+        // dense local ids in slot order (deterministic)
         uint32_t occ = 0;
 #pragma unroll
         for (uint32_t k = 0; k < T_HASH / 256; k++) occ += s_keys[tid * (T_HASH / 256) + k] != KEY_EMPTY ? 1u : 0u;
         uint32_t nu;
         uint32_t lid = block_excl_scan(occ, nu, s_scan);
-        const bool tile_ok = (nu <= T_UCAP) && (s_bad == 0);
-        if (!tile_ok && nu > T_UCAP && tid == 0) atomicOr(&status[ST_TILE_OVERFLOW], 1u);
-        if (tile_ok) {
+        // vertex slots live in corner-ordinal space: tile t owns [3 * tbase, 3 * (tbase + ttri)), of which
+        // the first nu <= 3 * ttri are used -- no global allocation, no atomics
+        const uint32_t vbase = 3u * tbase;
+        const bool tile_ok = s_bad == 0;
+        if (tile_ok && (s_full || nu > T_UMAX) && tid == 0) atomicOr(&status[ST_TILE_OVERFLOW], 1u);
+        const bool fits = tile_ok && !s_full && nu <= T_UMAX && (vbase + nu <= ucap) && (tbase + ttri <= tcap);
+        if (tile_ok && !fits && tid == 0) atomicOr(&status[ST_OVERFLOW], 2u);
+        if (tid == 0) tdesc[tile] = fits ? make_uint4(vbase, nu, tbase, ttri) : make_uint4(0u, 0u, tbase, 0u);
+        if (fits) {
 #pragma unroll
             for (uint32_t k = 0; k < T_HASH / 256; k++) {
                 const uint32_t s = tid * (T_HASH / 256) + k;
@@ -388,112 +441,142 @@ __global__ __launch_bounds__(256) void k_mesh_tile(const Point *__restrict__ vox
                 if (key != KEY_EMPTY) {
                     const int kx = (int) (key & 0x1FFFFF), ky = (int) ((key >> 21) & 0x1FFFFF), kz = (int) ((key >> 42) & 0x1FFFFF);
                     // midpoint = a*0.5 + b*0.5 of the two lattice corners (marching_cubes.cu:13-16)
-                    s_pos[3 * lid + 0] = lat(kx >> 1, vs.x) * 0.5f + lat((kx + 1) >> 1, vs.x) * 0.5f;
-                    s_pos[3 * lid + 1] = lat(ky >> 1, vs.y) * 0.5f + lat((ky + 1) >> 1, vs.y) * 0.5f;
-                    s_pos[3 * lid + 2] = lat(kz >> 1, vs.z) * 0.5f + lat((kz + 1) >> 1, vs.z) * 0.5f;
+                    Point m;
+                    m.x = lat(kx >> 1, vs.x) * 0.5f + lat((kx + 1) >> 1, vs.x) * 0.5f;
+                    m.y = lat(ky >> 1, vs.y) * 0.5f + lat((ky + 1) >> 1, vs.y) * 0.5f;
+                    m.z = lat(kz >> 1, vs.z) * 0.5f + lat((kz + 1) >> 1, vs.z) * 0.5f;
+                    uverts[vbase + lid].position = m;
                     s_lid[s] = (uint16_t) lid;
                     lid++;
                 }
             }
         }
         __syncthreads();
-        if (tile_ok) {
-            // ---- B3: corner slot -> local vertex id
-            for (uint32_t i = tid; i < 3 * ttri; i += 256) s_tri[i] = s_lid[s_tri[i]];
+        if (fits)
+            for (uint32_t i = tid; i < 3 * ttri; i += 256)
+                if (tbase + i / 3u < tcap) tri_e[3u * tbase + i] = vbase + s_lid[s_tri[i]];
+        __syncthreads();
+    }
+}
 
-            // ---- C: Newton projection + vertex normal, one item per tile-unique edge, 4 lanes per item
-            {
-                bool have = false, finalize = false, done = false;
-                uint32_t item = 0;
-                int it = 0;
-                f3 g = mk(0.0f, 0.0f, 0.0f);
-                for (;;) {
-                    if (!have && !done) {
-                        uint32_t t = 0;
-                        if (sub == 0) t = atomicAdd(&s_q, 1u);
-                        item = __shfl(t, (int) gbase, 64);
-                        if (item < nu) {
-                            g = mk(s_pos[3 * item], s_pos[3 * item + 1], s_pos[3 * item + 2]);
-                            have = true; finalize = false; it = 0;
-                        } else {
-                            done = true;
-                        }
-                    }
-                    if (__ballot(have) == 0ull) break;
-                    if (have) {
-                        float centre;
-                        const float d = stencil_lane<SCENE>(g, sub, sp, centre);
-                        const float dx = __shfl(d, (int) gbase, 64), dy = __shfl(d, (int) gbase + 1, 64), dz = __shfl(d, (int) gbase + 2, 64);
-                        const float sd = __shfl(centre, (int) gbase + 3, 64);
-                        const f3 nn = normalize3(mk(dx, dy, dz));
-                        if (!finalize) {
-                            g = sub3(g, scale3(nn, sd));
-                            it++;
-                            if (fabsf(sd) <= 0.00001f) finalize = true;
-                            else if (it >= SDM_MAX_NEWTON) { finalize = true; if (sub == 0) atomicOr(&status[ST_NEWTON_CAPPED], 1u); }
-                        } else {
-                            if (sub == 0) {
-                                s_pos[3 * item] = g.x; s_pos[3 * item + 1] = g.y; s_pos[3 * item + 2] = g.z;
-                                s_nrm[3 * item] = nn.x; s_nrm[3 * item + 1] = nn.y; s_nrm[3 * item + 2] = nn.z;
-                            }
-                            have = false;
-                        }
-                    }
+// exclusive prefix of the per-tile unique-vertex counts (dense work index for k_project); total -> *nu_out
+__global__ __launch_bounds__(1024) void k_tile_prefix(const uint4 *__restrict__ tdesc, const uint32_t *__restrict__ ntiles_ptr,
+                                                       uint32_t *__restrict__ tpre, uint32_t *__restrict__ nu_out) {
+    __shared__ uint32_t lds[17];
+    const uint32_t ntiles = *ntiles_ptr;
+    uint32_t carry = 0;
+    for (uint32_t base = 0; base < ntiles; base += blockDim.x) {
+        const uint32_t i = base + threadIdx.x;
+        const uint32_t v = i < ntiles ? tdesc[i].y : 0u;
+        uint32_t total;
+        const uint32_t ex = block_excl_scan(v, total, lds);
+        if (i < ntiles) tpre[i] = carry + ex;
+        carry += total;
+    }
+    if (threadIdx.x == 0) { tpre[ntiles] = carry; *nu_out = carry; }
+}
+
+// A5/A6: closest_surface_point + vertex normal for every unique vertex; position read from and written
+// back to uverts[].position.  16 items in flight per wave (4 lanes each); finished groups refill from
+// the wave's round-robin share of the U work items; item i is mapped to its vertex slot with a binary
+// search in the tile prefix.
+template <int SCENE>
+__global__ __launch_bounds__(256) void k_project(Vertex *__restrict__ uverts, const uint4 *__restrict__ tdesc,
+                                                  const uint32_t *__restrict__ tpre, const uint32_t *__restrict__ ntiles_ptr,
+                                                  SceneParams sp, uint32_t *__restrict__ status) {
+    const uint32_t ntiles = *ntiles_ptr;
+    const uint32_t U = ntiles ? tpre[ntiles] : 0u;
+    const uint32_t lane = lane_id(), sub = lane & 3u, gbase = lane & ~3u;
+    const uint32_t nwaves = gridDim.x * (blockDim.x >> 6);
+    const uint32_t wave = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    // Work items are dealt to the waves in batches of 16 (one per 4-lane group), round robin: iteration
+    // counts are spatially correlated (slow convergence near the smooth-min blends), so a contiguous run
+    // per wave leaves half the waves idle behind the slow ones (measured: waves alive 46 % of the kernel).
+    // The wave's j-th item is item ((j / 16) * nwaves + wave) * 16 + j % 16.
+    const uint32_t nbatch = (U + 15u) >> 4;
+    if (wave >= nbatch) return;
+    const uint32_t myb = (nbatch - wave - 1u) / nwaves + 1u;          // batches owned by this wave
+    uint32_t qhead = 0;                                               // items handed out so far
+    const uint32_t qend = myb * 16u;
+    const uint64_t lt_leaders = 0x1111111111111111ull & ((1ull << gbase) - 1ull);   // leader lanes below this group
+    bool have = false, finalize = false;
+    uint32_t slot = 0;
+    int it = 0;
+    f3 g = mk(0.0f, 0.0f, 0.0f);
+    for (;;) {
+        const uint64_t need = __ballot(!have && sub == 0);
+        const uint32_t avail = qend - qhead;
+        if (need != 0ull && avail != 0u) {
+            const uint32_t rank = __popcll(need & lt_leaders);
+            const uint32_t j = qhead + rank;
+            const uint32_t item = ((j >> 4) * nwaves + wave) * 16u + (j & 15u);
+            if (!have && rank < avail && item < U) {
+                uint32_t lo = 0, hi = ntiles;                          // last tile with tpre[tile] <= item
+                while (hi - lo > 1u) {
+                    const uint32_t mid = (lo + hi) >> 1;
+                    if (tpre[mid] <= item) lo = mid; else hi = mid;
                 }
+                slot = tdesc[lo].x + (item - tpre[lo]);
+                const Point p = uverts[slot].position;
+                g = mk(p.x, p.y, p.z);
+                have = true; finalize = false; it = 0;
             }
-            __syncthreads();
-
-            // ---- D: orientation test per triangle (compute_mesh_generation.cu:102-105), 4 lanes per triangle
-            for (uint32_t tl = tid >> 2; tl < ((ttri + 63u) & ~63u); tl += 64) {
-                const bool act = tl < ttri;
-                f3 v0 = mk(0, 0, 0), v1 = v0, v2 = v0, c = v0;
-                uint32_t l0 = 0, l1 = 0, l2 = 0;
-                if (act) {
-                    l0 = s_tri[3 * tl]; l1 = s_tri[3 * tl + 1]; l2 = s_tri[3 * tl + 2];
-                    v0 = mk(s_pos[3 * l0], s_pos[3 * l0 + 1], s_pos[3 * l0 + 2]);
-                    v1 = mk(s_pos[3 * l1], s_pos[3 * l1 + 1], s_pos[3 * l1 + 2]);
-                    v2 = mk(s_pos[3 * l2], s_pos[3 * l2 + 1], s_pos[3 * l2 + 2]);
-                    const f3 s = add3(add3(v0, v1), v2);
-                    c = mk(s.x / 3.0f, s.y / 3.0f, s.z / 3.0f);
-                }
-                float centre;
-                const float d = (act && sub < 3) ? stencil_lane<SCENE>(c, sub, sp, centre) : 0.0f;
-                const float dx = __shfl(d, (int) gbase, 64), dy = __shfl(d, (int) gbase + 1, 64), dz = __shfl(d, (int) gbase + 2, 64);
-                if (act && sub == 0) {
-                    const f3 an = normalize3(mk(dx, dy, dz));
-                    const f3 tn = normalize3(cross3(sub3(v1, v0), sub3(v2, v0)));
-                    const bool flip = dot3(tn, an) <= 0.0f;
-                    s_flip[tl] = flip ? 1 : 0;
-                    atomicMin(&s_first[flip ? l2 : l0], 3 * tl + 0);
-                    atomicMin(&s_first[l1], 3 * tl + 1);
-                    atomicMin(&s_first[flip ? l0 : l2], 3 * tl + 2);
-                }
-            }
-            __syncthreads();
-
-            // ---- E: publish
-            if (tid == 0) s_vbase = atomicAdd(n_unique, nu);
-            __syncthreads();
-            const uint32_t vbase = s_vbase;
-            if (vbase + nu > ucap) {
-                if (tid == 0) atomicOr(&status[ST_OVERFLOW], 2u);
+            const uint32_t want = __popcll(need);
+            qhead += want < avail ? want : avail;
+        }
+        if (__ballot(have) == 0ull) break;
+        if (have) {
+            float centre;
+            const float d = stencil_lane<SCENE>(g, sub, sp, centre);
+            const float dx = __shfl(d, (int) gbase, 64), dy = __shfl(d, (int) gbase + 1, 64), dz = __shfl(d, (int) gbase + 2, 64);
+            const float sd = __shfl(centre, (int) gbase + 3, 64);
+            const f3 nn = normalize3(mk(dx, dy, dz));
+            if (!finalize) {
+                g = sub3(g, scale3(nn, sd));
+                it++;
+                if (fabsf(sd) <= 0.00001f) finalize = true;
+                else if (it >= SDM_MAX_NEWTON) { finalize = true; if (sub == 0) atomicOr(&status[ST_NEWTON_CAPPED], 1u); }
             } else {
-                for (uint32_t i = tid; i < nu; i += 256) {
+                if (sub == 0) {
                     Vertex o;
-                    o.position.x = s_pos[3 * i]; o.position.y = s_pos[3 * i + 1]; o.position.z = s_pos[3 * i + 2];
-                    o.normal.x = s_nrm[3 * i]; o.normal.y = s_nrm[3 * i + 1]; o.normal.z = s_nrm[3 * i + 2];
-                    uverts[vbase + i] = o;
-                    const uint32_t f = s_first[i];
-                    first_ord[vbase + i] = f == U32_NONE ? U32_NONE : 3u * tbase + f;
+                    o.position.x = g.x; o.position.y = g.y; o.position.z = g.z;
+                    o.normal.x = nn.x; o.normal.y = nn.y; o.normal.z = nn.z;
+                    uverts[slot] = o;
                 }
-                for (uint32_t i = tid; i < 3 * ttri; i += 256) {
-                    const uint32_t tl = i / 3u, q = i - 3u * tl;
-                    const uint32_t qq = s_flip[tl] ? 2u - q : q;
-                    if (tbase + tl < tcap) tri_e[3u * (tbase + tl) + q] = vbase + s_tri[3 * tl + qq];
-                }
+                have = false;
             }
         }
-        __syncthreads();
+    }
+}
+
+// A7 orientation test (compute_mesh_generation.cu:102-105) for every triangle: 3 lanes per triangle
+// (lane a = 4-point stencil of axis a at the centroid), 21 triangles per wave
+template <int SCENE>
+__global__ __launch_bounds__(256) void k_flip(const Vertex *__restrict__ uverts, const uint32_t *__restrict__ tri_e,
+                                               const uint32_t *__restrict__ ntri_ptr, SceneParams sp, uint8_t *__restrict__ flip) {
+    const uint32_t T = *ntri_ptr;
+    const uint32_t lane = lane_id(), g3 = lane / 3u, sub = lane - 3u * g3, gbase = 3u * g3;   // lane 63: g3 = 21, unused
+    const uint32_t nwaves = gridDim.x * (blockDim.x >> 6);
+    const uint32_t wave = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    for (uint32_t t0 = wave * 21u; t0 < T; t0 += nwaves * 21u) {
+        const uint32_t t = t0 + g3;
+        const bool act = (g3 < 21u) && (t < T);
+        f3 v0 = mk(0, 0, 0), v1 = v0, v2 = v0, c = v0;
+        if (act) {
+            const Point p0 = uverts[tri_e[3 * t]].position, p1 = uverts[tri_e[3 * t + 1]].position, p2 = uverts[tri_e[3 * t + 2]].position;
+            v0 = mk(p0.x, p0.y, p0.z); v1 = mk(p1.x, p1.y, p1.z); v2 = mk(p2.x, p2.y, p2.z);
+            const f3 s = add3(add3(v0, v1), v2);
+            c = mk(s.x / 3.0f, s.y / 3.0f, s.z / 3.0f);
+        }
+        float centre;
+        const float d = act ? stencil_lane<SCENE>(c, sub, sp, centre) : 0.0f;
+        const int gb = (int) (gbase < 61u ? gbase : 60u);
+        const float dx = __shfl(d, gb, 64), dy = __shfl(d, gb + 1, 64), dz = __shfl(d, gb + 2, 64);
+        if (act && sub == 0) {
+            const f3 an = normalize3(mk(dx, dy, dz));
+            const f3 tn = normalize3(cross3(sub3(v1, v0), sub3(v2, v0)));
+            flip[t] = dot3(tn, an) <= 0.0f ? 1 : 0;
+        }
     }
 }
 
@@ -505,96 +588,162 @@ __global__ __launch_bounds__(256) void k_first_ord(const uint32_t *__restrict__ 
         atomicMin(&first_ord[tri_e[o]], o);
 }
 
+// tile descriptors for a plain triangle list (generic weld): tiles of 256 triangles, every corner
+// its own vertex (tri_e = identity), no flips
+__global__ __launch_bounds__(256) void k_raw_desc(const uint32_t *__restrict__ ntri_ptr, uint4 *__restrict__ tdesc,
+                                                   uint8_t *__restrict__ flip, uint32_t *__restrict__ ntiles_out,
+                                                   uint32_t *__restrict__ nu_out) {
+    const uint32_t T = *ntri_ptr, ntiles = (T + 255u) / 256u;
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < T; i += gridDim.x * blockDim.x) flip[i] = 0;
+    for (uint32_t t = blockIdx.x * blockDim.x + threadIdx.x; t < ntiles; t += gridDim.x * blockDim.x) {
+        const uint32_t tt = T - 256u * t < 256u ? T - 256u * t : 256u;
+        tdesc[t] = make_uint4(768u * t, 3u * tt, 256u * t, tt);
+    }
+    if (blockIdx.x == 0 && threadIdx.x == 0) { *ntiles_out = ntiles; *nu_out = 3u * T; }
+}
+
 // ------------------------------------------------------------------------------------------
-// A8 weld (src/cuda/mod.rs:263-296) on the unique-vertex list.
+// A8 weld (src/cuda/mod.rs:263-296), per tile.
 //   key   = 3 x 21-bit biased round(x * 1e5)  (covers +-10.48 units; bounding cube is +-2.5)
 //   The vertex that claims a slot records its first-seen ordinal with a plain store (wfirst);
 //   only vertices that find the key already present pay an atomicMin (wmin).  The first-seen
 //   ordinal of a key is min(wfirst, wmin): order independent.
+// k_tile_weld_insert also applies the orientation flips to tri_e and derives each tile vertex's
+// first-seen ordinal with LDS atomics.
 // ------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_weld_insert(const Vertex *__restrict__ uverts, const uint32_t *__restrict__ nu_ptr,
-                                                      uint32_t ucap, const uint32_t *__restrict__ first_ord,
-                                                      uint64_t *__restrict__ wkeys, uint32_t *__restrict__ wmin,
-                                                      uint32_t *__restrict__ wfirst, uint32_t wsize,
-                                                      uint32_t *__restrict__ vslot, uint32_t *__restrict__ status) {
-    uint32_t U = *nu_ptr;
-    if (U > ucap) U = ucap;
-    for (uint32_t e = blockIdx.x * blockDim.x + threadIdx.x; e < U; e += gridDim.x * blockDim.x) {
-        const uint32_t fo = first_ord[e];
-        uint32_t slot = U32_NONE;
-        if (fo != U32_NONE) {
-            const Point p = uverts[e].position;
-            const long long qx = weld_quant(p.x) + 1048576LL, qy = weld_quant(p.y) + 1048576LL, qz = weld_quant(p.z) + 1048576LL;
-            if (((unsigned long long) qx | (unsigned long long) qy | (unsigned long long) qz) >> 21) {
-                atomicOr(&status[ST_WELD_RANGE], 1u);
-            } else {
-                const uint64_t key = (uint64_t) qx | ((uint64_t) qy << 21) | ((uint64_t) qz << 42);
-                uint32_t s = hash_home(key, wsize);
-                for (uint32_t probe = 0; probe < wsize; probe++) {
-                    const uint64_t prev = atomicCAS((unsigned long long *) &wkeys[s], (unsigned long long) KEY_EMPTY,
-                                                    (unsigned long long) key);
-                    if (prev == KEY_EMPTY) { slot = s; wfirst[s] = fo; break; }
-                    if (prev == key) { slot = s; atomicMin(&wmin[s], fo); break; }
-                    s = hash_next(s, wsize);
+static constexpr uint32_t T_VMAX = 3072;
+
+__global__ __launch_bounds__(256) void k_tile_weld_insert(const Vertex *__restrict__ uverts, const uint4 *__restrict__ tdesc,
+                                                           const uint32_t *__restrict__ ntiles_ptr, uint32_t *__restrict__ tri_e,
+                                                           const uint8_t *__restrict__ flip, uint32_t *__restrict__ first_ord,
+                                                           uint64_t *__restrict__ wkeys, uint32_t *__restrict__ wmin,
+                                                           uint32_t *__restrict__ wfirst, uint32_t wsize,
+                                                           uint32_t *__restrict__ vslot, uint32_t *__restrict__ status) {
+    __shared__ uint32_t s_first[T_VMAX];
+    const uint32_t ntiles = *ntiles_ptr, tid = threadIdx.x;
+    for (uint32_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        const uint4 d = tdesc[tile];
+        const uint32_t vbase = d.x, nu = d.y, tbase = d.z, ttri = d.w;
+        for (uint32_t i = tid; i < nu; i += 256) s_first[i] = U32_NONE;
+        __syncthreads();
+        for (uint32_t tl = tid; tl < ttri; tl += 256) {
+            const uint32_t t = tbase + tl;
+            uint32_t e0 = tri_e[3 * t], e1 = tri_e[3 * t + 1], e2 = tri_e[3 * t + 2];
+            if (flip[t]) {
+                const uint32_t x = e0; e0 = e2; e2 = x;
+                tri_e[3 * t] = e0; tri_e[3 * t + 2] = e2;
+            }
+            atomicMin(&s_first[e0 - vbase], 3 * tl + 0);
+            atomicMin(&s_first[e1 - vbase], 3 * tl + 1);
+            atomicMin(&s_first[e2 - vbase], 3 * tl + 2);
+        }
+        __syncthreads();
+        for (uint32_t i = tid; i < nu; i += 256) {
+            const uint32_t e = vbase + i, lf = s_first[i];
+            const uint32_t fo = lf == U32_NONE ? U32_NONE : 3u * tbase + lf;
+            first_ord[e] = fo;
+            uint32_t slot = U32_NONE;
+            if (fo != U32_NONE) {
+                const Point p = uverts[e].position;
+                const long long qx = weld_quant(p.x) + 1048576LL, qy = weld_quant(p.y) + 1048576LL, qz = weld_quant(p.z) + 1048576LL;
+                if (((unsigned long long) qx | (unsigned long long) qy | (unsigned long long) qz) >> 21) {
+                    atomicOr(&status[ST_WELD_RANGE], 1u);
+                } else {
+                    const uint64_t key = (uint64_t) qx | ((uint64_t) qy << 21) | ((uint64_t) qz << 42);
+                    uint32_t s = hash_home(key, wsize);
+                    for (uint32_t probe = 0; probe < wsize; probe++) {
+                        const uint64_t prev = atomicCAS((unsigned long long *) &wkeys[s], (unsigned long long) KEY_EMPTY,
+                                                        (unsigned long long) key);
+                        if (prev == KEY_EMPTY) { slot = s; wfirst[s] = fo; break; }
+                        if (prev == key) { slot = s; atomicMin(&wmin[s], fo); break; }
+                        s = hash_next(s, wsize);
+                    }
+                    if (slot == U32_NONE) atomicOr(&status[ST_OVERFLOW], 8u);
                 }
-                if (slot == U32_NONE) atomicOr(&status[ST_OVERFLOW], 8u);
+            }
+            vslot[e] = slot;
+        }
+        __syncthreads();
+    }
+}
+
+__device__ __forceinline__ bool is_first(uint32_t e, const uint32_t *first_ord, const uint32_t *wmin, const uint32_t *wfirst,
+                                         const uint32_t *vslot, uint32_t &fo, uint32_t &slot) {
+    slot = vslot[e];
+    if (slot == U32_NONE) return false;
+    fo = first_ord[e];
+    const uint32_t a = wfirst[slot], b = wmin[slot];
+    return (a < b ? a : b) == fo;
+}
+
+// number of first-seen vertices per tile
+__global__ __launch_bounds__(256) void k_tile_weld_count(const uint4 *__restrict__ tdesc, const uint32_t *__restrict__ ntiles_ptr,
+                                                          const uint32_t *__restrict__ first_ord, const uint32_t *__restrict__ wmin,
+                                                          const uint32_t *__restrict__ wfirst, const uint32_t *__restrict__ vslot,
+                                                          uint32_t *__restrict__ tfirst) {
+    __shared__ uint32_t s_cnt;
+    const uint32_t ntiles = *ntiles_ptr, tid = threadIdx.x;
+    for (uint32_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        const uint4 d = tdesc[tile];
+        if (tid == 0) s_cnt = 0;
+        __syncthreads();
+        uint32_t c = 0;
+        for (uint32_t i = tid; i < d.y; i += 256) {
+            uint32_t fo, slot;
+            c += is_first(d.x + i, first_ord, wmin, wfirst, vslot, fo, slot) ? 1u : 0u;
+        }
+        c = wave_sum(c);
+        if (lane_id() == 0 && c) atomicAdd(&s_cnt, c);
+        __syncthreads();
+        if (tid == 0) tfirst[tile] = s_cnt;
+        __syncthreads();
+    }
+}
+
+// welded index of every first-seen vertex = (firsts of earlier tiles) + rank by ordinal inside the tile
+__global__ __launch_bounds__(256) void k_tile_weld_assign(const Vertex *__restrict__ uverts, const uint4 *__restrict__ tdesc,
+                                                           const uint32_t *__restrict__ ntiles_ptr, const uint32_t *__restrict__ tfirst,
+                                                           const uint32_t *__restrict__ first_ord, const uint32_t *__restrict__ wmin,
+                                                           const uint32_t *__restrict__ wfirst, const uint32_t *__restrict__ vslot,
+                                                           uint32_t *__restrict__ wvidx, Vertex *__restrict__ vertices, uint32_t vcap,
+                                                           uint32_t *__restrict__ nverts_out, uint32_t *__restrict__ status) {
+    __shared__ uint32_t s_bits[3 * T_TRI / 32];      // 120 words: one bit per local ordinal
+    __shared__ uint32_t s_pre[3 * T_TRI / 32];
+    __shared__ uint32_t s_scan[17];
+    const uint32_t ntiles = *ntiles_ptr, tid = threadIdx.x;
+    if (ntiles == 0 && blockIdx.x == 0 && tid == 0) *nverts_out = 0;
+    for (uint32_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        const uint4 d = tdesc[tile];
+        uint32_t part = 0;
+        for (uint32_t i = tid; i < tile; i += 256) part += tfirst[i];
+        uint32_t base;
+        (void) block_excl_scan(part, base, s_scan);
+        if (tid < 3 * T_TRI / 32) s_bits[tid] = 0;
+        __syncthreads();
+        for (uint32_t i = tid; i < d.y; i += 256) {
+            uint32_t fo, slot;
+            if (is_first(d.x + i, first_ord, wmin, wfirst, vslot, fo, slot)) {
+                const uint32_t lo = fo - 3u * d.z;
+                atomicOr(&s_bits[lo >> 5], 1u << (lo & 31u));
             }
         }
-        vslot[e] = slot;
-    }
-}
-
-__global__ __launch_bounds__(256) void k_weld_mark(const uint32_t *__restrict__ nu_ptr, uint32_t ucap,
-                                                    const uint32_t *__restrict__ first_ord, const uint32_t *__restrict__ wmin,
-                                                    const uint32_t *__restrict__ wfirst, const uint32_t *__restrict__ vslot,
-                                                    uint32_t *__restrict__ bitmap) {
-    uint32_t U = *nu_ptr;
-    if (U > ucap) U = ucap;
-    for (uint32_t e = blockIdx.x * blockDim.x + threadIdx.x; e < U; e += gridDim.x * blockDim.x) {
-        const uint32_t s = vslot[e];
-        if (s == U32_NONE) continue;
-        const uint32_t fo = first_ord[e];
-        const uint32_t a = wfirst[s], b = wmin[s];
-        if ((a < b ? a : b) == fo) atomicOr(&bitmap[fo >> 5], 1u << (fo & 31u));
-    }
-}
-
-// exclusive scan of popcounts over the first-seen bitmap (3T bits); total -> n_verts.
-// Single workgroup; every thread owns a contiguous run of words (sum, block scan, rewrite).
-__global__ __launch_bounds__(1024) void k_scan_bitmap(const uint32_t *__restrict__ bitmap, const uint32_t *__restrict__ ntri_ptr,
-                                                       uint32_t *__restrict__ wordpre, uint32_t *__restrict__ nverts_out) {
-    __shared__ uint32_t lds[17];
-    const uint32_t nwords = (3u * *ntri_ptr + 31u) >> 5;
-    const uint32_t per = (nwords + blockDim.x - 1) / blockDim.x;
-    const uint32_t lo = threadIdx.x * per, hi = lo + per < nwords ? lo + per : nwords;
-    uint32_t sum = 0;
-    for (uint32_t i = lo; i < hi; i++) sum += __popc(bitmap[i]);
-    uint32_t total;
-    uint32_t run = block_excl_scan(sum, total, lds);
-    for (uint32_t i = lo; i < hi; i++) {
-        wordpre[i] = run;
-        run += __popc(bitmap[i]);
-    }
-    if (threadIdx.x == 0) *nverts_out = total;
-}
-
-__global__ __launch_bounds__(256) void k_weld_assign(const Vertex *__restrict__ uverts, const uint32_t *__restrict__ nu_ptr,
-                                                      uint32_t ucap, const uint32_t *__restrict__ first_ord,
-                                                      const uint32_t *__restrict__ wmin, const uint32_t *__restrict__ wfirst,
-                                                      const uint32_t *__restrict__ vslot, const uint32_t *__restrict__ bitmap,
-                                                      const uint32_t *__restrict__ wordpre, uint32_t *__restrict__ wvidx,
-                                                      Vertex *__restrict__ vertices, uint32_t vcap, uint32_t *__restrict__ status) {
-    uint32_t U = *nu_ptr;
-    if (U > ucap) U = ucap;
-    for (uint32_t e = blockIdx.x * blockDim.x + threadIdx.x; e < U; e += gridDim.x * blockDim.x) {
-        const uint32_t s = vslot[e];
-        if (s == U32_NONE) continue;
-        const uint32_t fo = first_ord[e];
-        const uint32_t a = wfirst[s], b = wmin[s];
-        if ((a < b ? a : b) != fo) continue;
-        const uint32_t vi = wordpre[fo >> 5] + __popc(bitmap[fo >> 5] & ((1u << (fo & 31u)) - 1u));
-        wvidx[s] = vi;
-        if (vi < vcap) vertices[vi] = uverts[e]; else atomicOr(&status[ST_OVERFLOW], 16u);
+        __syncthreads();
+        uint32_t total;
+        const uint32_t w = tid < 3 * T_TRI / 32 ? __popc(s_bits[tid]) : 0u;
+        const uint32_t ex = block_excl_scan(w, total, s_scan);
+        if (tid < 3 * T_TRI / 32) s_pre[tid] = ex;
+        __syncthreads();
+        if (tile == ntiles - 1 && tid == 0) *nverts_out = base + total;
+        for (uint32_t i = tid; i < d.y; i += 256) {
+            uint32_t fo, slot;
+            if (is_first(d.x + i, first_ord, wmin, wfirst, vslot, fo, slot)) {
+                const uint32_t lo = fo - 3u * d.z;
+                const uint32_t vi = base + s_pre[lo >> 5] + __popc(s_bits[lo >> 5] & ((1u << (lo & 31u)) - 1u));
+                wvidx[slot] = vi;
+                if (vi < vcap) vertices[vi] = uverts[d.x + i]; else atomicOr(&status[ST_OVERFLOW], 16u);
+            }
+        }
+        __syncthreads();
     }
 }
 
@@ -612,26 +761,32 @@ __global__ __launch_bounds__(256) void k_weld_index(const uint32_t *__restrict__
 // layout converters
 // ------------------------------------------------------------------------------------------
 // compact triangle list (72 B each, emission order) from (uverts, tri_e)
+// (flip == nullptr: tri_e already holds the final corner order, i.e. the weld has run)
 __global__ __launch_bounds__(256) void k_expand_compact(const Vertex *__restrict__ uverts, const uint32_t *__restrict__ tri_e,
-                                                         const uint32_t *__restrict__ ntri_ptr, Triangle *__restrict__ out,
-                                                         uint32_t cap) {
+                                                         const uint8_t *__restrict__ flip, const uint32_t *__restrict__ ntri_ptr,
+                                                         Triangle *__restrict__ out, uint32_t cap) {
     uint32_t n3 = 3u * *ntri_ptr;
     if (n3 > 3u * cap) n3 = 3u * cap;
     Vertex *o = reinterpret_cast<Vertex *>(out);
-    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n3; i += gridDim.x * blockDim.x) o[i] = uverts[tri_e[i]];
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n3; i += gridDim.x * blockDim.x) {
+        const uint32_t t = i / 3u, q = i - 3u * t;
+        const uint32_t qq = (flip && flip[t]) ? 2u - q : q;
+        o[i] = uverts[tri_e[3u * t + qq]];
+    }
 }
 
 // reference raw layout: 5 slots per voxel, NaN/zero padded (compute_mesh_generation.cu:116-118)
 __global__ __launch_bounds__(256) void k_expand_raw(const Vertex *__restrict__ uverts, const uint32_t *__restrict__ tri_e,
-                                                     const uint8_t *__restrict__ cubeidx, const uint32_t *__restrict__ trioff,
-                                                     uint32_t n, Triangle *__restrict__ out) {
+                                                     const uint8_t *__restrict__ flip, const uint8_t *__restrict__ cubeidx,
+                                                     const uint32_t *__restrict__ trioff, uint32_t n, Triangle *__restrict__ out) {
     const uint32_t total = n * 5u;
     for (uint32_t s = blockIdx.x * blockDim.x + threadIdx.x; s < total; s += gridDim.x * blockDim.x) {
         const uint32_t v = s / 5u, j = s - v * 5u;
         Triangle t;
         if (j < MC_TRI_COUNT[cubeidx[v]]) {
-            const uint32_t o = 3u * (trioff[v] + j);
-            t.vertices[0] = uverts[tri_e[o]]; t.vertices[1] = uverts[tri_e[o + 1]]; t.vertices[2] = uverts[tri_e[o + 2]];
+            const uint32_t tt = trioff[v] + j, o = 3u * tt;
+            const bool f = flip && flip[tt];
+            t.vertices[0] = uverts[tri_e[f ? o + 2 : o]]; t.vertices[1] = uverts[tri_e[o + 1]]; t.vertices[2] = uverts[tri_e[f ? o : o + 2]];
         } else {
             nan_pad(t);
         }
@@ -792,8 +947,14 @@ hipError_t launch_scan_tiles(hipStream_t st, uint32_t *cnt, const uint32_t *n_pt
 }
 
 hipError_t launch_refine_emit(hipStream_t st, int grid, const Point *vox, const uint32_t *n_ptr, Point cs,
-                              const uint8_t *mask, const uint32_t *tileoff, Point *out, uint32_t cap) {
-    hipLaunchKernelGGL(k_refine_emit, dim3(grid), dim3(256), 0, st, vox, n_ptr, cs, mask, tileoff, out, cap);
+                              const uint8_t *mask, const uint32_t *tilecnt, Point *out, uint32_t cap, uint32_t *n_out,
+                              uint32_t *status) {
+    hipLaunchKernelGGL(k_refine_emit, dim3(grid), dim3(256), 0, st, vox, n_ptr, cs, mask, tilecnt, out, cap, n_out, status);
+    return hipGetLastError();
+}
+
+hipError_t launch_sum_tiles(hipStream_t st, const uint32_t *tilecnt, const uint32_t *n_ptr, uint32_t *total_out) {
+    hipLaunchKernelGGL(k_sum_tiles, dim3(1), dim3(1024), 0, st, tilecnt, n_ptr, total_out);
     return hipGetLastError();
 }
 
@@ -809,12 +970,34 @@ hipError_t launch_classify(hipStream_t st, int grid, int scene, const SceneParam
     return hipGetLastError();
 }
 
-hipError_t launch_mesh_tile(hipStream_t st, int grid, int scene, const SceneParams &sp, const Point *vox,
-                            const uint32_t *n_ptr, Point vs, const uint8_t *cubeidx, const uint32_t *tilecnt,
-                            uint32_t *trioff, uint32_t *tri_e, Vertex *uverts, uint32_t *first_ord, uint32_t ucap,
-                            uint32_t tcap, uint32_t *n_unique, uint32_t *ntri_out, uint32_t *status) {
-    SDM_DISPATCH(scene, hipLaunchKernelGGL(k_mesh_tile<S>, dim3(grid), dim3(256), 0, st, vox, n_ptr, vs, sp, cubeidx, tilecnt,
-                                           trioff, tri_e, uverts, first_ord, ucap, tcap, n_unique, ntri_out, status));
+hipError_t launch_tile_dedupe(hipStream_t st, int grid, const Point *vox, const uint32_t *n_ptr, Point vs, const uint8_t *cubeidx,
+                              const uint32_t *tilecnt, uint32_t *trioff, uint32_t *tri_e, Vertex *uverts, uint4 *tdesc,
+                              uint32_t ucap, uint32_t tcap, uint32_t *ntri_out, uint32_t *ntiles_out, uint32_t *status) {
+    hipLaunchKernelGGL(k_tile_dedupe, dim3(grid), dim3(256), 0, st, vox, n_ptr, vs, cubeidx, tilecnt, trioff, tri_e, uverts, tdesc,
+                       ucap, tcap, ntri_out, ntiles_out, status);
+    return hipGetLastError();
+}
+
+hipError_t launch_tile_prefix(hipStream_t st, const uint4 *tdesc, const uint32_t *ntiles_ptr, uint32_t *tpre, uint32_t *nu_out) {
+    hipLaunchKernelGGL(k_tile_prefix, dim3(1), dim3(1024), 0, st, tdesc, ntiles_ptr, tpre, nu_out);
+    return hipGetLastError();
+}
+
+hipError_t launch_project(hipStream_t st, int grid, int scene, const SceneParams &sp, Vertex *uverts, const uint4 *tdesc,
+                          const uint32_t *tpre, const uint32_t *ntiles_ptr, uint32_t *status) {
+    SDM_DISPATCH(scene, hipLaunchKernelGGL(k_project<S>, dim3(grid), dim3(256), 0, st, uverts, tdesc, tpre, ntiles_ptr, sp, status));
+    return hipGetLastError();
+}
+
+hipError_t launch_flip(hipStream_t st, int grid, int scene, const SceneParams &sp, const Vertex *uverts, const uint32_t *tri_e,
+                       const uint32_t *ntri_ptr, uint8_t *flip) {
+    SDM_DISPATCH(scene, hipLaunchKernelGGL(k_flip<S>, dim3(grid), dim3(256), 0, st, uverts, tri_e, ntri_ptr, sp, flip));
+    return hipGetLastError();
+}
+
+hipError_t launch_raw_desc(hipStream_t st, int grid, const uint32_t *ntri_ptr, uint4 *tdesc, uint8_t *flip, uint32_t *ntiles_out,
+                           uint32_t *nu_out) {
+    hipLaunchKernelGGL(k_raw_desc, dim3(grid), dim3(256), 0, st, ntri_ptr, tdesc, flip, ntiles_out, nu_out);
     return hipGetLastError();
 }
 
@@ -823,30 +1006,28 @@ hipError_t launch_first_ord(hipStream_t st, int grid, const uint32_t *tri_e, con
     return hipGetLastError();
 }
 
-hipError_t launch_weld(hipStream_t st, int grid, const Vertex *uverts, const uint32_t *nu_ptr, uint32_t ucap,
-                       const uint32_t *tri_e, const uint32_t *ntri_ptr, const uint32_t *first_ord, uint64_t *wkeys,
-                       uint32_t *wmin, uint32_t *wfirst, uint32_t wsize, uint32_t *vslot, uint32_t *bitmap,
-                       uint32_t *wordpre, uint32_t *wvidx, Vertex *vertices, uint32_t vcap, uint32_t *nverts_out,
-                       uint32_t *indices, uint32_t *status) {
-    hipLaunchKernelGGL(k_weld_insert, dim3(grid), dim3(256), 0, st, uverts, nu_ptr, ucap, first_ord, wkeys, wmin, wfirst, wsize,
-                       vslot, status);
-    hipLaunchKernelGGL(k_weld_mark, dim3(grid), dim3(256), 0, st, nu_ptr, ucap, first_ord, wmin, wfirst, vslot, bitmap);
-    hipLaunchKernelGGL(k_scan_bitmap, dim3(1), dim3(1024), 0, st, bitmap, ntri_ptr, wordpre, nverts_out);
-    hipLaunchKernelGGL(k_weld_assign, dim3(grid), dim3(256), 0, st, uverts, nu_ptr, ucap, first_ord, wmin, wfirst, vslot, bitmap,
-                       wordpre, wvidx, vertices, vcap, status);
+hipError_t launch_weld(hipStream_t st, int grid, const Vertex *uverts, const uint4 *tdesc, const uint32_t *ntiles_ptr,
+                       uint32_t *tri_e, const uint8_t *flip, const uint32_t *ntri_ptr, uint32_t *first_ord, uint64_t *wkeys,
+                       uint32_t *wmin, uint32_t *wfirst, uint32_t wsize, uint32_t *vslot, uint32_t *tfirst, uint32_t *wvidx,
+                       Vertex *vertices, uint32_t vcap, uint32_t *nverts_out, uint32_t *indices, uint32_t *status) {
+    hipLaunchKernelGGL(k_tile_weld_insert, dim3(grid), dim3(256), 0, st, uverts, tdesc, ntiles_ptr, tri_e, flip, first_ord, wkeys,
+                       wmin, wfirst, wsize, vslot, status);
+    hipLaunchKernelGGL(k_tile_weld_count, dim3(grid), dim3(256), 0, st, tdesc, ntiles_ptr, first_ord, wmin, wfirst, vslot, tfirst);
+    hipLaunchKernelGGL(k_tile_weld_assign, dim3(grid), dim3(256), 0, st, uverts, tdesc, ntiles_ptr, tfirst, first_ord, wmin, wfirst,
+                       vslot, wvidx, vertices, vcap, nverts_out, status);
     hipLaunchKernelGGL(k_weld_index, dim3(grid), dim3(256), 0, st, tri_e, ntri_ptr, vslot, wvidx, indices);
     return hipGetLastError();
 }
 
-hipError_t launch_expand_compact(hipStream_t st, int grid, const Vertex *uverts, const uint32_t *tri_e,
+hipError_t launch_expand_compact(hipStream_t st, int grid, const Vertex *uverts, const uint32_t *tri_e, const uint8_t *flip,
                                  const uint32_t *ntri_ptr, Triangle *out, uint32_t cap) {
-    hipLaunchKernelGGL(k_expand_compact, dim3(grid), dim3(256), 0, st, uverts, tri_e, ntri_ptr, out, cap);
+    hipLaunchKernelGGL(k_expand_compact, dim3(grid), dim3(256), 0, st, uverts, tri_e, flip, ntri_ptr, out, cap);
     return hipGetLastError();
 }
 
-hipError_t launch_expand_raw(hipStream_t st, int grid, const Vertex *uverts, const uint32_t *tri_e, const uint8_t *cubeidx,
-                             const uint32_t *trioff, uint32_t n, Triangle *out) {
-    hipLaunchKernelGGL(k_expand_raw, dim3(grid), dim3(256), 0, st, uverts, tri_e, cubeidx, trioff, n, out);
+hipError_t launch_expand_raw(hipStream_t st, int grid, const Vertex *uverts, const uint32_t *tri_e, const uint8_t *flip,
+                             const uint8_t *cubeidx, const uint32_t *trioff, uint32_t n, Triangle *out) {
+    hipLaunchKernelGGL(k_expand_raw, dim3(grid), dim3(256), 0, st, uverts, tri_e, flip, cubeidx, trioff, n, out);
     return hipGetLastError();
 }
 

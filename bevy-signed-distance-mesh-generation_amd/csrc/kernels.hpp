@@ -16,7 +16,7 @@ enum StatusWord : int {
     ST_WELD_RANGE = 2,      // a vertex lies outside +-10.48 units (21-bit weld key)
     ST_NEWTON_CAPPED = 3,   // informational: closest_surface_point hit the 10 000-iteration cap
     ST_INTERNAL = 4,        // invariant violated
-    ST_TILE_OVERFLOW = 5,   // a 256-voxel tile has > 1024 unique edges -> host takes the direct path
+    ST_TILE_OVERFLOW = 5,   // a 256-voxel tile has more unique edges than the LDS hash holds -> host takes the direct path
     ST_WORDS = 8
 };
 
@@ -25,25 +25,32 @@ hipError_t launch_refine_mask(hipStream_t st, int grid, int scene, const ScenePa
 hipError_t launch_scan_tiles(hipStream_t st, uint32_t *cnt, const uint32_t *n_ptr, uint32_t items_per_tile,
                              uint32_t *total_out, uint32_t cap, uint32_t *status);
 hipError_t launch_refine_emit(hipStream_t st, int grid, const Point *vox, const uint32_t *n_ptr, Point cs,
-                              const uint8_t *mask, const uint32_t *tileoff, Point *out, uint32_t cap);
+                              const uint8_t *mask, const uint32_t *tilecnt, Point *out, uint32_t cap, uint32_t *n_out,
+                              uint32_t *status);
+hipError_t launch_sum_tiles(hipStream_t st, const uint32_t *tilecnt, const uint32_t *n_ptr, uint32_t *total_out);
 hipError_t launch_refine_expand_raw(hipStream_t st, int grid, const Point *vox, uint32_t n, Point cs, const uint8_t *mask,
                                     Point *out);
 hipError_t launch_classify(hipStream_t st, int grid, int scene, const SceneParams &sp, const Point *vox,
                            const uint32_t *n_ptr, Point vs, uint8_t *cubeidx, uint32_t *tilecnt);
-hipError_t launch_mesh_tile(hipStream_t st, int grid, int scene, const SceneParams &sp, const Point *vox,
-                            const uint32_t *n_ptr, Point vs, const uint8_t *cubeidx, const uint32_t *tilecnt,
-                            uint32_t *trioff, uint32_t *tri_e, Vertex *uverts, uint32_t *first_ord, uint32_t ucap,
-                            uint32_t tcap, uint32_t *n_unique, uint32_t *ntri_out, uint32_t *status);
+hipError_t launch_tile_dedupe(hipStream_t st, int grid, const Point *vox, const uint32_t *n_ptr, Point vs, const uint8_t *cubeidx,
+                              const uint32_t *tilecnt, uint32_t *trioff, uint32_t *tri_e, Vertex *uverts, uint4 *tdesc,
+                              uint32_t ucap, uint32_t tcap, uint32_t *ntri_out, uint32_t *ntiles_out, uint32_t *status);
+hipError_t launch_tile_prefix(hipStream_t st, const uint4 *tdesc, const uint32_t *ntiles_ptr, uint32_t *tpre, uint32_t *nu_out);
+hipError_t launch_project(hipStream_t st, int grid, int scene, const SceneParams &sp, Vertex *uverts, const uint4 *tdesc,
+                          const uint32_t *tpre, const uint32_t *ntiles_ptr, uint32_t *status);
+hipError_t launch_flip(hipStream_t st, int grid, int scene, const SceneParams &sp, const Vertex *uverts, const uint32_t *tri_e,
+                       const uint32_t *ntri_ptr, uint8_t *flip);
+hipError_t launch_raw_desc(hipStream_t st, int grid, const uint32_t *ntri_ptr, uint4 *tdesc, uint8_t *flip, uint32_t *ntiles_out,
+                           uint32_t *nu_out);
 hipError_t launch_first_ord(hipStream_t st, int grid, const uint32_t *tri_e, const uint32_t *ntri_ptr, uint32_t *first_ord);
-hipError_t launch_weld(hipStream_t st, int grid, const Vertex *uverts, const uint32_t *nu_ptr, uint32_t ucap,
-                       const uint32_t *tri_e, const uint32_t *ntri_ptr, const uint32_t *first_ord, uint64_t *wkeys,
-                       uint32_t *wmin, uint32_t *wfirst, uint32_t wsize, uint32_t *vslot, uint32_t *bitmap,
-                       uint32_t *wordpre, uint32_t *wvidx, Vertex *vertices, uint32_t vcap, uint32_t *nverts_out,
-                       uint32_t *indices, uint32_t *status);
-hipError_t launch_expand_compact(hipStream_t st, int grid, const Vertex *uverts, const uint32_t *tri_e,
+hipError_t launch_weld(hipStream_t st, int grid, const Vertex *uverts, const uint4 *tdesc, const uint32_t *ntiles_ptr,
+                       uint32_t *tri_e, const uint8_t *flip, const uint32_t *ntri_ptr, uint32_t *first_ord, uint64_t *wkeys,
+                       uint32_t *wmin, uint32_t *wfirst, uint32_t wsize, uint32_t *vslot, uint32_t *tfirst, uint32_t *wvidx,
+                       Vertex *vertices, uint32_t vcap, uint32_t *nverts_out, uint32_t *indices, uint32_t *status);
+hipError_t launch_expand_compact(hipStream_t st, int grid, const Vertex *uverts, const uint32_t *tri_e, const uint8_t *flip,
                                  const uint32_t *ntri_ptr, Triangle *out, uint32_t cap);
-hipError_t launch_expand_raw(hipStream_t st, int grid, const Vertex *uverts, const uint32_t *tri_e, const uint8_t *cubeidx,
-                             const uint32_t *trioff, uint32_t n, Triangle *out);
+hipError_t launch_expand_raw(hipStream_t st, int grid, const Vertex *uverts, const uint32_t *tri_e, const uint8_t *flip,
+                             const uint8_t *cubeidx, const uint32_t *trioff, uint32_t n, Triangle *out);
 hipError_t launch_triangles_direct(hipStream_t st, int scene, const SceneParams &sp, const Point *vox, uint32_t n, Point vs,
                                    Triangle *out);
 hipError_t launch_sample_dense(hipStream_t st, int grid, int scene, const SceneParams &sp, float *out, uint32_t N, bool nt);
