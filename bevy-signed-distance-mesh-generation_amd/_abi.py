@@ -71,6 +71,7 @@ SYMBOLS = {
     "sdmesh_device_voxels": (_i, [_vp, ctypes.POINTER(VoxelField)]),
     "sdmesh_device_triangles": (_i, [_vp, _vp, _sz, _psz]),
     "sdmesh_weld_device_triangles": (_i, [_vp, _vp, _sz, ctypes.POINTER(RegenInfo)]),
+    "sdmesh_column_triangle_counts": (_i, [_vp, _vp]),
     "sdmesh_download_mesh": (_i, [_vp, _vp, _vp]),
     "sdmesh_download_voxels": (_i, [_vp, _vp]),
     "sdmesh_sample_dense": (_i, [_vp, _u32, _vp, ctypes.POINTER(ctypes.c_float)]),

@@ -51,6 +51,8 @@ struct sdmesh_handle {
     SceneParams sp{};
     int grid = 1024;           // workgroups per grid-stride launch (4 per CU)
     int force_direct = 0;
+    int skip_weld = 0;         // regen stops after the orientation test (multi-GPU ranks: the root welds)
+    bool welded = false;       // tri_e holds the final corner order
     uint32_t min_chunk = 128;  // unique edges per wave queue in k_project
     int dense_grid = 16384;    // workgroups for k_sample_dense
     int dense_nt = 1;          // nontemporal stores in k_sample_dense
@@ -366,7 +368,7 @@ int regen_impl(sdmesh_handle *h, int levels, int mode, int part, int nparts, sdm
         bool direct = h->force_direct != 0;
         if (!direct) {
             SDCHK(mesh_front(h, d_vox, n_ptr, vs, false));
-            SDCHK(mesh_weld(h, (const Vertex *) h->uverts.p));
+            if (!h->skip_weld) SDCHK(mesh_weld(h, (const Vertex *) h->uverts.p));
         }
         HIPCHK(hipEventRecord(h->ev1, st));
         SDCHK(read_back(h));
@@ -379,7 +381,7 @@ int regen_impl(sdmesh_handle *h, int levels, int mode, int part, int nparts, sdm
             SDCHK(layout_mesh(h, n_cap, c[CTR_NUNIQ] + 1024));
             SDCHK(zero_status(h));
             SDCHK(mesh_front(h, d_vox, n_ptr, vs, true));
-            SDCHK(mesh_weld(h, (const Vertex *) h->uverts.p));
+            if (!h->skip_weld) SDCHK(mesh_weld(h, (const Vertex *) h->uverts.p));
             HIPCHK(hipEventRecord(h->ev1, st));
             SDCHK(read_back(h));
             if (s[ST_OVERFLOW]) return fail(h, SDMESH_ERR_INTERNAL, "capacity overflow persists (status %u)", s[ST_OVERFLOW]);
@@ -405,6 +407,7 @@ int regen_impl(sdmesh_handle *h, int levels, int mode, int part, int nparts, sdm
         h->voxel_size = vs;
         h->mesh_valid = h->vox_valid = true;
         h->last_direct = direct;
+        h->welded = direct || !h->skip_weld;
         if (!direct) {
             h->plan_valid = true;
             h->plan_scene = h->scene; h->plan_levels = levels; h->plan_mode = mode; h->plan_part = part; h->plan_nparts = nparts;
@@ -533,6 +536,7 @@ int sdmesh_set_stream(sdmesh_handle *h, void *hip_stream) {
 int sdmesh_set_option(sdmesh_handle *h, const char *name, int value) {
     if (!h || !name) return SDMESH_ERR_INVALID;
     if (!strcmp(name, "direct")) { h->force_direct = value ? 1 : 0; h->plan_valid = false; return SDMESH_OK; }
+    if (!strcmp(name, "skip_weld")) { h->skip_weld = value ? 1 : 0; return SDMESH_OK; }
     if (!strcmp(name, "grid")) {
         if (value < 1 || value > 65535) return fail(h, SDMESH_ERR_INVALID, "grid out of range");
         h->grid = value;
@@ -665,6 +669,8 @@ int sdmesh_voxel_field_to_mesh(sdmesh_handle *h, const struct Point *voxels, siz
     h->n_tris = h->h_pinned[CTR_NTRI];
     h->n_verts = h->h_pinned[CTR_NVERT];
     h->mesh_valid = true;
+    h->welded = true;
+    h->last_direct = direct;
     *n_verts = h->n_verts;
     *n_tris = h->n_tris;
     if (verts || tris) {
@@ -713,6 +719,7 @@ int sdmesh_weld_device_triangles(sdmesh_handle *h, const struct Triangle *d_raw,
     h->n_tris = nslots ? h->h_pinned[CTR_NTRI] : 0;
     h->n_verts = nslots ? h->h_pinned[CTR_NVERT] : 0;
     h->mesh_valid = true;
+    h->welded = true;
     float ms = 0.0f;
     HIPCHK(hipEventElapsedTime(&ms, h->ev0, h->ev1));
     fill_info(h, info, 0, true, ms);
@@ -729,7 +736,7 @@ int sdmesh_regen_part(sdmesh_handle *h, int levels, int mode, int part, int npar
 
 int sdmesh_device_mesh(sdmesh_handle *h, struct Mesh *mesh, uint32_t *n_tris) {
     if (!h || !mesh) return SDMESH_ERR_INVALID;
-    if (!h->mesh_valid) return fail(h, SDMESH_ERR_INVALID, "no mesh on the device");
+    if (!h->mesh_valid || !h->welded) return fail(h, SDMESH_ERR_INVALID, "no welded mesh on the device");
     mesh->vertices = (Vertex *) h->vertices.p;
     mesh->vertex_count = h->n_verts;
     mesh->triangles = (IndexTriangle *) h->indices.p;
@@ -758,7 +765,22 @@ int sdmesh_device_triangles(sdmesh_handle *h, struct Triangle *d_out, size_t cap
         HIPCHK(hipMemcpyAsync(d_out, h->compact.p, sizeof(Triangle) * (size_t) h->n_tris, hipMemcpyDeviceToDevice, h->stream));
     } else {
         HIPCHK(launch_expand_compact(h->stream, h->grid, (const Vertex *) h->uverts.p, (const uint32_t *) h->tri_e.p,
-                                     nullptr /* tri_e already flipped by the weld */, h->d_ctr + CTR_NTRI, d_out, (uint32_t) std::min<size_t>(cap, 0xFFFFFFFFu)));
+                                     h->welded ? nullptr : (const uint8_t *) h->flip.p /* the weld applies the flips to tri_e */, h->d_ctr + CTR_NTRI, d_out, (uint32_t) std::min<size_t>(cap, 0xFFFFFFFFu)));
+    }
+    HIPCHK(hipStreamSynchronize(h->stream));
+    return SDMESH_OK;
+}
+
+int sdmesh_column_triangle_counts(sdmesh_handle *h, uint32_t *d_counts) {
+    if (!h || !d_counts) return SDMESH_ERR_INVALID;
+    if (!h->mesh_valid || !h->vox_valid) return fail(h, SDMESH_ERR_INVALID, "no regen result on the device");
+    if (h->last_direct) return fail(h, SDMESH_ERR_INVALID, "column counts need the lattice path");
+    const size_t bytes = sizeof(uint32_t) * MESH_GENERATION_INIT_FACTOR * MESH_GENERATION_INIT_FACTOR;
+    HIPCHK(hipMemsetAsync(d_counts, 0, bytes, h->stream));
+    if (h->n_vox) {
+        HIPCHK(launch_set_u32(h->stream, h->d_ctr + CTR_SCRATCH, h->n_vox));
+        HIPCHK(launch_column_counts(h->stream, std::min(h->grid, (int) tiles(h->n_vox)), (const Point *) h->vox[h->cur].p,
+                                    h->d_ctr + CTR_SCRATCH, (const uint8_t *) h->cubeidx.p, d_counts));
     }
     HIPCHK(hipStreamSynchronize(h->stream));
     return SDMESH_OK;

@@ -869,6 +869,32 @@ __global__ __launch_bounds__(256) void k_raw_compact(const Triangle *__restrict_
     }
 }
 
+// ------------------------------------------------------------------------------------------
+// multi-GPU order restoration: triangles per level-0 (x0, y0) column of this rank's list.
+// The global order has z0 as the least significant level-0 digit, so z-slabs interleave per column;
+// the per-column counts of every rank are all the merge needs.
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_column_counts(const Point *__restrict__ vox, const uint32_t *__restrict__ n_ptr,
+                                                        const uint8_t *__restrict__ cubeidx, uint32_t *__restrict__ colcnt) {
+    __shared__ uint32_t s_hist[MESH_GENERATION_INIT_FACTOR * MESH_GENERATION_INIT_FACTOR];
+    const uint32_t n = *n_ptr, F = MESH_GENERATION_INIT_FACTOR;
+    const float cell = MESH_GENERATION_BB_SIZE / (float) MESH_GENERATION_INIT_FACTOR;
+    for (uint32_t i = threadIdx.x; i < F * F; i += blockDim.x) s_hist[i] = 0;
+    __syncthreads();
+    for (uint32_t v = blockIdx.x * blockDim.x + threadIdx.x; v < n; v += gridDim.x * blockDim.x) {
+        const uint32_t nt = MC_TRI_COUNT[cubeidx[v]];
+        if (nt) {
+            const Point b = vox[v];
+            uint32_t x0 = (uint32_t) floorf((b.x + 2.5f) / cell), y0 = (uint32_t) floorf((b.y + 2.5f) / cell);
+            x0 = x0 < F ? x0 : F - 1; y0 = y0 < F ? y0 : F - 1;
+            atomicAdd(&s_hist[x0 * F + y0], nt);
+        }
+    }
+    __syncthreads();
+    for (uint32_t i = threadIdx.x; i < F * F; i += blockDim.x)
+        if (s_hist[i]) atomicAdd(&colcnt[i], s_hist[i]);
+}
+
 __global__ void k_set_u32(uint32_t *p, uint32_t v) { *p = v; }
 __global__ void k_mul3_u32(const uint32_t *a, uint32_t *out) { *out = 3u * *a; }
 
@@ -1059,6 +1085,12 @@ hipError_t launch_raw_count(hipStream_t st, int grid, const Triangle *raw, const
 hipError_t launch_raw_compact(hipStream_t st, int grid, const Triangle *raw, const uint32_t *n_ptr, const uint32_t *tileoff,
                               Triangle *out, uint32_t *tri_e, uint32_t cap) {
     hipLaunchKernelGGL(k_raw_compact, dim3(grid), dim3(256), 0, st, raw, n_ptr, tileoff, out, tri_e, cap);
+    return hipGetLastError();
+}
+
+hipError_t launch_column_counts(hipStream_t st, int grid, const Point *vox, const uint32_t *n_ptr, const uint8_t *cubeidx,
+                                uint32_t *colcnt) {
+    hipLaunchKernelGGL(k_column_counts, dim3(grid), dim3(256), 0, st, vox, n_ptr, cubeidx, colcnt);
     return hipGetLastError();
 }
 

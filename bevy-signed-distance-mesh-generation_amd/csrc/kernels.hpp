@@ -58,6 +58,8 @@ hipError_t launch_create_field(hipStream_t st, Point *vox, uint32_t z0, uint32_t
 hipError_t launch_raw_count(hipStream_t st, int grid, const Triangle *raw, const uint32_t *n_ptr, uint32_t *tilecnt);
 hipError_t launch_raw_compact(hipStream_t st, int grid, const Triangle *raw, const uint32_t *n_ptr, const uint32_t *tileoff,
                               Triangle *out, uint32_t *tri_e, uint32_t cap);
+hipError_t launch_column_counts(hipStream_t st, int grid, const Point *vox, const uint32_t *n_ptr, const uint8_t *cubeidx,
+                                uint32_t *colcnt);
 hipError_t launch_set_u32(hipStream_t st, uint32_t *p, uint32_t v);
 hipError_t launch_mul3_u32(hipStream_t st, const uint32_t *a, uint32_t *out);
 

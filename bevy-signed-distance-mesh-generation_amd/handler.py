@@ -201,6 +201,9 @@ class CudaHandler:
         self._chk(self._lib.sdmesh_device_triangles(self._h, None, 0, ctypes.byref(n)))
         return n.value
 
+    def column_triangle_counts_into(self, dev_ptr):
+        self._chk(self._lib.sdmesh_column_triangle_counts(self._h, ctypes.c_void_p(dev_ptr)))
+
     def weld_device_triangles(self, dev_ptr, nslots):
         info = RegenInfo()
         self._chk(self._lib.sdmesh_weld_device_triangles(self._h, ctypes.c_void_p(dev_ptr), int(nslots),

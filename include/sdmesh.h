@@ -79,7 +79,8 @@ int sdmesh_set_scene(sdmesh_handle *h, int scene, const float *params, int npara
 /* Run on a caller-owned hipStream_t (e.g. torch's current stream); NULL = the handle's own. */
 int sdmesh_set_stream(sdmesh_handle *h, void *hip_stream);
 /* Options: "direct" = 1 forces the per-corner projection path (no edge sharing) for A/B runs;
- * "grid" = workgroups per grid-stride launch. */
+ * "grid" = workgroups per grid-stride launch; "skip_weld" = 1 makes sdmesh_regen* stop after the orientation
+ * test (a multi-GPU rank exports sdmesh_device_triangles and the root welds). */
 int sdmesh_set_option(sdmesh_handle *h, const char *name, int value);
 
 /* ---- host-buffer API (B2) ----------------------------------------------------------------- */
@@ -134,6 +135,11 @@ int sdmesh_device_triangles(sdmesh_handle *h, struct Triangle *d_out, size_t cap
 /* Weld a compact/raw slot list that already lives on the DEVICE (root of the multi-GPU gather). */
 int sdmesh_weld_device_triangles(sdmesh_handle *h, const struct Triangle *d_raw, size_t nslots,
                                  sdmesh_regen_info *info);
+
+/* Triangles of the last regen per level-0 (x0, y0) column, index x0 * 32 + y0, written to a DEVICE array of
+ * 32 * 32 u32.  With every rank's counts the z-slab lists can be merged back into the single-GPU order
+ * (z0 is the least significant level-0 digit of the order key, so slabs interleave per column). */
+int sdmesh_column_triangle_counts(sdmesh_handle *h, uint32_t *d_counts);
 
 int sdmesh_download_mesh(sdmesh_handle *h, struct Vertex *verts, struct IndexTriangle *tris);
 int sdmesh_download_voxels(sdmesh_handle *h, struct Point *voxels);
