@@ -49,8 +49,20 @@ struct f3 {
 };
 
 SDM_HD f3 mk(float x, float y, float z) { f3 r; r.x = x; r.y = y; r.z = z; return r; }
-SDM_HD float gmin(float a, float b) { return (b < a) ? b : a; }
+SDM_HD float gmin(float a, float b) { return (b < a) ? b : a; }      // glm::min / glm::max, exact semantics
 SDM_HD float gmax(float a, float b) { return (a < b) ? b : a; }
+// Single-instruction min/max/clamp (v_min_f32 / v_max_f32 / v_med3_f32).  They differ from glm::min/max only
+// for NaN operands and in the sign of a zero result; they are used only where the operands are finite and a
+// -0 cannot occur (sums of squares, distances minus positive constants), so the values are identical.
+SDM_HD float fmin1(float a, float b) { return __builtin_fminf(a, b); }
+SDM_HD float fmax1(float a, float b) { return __builtin_fmaxf(a, b); }
+SDM_HD float clamp1(float t, float lo, float hi) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __builtin_amdgcn_fmed3f(t, lo, hi);
+#else
+    return __builtin_fminf(__builtin_fmaxf(t, lo), hi);
+#endif
+}
 SDM_HD float dot3(f3 a, f3 b) { return (a.x * b.x + a.y * b.y) + a.z * b.z; }
 SDM_HD f3 sub3(f3 a, f3 b) { return mk(a.x - b.x, a.y - b.y, a.z - b.z); }
 SDM_HD f3 add3(f3 a, f3 b) { return mk(a.x + b.x, a.y + b.y, a.z + b.z); }
@@ -61,17 +73,20 @@ SDM_HD f3 cross3(f3 x, f3 y) {
 }
 
 SDM_HD float smooth_min(float a, float b, float k) {
-    float h = gmax(k - fabsf(a - b), 0.0f) / k;
-    return gmin(a, b) - h * h * h * k * (1.0f / 6.0f);
+    // (fmax1/fmin1: k - |a-b| and a, b are finite; if a == b both forms return the same value, and a zero h has
+    // no effect on the result whatever its sign)
+    float h = fmax1(k - fabsf(a - b), 0.0f) / k;
+    return fmin1(a, b) - h * h * h * k * (1.0f / 6.0f);
 }
 
 // Squared residual along a bar's own axis: t = p - b0 (b0 = lo), bar length len.
 //   t < 0   -> closest point b0            -> e = p - lo
 //   t > len -> closest point b0 + len      -> e = p - (lo + len)   (lo + len is exact)
 //   else    -> closest point b0 + t        -> e = p - (lo + t)     (rounding residue, kept)
+// All three cases are lo + clamp(t, 0, len): lo + 0 == lo exactly (lo is never -0).
 SDM_HD float along_sq(float p, float lo, float len) {
     float t = p - lo;
-    float q = (t < 0.0f) ? lo : ((t > len) ? (lo + len) : (lo + t));
+    float q = lo + clamp1(t, 0.0f, len);
     float e = p - q;
     return e * e;
 }
@@ -92,13 +107,13 @@ SDM_HD float skeleton_min_d2(float px, float py, float pz) {
 
     // each d2 is (ex^2 + ey^2) + ez^2 in x, y, z order, as glm::dot evaluates it
     const float x0 = ax + ym05, x1 = ax + yp05;
-    float m = gmin(x0 + zm025, x0 + zp025);
-    m = gmin(m, gmin(x1 + zm025, x1 + zp025));
+    float m = fmin1(x0 + zm025, x0 + zp025);
+    m = fmin1(m, fmin1(x1 + zm025, x1 + zp025));
     const float y0 = xm15 + ay, y1 = xp15 + ay;
-    m = gmin(m, gmin(y0 + zm025, y0 + zp275));
-    m = gmin(m, gmin(y1 + zm025, y1 + zp275));
-    m = gmin(m, gmin((xm15 + ym05) + az, (xm15 + yp05) + az));
-    m = gmin(m, gmin((xm05 + ym05) + az, (xm05 + yp05) + az));
+    m = fmin1(m, fmin1(y0 + zm025, y0 + zp275));
+    m = fmin1(m, fmin1(y1 + zm025, y1 + zp275));
+    m = fmin1(m, fmin1((xm15 + ym05) + az, (xm15 + yp05) + az));
+    m = fmin1(m, fmin1((xm05 + ym05) + az, (xm05 + yp05) + az));
     return m;
 }
 
@@ -162,12 +177,12 @@ struct RowCtx {
         } else if (SCENE == SCENE_SDOBJ || SCENE == SCENE_ANIM) {
             const float az = along_sq(pz, -0.25f, 0.5f);
             const float zm025 = sq(pz - (-0.25f)), zp025 = sq(pz - 0.25f), zp275 = sq(pz - 2.75f);
-            float m = gmin(a[0] + zm025, a[0] + zp025);
-            m = gmin(m, gmin(a[1] + zm025, a[1] + zp025));
-            m = gmin(m, gmin(a[2] + zm025, a[2] + zp275));
-            m = gmin(m, gmin(a[3] + zm025, a[3] + zp275));
-            m = gmin(m, gmin(a[4] + az, a[5] + az));
-            m = gmin(m, gmin(a[6] + az, a[7] + az));
+            float m = fmin1(a[0] + zm025, a[0] + zp025);
+            m = fmin1(m, fmin1(a[1] + zm025, a[1] + zp025));
+            m = fmin1(m, fmin1(a[2] + zm025, a[2] + zp275));
+            m = fmin1(m, fmin1(a[3] + zm025, a[3] + zp275));
+            m = fmin1(m, fmin1(a[4] + az, a[5] + az));
+            m = fmin1(m, fmin1(a[6] + az, a[7] + az));
             const float a1 = sqrtf(m) - 0.1f;
             float sy = py;
             if (SCENE == SCENE_ANIM) sy = py - sp.p[0];
