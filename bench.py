@@ -35,6 +35,9 @@ import torch.distributed as dist  # noqa: E402
 import sdmesh_pkg  # noqa: E402
 
 HBM_PEAK_GBPS = 8000.0          # MI355X_MICROARCH.md "HBM3E peak BW 8.0 TB/s spec"
+# HBM bytes per P1 launch at N = 512 from the PMC passes committed under profiles/ (WRITE_SIZE 527 366 KiB exact for
+# 16-B streaming stores + 2 x FETCH_SIZE ~0.1 MB, gfx950 correction): equal to the algorithmic 4 B x 513^3.
+P1_TRAFFIC_512 = 527366 * 1024 + 2 * 54 * 1024
 
 
 def host_cores():
@@ -229,7 +232,8 @@ def main():
             ms = h.time_kernel(0, n_grid, buf.data_ptr(), 50)
             gbps = alg_bytes / (ms * 1e-3) / 1e9
             roofs[sc] = {"bound": "hbm", "kernel": f"k_sample_dense<{sc}>", "achieved": round(gbps, 1), "peak": HBM_PEAK_GBPS,
-                         "unit": "GB/s", "frac": round(gbps / HBM_PEAK_GBPS, 4), "traffic": None,
+                         "unit": "GB/s", "frac": round(gbps / HBM_PEAK_GBPS, 4),
+                         "traffic": P1_TRAFFIC_512 if n_grid == 512 else None,
                          "bytes_per_launch": alg_bytes, "avg_launch_ms": round(ms, 5),
                          "gsamples_per_s": round((n_grid + 1) ** 3 / (ms * 1e-3) / 1e9, 1)}
         h.set_scene(args.scene, params)
