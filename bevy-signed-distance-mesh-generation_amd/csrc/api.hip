@@ -47,6 +47,8 @@ struct sdmesh_handle {
     hipStream_t own_stream = nullptr;
     hipStream_t stream = nullptr;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    hipStream_t side = nullptr;                 // side stream: hash-table memset and weld claim overlap the main chain
+    hipEvent_t ev_fork = nullptr, ev_join = nullptr, ev_ff = nullptr;
     int scene = SDMESH_SCENE_SDOBJ;
     SceneParams sp{};
     int grid = 1024;           // workgroups per grid-stride launch (4 per CU)
@@ -68,7 +70,7 @@ struct sdmesh_handle {
     uint32_t *d_status = nullptr;  // ST_WORDS
     uint32_t *h_pinned = nullptr;  // CTR_WORDS + ST_WORDS, pinned
     // mesh stage
-    DevBuf cubeidx, trioff, ff_arena, first_ord_buf, wfirst, uverts, tri_e, vslot, tdesc, tfirst, tpre, flip, wvidx;
+    DevBuf cubeidx, trioff, ff_arena, first_ord_buf, wfirst, uverts, tri_e, vslot, tdesc, tfirst, tfpre, tpre, flip, wvidx, torder;
     DevBuf vertices, indices, raw, compact, staging;
     // capacities the device chain was laid out for
     uint32_t cap_vox = 0, ucap = 0, tcap = 0, wsize = 0;
@@ -154,6 +156,8 @@ int layout_mesh(sdmesh_handle *h, uint32_t n_cap, uint32_t u_cap_hint) {
     SDCHK(ensure(h, h->tdesc, 16ull * (tiles(n_cap) + tiles(tcap) + 16)));
     SDCHK(ensure(h, h->tfirst, 4ull * (tiles(n_cap) + tiles(tcap) + 16)));
     SDCHK(ensure(h, h->tpre, 4ull * (tiles(n_cap) + tiles(tcap) + 16)));
+    SDCHK(ensure(h, h->tfpre, 4ull * (tiles(n_cap) + tiles(tcap) + 16)));
+    SDCHK(ensure(h, h->torder, 4ull * ucap));
     SDCHK(ensure(h, h->flip, (size_t) tcap + 64));
     SDCHK(ensure(h, h->wvidx, 4ull * wsize));
     SDCHK(ensure(h, h->wfirst, 4ull * wsize));
@@ -176,9 +180,10 @@ size_t ff_bytes(const sdmesh_handle *h) {
 
 // classify -> tile dedupe -> project -> flip for the voxel list d_vox (count at *n_ptr, at most cap_vox):
 // leaves (uverts, tri_e, flip, trioff, tdesc) and the counters NUNIQ / NTRI / NTILES on the device
-int mesh_front(sdmesh_handle *h, const Point *d_vox, const uint32_t *n_ptr, Point vs, bool zero_counters) {
+int mesh_front(sdmesh_handle *h, const Point *d_vox, const uint32_t *n_ptr, Point vs, bool zero_counters, bool ff_done = false) {
     hipStream_t st = h->stream;
-    HIPCHK(hipMemsetAsync(h->ff_arena.p, 0xFF, ff_bytes(h), st));
+    if (!ff_done) HIPCHK(hipMemsetAsync(h->ff_arena.p, 0xFF, ff_bytes(h), st));
+    else HIPCHK(hipStreamWaitEvent(st, h->ev_ff, 0));          // table was cleared on the side stream during the refine
     if (zero_counters) HIPCHK(hipMemsetAsync(h->d_ctr + CTR_NUNIQ, 0, 4 * sizeof(uint32_t), st));
     HIPCHK(launch_classify(st, h->grid, h->scene, h->sp, d_vox, n_ptr, vs, (uint8_t *) h->cubeidx.p, (uint32_t *) h->tilecnt.p));
     HIPCHK(launch_tile_dedupe(st, h->grid, d_vox, n_ptr, vs, (const uint8_t *) h->cubeidx.p, (const uint32_t *) h->tilecnt.p,
@@ -187,8 +192,15 @@ int mesh_front(sdmesh_handle *h, const Point *d_vox, const uint32_t *n_ptr, Poin
     HIPCHK(launch_tile_prefix(st, (const uint4 *) h->tdesc.p, h->d_ctr + CTR_NTILES, (uint32_t *) h->tpre.p, h->d_ctr + CTR_NUNIQ));
     HIPCHK(launch_project(st, h->grid, h->scene, h->sp, (Vertex *) h->uverts.p, (const uint4 *) h->tdesc.p,
                           (const uint32_t *) h->tpre.p, h->d_ctr + CTR_NTILES, h->d_status));
+    // fork: the weld claim (scattered CAS, latency-bound) runs beside the orientation test (VALU-bound)
+    HIPCHK(hipEventRecord(h->ev_fork, st));
+    HIPCHK(hipStreamWaitEvent(h->side, h->ev_fork, 0));
+    HIPCHK(launch_tile_claim(h->side, h->grid, (const Vertex *) h->uverts.p, (const uint4 *) h->tdesc.p, h->d_ctr + CTR_NTILES,
+                             h->wkeys, h->wsize, (uint32_t *) h->vslot.p, h->d_status));
+    HIPCHK(hipEventRecord(h->ev_join, h->side));
     HIPCHK(launch_flip(st, h->grid, h->scene, h->sp, (const Vertex *) h->uverts.p, (const uint32_t *) h->tri_e.p,
                        h->d_ctr + CTR_NTRI, (uint8_t *) h->flip.p));
+    HIPCHK(hipStreamWaitEvent(st, h->ev_join, 0));
     return SDMESH_OK;
 }
 
@@ -196,9 +208,10 @@ int mesh_front(sdmesh_handle *h, const Point *d_vox, const uint32_t *n_ptr, Poin
 int mesh_weld(sdmesh_handle *h, const Vertex *uverts) {
     hipStream_t st = h->stream;
     HIPCHK(launch_weld(st, h->grid, uverts, (const uint4 *) h->tdesc.p, h->d_ctr + CTR_NTILES, (uint32_t *) h->tri_e.p,
-                       (const uint8_t *) h->flip.p, h->d_ctr + CTR_NTRI, h->first_ord, h->wkeys, h->wmin, (uint32_t *) h->wfirst.p,
-                       h->wsize, (uint32_t *) h->vslot.p, (uint32_t *) h->tfirst.p, (uint32_t *) h->wvidx.p, (Vertex *) h->vertices.p,
-                       (uint32_t) (h->vertices.cap / sizeof(Vertex)), h->d_ctr + CTR_NVERT, (uint32_t *) h->indices.p, h->d_status));
+                       (const uint8_t *) h->flip.p, h->first_ord, h->wmin, (uint32_t *) h->wfirst.p, (const uint32_t *) h->vslot.p,
+                       (uint32_t *) h->wvidx.p, (uint32_t *) h->torder.p, (uint32_t *) h->tfirst.p, (uint32_t *) h->tfpre.p,
+                       (Vertex *) h->vertices.p, (uint32_t) (h->vertices.cap / sizeof(Vertex)), h->d_ctr + CTR_NVERT,
+                       (uint32_t *) h->indices.p, h->d_status));
     return SDMESH_OK;
 }
 
@@ -265,6 +278,8 @@ int weld_raw_device(sdmesh_handle *h, const Triangle *d_raw, uint32_t nslots) {
                               (Triangle *) h->compact.p, (uint32_t *) h->tri_e.p, nslots));
     HIPCHK(launch_raw_desc(st, h->grid, h->d_ctr + CTR_NTRI, (uint4 *) h->tdesc.p, (uint8_t *) h->flip.p, h->d_ctr + CTR_NTILES,
                            h->d_ctr + CTR_NUNIQ));
+    HIPCHK(launch_tile_claim(st, h->grid, (const Vertex *) h->compact.p, (const uint4 *) h->tdesc.p, h->d_ctr + CTR_NTILES,
+                             h->wkeys, h->wsize, (uint32_t *) h->vslot.p, h->d_status));
     SDCHK(mesh_weld(h, (const Vertex *) h->compact.p));
     return SDMESH_OK;
 }
@@ -344,6 +359,12 @@ int regen_impl(sdmesh_handle *h, int levels, int mode, int part, int nparts, sdm
             SDCHK(ensure_ctl(h, lvl_words));
         }
         HIPCHK(hipEventRecord(h->ev0, st));
+        if (async) {
+            // the weld table (layout known from the plan) is cleared on the side stream while the refine runs
+            HIPCHK(hipStreamWaitEvent(h->side, h->ev0, 0));
+            HIPCHK(hipMemsetAsync(h->ff_arena.p, 0xFF, ff_bytes(h), h->side));
+            HIPCHK(hipEventRecord(h->ev_ff, h->side));
+        }
         SDCHK(zero_ctl(h, lvl_words));
         Point vs;
         vs.x = vs.y = vs.z = MESH_GENERATION_BB_SIZE / (float) MESH_GENERATION_INIT_FACTOR;
@@ -367,7 +388,7 @@ int regen_impl(sdmesh_handle *h, int levels, int mode, int part, int nparts, sdm
         const uint32_t *n_ptr = h->d_ctr + CTR_LEVEL0 + levels;
         bool direct = h->force_direct != 0;
         if (!direct) {
-            SDCHK(mesh_front(h, d_vox, n_ptr, vs, false));
+            SDCHK(mesh_front(h, d_vox, n_ptr, vs, false, async));
             if (!h->skip_weld) SDCHK(mesh_weld(h, (const Vertex *) h->uverts.p));
         }
         HIPCHK(hipEventRecord(h->ev1, st));
@@ -488,6 +509,10 @@ int sdmesh_create(int device, sdmesh_handle **out) {
     h->stream = h->own_stream;
     if ((e = hipEventCreate(&h->ev0)) != hipSuccess) return bail(e, "hipEventCreate");
     if ((e = hipEventCreate(&h->ev1)) != hipSuccess) return bail(e, "hipEventCreate");
+    if ((e = hipStreamCreateWithFlags(&h->side, hipStreamNonBlocking)) != hipSuccess) return bail(e, "hipStreamCreate");
+    if ((e = hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming)) != hipSuccess) return bail(e, "hipEventCreate");
+    if ((e = hipEventCreateWithFlags(&h->ev_join, hipEventDisableTiming)) != hipSuccess) return bail(e, "hipEventCreate");
+    if ((e = hipEventCreateWithFlags(&h->ev_ff, hipEventDisableTiming)) != hipSuccess) return bail(e, "hipEventCreate");
     if ((e = hipMalloc(&h->ctl.p, 4ull * (CTL_LVL0 + 65536))) != hipSuccess) return bail(e, "hipMalloc");
     h->ctl.cap = 4ull * (CTL_LVL0 + 65536);
     h->d_ctr = (uint32_t *) h->ctl.p;
@@ -505,12 +530,16 @@ void sdmesh_destroy(sdmesh_handle *h) {
     (void) hipSetDevice(h->device);
     if (h->stream) (void) hipStreamSynchronize(h->stream);
     DevBuf *bufs[] = {&h->vox[0], &h->vox[1], &h->mask, &h->tilecnt, &h->ctl, &h->cubeidx, &h->trioff, &h->ff_arena,
-                      &h->first_ord_buf, &h->wfirst, &h->uverts, &h->tri_e, &h->vslot, &h->tdesc, &h->tfirst, &h->tpre, &h->flip, &h->wvidx,
+                      &h->first_ord_buf, &h->wfirst, &h->uverts, &h->tri_e, &h->vslot, &h->tdesc, &h->tfirst, &h->tfpre, &h->tpre, &h->flip, &h->wvidx, &h->torder,
                       &h->vertices, &h->indices, &h->raw, &h->compact, &h->staging};
     for (DevBuf *b : bufs) release(*b);
     if (h->h_pinned) (void) hipHostFree(h->h_pinned);
     if (h->ev0) (void) hipEventDestroy(h->ev0);
     if (h->ev1) (void) hipEventDestroy(h->ev1);
+    if (h->side) { (void) hipStreamSynchronize(h->side); (void) hipStreamDestroy(h->side); }
+    if (h->ev_fork) (void) hipEventDestroy(h->ev_fork);
+    if (h->ev_join) (void) hipEventDestroy(h->ev_join);
+    if (h->ev_ff) (void) hipEventDestroy(h->ev_ff);
     if (h->own_stream) (void) hipStreamDestroy(h->own_stream);
     delete h;
 }

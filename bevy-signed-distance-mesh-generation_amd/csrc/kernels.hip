@@ -459,6 +459,36 @@ __global__ __launch_bounds__(256) void k_tile_dedupe(const Point *__restrict__ v
     }
 }
 
+// ------------------------------------------------------------------------------------------
+// A8 weld (src/cuda/mod.rs:263-296).
+//   key  = 3 x 21-bit biased round(x * 1e5)  (covers +-10.48 units; the bounding cube is +-2.5)
+//   claim: one CAS per pre-weld vertex; the claimer is the "winner" (bit 31 of its vslot entry), everyone
+//   else who finds the key present is a "loser".  Later the winner stores its first-seen ordinal with a
+//   plain store (wfirst) and only losers pay an atomicMin (wmin): min(wfirst, wmin) is the key's first-seen
+//   ordinal whatever the arrival order.
+// ------------------------------------------------------------------------------------------
+static constexpr uint32_t VS_WINNER = 0x80000000u;
+static constexpr uint32_t VS_SLOT = 0x7fffffffu;
+
+__device__ __forceinline__ uint32_t weld_claim(const Point p, uint64_t *__restrict__ wkeys, uint32_t wsize,
+                                               uint32_t *__restrict__ status) {
+    const long long qx = weld_quant(p.x) + 1048576LL, qy = weld_quant(p.y) + 1048576LL, qz = weld_quant(p.z) + 1048576LL;
+    if (((unsigned long long) qx | (unsigned long long) qy | (unsigned long long) qz) >> 21) {
+        atomicOr(&status[ST_WELD_RANGE], 1u);
+        return U32_NONE;
+    }
+    const uint64_t key = (uint64_t) qx | ((uint64_t) qy << 21) | ((uint64_t) qz << 42);
+    uint32_t s = hash_home(key, wsize);
+    for (uint32_t probe = 0; probe < wsize; probe++) {
+        const uint64_t prev = atomicCAS((unsigned long long *) &wkeys[s], (unsigned long long) KEY_EMPTY, (unsigned long long) key);
+        if (prev == KEY_EMPTY) return s | VS_WINNER;
+        if (prev == key) return s;
+        s = hash_next(s, wsize);
+    }
+    atomicOr(&status[ST_OVERFLOW], 8u);
+    return U32_NONE;
+}
+
 // exclusive prefix of the per-tile unique-vertex counts (dense work index for k_project); total -> *nu_out
 __global__ __launch_bounds__(1024) void k_tile_prefix(const uint4 *__restrict__ tdesc, const uint32_t *__restrict__ ntiles_ptr,
                                                        uint32_t *__restrict__ tpre, uint32_t *__restrict__ nu_out) {
@@ -602,23 +632,26 @@ __global__ __launch_bounds__(256) void k_raw_desc(const uint32_t *__restrict__ n
     if (blockIdx.x == 0 && threadIdx.x == 0) { *ntiles_out = ntiles; *nu_out = 3u * T; }
 }
 
-// ------------------------------------------------------------------------------------------
-// A8 weld (src/cuda/mod.rs:263-296), per tile.
-//   key   = 3 x 21-bit biased round(x * 1e5)  (covers +-10.48 units; bounding cube is +-2.5)
-//   The vertex that claims a slot records its first-seen ordinal with a plain store (wfirst);
-//   only vertices that find the key already present pay an atomicMin (wmin).  The first-seen
-//   ordinal of a key is min(wfirst, wmin): order independent.
-// k_tile_weld_insert also applies the orientation flips to tri_e and derives each tile vertex's
-// first-seen ordinal with LDS atomics.
-// ------------------------------------------------------------------------------------------
+// claim pass: one CAS per pre-weld vertex, per tile.  Latency-bound on scattered L2 atomics and independent of
+// the orientation test, so the host runs it on a side stream concurrently with the VALU-bound k_flip.
+__global__ __launch_bounds__(256) void k_tile_claim(const Vertex *__restrict__ uverts, const uint4 *__restrict__ tdesc,
+                                                     const uint32_t *__restrict__ ntiles_ptr, uint64_t *__restrict__ wkeys,
+                                                     uint32_t wsize, uint32_t *__restrict__ vslot, uint32_t *__restrict__ status) {
+    const uint32_t ntiles = *ntiles_ptr;
+    for (uint32_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        const uint4 d = tdesc[tile];
+        for (uint32_t i = threadIdx.x; i < d.y; i += 256) vslot[d.x + i] = weld_claim(uverts[d.x + i].position, wkeys, wsize, status);
+    }
+}
+
 static constexpr uint32_t T_VMAX = 3072;
 
-__global__ __launch_bounds__(256) void k_tile_weld_insert(const Vertex *__restrict__ uverts, const uint4 *__restrict__ tdesc,
-                                                           const uint32_t *__restrict__ ntiles_ptr, uint32_t *__restrict__ tri_e,
-                                                           const uint8_t *__restrict__ flip, uint32_t *__restrict__ first_ord,
-                                                           uint64_t *__restrict__ wkeys, uint32_t *__restrict__ wmin,
-                                                           uint32_t *__restrict__ wfirst, uint32_t wsize,
-                                                           uint32_t *__restrict__ vslot, uint32_t *__restrict__ status) {
+// per tile: apply the orientation flips to tri_e, derive every tile vertex's first-seen ordinal with LDS
+// atomics, publish it (winner: plain store, loser: atomicMin)
+__global__ __launch_bounds__(256) void k_tile_first(const uint4 *__restrict__ tdesc, const uint32_t *__restrict__ ntiles_ptr,
+                                                     uint32_t *__restrict__ tri_e, const uint8_t *__restrict__ flip,
+                                                     const uint32_t *__restrict__ vslot, uint32_t *__restrict__ first_ord,
+                                                     uint32_t *__restrict__ wmin, uint32_t *__restrict__ wfirst) {
     __shared__ uint32_t s_first[T_VMAX];
     const uint32_t ntiles = *ntiles_ptr, tid = threadIdx.x;
     for (uint32_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
@@ -642,89 +675,52 @@ __global__ __launch_bounds__(256) void k_tile_weld_insert(const Vertex *__restri
             const uint32_t e = vbase + i, lf = s_first[i];
             const uint32_t fo = lf == U32_NONE ? U32_NONE : 3u * tbase + lf;
             first_ord[e] = fo;
-            uint32_t slot = U32_NONE;
-            if (fo != U32_NONE) {
-                const Point p = uverts[e].position;
-                const long long qx = weld_quant(p.x) + 1048576LL, qy = weld_quant(p.y) + 1048576LL, qz = weld_quant(p.z) + 1048576LL;
-                if (((unsigned long long) qx | (unsigned long long) qy | (unsigned long long) qz) >> 21) {
-                    atomicOr(&status[ST_WELD_RANGE], 1u);
-                } else {
-                    const uint64_t key = (uint64_t) qx | ((uint64_t) qy << 21) | ((uint64_t) qz << 42);
-                    uint32_t s = hash_home(key, wsize);
-                    for (uint32_t probe = 0; probe < wsize; probe++) {
-                        const uint64_t prev = atomicCAS((unsigned long long *) &wkeys[s], (unsigned long long) KEY_EMPTY,
-                                                        (unsigned long long) key);
-                        if (prev == KEY_EMPTY) { slot = s; wfirst[s] = fo; break; }
-                        if (prev == key) { slot = s; atomicMin(&wmin[s], fo); break; }
-                        s = hash_next(s, wsize);
-                    }
-                    if (slot == U32_NONE) atomicOr(&status[ST_OVERFLOW], 8u);
-                }
+            const uint32_t vs = vslot[e];
+            if (vs != U32_NONE) {
+                if (vs & VS_WINNER) wfirst[vs & VS_SLOT] = fo;
+                else if (fo != U32_NONE) atomicMin(&wmin[vs & VS_SLOT], fo);
             }
-            vslot[e] = slot;
         }
         __syncthreads();
     }
 }
 
-__device__ __forceinline__ bool is_first(uint32_t e, const uint32_t *first_ord, const uint32_t *wmin, const uint32_t *wfirst,
-                                         const uint32_t *vslot, uint32_t &fo, uint32_t &slot) {
-    slot = vslot[e];
-    if (slot == U32_NONE) return false;
-    fo = first_ord[e];
-    const uint32_t a = wfirst[slot], b = wmin[slot];
-    return (a < b ? a : b) == fo;
-}
-
-// number of first-seen vertices per tile
-__global__ __launch_bounds__(256) void k_tile_weld_count(const uint4 *__restrict__ tdesc, const uint32_t *__restrict__ ntiles_ptr,
-                                                          const uint32_t *__restrict__ first_ord, const uint32_t *__restrict__ wmin,
-                                                          const uint32_t *__restrict__ wfirst, const uint32_t *__restrict__ vslot,
-                                                          uint32_t *__restrict__ tfirst) {
-    __shared__ uint32_t s_cnt;
-    const uint32_t ntiles = *ntiles_ptr, tid = threadIdx.x;
-    for (uint32_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
-        const uint4 d = tdesc[tile];
-        if (tid == 0) s_cnt = 0;
-        __syncthreads();
-        uint32_t c = 0;
-        for (uint32_t i = tid; i < d.y; i += 256) {
-            uint32_t fo, slot;
-            c += is_first(d.x + i, first_ord, wmin, wfirst, vslot, fo, slot) ? 1u : 0u;
-        }
-        c = wave_sum(c);
-        if (lane_id() == 0 && c) atomicAdd(&s_cnt, c);
-        __syncthreads();
-        if (tid == 0) tfirst[tile] = s_cnt;
-        __syncthreads();
-    }
-}
-
-// welded index of every first-seen vertex = (firsts of earlier tiles) + rank by ordinal inside the tile
-__global__ __launch_bounds__(256) void k_tile_weld_assign(const Vertex *__restrict__ uverts, const uint4 *__restrict__ tdesc,
-                                                           const uint32_t *__restrict__ ntiles_ptr, const uint32_t *__restrict__ tfirst,
-                                                           const uint32_t *__restrict__ first_ord, const uint32_t *__restrict__ wmin,
-                                                           const uint32_t *__restrict__ wfirst, const uint32_t *__restrict__ vslot,
-                                                           uint32_t *__restrict__ wvidx, Vertex *__restrict__ vertices, uint32_t vcap,
-                                                           uint32_t *__restrict__ nverts_out, uint32_t *__restrict__ status) {
+// per tile: which vertices are first-seen, their rank by ordinal inside the tile, the tile's count.
+// wv[slot] = tile * 4096 + rank for the key's first-seen vertex; torder[3 * tbase + rank] = that vertex.
+__global__ __launch_bounds__(256) void k_tile_rank(const uint4 *__restrict__ tdesc, const uint32_t *__restrict__ ntiles_ptr,
+                                                    const uint32_t *__restrict__ first_ord, const uint32_t *__restrict__ wmin,
+                                                    const uint32_t *__restrict__ wfirst, const uint32_t *__restrict__ vslot,
+                                                    uint32_t *__restrict__ wv, uint32_t *__restrict__ torder,
+                                                    uint32_t *__restrict__ tfirst) {
     __shared__ uint32_t s_bits[3 * T_TRI / 32];      // 120 words: one bit per local ordinal
     __shared__ uint32_t s_pre[3 * T_TRI / 32];
     __shared__ uint32_t s_scan[17];
     const uint32_t ntiles = *ntiles_ptr, tid = threadIdx.x;
-    if (ntiles == 0 && blockIdx.x == 0 && tid == 0) *nverts_out = 0;
     for (uint32_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
         const uint4 d = tdesc[tile];
-        uint32_t part = 0;
-        for (uint32_t i = tid; i < tile; i += 256) part += tfirst[i];
-        uint32_t base;
-        (void) block_excl_scan(part, base, s_scan);
         if (tid < 3 * T_TRI / 32) s_bits[tid] = 0;
         __syncthreads();
-        for (uint32_t i = tid; i < d.y; i += 256) {
-            uint32_t fo, slot;
-            if (is_first(d.x + i, first_ord, wmin, wfirst, vslot, fo, slot)) {
-                const uint32_t lo = fo - 3u * d.z;
-                atomicOr(&s_bits[lo >> 5], 1u << (lo & 31u));
+        // up to T_VMAX / 256 = 12 vertices per thread; typically 2: keep their state in registers
+        uint32_t lo_of[2], slot_of[2];
+        uint32_t extra = 0;
+#pragma unroll
+        for (uint32_t k = 0; k < 2; k++) {
+            const uint32_t i = tid + k * 256;
+            lo_of[k] = U32_NONE; slot_of[k] = 0;
+            if (i < d.y) {
+                const uint32_t vs = vslot[d.x + i], fo = first_ord[d.x + i];
+                if (vs != U32_NONE && fo != U32_NONE) {
+                    const uint32_t s = vs & VS_SLOT, a = wfirst[s], b = wmin[s];
+                    if ((a < b ? a : b) == fo) { lo_of[k] = fo - 3u * d.z; slot_of[k] = s; }
+                }
+            }
+            if (lo_of[k] != U32_NONE) atomicOr(&s_bits[lo_of[k] >> 5], 1u << (lo_of[k] & 31u));
+        }
+        for (uint32_t i = tid + 512; i < d.y; i += 256) {            // rare: tiles with > 512 vertices
+            const uint32_t vs = vslot[d.x + i], fo = first_ord[d.x + i];
+            if (vs != U32_NONE && fo != U32_NONE) {
+                const uint32_t s = vs & VS_SLOT, a = wfirst[s], b = wmin[s];
+                if ((a < b ? a : b) == fo) { const uint32_t lo = fo - 3u * d.z; atomicOr(&s_bits[lo >> 5], 1u << (lo & 31u)); extra = 1; }
             }
         }
         __syncthreads();
@@ -733,27 +729,77 @@ __global__ __launch_bounds__(256) void k_tile_weld_assign(const Vertex *__restri
         const uint32_t ex = block_excl_scan(w, total, s_scan);
         if (tid < 3 * T_TRI / 32) s_pre[tid] = ex;
         __syncthreads();
-        if (tile == ntiles - 1 && tid == 0) *nverts_out = base + total;
-        for (uint32_t i = tid; i < d.y; i += 256) {
-            uint32_t fo, slot;
-            if (is_first(d.x + i, first_ord, wmin, wfirst, vslot, fo, slot)) {
-                const uint32_t lo = fo - 3u * d.z;
-                const uint32_t vi = base + s_pre[lo >> 5] + __popc(s_bits[lo >> 5] & ((1u << (lo & 31u)) - 1u));
-                wvidx[slot] = vi;
-                if (vi < vcap) vertices[vi] = uverts[d.x + i]; else atomicOr(&status[ST_OVERFLOW], 16u);
+        if (tid == 0) tfirst[tile] = total;
+#pragma unroll
+        for (uint32_t k = 0; k < 2; k++) {
+            if (lo_of[k] != U32_NONE) {
+                const uint32_t lo = lo_of[k];
+                const uint32_t r = s_pre[lo >> 5] + __popc(s_bits[lo >> 5] & ((1u << (lo & 31u)) - 1u));
+                wv[slot_of[k]] = tile * 4096u + r;
+                torder[3u * d.z + r] = d.x + tid + k * 256;
             }
         }
+        if (d.y > 512) {
+            for (uint32_t i = tid + 512; i < d.y; i += 256) {
+                const uint32_t vs = vslot[d.x + i], fo = first_ord[d.x + i];
+                if (vs != U32_NONE && fo != U32_NONE) {
+                    const uint32_t s = vs & VS_SLOT, a = wfirst[s], b = wmin[s];
+                    if ((a < b ? a : b) == fo) {
+                        const uint32_t lo = fo - 3u * d.z;
+                        const uint32_t r = s_pre[lo >> 5] + __popc(s_bits[lo >> 5] & ((1u << (lo & 31u)) - 1u));
+                        wv[s] = tile * 4096u + r;
+                        torder[3u * d.z + r] = d.x + i;
+                    }
+                }
+            }
+        }
+        (void) extra;
         __syncthreads();
     }
 }
 
-__global__ __launch_bounds__(256) void k_weld_index(const uint32_t *__restrict__ tri_e, const uint32_t *__restrict__ ntri_ptr,
-                                                     const uint32_t *__restrict__ vslot, const uint32_t *__restrict__ wvidx,
-                                                     uint32_t *__restrict__ indices) {
-    const uint32_t n3 = 3u * *ntri_ptr;
-    for (uint32_t o = blockIdx.x * blockDim.x + threadIdx.x; o < n3; o += gridDim.x * blockDim.x) {
-        const uint32_t s = vslot[tri_e[o]];
-        indices[o] = s != U32_NONE ? wvidx[s] : U32_NONE;
+// exclusive prefix of a u32 array of *n_ptr entries (single workgroup); out[n] = total = *total_out
+__global__ __launch_bounds__(1024) void k_scan_u32(const uint32_t *__restrict__ in, const uint32_t *__restrict__ n_ptr,
+                                                    uint32_t *__restrict__ out, uint32_t *__restrict__ total_out) {
+    __shared__ uint32_t lds[17];
+    const uint32_t n = *n_ptr;
+    uint32_t carry = 0;
+    for (uint32_t base = 0; base < n; base += blockDim.x) {
+        const uint32_t i = base + threadIdx.x;
+        const uint32_t v = i < n ? in[i] : 0u;
+        uint32_t total;
+        const uint32_t ex = block_excl_scan(v, total, lds);
+        if (i < n) out[i] = carry + ex;
+        carry += total;
+    }
+    if (threadIdx.x == 0) { out[n] = carry; *total_out = carry; }
+}
+
+// per tile: welded vertices (dense, first-seen order) and the welded index of every corner
+__global__ __launch_bounds__(256) void k_tile_finish(const Vertex *__restrict__ uverts, const uint4 *__restrict__ tdesc,
+                                                      const uint32_t *__restrict__ ntiles_ptr, const uint32_t *__restrict__ tfpre,
+                                                      const uint32_t *__restrict__ tfirst, const uint32_t *__restrict__ torder,
+                                                      const uint32_t *__restrict__ tri_e, const uint32_t *__restrict__ vslot,
+                                                      const uint32_t *__restrict__ wv, Vertex *__restrict__ vertices, uint32_t vcap,
+                                                      uint32_t *__restrict__ indices, uint32_t *__restrict__ status) {
+    const uint32_t ntiles = *ntiles_ptr, tid = threadIdx.x;
+    for (uint32_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        const uint4 d = tdesc[tile];
+        const uint32_t base = tfpre[tile], nf = tfirst[tile];
+        for (uint32_t r = tid; r < nf; r += 256) {
+            if (base + r < vcap) vertices[base + r] = uverts[torder[3u * d.z + r]];
+            else atomicOr(&status[ST_OVERFLOW], 16u);
+        }
+        for (uint32_t i = tid; i < 3u * d.w; i += 256) {
+            const uint32_t o = 3u * d.z + i;
+            const uint32_t vs = vslot[tri_e[o]];
+            uint32_t idx = U32_NONE;
+            if (vs != U32_NONE) {
+                const uint32_t w = wv[vs & VS_SLOT];
+                idx = tfpre[w >> 12] + (w & 4095u);
+            }
+            indices[o] = idx;
+        }
     }
 }
 
@@ -1032,16 +1078,23 @@ hipError_t launch_first_ord(hipStream_t st, int grid, const uint32_t *tri_e, con
     return hipGetLastError();
 }
 
+hipError_t launch_tile_claim(hipStream_t st, int grid, const Vertex *uverts, const uint4 *tdesc, const uint32_t *ntiles_ptr,
+                             uint64_t *wkeys, uint32_t wsize, uint32_t *vslot, uint32_t *status) {
+    hipLaunchKernelGGL(k_tile_claim, dim3(grid), dim3(256), 0, st, uverts, tdesc, ntiles_ptr, wkeys, wsize, vslot, status);
+    return hipGetLastError();
+}
+
+// first -> rank -> scan -> finish (the claim has already happened: in k_project or k_weld_claim)
 hipError_t launch_weld(hipStream_t st, int grid, const Vertex *uverts, const uint4 *tdesc, const uint32_t *ntiles_ptr,
-                       uint32_t *tri_e, const uint8_t *flip, const uint32_t *ntri_ptr, uint32_t *first_ord, uint64_t *wkeys,
-                       uint32_t *wmin, uint32_t *wfirst, uint32_t wsize, uint32_t *vslot, uint32_t *tfirst, uint32_t *wvidx,
+                       uint32_t *tri_e, const uint8_t *flip, uint32_t *first_ord, uint32_t *wmin, uint32_t *wfirst,
+                       const uint32_t *vslot, uint32_t *wv, uint32_t *torder, uint32_t *tfirst, uint32_t *tfpre,
                        Vertex *vertices, uint32_t vcap, uint32_t *nverts_out, uint32_t *indices, uint32_t *status) {
-    hipLaunchKernelGGL(k_tile_weld_insert, dim3(grid), dim3(256), 0, st, uverts, tdesc, ntiles_ptr, tri_e, flip, first_ord, wkeys,
-                       wmin, wfirst, wsize, vslot, status);
-    hipLaunchKernelGGL(k_tile_weld_count, dim3(grid), dim3(256), 0, st, tdesc, ntiles_ptr, first_ord, wmin, wfirst, vslot, tfirst);
-    hipLaunchKernelGGL(k_tile_weld_assign, dim3(grid), dim3(256), 0, st, uverts, tdesc, ntiles_ptr, tfirst, first_ord, wmin, wfirst,
-                       vslot, wvidx, vertices, vcap, nverts_out, status);
-    hipLaunchKernelGGL(k_weld_index, dim3(grid), dim3(256), 0, st, tri_e, ntri_ptr, vslot, wvidx, indices);
+    hipLaunchKernelGGL(k_tile_first, dim3(grid), dim3(256), 0, st, tdesc, ntiles_ptr, tri_e, flip, vslot, first_ord, wmin, wfirst);
+    hipLaunchKernelGGL(k_tile_rank, dim3(grid), dim3(256), 0, st, tdesc, ntiles_ptr, first_ord, wmin, wfirst, vslot, wv, torder,
+                       tfirst);
+    hipLaunchKernelGGL(k_scan_u32, dim3(1), dim3(1024), 0, st, tfirst, ntiles_ptr, tfpre, nverts_out);
+    hipLaunchKernelGGL(k_tile_finish, dim3(grid), dim3(256), 0, st, uverts, tdesc, ntiles_ptr, tfpre, tfirst, torder, tri_e, vslot,
+                       wv, vertices, vcap, indices, status);
     return hipGetLastError();
 }
 
