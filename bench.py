@@ -82,6 +82,7 @@ def sharded_leg(pkg, h, levels, world, rank, steps, warmup):
     order and welds.  Returns ms per regen (max over ranks) and the root's mesh counts."""
     from bevy_signed_distance_mesh_generation_amd import partition as P
     dev = torch.device("cuda", torch.cuda.current_device())
+    h.set_option("graph", 0)
     h.set_stream(torch.cuda.current_stream().cuda_stream)      # one stream for kernels, merge and collectives
     h.set_option("skip_weld", 1)
     info = h.regen(levels, pkg.PART_ZSLAB, rank, world)        # capacity discovery
@@ -150,7 +151,9 @@ def main():
     ap.add_argument("--scene", default="sdobj")
     ap.add_argument("--levels", type=int, default=4)          # N = 32 * 2^levels = 512
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-anim", action="store_true")
     ap.add_argument("--no-sharded", action="store_true")
+    ap.add_argument("--no-graph", action="store_true", help="launch the planned chain eagerly instead of replaying a hipGraph")
     ap.add_argument("--sharded-selftest", action="store_true", help="run the sharded leg on 1 GPU (degenerate, for testing)")
     args = ap.parse_args()
 
@@ -179,6 +182,7 @@ def main():
         torch.cuda.synchronize()
 
     info = h.regen(args.levels)                      # capacity discovery pass (synchronous, untimed)
+    h.set_option("graph", 0 if args.no_graph else 1) # planned chain captured once, replayed per step
     for _ in range(args.warmup):
         info = h.regen(args.levels)
     sync_all()
@@ -209,6 +213,28 @@ def main():
         "triangles": int(info.triangles), "vertices": int(info.vertices), "active_voxels": int(info.voxel_count[args.levels]),
         "device_ms_per_step": round(float(np.median(dev_ms)), 4),
     }
+
+    # --- BASELINE config 5: per-frame animated SDF (sphere centre (0, 0.5 sin t, 0), t = frame / 60), same grid
+    if rank == 0 and not args.no_anim:
+        ha = pkg.CudaHandler(local_rank, "anim", [0.5])
+        for cy in (0.5, -0.5, 0.0):                  # widest frames first: one capacity plan covers the animation
+            ha.set_scene("anim", [cy]); ha.regen(args.levels)
+        ha.set_option("graph", 0 if args.no_graph else 1)
+        for f in range(10):
+            ha.set_animation_time(f / 60.0); ha.regen(args.levels)
+        torch.cuda.synchronize()
+        ta = time.perf_counter()
+        atris = 0
+        for f in range(120):
+            ha.set_animation_time(f / 60.0)
+            atris += ha.regen(args.levels).triangles
+        torch.cuda.synchronize()
+        da = time.perf_counter() - ta
+        out["animated"] = {"what": "120 frames, new scene uniform + full regen per frame, hipGraph replay" if not args.no_graph
+                           else "120 frames, new scene uniform + full regen per frame, eager launches",
+                           "frames_per_s": round(120 / da, 1), "ms_per_frame": round(da / 120 * 1e3, 4),
+                           "mtris_per_s": round(atris / da / 1e6, 1), "grid": n_grid}
+        ha.close()
 
     # --- ONE mesh sharded over the ranks (strong scaling; reported next to, never instead of, `value`)
     if (world > 1 and not args.no_sharded) or args.sharded_selftest:

@@ -51,6 +51,9 @@ struct sdmesh_handle {
     hipEvent_t ev_fork = nullptr, ev_join = nullptr, ev_ff = nullptr;
     int scene = SDMESH_SCENE_SDOBJ;
     SceneParams sp{};
+    SceneParams *d_sp = nullptr;   // device copy of sp (kernels read the scene uniform through this pointer)
+    SceneParams *h_sp = nullptr;   // pinned staging for it
+    bool sp_dirty = true;
     int grid = 1024;           // workgroups per grid-stride launch (4 per CU)
     int force_direct = 0;
     int skip_weld = 0;         // regen stops after the orientation test (multi-GPU ranks: the root welds)
@@ -59,6 +62,13 @@ struct sdmesh_handle {
     int dense_grid = 16384;    // workgroups for k_sample_dense
     int dense_nt = 1;          // nontemporal stores in k_sample_dense
     char err[512] = {0};
+    uint64_t buf_gen = 0;      // bumped whenever a device buffer is (re)allocated: invalidates a captured graph
+    int use_graph = 0;         // replay the planned regen as a hipGraph
+    hipGraph_t graph = nullptr;
+    hipGraphExec_t graph_exec = nullptr;
+    uint64_t graph_key[8] = {0};
+    int graph_cur = 0;
+    Point graph_vs{0, 0, 0};
 
     // voxel lists (ping-pong), refine scratch
     DevBuf vox[2];
@@ -125,6 +135,7 @@ int ensure(sdmesh_handle *h, DevBuf &b, size_t bytes) {
     }
     HIPCHK(hipMalloc(&b.p, bytes));
     b.cap = bytes;
+    h->buf_gen++;
     return SDMESH_OK;
 }
 
@@ -185,12 +196,12 @@ int mesh_front(sdmesh_handle *h, const Point *d_vox, const uint32_t *n_ptr, Poin
     if (!ff_done) HIPCHK(hipMemsetAsync(h->ff_arena.p, 0xFF, ff_bytes(h), st));
     else HIPCHK(hipStreamWaitEvent(st, h->ev_ff, 0));          // table was cleared on the side stream during the refine
     if (zero_counters) HIPCHK(hipMemsetAsync(h->d_ctr + CTR_NUNIQ, 0, 4 * sizeof(uint32_t), st));
-    HIPCHK(launch_classify(st, h->grid, h->scene, h->sp, d_vox, n_ptr, vs, (uint8_t *) h->cubeidx.p, (uint32_t *) h->tilecnt.p));
+    HIPCHK(launch_classify(st, h->grid, h->scene, h->d_sp, d_vox, n_ptr, vs, (uint8_t *) h->cubeidx.p, (uint32_t *) h->tilecnt.p));
     HIPCHK(launch_tile_dedupe(st, h->grid, d_vox, n_ptr, vs, (const uint8_t *) h->cubeidx.p, (const uint32_t *) h->tilecnt.p,
                               (uint32_t *) h->trioff.p, (uint32_t *) h->tri_e.p, (Vertex *) h->uverts.p, (uint4 *) h->tdesc.p,
                               h->ucap, h->tcap, h->d_ctr + CTR_NTRI, h->d_ctr + CTR_NTILES, h->d_status));
     HIPCHK(launch_tile_prefix(st, (const uint4 *) h->tdesc.p, h->d_ctr + CTR_NTILES, (uint32_t *) h->tpre.p, h->d_ctr + CTR_NUNIQ));
-    HIPCHK(launch_project(st, h->grid, h->scene, h->sp, (Vertex *) h->uverts.p, (const uint4 *) h->tdesc.p,
+    HIPCHK(launch_project(st, h->grid, h->scene, h->d_sp, (Vertex *) h->uverts.p, (const uint4 *) h->tdesc.p,
                           (const uint32_t *) h->tpre.p, h->d_ctr + CTR_NTILES, h->d_status));
     // fork: the weld claim (scattered CAS, latency-bound) runs beside the orientation test (VALU-bound)
     HIPCHK(hipEventRecord(h->ev_fork, st));
@@ -198,7 +209,7 @@ int mesh_front(sdmesh_handle *h, const Point *d_vox, const uint32_t *n_ptr, Poin
     HIPCHK(launch_tile_claim(h->side, h->grid, (const Vertex *) h->uverts.p, (const uint4 *) h->tdesc.p, h->d_ctr + CTR_NTILES,
                              h->wkeys, h->wsize, (uint32_t *) h->vslot.p, h->d_status));
     HIPCHK(hipEventRecord(h->ev_join, h->side));
-    HIPCHK(launch_flip(st, h->grid, h->scene, h->sp, (const Vertex *) h->uverts.p, (const uint32_t *) h->tri_e.p,
+    HIPCHK(launch_flip(st, h->grid, h->scene, h->d_sp, (const Vertex *) h->uverts.p, (const uint32_t *) h->tri_e.p,
                        h->d_ctr + CTR_NTRI, (uint8_t *) h->flip.p));
     HIPCHK(hipStreamWaitEvent(st, h->ev_join, 0));
     return SDMESH_OK;
@@ -216,8 +227,13 @@ int mesh_weld(sdmesh_handle *h, const Vertex *uverts) {
 }
 
 // read counters + status back (the one synchronisation point of a device chain)
-int read_back(sdmesh_handle *h) {
+int read_back_enqueue(sdmesh_handle *h) {
     HIPCHK(hipMemcpyAsync(h->h_pinned, h->d_ctr, (CTR_WORDS + ST_WORDS) * 4, hipMemcpyDeviceToHost, h->stream));
+    return SDMESH_OK;
+}
+
+int read_back(sdmesh_handle *h) {
+    SDCHK(read_back_enqueue(h));
     HIPCHK(hipStreamSynchronize(h->stream));
     return SDMESH_OK;
 }
@@ -226,6 +242,15 @@ int status_to_error(sdmesh_handle *h) {
     const uint32_t *s = h->h_pinned + CTR_WORDS;
     if (s[ST_INTERNAL]) return fail(h, SDMESH_ERR_INTERNAL, "device invariant violated (status %u)", s[ST_INTERNAL]);
     if (s[ST_WELD_RANGE]) return fail(h, SDMESH_ERR_WELD_RANGE, "vertex outside the +-10.48 unit weld key range");
+    return SDMESH_OK;
+}
+
+// push the scene uniform to the device if it changed since the last upload
+int sync_scene(sdmesh_handle *h) {
+    if (!h->sp_dirty) return SDMESH_OK;
+    *h->h_sp = h->sp;
+    HIPCHK(hipMemcpyAsync(h->d_sp, h->h_sp, sizeof(SceneParams), hipMemcpyHostToDevice, h->stream));
+    h->sp_dirty = false;
     return SDMESH_OK;
 }
 
@@ -246,6 +271,7 @@ int ensure_ctl(sdmesh_handle *h, size_t lvl_words) {
     HIPCHK(hipFree(h->ctl.p));
     h->ctl.p = p;
     h->ctl.cap = need * 2;
+    h->buf_gen++;
     h->d_ctr = (uint32_t *) p;
     h->d_status = h->d_ctr + CTR_WORDS;
     return SDMESH_OK;
@@ -308,7 +334,7 @@ int refine_level(sdmesh_handle *h, int L, uint32_t n_cap_in, uint32_t out_cap, P
     SDCHK(ensure(h, h->mask, n_cap_in));
     const uint32_t *n_in = h->d_ctr + CTR_LEVEL0 + L;
     uint32_t *n_out = h->d_ctr + CTR_LEVEL0 + L + 1;
-    HIPCHK(launch_refine_mask(st, h->grid, h->scene, h->sp, (const Point *) h->vox[src].p, n_in, cs, (uint8_t *) h->mask.p,
+    HIPCHK(launch_refine_mask(st, h->grid, h->scene, h->d_sp, (const Point *) h->vox[src].p, n_in, cs, (uint8_t *) h->mask.p,
                               cnt_region));
     uint32_t cap = out_cap;
     if (out_cap == 0) {
@@ -328,6 +354,60 @@ int refine_level(sdmesh_handle *h, int L, uint32_t n_cap_in, uint32_t out_cap, P
 
 uint32_t padded(uint32_t n) { return n + n / 4 + 4096; }
 
+// The planned, synchronisation-free device chain of one regen (capacities from the plan).  Every buffer has
+// been sized by the caller, so nothing here allocates: the same code runs eagerly or under stream capture.
+int enqueue_planned_chain(sdmesh_handle *h, int levels, uint32_t z0, uint32_t z1, uint32_t n0, uint32_t lvl_words, Point *vs_out) {
+    hipStream_t st = h->stream;
+    // fork: the weld table is cleared on the side stream while the refine runs
+    HIPCHK(hipEventRecord(h->ev_fork, st));
+    HIPCHK(hipStreamWaitEvent(h->side, h->ev_fork, 0));
+    HIPCHK(hipMemsetAsync(h->ff_arena.p, 0xFF, ff_bytes(h), h->side));
+    HIPCHK(hipEventRecord(h->ev_ff, h->side));
+    SDCHK(zero_ctl(h, lvl_words));
+    Point vs;
+    vs.x = vs.y = vs.z = MESH_GENERATION_BB_SIZE / (float) MESH_GENERATION_INIT_FACTOR;
+    if (n0) HIPCHK(launch_create_field(st, (Point *) h->vox[0].p, z0, z1, h->d_ctr + CTR_LEVEL0));
+    uint32_t n_cap = n0;
+    h->cur = 0;
+    for (int L = 0; L < levels; L++) {
+        const Point cs = half_size(vs);
+        const uint32_t out_cap = padded(h->plan_counts[L + 1]);
+        SDCHK(refine_level(h, L, std::max<uint32_t>(n_cap, 64), out_cap, cs, h->d_ctr + CTL_LVL0 + h->lvl_off[L], nullptr));
+        vs = cs;
+        n_cap = out_cap;
+    }
+    SDCHK(mesh_front(h, (const Point *) h->vox[h->cur].p, h->d_ctr + CTR_LEVEL0 + levels, vs, false, true));
+    if (!h->skip_weld) SDCHK(mesh_weld(h, (const Vertex *) h->uverts.p));
+    *vs_out = vs;
+    return SDMESH_OK;
+}
+
+// size every buffer the planned chain touches (idempotent; may allocate, so it runs before any capture)
+int presize_planned_chain(sdmesh_handle *h, int levels, uint32_t n0, uint32_t *lvl_words_out) {
+    SDCHK(ensure(h, h->vox[0], sizeof(Point) * (size_t) std::max<uint32_t>(n0, 64)));
+    SDCHK(layout_mesh(h, padded(h->plan_counts[levels]), padded(h->plan_uniq)));
+    uint32_t lvl_words = 0, n_cap = n0;
+    int cur = 0;
+    for (int L = 0; L < levels; L++) {
+        h->lvl_off[L] = lvl_words;
+        lvl_words += tiles(L == 0 ? n0 : padded(h->plan_counts[L])) + 16;
+        SDCHK(ensure(h, h->mask, std::max<uint32_t>(n_cap, 64)));
+        n_cap = padded(h->plan_counts[L + 1]);
+        SDCHK(ensure(h, h->vox[1 - cur], sizeof(Point) * (size_t) std::max<uint32_t>(n_cap, 64)));
+        cur = 1 - cur;
+    }
+    SDCHK(ensure_ctl(h, lvl_words));
+    *lvl_words_out = lvl_words;
+    return SDMESH_OK;
+}
+
+void drop_graph(sdmesh_handle *h) {
+    if (h->graph_exec) (void) hipGraphExecDestroy(h->graph_exec);
+    if (h->graph) (void) hipGraphDestroy(h->graph);
+    h->graph_exec = nullptr;
+    h->graph = nullptr;
+}
+
 int regen_impl(sdmesh_handle *h, int levels, int mode, int part, int nparts, sdmesh_regen_info *info) {
     if (!h) return SDMESH_ERR_INVALID;
     if (levels < 0 || levels > SDMESH_MAX_LEVELS) return fail(h, SDMESH_ERR_INVALID, "levels must be 0..%d", SDMESH_MAX_LEVELS);
@@ -335,6 +415,7 @@ int regen_impl(sdmesh_handle *h, int levels, int mode, int part, int nparts, sdm
     if (mode == SDMESH_PART_NONE) { part = 0; nparts = 1; }
     if (nparts < 1 || nparts > 32 || part < 0 || part >= nparts) return fail(h, SDMESH_ERR_INVALID, "bad partition %d/%d", part, nparts);
     HIPCHK(hipSetDevice(h->device));
+    SDCHK(sync_scene(h));
     hipStream_t st = h->stream;
     const uint32_t F = MESH_GENERATION_INIT_FACTOR;
     const uint32_t z0 = F * (uint32_t) part / (uint32_t) nparts, z1 = F * (uint32_t) (part + 1) / (uint32_t) nparts;
@@ -345,57 +426,77 @@ int regen_impl(sdmesh_handle *h, int levels, int mode, int part, int nparts, sdm
                            h->plan_part == part && h->plan_nparts == nparts && attempt == 0;
         h->mesh_valid = h->vox_valid = false;
         h->cur = 0;
-        SDCHK(ensure(h, h->vox[0], sizeof(Point) * (size_t) std::max<uint32_t>(n0, 64)));
-        if (async) SDCHK(layout_mesh(h, padded(h->plan_counts[levels]), padded(h->plan_uniq)));
-
-        // per-level tile counters live behind the counters in the control block; with a capacity plan
-        // the whole block is zeroed by ONE memset, otherwise level by level as the sizes become known
-        uint32_t lvl_words = 0;
-        if (async) {
-            for (int L = 0; L < levels; L++) {
-                h->lvl_off[L] = lvl_words;
-                lvl_words += tiles(L == 0 ? n0 : padded(h->plan_counts[L])) + 16;
-            }
-            SDCHK(ensure_ctl(h, lvl_words));
-        }
-        HIPCHK(hipEventRecord(h->ev0, st));
-        if (async) {
-            // the weld table (layout known from the plan) is cleared on the side stream while the refine runs
-            HIPCHK(hipStreamWaitEvent(h->side, h->ev0, 0));
-            HIPCHK(hipMemsetAsync(h->ff_arena.p, 0xFF, ff_bytes(h), h->side));
-            HIPCHK(hipEventRecord(h->ev_ff, h->side));
-        }
-        SDCHK(zero_ctl(h, lvl_words));
         Point vs;
         vs.x = vs.y = vs.z = MESH_GENERATION_BB_SIZE / (float) MESH_GENERATION_INIT_FACTOR;
-        if (n0) HIPCHK(launch_create_field(st, (Point *) h->vox[0].p, z0, z1, h->d_ctr + CTR_LEVEL0));
         uint32_t n_cap = n0;
-        for (int L = 0; L < levels; L++) {
-            const Point cs = half_size(vs);
-            const uint32_t out_cap = async ? padded(h->plan_counts[L + 1]) : 0u;
-            uint32_t cnt = out_cap;
-            if (!async) {
+        bool direct = h->force_direct != 0;
+        if (async && !direct) {
+            // ---- planned path: no host round trip until the final read-back; optionally replayed as a hipGraph
+            uint32_t lvl_words = 0;
+            SDCHK(presize_planned_chain(h, levels, n0, &lvl_words));
+            n_cap = padded(h->plan_counts[levels]);
+            if (h->use_graph) {
+                uint64_t key[8] = {h->buf_gen, (uint64_t) h->scene, (uint64_t) levels, ((uint64_t) mode << 40) | ((uint64_t) part << 20) | (uint64_t) nparts,
+                                   (uint64_t) h->skip_weld, (uint64_t) (uintptr_t) st, (uint64_t) h->grid, 0};
+                for (int i = 0; i <= levels; i++) key[7] = key[7] * 1000003ull + h->plan_counts[i];
+                key[7] = key[7] * 1000003ull + h->plan_uniq;
+                if (!h->graph_exec || memcmp(key, h->graph_key, sizeof key) != 0) {
+                    drop_graph(h);
+                    HIPCHK(hipStreamSynchronize(st));
+                    HIPCHK(hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal));
+                    int rc = enqueue_planned_chain(h, levels, z0, z1, n0, lvl_words, &vs);
+                    if (rc == SDMESH_OK) rc = read_back_enqueue(h);
+                    hipGraph_t g = nullptr;
+                    hipError_t ce = hipStreamEndCapture(st, &g);
+                    if (rc != SDMESH_OK) { if (g) (void) hipGraphDestroy(g); return rc; }
+                    if (ce != hipSuccess) return fail(h, SDMESH_ERR_HIP, "hipStreamEndCapture failed: %s", hipGetErrorString(ce));
+                    h->graph = g;
+                    HIPCHK(hipGraphInstantiate(&h->graph_exec, g, nullptr, nullptr, 0));
+                    memcpy(h->graph_key, key, sizeof key);
+                    h->graph_cur = h->cur;
+                    h->graph_vs = vs;
+                }
+                h->cur = h->graph_cur;
+                vs = h->graph_vs;
+                HIPCHK(hipEventRecord(h->ev0, st));
+                HIPCHK(hipGraphLaunch(h->graph_exec, st));
+                HIPCHK(hipEventRecord(h->ev1, st));
+                HIPCHK(hipStreamSynchronize(st));
+            } else {
+                HIPCHK(hipEventRecord(h->ev0, st));
+                SDCHK(enqueue_planned_chain(h, levels, z0, z1, n0, lvl_words, &vs));
+                HIPCHK(hipEventRecord(h->ev1, st));
+                SDCHK(read_back(h));
+            }
+        } else {
+            // ---- discovery path: sizes become known level by level (one host sync per level)
+            SDCHK(ensure(h, h->vox[0], sizeof(Point) * (size_t) std::max<uint32_t>(n0, 64)));
+            HIPCHK(hipEventRecord(h->ev0, st));
+            SDCHK(zero_ctl(h, 0));
+            if (n0) HIPCHK(launch_create_field(st, (Point *) h->vox[0].p, z0, z1, h->d_ctr + CTR_LEVEL0));
+            for (int L = 0; L < levels; L++) {
+                const Point cs = half_size(vs);
+                uint32_t cnt = 0;
                 h->lvl_off[L] = 0;
                 SDCHK(ensure_ctl(h, tiles(n_cap) + 16));
                 HIPCHK(hipMemsetAsync(h->d_ctr + CTL_LVL0, 0, 4ull * (tiles(n_cap) + 16), st));
+                SDCHK(refine_level(h, L, std::max<uint32_t>(n_cap, 64), 0u, cs, h->d_ctr + CTL_LVL0, &cnt));
+                vs = cs;
+                n_cap = cnt;
             }
-            SDCHK(refine_level(h, L, std::max<uint32_t>(n_cap, 64), out_cap, cs, h->d_ctr + CTL_LVL0 + h->lvl_off[L], &cnt));
-            vs = cs;
-            n_cap = cnt;
+            if (!direct) {
+                SDCHK(layout_mesh(h, n_cap, 0));
+                SDCHK(mesh_front(h, (const Point *) h->vox[h->cur].p, h->d_ctr + CTR_LEVEL0 + levels, vs, false, false));
+                if (!h->skip_weld) SDCHK(mesh_weld(h, (const Vertex *) h->uverts.p));
+            }
+            HIPCHK(hipEventRecord(h->ev1, st));
+            SDCHK(read_back(h));
         }
-        if (!async) SDCHK(layout_mesh(h, n_cap, 0));
         const Point *d_vox = (const Point *) h->vox[h->cur].p;
         const uint32_t *n_ptr = h->d_ctr + CTR_LEVEL0 + levels;
-        bool direct = h->force_direct != 0;
-        if (!direct) {
-            SDCHK(mesh_front(h, d_vox, n_ptr, vs, false, async));
-            if (!h->skip_weld) SDCHK(mesh_weld(h, (const Vertex *) h->uverts.p));
-        }
-        HIPCHK(hipEventRecord(h->ev1, st));
-        SDCHK(read_back(h));
         const uint32_t *c = h->h_pinned, *s = h->h_pinned + CTR_WORDS;
         if (!direct && s[ST_OVERFLOW]) {
-            if (async) { h->plan_valid = false; continue; }   // capacities were too tight: redo synchronously
+            if (async) { h->plan_valid = false; drop_graph(h); continue; }   // capacities were too tight: redo synchronously
             // synchronous path: voxel buffers are exact, so only the unique-edge estimate can be too
             // small -- lay out for the observed count and run the mesh stage again
             h->plan_valid = false;
@@ -412,7 +513,7 @@ int regen_impl(sdmesh_handle *h, int levels, int mode, int part, int nparts, sdm
         if (direct) {
             SDCHK(ensure(h, h->raw, sizeof(Triangle) * 5ull * std::max<uint32_t>(n, 1)));
             SDCHK(zero_status(h));
-            HIPCHK(launch_triangles_direct(st, h->scene, h->sp, d_vox, n, vs, (Triangle *) h->raw.p));
+            HIPCHK(launch_triangles_direct(st, h->scene, h->d_sp, d_vox, n, vs, (Triangle *) h->raw.p));
             SDCHK(weld_raw_device(h, (const Triangle *) h->raw.p, 5u * n));
             HIPCHK(hipEventRecord(h->ev1, st));
             // keep the level counters: weld_raw_device only touches the mesh counters
@@ -470,7 +571,7 @@ int host_mesh_front(sdmesh_handle *h, const Point *voxels, uint32_t n, Point vs,
     if (direct) {
         SDCHK(ensure(h, h->raw, sizeof(Triangle) * 5ull * n));
         SDCHK(zero_status(h));
-        HIPCHK(launch_triangles_direct(st, h->scene, h->sp, (const Point *) h->vox[0].p, n, vs, (Triangle *) h->raw.p));
+        HIPCHK(launch_triangles_direct(st, h->scene, h->d_sp, (const Point *) h->vox[0].p, n, vs, (Triangle *) h->raw.p));
     }
     h->n_vox = n;
     h->voxel_size = vs;
@@ -521,6 +622,8 @@ int sdmesh_create(int device, sdmesh_handle **out) {
     if ((e = hipHostMalloc((void **) &h->h_pinned, (CTR_WORDS + ST_WORDS) * 4, hipHostMallocDefault)) != hipSuccess)
         return bail(e, "hipHostMalloc");
     memset(h->h_pinned, 0, (CTR_WORDS + ST_WORDS) * 4);
+    if ((e = hipMalloc((void **) &h->d_sp, sizeof(SceneParams))) != hipSuccess) return bail(e, "hipMalloc");
+    if ((e = hipHostMalloc((void **) &h->h_sp, sizeof(SceneParams), hipHostMallocDefault)) != hipSuccess) return bail(e, "hipHostMalloc");
     *out = h;
     return SDMESH_OK;
 }
@@ -529,11 +632,14 @@ void sdmesh_destroy(sdmesh_handle *h) {
     if (!h) return;
     (void) hipSetDevice(h->device);
     if (h->stream) (void) hipStreamSynchronize(h->stream);
+    drop_graph(h);
     DevBuf *bufs[] = {&h->vox[0], &h->vox[1], &h->mask, &h->tilecnt, &h->ctl, &h->cubeidx, &h->trioff, &h->ff_arena,
                       &h->first_ord_buf, &h->wfirst, &h->uverts, &h->tri_e, &h->vslot, &h->tdesc, &h->tfirst, &h->tfpre, &h->tpre, &h->flip, &h->wvidx, &h->torder,
                       &h->vertices, &h->indices, &h->raw, &h->compact, &h->staging};
     for (DevBuf *b : bufs) release(*b);
     if (h->h_pinned) (void) hipHostFree(h->h_pinned);
+    if (h->d_sp) (void) hipFree(h->d_sp);
+    if (h->h_sp) (void) hipHostFree(h->h_sp);
     if (h->ev0) (void) hipEventDestroy(h->ev0);
     if (h->ev1) (void) hipEventDestroy(h->ev1);
     if (h->side) { (void) hipStreamSynchronize(h->side); (void) hipStreamDestroy(h->side); }
@@ -552,12 +658,14 @@ int sdmesh_set_scene(sdmesh_handle *h, int scene, const float *params, int npara
     if (nparams < 0 || nparams > 4 || (nparams > 0 && !params)) return fail(h, SDMESH_ERR_INVALID, "bad scene params");
     h->scene = scene;
     for (int i = 0; i < 4; i++) h->sp.p[i] = i < nparams ? params[i] : 0.0f;
+    h->sp_dirty = true;
     return SDMESH_OK;
 }
 
 int sdmesh_set_stream(sdmesh_handle *h, void *hip_stream) {
     if (!h) return SDMESH_ERR_INVALID;
     HIPCHK(hipStreamSynchronize(h->stream));
+    drop_graph(h);
     h->stream = hip_stream ? (hipStream_t) hip_stream : h->own_stream;
     return SDMESH_OK;
 }
@@ -566,6 +674,7 @@ int sdmesh_set_option(sdmesh_handle *h, const char *name, int value) {
     if (!h || !name) return SDMESH_ERR_INVALID;
     if (!strcmp(name, "direct")) { h->force_direct = value ? 1 : 0; h->plan_valid = false; return SDMESH_OK; }
     if (!strcmp(name, "skip_weld")) { h->skip_weld = value ? 1 : 0; return SDMESH_OK; }
+    if (!strcmp(name, "graph")) { h->use_graph = value ? 1 : 0; if (!value) drop_graph(h); return SDMESH_OK; }
     if (!strcmp(name, "grid")) {
         if (value < 1 || value > 65535) return fail(h, SDMESH_ERR_INVALID, "grid out of range");
         h->grid = value;
@@ -600,6 +709,7 @@ int sdmesh_create_voxel_field(struct Point *voxels, struct Point *voxel_size) {
 static int refine_host_common(sdmesh_handle *h, const Point *in, size_t n, Point voxel_size) {
     hipStream_t st = h->stream;
     HIPCHK(hipSetDevice(h->device));
+    SDCHK(sync_scene(h));
     SDCHK(ensure(h, h->vox[0], sizeof(Point) * n));
     SDCHK(ensure(h, h->mask, n));
     SDCHK(ensure_ctl(h, tiles((uint32_t) n) + 16));
@@ -608,7 +718,7 @@ static int refine_host_common(sdmesh_handle *h, const Point *in, size_t n, Point
     HIPCHK(hipMemcpyAsync(h->vox[0].p, in, sizeof(Point) * n, hipMemcpyHostToDevice, st));
     SDCHK(zero_ctl(h, tiles((uint32_t) n) + 16));
     HIPCHK(launch_set_u32(st, h->d_ctr + CTR_LEVEL0, (uint32_t) n));
-    HIPCHK(launch_refine_mask(st, h->grid, h->scene, h->sp, (const Point *) h->vox[0].p, h->d_ctr + CTR_LEVEL0, half_size(voxel_size),
+    HIPCHK(launch_refine_mask(st, h->grid, h->scene, h->d_sp, (const Point *) h->vox[0].p, h->d_ctr + CTR_LEVEL0, half_size(voxel_size),
                               (uint8_t *) h->mask.p, h->d_ctr + CTL_LVL0));
     return SDMESH_OK;
 }
@@ -664,6 +774,7 @@ int sdmesh_voxel_field_to_triangles_raw(sdmesh_handle *h, const struct Point *vo
     if (n == 0) return SDMESH_OK;
     if (n > 0x0FFFFFFFu) return fail(h, SDMESH_ERR_INVALID, "too many voxels");
     HIPCHK(hipSetDevice(h->device));
+    SDCHK(sync_scene(h));
     hipStream_t st = h->stream;
     bool direct = false;
     SDCHK(host_mesh_front(h, voxels, (uint32_t) n, voxel_size, direct));
@@ -688,6 +799,7 @@ int sdmesh_voxel_field_to_mesh(sdmesh_handle *h, const struct Point *voxels, siz
     }
     if (n > 0x0FFFFFFFu) return fail(h, SDMESH_ERR_INVALID, "too many voxels");
     HIPCHK(hipSetDevice(h->device));
+    SDCHK(sync_scene(h));
     bool direct = false;
     SDCHK(host_mesh_front(h, voxels, (uint32_t) n, voxel_size, direct));
     if (direct) SDCHK(weld_raw_device(h, (const Triangle *) h->raw.p, 5u * (uint32_t) n));
@@ -716,6 +828,7 @@ int sdmesh_weld_triangles(sdmesh_handle *h, const struct Triangle *raw, size_t n
     *n_verts = *n_tris = 0;
     if (nslots > 0x0FFFFFFFu) return fail(h, SDMESH_ERR_INVALID, "too many slots");
     HIPCHK(hipSetDevice(h->device));
+    SDCHK(sync_scene(h));
     if (nslots) {
         SDCHK(ensure(h, h->staging, sizeof(Triangle) * nslots));
         HIPCHK(hipMemcpyAsync(h->staging.p, raw, sizeof(Triangle) * nslots, hipMemcpyHostToDevice, h->stream));
@@ -735,6 +848,7 @@ int sdmesh_weld_device_triangles(sdmesh_handle *h, const struct Triangle *d_raw,
     if (!h || (nslots && !d_raw)) return SDMESH_ERR_INVALID;
     if (nslots > 0x0FFFFFFFu) return fail(h, SDMESH_ERR_INVALID, "too many slots");
     HIPCHK(hipSetDevice(h->device));
+    SDCHK(sync_scene(h));
     h->mesh_valid = false;
     HIPCHK(hipEventRecord(h->ev0, h->stream));
     SDCHK(zero_status(h));
@@ -838,8 +952,9 @@ int sdmesh_download_voxels(sdmesh_handle *h, struct Point *voxels) {
 int sdmesh_sample_dense(sdmesh_handle *h, uint32_t N, float *d_out, float *kernel_ms) {
     if (!h || !d_out || N == 0 || N > 4096) return SDMESH_ERR_INVALID;
     HIPCHK(hipSetDevice(h->device));
+    SDCHK(sync_scene(h));
     HIPCHK(hipEventRecord(h->ev0, h->stream));
-    HIPCHK(launch_sample_dense(h->stream, h->dense_grid > 0 ? h->dense_grid : 8 * h->grid, h->scene, h->sp, d_out, N, h->dense_nt != 0));
+    HIPCHK(launch_sample_dense(h->stream, h->dense_grid > 0 ? h->dense_grid : 8 * h->grid, h->scene, h->d_sp, d_out, N, h->dense_nt != 0));
     HIPCHK(hipEventRecord(h->ev1, h->stream));
     HIPCHK(hipStreamSynchronize(h->stream));
     if (kernel_ms) HIPCHK(hipEventElapsedTime(kernel_ms, h->ev0, h->ev1));
@@ -849,9 +964,10 @@ int sdmesh_sample_dense(sdmesh_handle *h, uint32_t N, float *d_out, float *kerne
 int sdmesh_time_kernel(sdmesh_handle *h, int which, uint32_t N, float *d_buf, int iters, float *avg_ms) {
     if (!h || !avg_ms || iters < 1 || which != 0 || !d_buf || N == 0 || N > 4096) return SDMESH_ERR_INVALID;
     HIPCHK(hipSetDevice(h->device));
-    HIPCHK(launch_sample_dense(h->stream, h->dense_grid > 0 ? h->dense_grid : 8 * h->grid, h->scene, h->sp, d_buf, N, h->dense_nt != 0));   // warm-up
+    SDCHK(sync_scene(h));
+    HIPCHK(launch_sample_dense(h->stream, h->dense_grid > 0 ? h->dense_grid : 8 * h->grid, h->scene, h->d_sp, d_buf, N, h->dense_nt != 0));   // warm-up
     HIPCHK(hipEventRecord(h->ev0, h->stream));
-    for (int i = 0; i < iters; i++) HIPCHK(launch_sample_dense(h->stream, h->dense_grid > 0 ? h->dense_grid : 8 * h->grid, h->scene, h->sp, d_buf, N, h->dense_nt != 0));
+    for (int i = 0; i < iters; i++) HIPCHK(launch_sample_dense(h->stream, h->dense_grid > 0 ? h->dense_grid : 8 * h->grid, h->scene, h->d_sp, d_buf, N, h->dense_nt != 0));
     HIPCHK(hipEventRecord(h->ev1, h->stream));
     HIPCHK(hipStreamSynchronize(h->stream));
     float ms = 0.0f;

@@ -133,8 +133,9 @@ static constexpr uint32_t MASK_CHUNK = 32;
 
 template <int SCENE>
 __global__ __launch_bounds__(256) void k_refine_mask(const Point *__restrict__ vox, const uint32_t *__restrict__ n_ptr,
-                                                      Point cs /* child size = parent size / 2 */, SceneParams sp,
+                                                      Point cs /* child size = parent size / 2 */, const SceneParams *__restrict__ spp,
                                                       uint8_t *__restrict__ mask, uint32_t *__restrict__ tilecnt) {
+    const SceneParams sp = *spp;   // scene uniform (device memory: a captured graph replays with new values)
     __shared__ uint32_t s_cnt;
     const uint32_t n = *n_ptr;
     const uint32_t nchunks = (n + MASK_CHUNK - 1) / MASK_CHUNK;
@@ -281,8 +282,9 @@ __global__ __launch_bounds__(256) void k_refine_expand_raw(const Point *__restri
 // ------------------------------------------------------------------------------------------
 template <int SCENE>
 __global__ __launch_bounds__(256) void k_classify(const Point *__restrict__ vox, const uint32_t *__restrict__ n_ptr,
-                                                   Point vs, SceneParams sp, uint8_t *__restrict__ cubeidx,
+                                                   Point vs, const SceneParams *__restrict__ spp, uint8_t *__restrict__ cubeidx,
                                                    uint32_t *__restrict__ tilecnt) {
+    const SceneParams sp = *spp;   // scene uniform (device memory: a captured graph replays with new values)
     __shared__ uint32_t s_cnt;
     const uint32_t n = *n_ptr;
     const uint32_t ntiles = (n + TILE - 1) / TILE;
@@ -513,7 +515,8 @@ __global__ __launch_bounds__(1024) void k_tile_prefix(const uint4 *__restrict__ 
 template <int SCENE>
 __global__ __launch_bounds__(256) void k_project(Vertex *__restrict__ uverts, const uint4 *__restrict__ tdesc,
                                                   const uint32_t *__restrict__ tpre, const uint32_t *__restrict__ ntiles_ptr,
-                                                  SceneParams sp, uint32_t *__restrict__ status) {
+                                                  const SceneParams *__restrict__ spp, uint32_t *__restrict__ status) {
+    const SceneParams sp = *spp;   // scene uniform (device memory: a captured graph replays with new values)
     const uint32_t ntiles = *ntiles_ptr;
     const uint32_t U = ntiles ? tpre[ntiles] : 0u;
     const uint32_t lane = lane_id(), sub = lane & 3u, gbase = lane & ~3u;
@@ -583,7 +586,8 @@ __global__ __launch_bounds__(256) void k_project(Vertex *__restrict__ uverts, co
 // (lane a = 4-point stencil of axis a at the centroid), 21 triangles per wave
 template <int SCENE>
 __global__ __launch_bounds__(256) void k_flip(const Vertex *__restrict__ uverts, const uint32_t *__restrict__ tri_e,
-                                               const uint32_t *__restrict__ ntri_ptr, SceneParams sp, uint8_t *__restrict__ flip) {
+                                               const uint32_t *__restrict__ ntri_ptr, const SceneParams *__restrict__ spp, uint8_t *__restrict__ flip) {
+    const SceneParams sp = *spp;   // scene uniform (device memory: a captured graph replays with new values)
     const uint32_t T = *ntri_ptr;
     const uint32_t lane = lane_id(), g3 = lane / 3u, sub = lane - 3u * g3, gbase = 3u * g3;   // lane 63: g3 = 21, unused
     const uint32_t nwaves = gridDim.x * (blockDim.x >> 6);
@@ -846,8 +850,9 @@ __global__ __launch_bounds__(256) void k_expand_raw(const Vertex *__restrict__ u
 // "no edge sharing" A/B baseline.
 // ------------------------------------------------------------------------------------------
 template <int SCENE>
-__global__ __launch_bounds__(128) void k_triangles_direct(const Point *__restrict__ vox, uint32_t n, Point vs, SceneParams sp,
+__global__ __launch_bounds__(128) void k_triangles_direct(const Point *__restrict__ vox, uint32_t n, Point vs, const SceneParams *__restrict__ spp,
                                                            Triangle *__restrict__ out) {
+    const SceneParams sp = *spp;   // scene uniform (device memory: a captured graph replays with new values)
     const uint32_t v = blockIdx.x * blockDim.x + threadIdx.x;
     if (v < n) voxel_triangles_direct<SCENE>(vox[v], vs, sp, out + 5u * (size_t) v);
 }
@@ -948,7 +953,8 @@ __global__ void k_mul3_u32(const uint32_t *a, uint32_t *out) { *out = 3u * *a; }
 // P1: dense SDF sample pass, (N+1)^3 f32, x outer / z inner, one float4 store per thread
 // ------------------------------------------------------------------------------------------
 template <int SCENE, bool NT>
-__global__ __launch_bounds__(256) void k_sample_dense(float *__restrict__ out, uint32_t N, uint64_t total, SceneParams sp) {
+__global__ __launch_bounds__(256) void k_sample_dense(float *__restrict__ out, uint32_t N, uint64_t total, const SceneParams *__restrict__ spp) {
+    const SceneParams sp = *spp;   // scene uniform (device memory: a captured graph replays with new values)
     // Flat quads (4 consecutive samples, 16-B aligned float4 store) over the x-outer / z-inner volume.
     // (x, y, z) of a thread's first quad comes from one division; every further grid-stride step adds
     // the stride decomposed in base S, so the loop body has no division.  The (x, y)-only part of the
@@ -1006,7 +1012,7 @@ __global__ __launch_bounds__(256) void k_sample_dense(float *__restrict__ out, u
     default: return hipErrorInvalidValue;                                                         \
     }
 
-hipError_t launch_refine_mask(hipStream_t st, int grid, int scene, const SceneParams &sp, const Point *vox,
+hipError_t launch_refine_mask(hipStream_t st, int grid, int scene, const SceneParams *sp, const Point *vox,
                               const uint32_t *n_ptr, Point cs, uint8_t *mask, uint32_t *tilecnt) {
     SDM_DISPATCH(scene, hipLaunchKernelGGL(k_refine_mask<S>, dim3(grid), dim3(256), 0, st, vox, n_ptr, cs, sp, mask, tilecnt));
     return hipGetLastError();
@@ -1036,7 +1042,7 @@ hipError_t launch_refine_expand_raw(hipStream_t st, int grid, const Point *vox, 
     return hipGetLastError();
 }
 
-hipError_t launch_classify(hipStream_t st, int grid, int scene, const SceneParams &sp, const Point *vox,
+hipError_t launch_classify(hipStream_t st, int grid, int scene, const SceneParams *sp, const Point *vox,
                            const uint32_t *n_ptr, Point vs, uint8_t *cubeidx, uint32_t *tilecnt) {
     SDM_DISPATCH(scene, hipLaunchKernelGGL(k_classify<S>, dim3(grid), dim3(256), 0, st, vox, n_ptr, vs, sp, cubeidx, tilecnt));
     return hipGetLastError();
@@ -1055,13 +1061,13 @@ hipError_t launch_tile_prefix(hipStream_t st, const uint4 *tdesc, const uint32_t
     return hipGetLastError();
 }
 
-hipError_t launch_project(hipStream_t st, int grid, int scene, const SceneParams &sp, Vertex *uverts, const uint4 *tdesc,
+hipError_t launch_project(hipStream_t st, int grid, int scene, const SceneParams *sp, Vertex *uverts, const uint4 *tdesc,
                           const uint32_t *tpre, const uint32_t *ntiles_ptr, uint32_t *status) {
     SDM_DISPATCH(scene, hipLaunchKernelGGL(k_project<S>, dim3(grid), dim3(256), 0, st, uverts, tdesc, tpre, ntiles_ptr, sp, status));
     return hipGetLastError();
 }
 
-hipError_t launch_flip(hipStream_t st, int grid, int scene, const SceneParams &sp, const Vertex *uverts, const uint32_t *tri_e,
+hipError_t launch_flip(hipStream_t st, int grid, int scene, const SceneParams *sp, const Vertex *uverts, const uint32_t *tri_e,
                        const uint32_t *ntri_ptr, uint8_t *flip) {
     SDM_DISPATCH(scene, hipLaunchKernelGGL(k_flip<S>, dim3(grid), dim3(256), 0, st, uverts, tri_e, ntri_ptr, sp, flip));
     return hipGetLastError();
@@ -1110,7 +1116,7 @@ hipError_t launch_expand_raw(hipStream_t st, int grid, const Vertex *uverts, con
     return hipGetLastError();
 }
 
-hipError_t launch_triangles_direct(hipStream_t st, int scene, const SceneParams &sp, const Point *vox, uint32_t n, Point vs,
+hipError_t launch_triangles_direct(hipStream_t st, int scene, const SceneParams *sp, const Point *vox, uint32_t n, Point vs,
                                    Triangle *out) {
     const int grid = (int) ((n + 127u) / 128u);
     if (grid == 0) return hipSuccess;
@@ -1118,7 +1124,7 @@ hipError_t launch_triangles_direct(hipStream_t st, int scene, const SceneParams 
     return hipGetLastError();
 }
 
-hipError_t launch_sample_dense(hipStream_t st, int grid, int scene, const SceneParams &sp, float *out, uint32_t N, bool nt) {
+hipError_t launch_sample_dense(hipStream_t st, int grid, int scene, const SceneParams *sp, float *out, uint32_t N, bool nt) {
     const uint64_t total = (uint64_t) (N + 1) * (N + 1) * (N + 1);
     if (nt) { SDM_DISPATCH(scene, hipLaunchKernelGGL((k_sample_dense<S, true>), dim3(grid), dim3(256), 0, st, out, N, total, sp)); }
     else { SDM_DISPATCH(scene, hipLaunchKernelGGL((k_sample_dense<S, false>), dim3(grid), dim3(256), 0, st, out, N, total, sp)); }

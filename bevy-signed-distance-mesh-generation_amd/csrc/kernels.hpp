@@ -20,7 +20,7 @@ enum StatusWord : int {
     ST_WORDS = 8
 };
 
-hipError_t launch_refine_mask(hipStream_t st, int grid, int scene, const SceneParams &sp, const Point *vox,
+hipError_t launch_refine_mask(hipStream_t st, int grid, int scene, const SceneParams *sp, const Point *vox,
                               const uint32_t *n_ptr, Point cs, uint8_t *mask, uint32_t *tilecnt);
 hipError_t launch_scan_tiles(hipStream_t st, uint32_t *cnt, const uint32_t *n_ptr, uint32_t items_per_tile,
                              uint32_t *total_out, uint32_t cap, uint32_t *status);
@@ -30,15 +30,15 @@ hipError_t launch_refine_emit(hipStream_t st, int grid, const Point *vox, const 
 hipError_t launch_sum_tiles(hipStream_t st, const uint32_t *tilecnt, const uint32_t *n_ptr, uint32_t *total_out);
 hipError_t launch_refine_expand_raw(hipStream_t st, int grid, const Point *vox, uint32_t n, Point cs, const uint8_t *mask,
                                     Point *out);
-hipError_t launch_classify(hipStream_t st, int grid, int scene, const SceneParams &sp, const Point *vox,
+hipError_t launch_classify(hipStream_t st, int grid, int scene, const SceneParams *sp, const Point *vox,
                            const uint32_t *n_ptr, Point vs, uint8_t *cubeidx, uint32_t *tilecnt);
 hipError_t launch_tile_dedupe(hipStream_t st, int grid, const Point *vox, const uint32_t *n_ptr, Point vs, const uint8_t *cubeidx,
                               const uint32_t *tilecnt, uint32_t *trioff, uint32_t *tri_e, Vertex *uverts, uint4 *tdesc,
                               uint32_t ucap, uint32_t tcap, uint32_t *ntri_out, uint32_t *ntiles_out, uint32_t *status);
 hipError_t launch_tile_prefix(hipStream_t st, const uint4 *tdesc, const uint32_t *ntiles_ptr, uint32_t *tpre, uint32_t *nu_out);
-hipError_t launch_project(hipStream_t st, int grid, int scene, const SceneParams &sp, Vertex *uverts, const uint4 *tdesc,
+hipError_t launch_project(hipStream_t st, int grid, int scene, const SceneParams *sp, Vertex *uverts, const uint4 *tdesc,
                           const uint32_t *tpre, const uint32_t *ntiles_ptr, uint32_t *status);
-hipError_t launch_flip(hipStream_t st, int grid, int scene, const SceneParams &sp, const Vertex *uverts, const uint32_t *tri_e,
+hipError_t launch_flip(hipStream_t st, int grid, int scene, const SceneParams *sp, const Vertex *uverts, const uint32_t *tri_e,
                        const uint32_t *ntri_ptr, uint8_t *flip);
 hipError_t launch_raw_desc(hipStream_t st, int grid, const uint32_t *ntri_ptr, uint4 *tdesc, uint8_t *flip, uint32_t *ntiles_out,
                            uint32_t *nu_out);
@@ -53,9 +53,9 @@ hipError_t launch_expand_compact(hipStream_t st, int grid, const Vertex *uverts,
                                  const uint32_t *ntri_ptr, Triangle *out, uint32_t cap);
 hipError_t launch_expand_raw(hipStream_t st, int grid, const Vertex *uverts, const uint32_t *tri_e, const uint8_t *flip,
                              const uint8_t *cubeidx, const uint32_t *trioff, uint32_t n, Triangle *out);
-hipError_t launch_triangles_direct(hipStream_t st, int scene, const SceneParams &sp, const Point *vox, uint32_t n, Point vs,
+hipError_t launch_triangles_direct(hipStream_t st, int scene, const SceneParams *sp, const Point *vox, uint32_t n, Point vs,
                                    Triangle *out);
-hipError_t launch_sample_dense(hipStream_t st, int grid, int scene, const SceneParams &sp, float *out, uint32_t N, bool nt);
+hipError_t launch_sample_dense(hipStream_t st, int grid, int scene, const SceneParams *sp, float *out, uint32_t N, bool nt);
 hipError_t launch_create_field(hipStream_t st, Point *vox, uint32_t z0, uint32_t z1, uint32_t *n_out);
 hipError_t launch_raw_count(hipStream_t st, int grid, const Triangle *raw, const uint32_t *n_ptr, uint32_t *tilecnt);
 hipError_t launch_raw_compact(hipStream_t st, int grid, const Triangle *raw, const uint32_t *n_ptr, const uint32_t *tileoff,

@@ -44,18 +44,51 @@ class ObjData:
     texture: np.ndarray = dataclasses.field(default_factory=lambda: np.zeros((1, 2), np.float32))
 
     def save(self, path):
-        """Wavefront OBJ in the layout obj-rs writes for the reference (`v`, `vt 0 0`, `vn`, then
-        `f i/1/i` with 1-based indices; src/renderer/mod.rs:204)."""
+        """Wavefront OBJ with the content the reference saves through obj-rs 0.10 (`obj.save`,
+        src/renderer/mod.rs:204): every position as `v`, the single texture coordinate `vt 0 0`, every normal as
+        `vn`, one object/group "default", and per triangle `f i/1/i j/1/j k/1/k` with 1-based indices, where the
+        position index equals the normal index (src/cuda/mod.rs:316-321).  Floats are written with the shortest
+        representation that round-trips f32, so loading the file restores the arrays bit for bit."""
         with open(path, "w") as f:
-            f.write("o default\ng default\n")
             for p in self.position:
-                f.write("v %s %s %s\n" % (repr(float(p[0])), repr(float(p[1])), repr(float(p[2]))))
+                f.write("v %s %s %s\n" % tuple(_f32_str(c) for c in p))
             f.write("vt 0 0\n")
             for n in self.normal:
-                f.write("vn %s %s %s\n" % (repr(float(n[0])), repr(float(n[1])), repr(float(n[2]))))
+                f.write("vn %s %s %s\n" % tuple(_f32_str(c) for c in n))
+            f.write("o default\ng default\n")
             for t in self.indices:
                 a, b, c = int(t[0]) + 1, int(t[1]) + 1, int(t[2]) + 1
                 f.write(f"f {a}/1/{a} {b}/1/{b} {c}/1/{c}\n")
+
+    @staticmethod
+    def load(path):
+        """Inverse of save() (and a reader for obj files with the same v/vt/vn/f i/j/k layout)."""
+        pos, nrm, idx = [], [], []
+        with open(path) as f:
+            for line in f:
+                w = line.split()
+                if not w:
+                    continue
+                if w[0] == "v":
+                    pos.append([np.float32(x) for x in w[1:4]])
+                elif w[0] == "vn":
+                    nrm.append([np.float32(x) for x in w[1:4]])
+                elif w[0] == "f":
+                    tri = [c.split("/") for c in w[1:4]]
+                    assert all(c[0] == c[2] for c in tri), "position index must equal normal index"
+                    idx.append([int(c[0]) - 1 for c in tri])
+        return ObjData(np.array(pos, np.float32).reshape(-1, 3), np.array(nrm, np.float32).reshape(-1, 3),
+                       np.array(idx, np.uint32).reshape(-1, 3))
+
+
+def _f32_str(x):
+    """Shortest decimal string that parses back to the same f32."""
+    x = np.float32(x)
+    for prec in range(1, 10):
+        t = "%.*g" % (prec, float(x))
+        if np.float32(t) == x:
+            return t
+    return repr(float(x))
 
 
 def _pt(a):
