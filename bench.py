@@ -262,6 +262,13 @@ def main():
                          "traffic": P1_TRAFFIC_512 if n_grid == 512 else None,
                          "bytes_per_launch": alg_bytes, "avg_launch_ms": round(ms, 5),
                          "gsamples_per_s": round((n_grid + 1) ** 3 / (ms * 1e-3) / 1e9, 1)}
+        # P2a: sign bits of the dense lattice -- the streaming-READ pass (4 B x (N+1)^3 in, 1 bit per sample out)
+        h.set_scene("sphere")
+        ms2 = h.time_kernel(1, n_grid, buf.data_ptr(), 50)
+        gb2 = alg_bytes / (ms2 * 1e-3) / 1e9
+        out["roofline_p2_sign_bits"] = {"bound": "hbm", "kernel": "k_sign_bits", "achieved": round(gb2, 1), "peak": HBM_PEAK_GBPS,
+                                        "unit": "GB/s", "frac": round(gb2 / HBM_PEAK_GBPS, 4), "traffic": None,
+                                        "bytes_per_launch": alg_bytes + alg_bytes / 32, "avg_launch_ms": round(ms2, 5)}
         h.set_scene(args.scene, params)
         del buf
         out["roofline"] = roofs["sphere"]

@@ -74,6 +74,7 @@ SYMBOLS = {
     "sdmesh_column_triangle_counts": (_i, [_vp, _vp]),
     "sdmesh_download_mesh": (_i, [_vp, _vp, _vp]),
     "sdmesh_download_voxels": (_i, [_vp, _vp]),
+    "sdmesh_regen_dense": (_i, [_vp, _i, ctypes.POINTER(RegenInfo)]),
     "sdmesh_sample_dense": (_i, [_vp, _u32, _vp, ctypes.POINTER(ctypes.c_float)]),
     "sdmesh_time_kernel": (_i, [_vp, _i, _u32, _vp, _i, ctypes.POINTER(ctypes.c_float)]),
 }

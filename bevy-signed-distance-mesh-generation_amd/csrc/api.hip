@@ -81,7 +81,7 @@ struct sdmesh_handle {
     uint32_t *h_pinned = nullptr;  // CTR_WORDS + ST_WORDS, pinned
     // mesh stage
     DevBuf cubeidx, trioff, ff_arena, first_ord_buf, wfirst, uverts, tri_e, vslot, tdesc, tfirst, tfpre, tpre, flip, wvidx, torder;
-    DevBuf vertices, indices, raw, compact, staging;
+    DevBuf vertices, indices, raw, compact, staging, dense_samples, dense_bits, cellcnt;
     // capacities the device chain was laid out for
     uint32_t cap_vox = 0, ucap = 0, tcap = 0, wsize = 0;
     uint64_t *wkeys = nullptr;
@@ -191,12 +191,14 @@ size_t ff_bytes(const sdmesh_handle *h) {
 
 // classify -> tile dedupe -> project -> flip for the voxel list d_vox (count at *n_ptr, at most cap_vox):
 // leaves (uverts, tri_e, flip, trioff, tdesc) and the counters NUNIQ / NTRI / NTILES on the device
-int mesh_front(sdmesh_handle *h, const Point *d_vox, const uint32_t *n_ptr, Point vs, bool zero_counters, bool ff_done = false) {
+int mesh_front(sdmesh_handle *h, const Point *d_vox, const uint32_t *n_ptr, Point vs, bool zero_counters, bool ff_done = false,
+               bool have_cubeidx = false) {
     hipStream_t st = h->stream;
     if (!ff_done) HIPCHK(hipMemsetAsync(h->ff_arena.p, 0xFF, ff_bytes(h), st));
     else HIPCHK(hipStreamWaitEvent(st, h->ev_ff, 0));          // table was cleared on the side stream during the refine
     if (zero_counters) HIPCHK(hipMemsetAsync(h->d_ctr + CTR_NUNIQ, 0, 4 * sizeof(uint32_t), st));
-    HIPCHK(launch_classify(st, h->grid, h->scene, h->d_sp, d_vox, n_ptr, vs, (uint8_t *) h->cubeidx.p, (uint32_t *) h->tilecnt.p));
+    if (have_cubeidx) HIPCHK(launch_tile_tricount(st, h->grid, (const uint8_t *) h->cubeidx.p, n_ptr, (uint32_t *) h->tilecnt.p));
+    else HIPCHK(launch_classify(st, h->grid, h->scene, h->d_sp, d_vox, n_ptr, vs, (uint8_t *) h->cubeidx.p, (uint32_t *) h->tilecnt.p));
     HIPCHK(launch_tile_dedupe(st, h->grid, d_vox, n_ptr, vs, (const uint8_t *) h->cubeidx.p, (const uint32_t *) h->tilecnt.p,
                               (uint32_t *) h->trioff.p, (uint32_t *) h->tri_e.p, (Vertex *) h->uverts.p, (uint4 *) h->tdesc.p,
                               h->ucap, h->tcap, h->d_ctr + CTR_NTRI, h->d_ctr + CTR_NTILES, h->d_status));
@@ -635,7 +637,8 @@ void sdmesh_destroy(sdmesh_handle *h) {
     drop_graph(h);
     DevBuf *bufs[] = {&h->vox[0], &h->vox[1], &h->mask, &h->tilecnt, &h->ctl, &h->cubeidx, &h->trioff, &h->ff_arena,
                       &h->first_ord_buf, &h->wfirst, &h->uverts, &h->tri_e, &h->vslot, &h->tdesc, &h->tfirst, &h->tfpre, &h->tpre, &h->flip, &h->wvidx, &h->torder,
-                      &h->vertices, &h->indices, &h->raw, &h->compact, &h->staging};
+                      &h->vertices, &h->indices, &h->raw, &h->compact, &h->staging, &h->dense_samples, &h->dense_bits,
+                      &h->cellcnt};
     for (DevBuf *b : bufs) release(*b);
     if (h->h_pinned) (void) hipHostFree(h->h_pinned);
     if (h->d_sp) (void) hipFree(h->d_sp);
@@ -949,6 +952,67 @@ int sdmesh_download_voxels(sdmesh_handle *h, struct Point *voxels) {
     return SDMESH_OK;
 }
 
+int sdmesh_regen_dense(sdmesh_handle *h, int levels, sdmesh_regen_info *info) {
+    if (!h) return SDMESH_ERR_INVALID;
+    if (levels < 0 || levels > 5) return fail(h, SDMESH_ERR_INVALID, "dense mode supports levels 0..5 (N <= 1024)");
+    HIPCHK(hipSetDevice(h->device));
+    SDCHK(sync_scene(h));
+    hipStream_t st = h->stream;
+    const uint32_t F = MESH_GENERATION_INIT_FACTOR, N = F << levels;
+    const uint64_t total = (uint64_t) (N + 1) * (N + 1) * (N + 1);
+    h->mesh_valid = h->vox_valid = false;
+    h->plan_valid = false;
+    SDCHK(ensure(h, h->dense_samples, 4ull * total + 64));
+    SDCHK(ensure(h, h->dense_bits, 4ull * (total / 32 + 8)));
+    SDCHK(ensure(h, h->cellcnt, 4ull * (F * F * F + 16)));
+    HIPCHK(hipEventRecord(h->ev0, st));
+    SDCHK(zero_ctl(h, 0));
+    HIPCHK(hipMemsetAsync(h->dense_bits.p, 0, 4ull * (total / 32 + 8), st));
+    HIPCHK(launch_sample_dense(st, h->dense_grid, h->scene, h->d_sp, (float *) h->dense_samples.p, N, h->dense_nt != 0));
+    HIPCHK(launch_sign_bits(st, h->dense_grid, (const float *) h->dense_samples.p, total, (uint32_t *) h->dense_bits.p));
+    HIPCHK(launch_dense_classify(st, 8 * h->grid, false, (const uint32_t *) h->dense_bits.p, (uint32_t) levels,
+                                 (uint32_t *) h->cellcnt.p, nullptr, nullptr, 0));
+    HIPCHK(launch_set_u32(st, h->d_ctr + CTR_SCRATCH, F * F * F));
+    HIPCHK(launch_scan_tiles(st, (uint32_t *) h->cellcnt.p, h->d_ctr + CTR_SCRATCH, 1, h->d_ctr + CTR_LEVEL0 + levels, 0xFFFFFFFFu,
+                             h->d_status));
+    uint32_t n = 0;
+    HIPCHK(hipMemcpyAsync(&n, h->d_ctr + CTR_LEVEL0 + levels, 4, hipMemcpyDeviceToHost, st));
+    HIPCHK(hipStreamSynchronize(st));
+    SDCHK(ensure(h, h->vox[0], sizeof(Point) * (size_t) std::max<uint32_t>(n, 64)));
+    SDCHK(layout_mesh(h, n, 0));
+    h->cur = 0;
+    HIPCHK(launch_dense_classify(st, 8 * h->grid, true, (const uint32_t *) h->dense_bits.p, (uint32_t) levels,
+                                 (uint32_t *) h->cellcnt.p, (Point *) h->vox[0].p, (uint8_t *) h->cubeidx.p, n));
+    Point vs;
+    vs.x = vs.y = vs.z = (MESH_GENERATION_BB_SIZE / (float) MESH_GENERATION_INIT_FACTOR) / (float) (1u << levels);
+    for (int attempt = 0; attempt < 2; attempt++) {
+        SDCHK(mesh_front(h, (const Point *) h->vox[0].p, h->d_ctr + CTR_LEVEL0 + levels, vs, true, false, true));
+        SDCHK(mesh_weld(h, (const Vertex *) h->uverts.p));
+        HIPCHK(hipEventRecord(h->ev1, st));
+        SDCHK(read_back(h));
+        if (!h->h_pinned[CTR_WORDS + ST_OVERFLOW]) break;
+        if (attempt == 1) return fail(h, SDMESH_ERR_INTERNAL, "capacity overflow persists");
+        SDCHK(layout_mesh(h, n, h->h_pinned[CTR_NUNIQ] + 1024));
+        SDCHK(zero_status(h));
+    }
+    SDCHK(status_to_error(h));
+    if (h->h_pinned[CTR_WORDS + ST_NOT_LATTICE] || h->h_pinned[CTR_WORDS + ST_TILE_OVERFLOW])
+        return fail(h, SDMESH_ERR_INTERNAL, "dense mode produced a non-lattice field");
+    float ms = 0.0f;
+    HIPCHK(hipEventElapsedTime(&ms, h->ev0, h->ev1));
+    h->n_vox = n;
+    h->n_unique = h->h_pinned[CTR_NUNIQ];
+    h->n_tris = h->h_pinned[CTR_NTRI];
+    h->n_verts = h->h_pinned[CTR_NVERT];
+    h->voxel_size = vs;
+    h->mesh_valid = h->vox_valid = true;
+    h->last_direct = false;
+    h->welded = true;
+    fill_info(h, info, levels, false, ms);
+    if (info) { for (int i = 0; i < levels; i++) info->voxel_count[i] = 0; info->voxel_count[levels] = n; }
+    return SDMESH_OK;
+}
+
 int sdmesh_sample_dense(sdmesh_handle *h, uint32_t N, float *d_out, float *kernel_ms) {
     if (!h || !d_out || N == 0 || N > 4096) return SDMESH_ERR_INVALID;
     HIPCHK(hipSetDevice(h->device));
@@ -962,9 +1026,23 @@ int sdmesh_sample_dense(sdmesh_handle *h, uint32_t N, float *d_out, float *kerne
 }
 
 int sdmesh_time_kernel(sdmesh_handle *h, int which, uint32_t N, float *d_buf, int iters, float *avg_ms) {
-    if (!h || !avg_ms || iters < 1 || which != 0 || !d_buf || N == 0 || N > 4096) return SDMESH_ERR_INVALID;
+    if (!h || !avg_ms || iters < 1 || which < 0 || which > 1 || !d_buf || N == 0 || N > 4096) return SDMESH_ERR_INVALID;
     HIPCHK(hipSetDevice(h->device));
     SDCHK(sync_scene(h));
+    if (which == 1) {     // P2a: sign bits of the dense lattice in d_buf (fills it first)
+        const uint64_t total = (uint64_t) (N + 1) * (N + 1) * (N + 1);
+        SDCHK(ensure(h, h->dense_bits, 4ull * (total / 32 + 8)));
+        HIPCHK(launch_sample_dense(h->stream, h->dense_grid, h->scene, h->d_sp, d_buf, N, h->dense_nt != 0));
+        HIPCHK(launch_sign_bits(h->stream, h->dense_grid, d_buf, total, (uint32_t *) h->dense_bits.p));
+        HIPCHK(hipEventRecord(h->ev0, h->stream));
+        for (int i = 0; i < iters; i++) HIPCHK(launch_sign_bits(h->stream, h->dense_grid, d_buf, total, (uint32_t *) h->dense_bits.p));
+        HIPCHK(hipEventRecord(h->ev1, h->stream));
+        HIPCHK(hipStreamSynchronize(h->stream));
+        float ms1 = 0.0f;
+        HIPCHK(hipEventElapsedTime(&ms1, h->ev0, h->ev1));
+        *avg_ms = ms1 / (float) iters;
+        return SDMESH_OK;
+    }
     HIPCHK(launch_sample_dense(h->stream, h->dense_grid > 0 ? h->dense_grid : 8 * h->grid, h->scene, h->d_sp, d_buf, N, h->dense_nt != 0));   // warm-up
     HIPCHK(hipEventRecord(h->ev0, h->stream));
     for (int i = 0; i < iters; i++) HIPCHK(launch_sample_dense(h->stream, h->dense_grid > 0 ? h->dense_grid : 8 * h->grid, h->scene, h->d_sp, d_buf, N, h->dense_nt != 0));

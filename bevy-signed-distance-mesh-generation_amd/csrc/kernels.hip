@@ -317,6 +317,24 @@ __global__ __launch_bounds__(256) void k_classify(const Point *__restrict__ vox,
     }
 }
 
+// triangle count per tile when the cube indices are already known (dense mode)
+__global__ __launch_bounds__(256) void k_tile_tricount(const uint8_t *__restrict__ cubeidx, const uint32_t *__restrict__ n_ptr,
+                                                        uint32_t *__restrict__ tilecnt) {
+    __shared__ uint32_t s_cnt;
+    const uint32_t n = *n_ptr;
+    const uint32_t ntiles = (n + TILE - 1) / TILE;
+    for (uint32_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        if (threadIdx.x == 0) s_cnt = 0;
+        __syncthreads();
+        const uint32_t v = tile * TILE + threadIdx.x;
+        const uint32_t ws = wave_sum(v < n ? (uint32_t) MC_TRI_COUNT[cubeidx[v]] : 0u);
+        if (lane_id() == 0 && ws) atomicAdd(&s_cnt, ws);
+        __syncthreads();
+        if (threadIdx.x == 0) tilecnt[tile] = s_cnt;
+        __syncthreads();
+    }
+}
+
 // ------------------------------------------------------------------------------------------
 // A4-A7 mesh stage 2.  Work is split by what bounds it:
 //   k_tile_dedupe   per 256-voxel tile, LDS hash: tile-unique lattice edges, corner->vertex table
@@ -946,6 +964,145 @@ __global__ __launch_bounds__(256) void k_column_counts(const Point *__restrict__
         if (s_hist[i]) atomicAdd(&colcnt[i], s_hist[i]);
 }
 
+// ------------------------------------------------------------------------------------------
+// Dense mode: the same voxel list as the hierarchical refine, derived from
+// the dense (N+1)^3 sample lattice.
+//   P2a k_sign_bits      one bit per sample (sd <= 0): a pure streaming read, 4 B x (N+1)^3 -> HBM-bound
+//   P2b k_dense_classify one workgroup per level-0 cell: the (T+1)^3 sign bits of the cell (T = 2^k) are staged
+//                        in LDS as (T+1)^2 rows of T+1 bits; every fine cell tests itself and all its ancestors
+//                        (levels 1..k, corners at stride 2^(k-j): the emergent criterion A2' of the reference's
+//                        refine-then-retain loop); threads run in the reference's child-slot (Morton, x-major)
+//                        order, so a block scan gives the ordered compaction.
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_sign_bits(const float *__restrict__ samples, uint64_t total, uint32_t *__restrict__ bits) {
+    typedef float v4f __attribute__((ext_vector_type(4)));
+    const uint64_t nquads = (total + 3ull) >> 2;
+    const uint64_t stride = (uint64_t) gridDim.x * blockDim.x;
+    const uint32_t lane = lane_id();
+    // grid-stride in whole waves so the 8 lanes that share an output word always run together
+    for (uint64_t q0 = ((uint64_t) blockIdx.x * blockDim.x + threadIdx.x) - lane; q0 < nquads; q0 += stride) {
+        const uint64_t q = q0 + lane;
+        uint32_t nib = 0;
+        if (q < nquads) {
+            const uint64_t i0 = q << 2;
+            if (i0 + 3 < total) {
+                const v4f v = __builtin_nontemporal_load(reinterpret_cast<const v4f *>(samples + i0));
+                nib = (v.x <= 0.0f ? 1u : 0u) | (v.y <= 0.0f ? 2u : 0u) | (v.z <= 0.0f ? 4u : 0u) | (v.w <= 0.0f ? 8u : 0u);
+            } else {
+                for (int k = 0; k < 4 && i0 + k < total; k++) nib |= (samples[i0 + k] <= 0.0f ? 1u : 0u) << k;
+            }
+        }
+        uint32_t w = nib << (4u * (lane & 7u));
+        w |= __shfl_xor(w, 1, 64);
+        w |= __shfl_xor(w, 2, 64);
+        w |= __shfl_xor(w, 4, 64);
+        if ((lane & 7u) == 0 && q < nquads) bits[q >> 3] = w;
+    }
+}
+
+__device__ __forceinline__ uint32_t lattice_bit(const uint32_t *__restrict__ bits, uint64_t i) {
+    return (bits[i >> 5] >> (i & 31u)) & 1u;
+}
+
+template <bool EMIT>
+__global__ __launch_bounds__(256) void k_dense_classify(const uint32_t *__restrict__ bits, uint32_t k /* levels */,
+                                                         uint32_t *__restrict__ cellcnt /* per level-0 cell: count (in) / offset (EMIT) */,
+                                                         Point *__restrict__ vox, uint8_t *__restrict__ cubeidx, uint32_t cap) {
+    __shared__ uint64_t s_row[33 * 33];      // row (lx, ly): bit lz = sign at (X0*T + lx, Y0*T + ly, Z0*T + lz); T <= 32
+    __shared__ uint32_t s_scan[17];
+    __shared__ uint32_t s_mixed;
+    const uint32_t F = MESH_GENERATION_INIT_FACTOR;
+    const uint32_t T = 1u << k, N = F * T, S = N + 1u, R = T + 1u;
+    const float h = (MESH_GENERATION_BB_SIZE / (float) MESH_GENERATION_INIT_FACTOR) / (float) T;
+    const uint32_t tid = threadIdx.x;
+    for (uint32_t cell = blockIdx.x; cell < F * F * F; cell += gridDim.x) {
+        const uint32_t X0 = cell / (F * F), Y0 = (cell / F) % F, Z0 = cell % F;
+        if (tid == 0) s_mixed = 0;
+        __syncthreads();
+        uint64_t any = 0, all = ~0ull;
+        bool seen = false;
+        const uint64_t rowmask = R >= 64 ? ~0ull : ((1ull << R) - 1ull);
+        for (uint32_t r = tid; r < R * R; r += 256) {
+            seen = true;
+            const uint32_t lx = r / R, ly = r % R;
+            const uint64_t i0 = ((uint64_t) (X0 * T + lx) * S + (Y0 * T + ly)) * S + (uint64_t) Z0 * T;
+            // R <= 33 bits starting at bit i0: at most three 32-bit words
+            const uint64_t w0 = i0 >> 5;
+            const uint32_t sh = (uint32_t) (i0 & 31u);
+            uint64_t lo = (uint64_t) bits[w0] | ((uint64_t) bits[w0 + 1] << 32);
+            uint64_t v = lo >> sh;
+            if (sh + R > 64u) v |= (uint64_t) bits[w0 + 2] << (64u - sh);
+            v &= rowmask;
+            s_row[r] = v;
+            any |= v;
+            all &= v | ~rowmask;
+        }
+        if (seen) {
+            if (any != 0ull && all != ~0ull) atomicOr(&s_mixed, 1u);   // this thread saw both signs
+            else if (any != 0ull) atomicOr(&s_mixed, 2u);              // saw only "inside"
+            else atomicOr(&s_mixed, 4u);                               // saw only "outside"
+        }
+        __syncthreads();
+        const uint32_t mm = s_mixed;
+        const bool cell_mixed = (mm & 1u) || ((mm & 6u) == 6u);
+        if (!cell_mixed && k > 0) {                             // uniform level-0 cell: nothing survives level 1 (level 0 itself is unfiltered)
+            if (!EMIT && tid == 0) cellcnt[cell] = 0;
+            __syncthreads();
+            continue;
+        }
+        uint32_t running = EMIT ? cellcnt[cell] : 0u;
+        const uint32_t ncode = 1u << (3u * k);
+        for (uint32_t base = 0; base < ncode; base += 256) {
+            const uint32_t code = base + tid;
+            bool active = false;
+            uint32_t x = 0, y = 0, z = 0, ci = 0;
+            if (code < ncode) {
+                for (uint32_t m = 0; m < k; m++) {               // triple m: z = bit 3m, y = 3m+1, x = 3m+2
+                    z |= ((code >> (3u * m)) & 1u) << m;
+                    y |= ((code >> (3u * m + 1u)) & 1u) << m;
+                    x |= ((code >> (3u * m + 2u)) & 1u) << m;
+                }
+                active = true;
+                for (uint32_t j = 1; j <= k && active; j++) {     // the cell's ancestor at level j (j = k: itself)
+                    const uint32_t s = k - j, step = 1u << s;
+                    const uint32_t ax = (x >> s) << s, ay = (y >> s) << s, az = (z >> s) << s;
+                    uint32_t cnt = 0;
+#pragma unroll
+                    for (int c = 0; c < 8; c++) {
+                        const uint32_t cx = ax + (cox(c) ? step : 0u), cy = ay + (coy(c) ? step : 0u), cz = az + (coz(c) ? step : 0u);
+                        const uint32_t b = (uint32_t) (s_row[cx * R + cy] >> cz) & 1u;
+                        cnt += b;
+                        if (j == k) ci |= b << c;
+                    }
+                    active = cnt != 0 && cnt != 8;
+                }
+                if (k == 0) {                                     // level 0 is unfiltered (src/cuda/mod.rs:105-122)
+                    active = true;
+#pragma unroll
+                    for (int c = 0; c < 8; c++)
+                        ci |= ((uint32_t) (s_row[(uint32_t) cox(c) * R + (uint32_t) coy(c)] >> coz(c)) & 1u) << c;
+                }
+            }
+            uint32_t total;
+            const uint32_t ex = block_excl_scan(active ? 1u : 0u, total, s_scan);
+            if (EMIT && active) {
+                const uint32_t o = running + ex;
+                if (o < cap) {
+                    Point p;
+                    p.x = (float) (X0 * T + x) * h - 2.5f;
+                    p.y = (float) (Y0 * T + y) * h - 2.5f;
+                    p.z = (float) (Z0 * T + z) * h - 2.5f;
+                    vox[o] = p;
+                    cubeidx[o] = (uint8_t) ci;
+                }
+            }
+            running += total;
+        }
+        if (!EMIT && tid == 0) cellcnt[cell] = running;
+        __syncthreads();
+    }
+}
+
 __global__ void k_set_u32(uint32_t *p, uint32_t v) { *p = v; }
 __global__ void k_mul3_u32(const uint32_t *a, uint32_t *out) { *out = 3u * *a; }
 
@@ -1150,6 +1307,23 @@ hipError_t launch_raw_compact(hipStream_t st, int grid, const Triangle *raw, con
 hipError_t launch_column_counts(hipStream_t st, int grid, const Point *vox, const uint32_t *n_ptr, const uint8_t *cubeidx,
                                 uint32_t *colcnt) {
     hipLaunchKernelGGL(k_column_counts, dim3(grid), dim3(256), 0, st, vox, n_ptr, cubeidx, colcnt);
+    return hipGetLastError();
+}
+
+hipError_t launch_tile_tricount(hipStream_t st, int grid, const uint8_t *cubeidx, const uint32_t *n_ptr, uint32_t *tilecnt) {
+    hipLaunchKernelGGL(k_tile_tricount, dim3(grid), dim3(256), 0, st, cubeidx, n_ptr, tilecnt);
+    return hipGetLastError();
+}
+
+hipError_t launch_sign_bits(hipStream_t st, int grid, const float *samples, uint64_t total, uint32_t *bits) {
+    hipLaunchKernelGGL(k_sign_bits, dim3(grid), dim3(256), 0, st, samples, total, bits);
+    return hipGetLastError();
+}
+
+hipError_t launch_dense_classify(hipStream_t st, int grid, bool emit, const uint32_t *bits, uint32_t k, uint32_t *cellcnt,
+                                 Point *vox, uint8_t *cubeidx, uint32_t cap) {
+    if (emit) hipLaunchKernelGGL(k_dense_classify<true>, dim3(grid), dim3(256), 0, st, bits, k, cellcnt, vox, cubeidx, cap);
+    else hipLaunchKernelGGL(k_dense_classify<false>, dim3(grid), dim3(256), 0, st, bits, k, cellcnt, vox, cubeidx, cap);
     return hipGetLastError();
 }
 

@@ -62,6 +62,10 @@ hipError_t launch_raw_compact(hipStream_t st, int grid, const Triangle *raw, con
                               Triangle *out, uint32_t *tri_e, uint32_t cap);
 hipError_t launch_column_counts(hipStream_t st, int grid, const Point *vox, const uint32_t *n_ptr, const uint8_t *cubeidx,
                                 uint32_t *colcnt);
+hipError_t launch_tile_tricount(hipStream_t st, int grid, const uint8_t *cubeidx, const uint32_t *n_ptr, uint32_t *tilecnt);
+hipError_t launch_sign_bits(hipStream_t st, int grid, const float *samples, uint64_t total, uint32_t *bits);
+hipError_t launch_dense_classify(hipStream_t st, int grid, bool emit, const uint32_t *bits, uint32_t k, uint32_t *cellcnt,
+                                 Point *vox, uint8_t *cubeidx, uint32_t cap);
 hipError_t launch_set_u32(hipStream_t st, uint32_t *p, uint32_t v);
 hipError_t launch_mul3_u32(hipStream_t st, const uint32_t *a, uint32_t *out);
 

@@ -204,6 +204,12 @@ class CudaHandler:
                                                ctypes.byref(info)))
         return info
 
+    def regen_dense(self, levels):
+        """Same result as regen(levels) via the dense lattice (sample -> sign bits -> LDS-tiled classify)."""
+        info = RegenInfo()
+        self._chk(self._lib.sdmesh_regen_dense(self._h, int(levels), ctypes.byref(info)))
+        return info
+
     def download_mesh(self, info=None):
         m = Mesh()
         nt = ctypes.c_uint32(0)

@@ -144,12 +144,17 @@ int sdmesh_column_triangle_counts(sdmesh_handle *h, uint32_t *d_counts);
 int sdmesh_download_mesh(sdmesh_handle *h, struct Vertex *verts, struct IndexTriangle *tris);
 int sdmesh_download_voxels(sdmesh_handle *h, struct Point *voxels);
 
+/* Dense mode: the same regen through the dense (N+1)^3 lattice -- P1 sample, P2a sign bits, P2b
+ * LDS-tiled classify with the hierarchical ancestor criterion (A2'), then the usual mesh stage.  O(N^3) work; it
+ * exists as the cross-check that "dense == hierarchical" and to measure the two HBM passes, not as the fast path. */
+int sdmesh_regen_dense(sdmesh_handle *h, int levels, sdmesh_regen_info *info);
+
 /* P1: dense (N+1)^3 f32 sample of the scene SDF into a DEVICE buffer, x outer /
  * z inner, sample m at (float)m * (5/N) - 2.5.  *kernel_ms (optional) = HIP-event time. */
 int sdmesh_sample_dense(sdmesh_handle *h, uint32_t N, float *d_out, float *kernel_ms);
 
 /* Time `iters` back-to-back launches of one internal kernel with HIP events on the handle's stream
- * (bench.py's live roofline measurement).  which: 0 = sample_dense(N) into d_buf. */
+ * (bench.py's live roofline measurement).  which: 0 = P1 sample_dense(N) into d_buf; 1 = P2a sign bits of d_buf. */
 int sdmesh_time_kernel(sdmesh_handle *h, int which, uint32_t N, float *d_buf, int iters, float *avg_ms);
 
 #ifdef __cplusplus
