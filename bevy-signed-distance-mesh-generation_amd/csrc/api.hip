@@ -61,6 +61,7 @@ struct sdmesh_handle {
     uint32_t min_chunk = 128;  // unique edges per wave queue in k_project
     int dense_grid = 16384;    // workgroups for k_sample_dense
     int dense_nt = 1;          // nontemporal stores in k_sample_dense
+    int dense_rows = 2;        // P1 kernel: 0 = flat 16-B aligned quads, 1 = one wave per z-row, 2 = auto
     char err[512] = {0};
     uint64_t buf_gen = 0;      // bumped whenever a device buffer is (re)allocated: invalidates a captured graph
     int use_graph = 0;         // replay the planned regen as a hipGraph
@@ -690,6 +691,7 @@ int sdmesh_set_option(sdmesh_handle *h, const char *name, int value) {
     }
     if (!strcmp(name, "dense_grid")) { h->dense_grid = value; return SDMESH_OK; }
     if (!strcmp(name, "dense_nt")) { h->dense_nt = value ? 1 : 0; return SDMESH_OK; }
+    if (!strcmp(name, "dense_rows")) { h->dense_rows = value; return SDMESH_OK; }
     if (!strcmp(name, "forget_plan")) { h->plan_valid = false; return SDMESH_OK; }
     return fail(h, SDMESH_ERR_INVALID, "unknown option %s", name);
 }
@@ -952,6 +954,15 @@ int sdmesh_download_voxels(sdmesh_handle *h, struct Point *voxels) {
     return SDMESH_OK;
 }
 
+static hipError_t launch_p1(sdmesh_handle *h, float *d_out, uint32_t N) {
+    const int grid = h->dense_grid > 0 ? h->dense_grid : 8 * h->grid;
+    // measured (tools/dense_sweep.py): the write-bound sphere wants whole 16-B aligned cache lines per store (flat
+    // quads, 5.5 TB/s vs 3.9 with dword-aligned row stores); the VALU-bound scenes want the leaner row kernel
+    const bool rows = h->dense_rows == 2 ? (h->scene != SDMESH_SCENE_SPHERE) : (h->dense_rows != 0);
+    return rows ? launch_sample_dense_rows(h->stream, grid, h->scene, h->d_sp, d_out, N, h->dense_nt != 0)
+                         : launch_sample_dense(h->stream, grid, h->scene, h->d_sp, d_out, N, h->dense_nt != 0);
+}
+
 int sdmesh_regen_dense(sdmesh_handle *h, int levels, sdmesh_regen_info *info) {
     if (!h) return SDMESH_ERR_INVALID;
     if (levels < 0 || levels > 5) return fail(h, SDMESH_ERR_INVALID, "dense mode supports levels 0..5 (N <= 1024)");
@@ -968,7 +979,7 @@ int sdmesh_regen_dense(sdmesh_handle *h, int levels, sdmesh_regen_info *info) {
     HIPCHK(hipEventRecord(h->ev0, st));
     SDCHK(zero_ctl(h, 0));
     HIPCHK(hipMemsetAsync(h->dense_bits.p, 0, 4ull * (total / 32 + 8), st));
-    HIPCHK(launch_sample_dense(st, h->dense_grid, h->scene, h->d_sp, (float *) h->dense_samples.p, N, h->dense_nt != 0));
+    HIPCHK(launch_p1(h, (float *) h->dense_samples.p, N));
     HIPCHK(launch_sign_bits(st, h->dense_grid, (const float *) h->dense_samples.p, total, (uint32_t *) h->dense_bits.p));
     HIPCHK(launch_dense_classify(st, 8 * h->grid, false, (const uint32_t *) h->dense_bits.p, (uint32_t) levels,
                                  (uint32_t *) h->cellcnt.p, nullptr, nullptr, 0));
@@ -1018,7 +1029,7 @@ int sdmesh_sample_dense(sdmesh_handle *h, uint32_t N, float *d_out, float *kerne
     HIPCHK(hipSetDevice(h->device));
     SDCHK(sync_scene(h));
     HIPCHK(hipEventRecord(h->ev0, h->stream));
-    HIPCHK(launch_sample_dense(h->stream, h->dense_grid > 0 ? h->dense_grid : 8 * h->grid, h->scene, h->d_sp, d_out, N, h->dense_nt != 0));
+    HIPCHK(launch_p1(h, d_out, N));
     HIPCHK(hipEventRecord(h->ev1, h->stream));
     HIPCHK(hipStreamSynchronize(h->stream));
     if (kernel_ms) HIPCHK(hipEventElapsedTime(kernel_ms, h->ev0, h->ev1));
@@ -1032,7 +1043,7 @@ int sdmesh_time_kernel(sdmesh_handle *h, int which, uint32_t N, float *d_buf, in
     if (which == 1) {     // P2a: sign bits of the dense lattice in d_buf (fills it first)
         const uint64_t total = (uint64_t) (N + 1) * (N + 1) * (N + 1);
         SDCHK(ensure(h, h->dense_bits, 4ull * (total / 32 + 8)));
-        HIPCHK(launch_sample_dense(h->stream, h->dense_grid, h->scene, h->d_sp, d_buf, N, h->dense_nt != 0));
+        HIPCHK(launch_p1(h, d_buf, N));
         HIPCHK(launch_sign_bits(h->stream, h->dense_grid, d_buf, total, (uint32_t *) h->dense_bits.p));
         HIPCHK(hipEventRecord(h->ev0, h->stream));
         for (int i = 0; i < iters; i++) HIPCHK(launch_sign_bits(h->stream, h->dense_grid, d_buf, total, (uint32_t *) h->dense_bits.p));
@@ -1043,9 +1054,9 @@ int sdmesh_time_kernel(sdmesh_handle *h, int which, uint32_t N, float *d_buf, in
         *avg_ms = ms1 / (float) iters;
         return SDMESH_OK;
     }
-    HIPCHK(launch_sample_dense(h->stream, h->dense_grid > 0 ? h->dense_grid : 8 * h->grid, h->scene, h->d_sp, d_buf, N, h->dense_nt != 0));   // warm-up
+    HIPCHK(launch_p1(h, d_buf, N));   // warm-up
     HIPCHK(hipEventRecord(h->ev0, h->stream));
-    for (int i = 0; i < iters; i++) HIPCHK(launch_sample_dense(h->stream, h->dense_grid > 0 ? h->dense_grid : 8 * h->grid, h->scene, h->d_sp, d_buf, N, h->dense_nt != 0));
+    for (int i = 0; i < iters; i++) HIPCHK(launch_p1(h, d_buf, N));
     HIPCHK(hipEventRecord(h->ev1, h->stream));
     HIPCHK(hipStreamSynchronize(h->stream));
     float ms = 0.0f;

@@ -1157,6 +1157,36 @@ __global__ __launch_bounds__(256) void k_sample_dense(float *__restrict__ out, u
     }
 }
 
+// P1, row-structured variant: one wave per z-row of S = N + 1 samples.  Lane l evaluates the quads l, l + 64, ...
+// of its row and stores them as dword-aligned float4 (a row starts at byte 4 * S * row, S odd), the S % 4 tail samples
+// go out as scalars.  No div/mod or row-wrap logic in the sample loop; the (x, y) terms are computed once per row.
+template <int SCENE, bool NT>
+__global__ __launch_bounds__(256) void k_sample_dense_rows(float *__restrict__ out, uint32_t N, const SceneParams *__restrict__ spp) {
+    typedef float v4fu __attribute__((ext_vector_type(4), aligned(4)));
+    const SceneParams sp = *spp;
+    const float h = 5.0f / (float) N;
+    const uint32_t S = N + 1u, nrows = S * S, nq = S >> 2, lane = lane_id();
+    const uint32_t nwaves = gridDim.x * (blockDim.x >> 6);
+    for (uint32_t row = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6); row < nrows; row += nwaves) {
+        const uint32_t x = row / S, y = row - x * S;
+        RowCtx<SCENE> rc;
+        rc.init((float) x * h - 2.5f, (float) y * h - 2.5f, sp);
+        float *__restrict__ o = out + (uint64_t) row * S;
+        for (uint32_t q = lane; q < nq; q += 64) {
+            const uint32_t z = q << 2;
+            v4fu v;
+            v.x = rc.eval((float) z * h - 2.5f, sp);
+            v.y = rc.eval((float) (z + 1u) * h - 2.5f, sp);
+            v.z = rc.eval((float) (z + 2u) * h - 2.5f, sp);
+            v.w = rc.eval((float) (z + 3u) * h - 2.5f, sp);
+            if (NT) __builtin_nontemporal_store(v, reinterpret_cast<v4fu *>(o + z));
+            else *reinterpret_cast<v4fu *>(o + z) = v;
+        }
+        const uint32_t zt = (nq << 2) + lane;
+        if (zt < S) o[zt] = rc.eval((float) zt * h - 2.5f, sp);
+    }
+}
+
 // ------------------------------------------------------------------------------------------
 // host-side launchers (scene dispatch)
 // ------------------------------------------------------------------------------------------
@@ -1278,6 +1308,12 @@ hipError_t launch_triangles_direct(hipStream_t st, int scene, const SceneParams 
     const int grid = (int) ((n + 127u) / 128u);
     if (grid == 0) return hipSuccess;
     SDM_DISPATCH(scene, hipLaunchKernelGGL(k_triangles_direct<S>, dim3(grid), dim3(128), 0, st, vox, n, vs, sp, out));
+    return hipGetLastError();
+}
+
+hipError_t launch_sample_dense_rows(hipStream_t st, int grid, int scene, const SceneParams *sp, float *out, uint32_t N, bool nt) {
+    if (nt) { SDM_DISPATCH(scene, hipLaunchKernelGGL((k_sample_dense_rows<S, true>), dim3(grid), dim3(256), 0, st, out, N, sp)); }
+    else { SDM_DISPATCH(scene, hipLaunchKernelGGL((k_sample_dense_rows<S, false>), dim3(grid), dim3(256), 0, st, out, N, sp)); }
     return hipGetLastError();
 }
 

@@ -13,9 +13,11 @@ b = 4.0 * (N + 1) ** 3
 print("cgroup cpu.max:", open("/sys/fs/cgroup/cpu.max").read().strip() if os.path.exists("/sys/fs/cgroup/cpu.max") else "n/a", "affinity", len(os.sched_getaffinity(0)))
 for scene in ("sphere", "sdobj"):
     h.set_scene(scene)
-    for nt in (0, 1):
-        h.set_option("dense_nt", nt)
-        for grid in (1024, 2048, 4096, 8192, 16384, 32768, 65535):
-            h.set_option("dense_grid", grid)
-            ms = min(h.time_kernel(0, N, buf.data_ptr(), 30) for _ in range(3))
-            print(f"{scene} nt={nt} grid={grid:6d} ms={ms:.4f} GB/s={b / ms / 1e6:.0f} frac={b / ms / 1e6 / 8000:.3f}", flush=True)
+    for rows in (0, 1):
+        h.set_option("dense_rows", rows)
+        for nt in (1,):
+            h.set_option("dense_nt", nt)
+            for grid in (1024, 2048, 4096, 8192, 16384, 32768, 65535):
+                h.set_option("dense_grid", grid)
+                ms = min(h.time_kernel(0, N, buf.data_ptr(), 30) for _ in range(3))
+                print(f"{scene} rows={rows} nt={nt} grid={grid:6d} ms={ms:.4f} GB/s={b / ms / 1e6:.0f} frac={b / ms / 1e6 / 8000:.3f}", flush=True)
