@@ -236,17 +236,35 @@ def main():
                            "mtris_per_s": round(atris / da / 1e6, 1), "grid": n_grid}
         ha.close()
 
-    # --- ONE mesh sharded over the ranks (strong scaling; reported next to, never instead of, `value`)
+    # --- ONE mesh sharded over the ranks (strong scaling; reported next to, never instead of, `value`).
+    # This leg is the only one with data-path collectives; a watchdog makes sure a stuck collective can never cost
+    # the primary line: after 120 s rank 0 prints what it has and every rank leaves.
     if (world > 1 and not args.no_sharded) or args.sharded_selftest:
-        shard = {}
-        for lv in (args.levels, args.levels + 1):
-            ms, res = sharded_leg(pkg, h, lv, world, rank, 20, 3)
-            n = 32 << lv
-            shard[f"{n}^3"] = {"ms_per_regen": round(ms, 4), "mvoxels_per_s": round(n ** 3 / ms / 1e3, 1), **res}
-        out["sharded"] = {"what": "one mesh, level-0 z-slabs over the ranks, all-gather of 1024 column counts + NCCL "
-                                  "send/recv of compact triangle lists to the root + root weld (strong scaling)",
-                          "n_gpus": world, **shard}
-        h.regen(args.levels)        # back to the unpartitioned plan
+        import threading
+
+        def bail():
+            if rank == 0:
+                out["sharded"] = {"error": "sharded leg did not finish within 120 s (watchdog)"}
+                print(json.dumps(out), flush=True)
+            os._exit(0)
+
+        dog = threading.Timer(120.0, bail)
+        dog.daemon = True
+        dog.start()
+        try:
+            shard = {}
+            for lv in (args.levels, args.levels + 1):
+                ms, res = sharded_leg(pkg, h, lv, world, rank, 20, 3)
+                n = 32 << lv
+                shard[f"{n}^3"] = {"ms_per_regen": round(ms, 4), "mvoxels_per_s": round(n ** 3 / ms / 1e3, 1), **res}
+            out["sharded"] = {"what": "one mesh, level-0 z-slabs over the ranks, all-gather of 1024 column counts + NCCL "
+                                      "send/recv of compact triangle lists to the root + root weld (strong scaling)",
+                              "n_gpus": world, **shard}
+            h.regen(args.levels)        # back to the unpartitioned plan
+        except Exception as e:          # noqa: BLE001 -- report, never lose the primary metric
+            out["sharded"] = {"error": f"{type(e).__name__}: {e}"[:300]}
+        finally:
+            dog.cancel()
 
     if rank == 0:
         # --- roofline of the north-star HBM pass (P1 dense SDF sample), HIP-event timed on the handle's stream
