@@ -22,6 +22,23 @@ MESH_GENERATION_BB_SIZE = 5.0
 MAX_LEVELS = 15
 
 SCENES = {"sdobj": 0, "sphere": 1, "csg3": 2, "anim": 3}
+OPS = {"sphere": 1, "box": 2, "box_skeleton": 3, "capsule": 4, "torus_y": 5}
+COMBINES = {"set": 0, "min": 1, "max": 2, "smooth_min": 3, "subtract": 4}
+INSTR = np.dtype([("op", "<u4"), ("combine", "<u4"), ("k", "<f4"), ("a", "<f4", (7,))])
+assert INSTR.itemsize == 40
+
+
+def pack_program(program):
+    """[(op, args, combine[, k]), ...] -> structured array in sdmesh_instr layout."""
+    out = np.zeros(len(program), INSTR)
+    for i, ins in enumerate(program):
+        op, args, comb = ins[0], ins[1], ins[2]
+        out[i]["op"] = OPS[op]
+        out[i]["combine"] = COMBINES[comb]
+        out[i]["k"] = np.float32(ins[3]) if len(ins) > 3 else np.float32(0)
+        a = np.asarray(args, np.float32).ravel()
+        out[i]["a"][: a.size] = a
+    return out
 PART_NONE, PART_ZSLAB = 0, 1
 
 ERRORS = {1: "invalid argument", 2: "HIP runtime error", 3: "no gfx950 device", 4: "output buffer too small",
@@ -57,6 +74,7 @@ SYMBOLS = {
     "sdmesh_destroy": (None, [_vp]),
     "sdmesh_last_error": (ctypes.c_char_p, [_vp]),
     "sdmesh_set_scene": (_i, [_vp, _i, _vp, _i]),
+    "sdmesh_set_program": (_i, [_vp, _vp, _i]),
     "sdmesh_set_stream": (_i, [_vp, _vp]),
     "sdmesh_set_option": (_i, [_vp, ctypes.c_char_p, _i]),
     "sdmesh_create_voxel_field": (_i, [_vp, _vp]),

@@ -658,11 +658,30 @@ const char *sdmesh_last_error(const sdmesh_handle *h) { return h ? h->err : "nul
 
 int sdmesh_set_scene(sdmesh_handle *h, int scene, const float *params, int nparams) {
     if (!h) return SDMESH_ERR_INVALID;
-    if (scene < 0 || scene >= SCENE_COUNT) return fail(h, SDMESH_ERR_INVALID, "unknown scene %d", scene);
+    if (scene < 0 || scene >= SCENE_PROGRAM) return fail(h, SDMESH_ERR_INVALID, "unknown scene %d (programs: sdmesh_set_program)", scene);
     if (nparams < 0 || nparams > 4 || (nparams > 0 && !params)) return fail(h, SDMESH_ERR_INVALID, "bad scene params");
     h->scene = scene;
+    h->sp.ninstr = 0;
     for (int i = 0; i < 4; i++) h->sp.p[i] = i < nparams ? params[i] : 0.0f;
     h->sp_dirty = true;
+    return SDMESH_OK;
+}
+
+int sdmesh_set_program(sdmesh_handle *h, const sdmesh_instr *instrs, int n) {
+    if (!h || !instrs) return SDMESH_ERR_INVALID;
+    if (n < 1 || n > SDM_MAX_INSTR) return fail(h, SDMESH_ERR_INVALID, "a program has 1..%d instructions", SDM_MAX_INSTR);
+    static_assert(sizeof(sdmesh_instr) == sizeof(SdfInstr), "sdmesh_instr layout");
+    for (int i = 0; i < n; i++) {
+        if (instrs[i].op < OP_SPHERE || instrs[i].op > OP_TORUS_Y || instrs[i].combine > CB_SUBTRACT)
+            return fail(h, SDMESH_ERR_INVALID, "instruction %d: unknown op/combine", i);
+    }
+    if (instrs[0].combine != CB_SET) return fail(h, SDMESH_ERR_INVALID, "the first instruction must use SDMESH_CB_SET");
+    h->scene = SCENE_PROGRAM;
+    memset(&h->sp, 0, sizeof h->sp);
+    h->sp.ninstr = (uint32_t) n;
+    memcpy(h->sp.prog, instrs, sizeof(SdfInstr) * (size_t) n);
+    h->sp_dirty = true;
+    h->plan_valid = false;
     return SDMESH_OK;
 }
 

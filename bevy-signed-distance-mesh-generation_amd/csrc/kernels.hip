@@ -135,7 +135,7 @@ template <int SCENE>
 __global__ __launch_bounds__(256) void k_refine_mask(const Point *__restrict__ vox, const uint32_t *__restrict__ n_ptr,
                                                       Point cs /* child size = parent size / 2 */, const SceneParams *__restrict__ spp,
                                                       uint8_t *__restrict__ mask, uint32_t *__restrict__ tilecnt) {
-    const SceneParams sp = *spp;   // scene uniform (device memory: a captured graph replays with new values)
+    const SceneParams &sp = *spp;  // scene uniform in device memory (a captured graph replays with new values)
     __shared__ uint32_t s_cnt;
     const uint32_t n = *n_ptr;
     const uint32_t nchunks = (n + MASK_CHUNK - 1) / MASK_CHUNK;
@@ -284,7 +284,7 @@ template <int SCENE>
 __global__ __launch_bounds__(256) void k_classify(const Point *__restrict__ vox, const uint32_t *__restrict__ n_ptr,
                                                    Point vs, const SceneParams *__restrict__ spp, uint8_t *__restrict__ cubeidx,
                                                    uint32_t *__restrict__ tilecnt) {
-    const SceneParams sp = *spp;   // scene uniform (device memory: a captured graph replays with new values)
+    const SceneParams &sp = *spp;  // scene uniform in device memory (a captured graph replays with new values)
     __shared__ uint32_t s_cnt;
     const uint32_t n = *n_ptr;
     const uint32_t ntiles = (n + TILE - 1) / TILE;
@@ -534,7 +534,7 @@ template <int SCENE>
 __global__ __launch_bounds__(256) void k_project(Vertex *__restrict__ uverts, const uint4 *__restrict__ tdesc,
                                                   const uint32_t *__restrict__ tpre, const uint32_t *__restrict__ ntiles_ptr,
                                                   const SceneParams *__restrict__ spp, uint32_t *__restrict__ status) {
-    const SceneParams sp = *spp;   // scene uniform (device memory: a captured graph replays with new values)
+    const SceneParams &sp = *spp;  // scene uniform in device memory (a captured graph replays with new values)
     const uint32_t ntiles = *ntiles_ptr;
     const uint32_t U = ntiles ? tpre[ntiles] : 0u;
     const uint32_t lane = lane_id(), sub = lane & 3u, gbase = lane & ~3u;
@@ -605,7 +605,7 @@ __global__ __launch_bounds__(256) void k_project(Vertex *__restrict__ uverts, co
 template <int SCENE>
 __global__ __launch_bounds__(256) void k_flip(const Vertex *__restrict__ uverts, const uint32_t *__restrict__ tri_e,
                                                const uint32_t *__restrict__ ntri_ptr, const SceneParams *__restrict__ spp, uint8_t *__restrict__ flip) {
-    const SceneParams sp = *spp;   // scene uniform (device memory: a captured graph replays with new values)
+    const SceneParams &sp = *spp;  // scene uniform in device memory (a captured graph replays with new values)
     const uint32_t T = *ntri_ptr;
     const uint32_t lane = lane_id(), g3 = lane / 3u, sub = lane - 3u * g3, gbase = 3u * g3;   // lane 63: g3 = 21, unused
     const uint32_t nwaves = gridDim.x * (blockDim.x >> 6);
@@ -870,7 +870,7 @@ __global__ __launch_bounds__(256) void k_expand_raw(const Vertex *__restrict__ u
 template <int SCENE>
 __global__ __launch_bounds__(128) void k_triangles_direct(const Point *__restrict__ vox, uint32_t n, Point vs, const SceneParams *__restrict__ spp,
                                                            Triangle *__restrict__ out) {
-    const SceneParams sp = *spp;   // scene uniform (device memory: a captured graph replays with new values)
+    const SceneParams &sp = *spp;  // scene uniform in device memory (a captured graph replays with new values)
     const uint32_t v = blockIdx.x * blockDim.x + threadIdx.x;
     if (v < n) voxel_triangles_direct<SCENE>(vox[v], vs, sp, out + 5u * (size_t) v);
 }
@@ -1111,7 +1111,7 @@ __global__ void k_mul3_u32(const uint32_t *a, uint32_t *out) { *out = 3u * *a; }
 // ------------------------------------------------------------------------------------------
 template <int SCENE, bool NT>
 __global__ __launch_bounds__(256) void k_sample_dense(float *__restrict__ out, uint32_t N, uint64_t total, const SceneParams *__restrict__ spp) {
-    const SceneParams sp = *spp;   // scene uniform (device memory: a captured graph replays with new values)
+    const SceneParams &sp = *spp;  // scene uniform in device memory (a captured graph replays with new values)
     // Flat quads (4 consecutive samples, 16-B aligned float4 store) over the x-outer / z-inner volume.
     // (x, y, z) of a thread's first quad comes from one division; every further grid-stride step adds
     // the stride decomposed in base S, so the loop body has no division.  The (x, y)-only part of the
@@ -1163,7 +1163,7 @@ __global__ __launch_bounds__(256) void k_sample_dense(float *__restrict__ out, u
 template <int SCENE, bool NT>
 __global__ __launch_bounds__(256) void k_sample_dense_rows(float *__restrict__ out, uint32_t N, const SceneParams *__restrict__ spp) {
     typedef float v4fu __attribute__((ext_vector_type(4), aligned(4)));
-    const SceneParams sp = *spp;
+    const SceneParams &sp = *spp;
     const float h = 5.0f / (float) N;
     const uint32_t S = N + 1u, nrows = S * S, nq = S >> 2, lane = lane_id();
     const uint32_t nwaves = gridDim.x * (blockDim.x >> 6);
@@ -1196,6 +1196,7 @@ __global__ __launch_bounds__(256) void k_sample_dense_rows(float *__restrict__ o
     case SCENE_SPHERE: { constexpr int S = SCENE_SPHERE; CALL; } break;                           \
     case SCENE_CSG3: { constexpr int S = SCENE_CSG3; CALL; } break;                               \
     case SCENE_ANIM: { constexpr int S = SCENE_ANIM; CALL; } break;                               \
+    case SCENE_PROGRAM: { constexpr int S = SCENE_PROGRAM; CALL; } break;                         \
     default: return hipErrorInvalidValue;                                                         \
     }
 

@@ -38,10 +38,26 @@
 
 namespace sdm {
 
-enum Scene : int { SCENE_SDOBJ = 0, SCENE_SPHERE = 1, SCENE_CSG3 = 2, SCENE_ANIM = 3, SCENE_COUNT = 4 };
+enum Scene : int { SCENE_SDOBJ = 0, SCENE_SPHERE = 1, SCENE_CSG3 = 2, SCENE_ANIM = 3, SCENE_PROGRAM = 4, SCENE_COUNT = 5 };
+
+// Runtime SDF program: a linear CSG chain  acc = combine_i(acc, primitive_i(p)).
+// Primitives are the reference's (cuda/includes/signed_distance.cu:61-113) plus a torus; layout == sdmesh_instr.
+enum SdfOp : uint32_t { OP_SPHERE = 1, OP_BOX = 2, OP_BOX_SKELETON = 3, OP_CAPSULE = 4, OP_TORUS_Y = 5 };
+enum SdfCombine : uint32_t { CB_SET = 0, CB_MIN = 1, CB_MAX = 2, CB_SMOOTH_MIN = 3, CB_SUBTRACT = 4 };
+#define SDM_MAX_INSTR 16
+
+struct SdfInstr {
+    uint32_t op;
+    uint32_t combine;
+    float k;          // smooth-min radius
+    float a[7];       // primitive arguments
+};
 
 struct SceneParams {
     float p[4];
+    uint32_t ninstr;
+    uint32_t pad[3];
+    SdfInstr prog[SDM_MAX_INSTR];
 };
 
 struct f3 {
@@ -128,9 +144,78 @@ SDM_HD float sd_box(f3 p, f3 bp, f3 bs) {
     return udst + idst;
 }
 
+// ---- generic (runtime-parameter) primitives, literal op order of the reference -------------------------
+SDM_HD float sd_ray_g(f3 p, f3 bl, f3 bd, float len) {              // signed_distance.cu:65-75
+    float d = dot3(sub3(p, bl), bd);
+    f3 q;
+    if (d < 0) q = bl;
+    else if (d > len) q = add3(bl, scale3(bd, len));
+    else q = add3(bl, scale3(bd, d));
+    f3 e = sub3(p, q);
+    return sqrtf(dot3(e, e));
+}
+
+SDM_HD float sd_line_g(f3 p, f3 b0, f3 b1) {                        // signed_distance.cu:77-80
+    f3 d = sub3(b1, b0);
+    float len = sqrtf(dot3(d, d));
+    return sd_ray_g(p, b0, mk(d.x / len, d.y / len, d.z / len), len);
+}
+
+SDM_HD float vget3(f3 v, int i) { return i == 0 ? v.x : (i == 1 ? v.y : v.z); }
+SDM_HD void vadd3i(f3 &v, int i, float s) { if (i == 0) v.x += s; else if (i == 1) v.y += s; else v.z += s; }
+
+SDM_HD float sd_box_skeleton_g(f3 p, f3 bp, f3 bs, float lw) {      // signed_distance.cu:93-113 incl. the % 2 at :101
+    f3 bpl = sub3(bp, mk(bs.x / 2.0f, bs.y / 2.0f, bs.z / 2.0f));
+    float sd = 3.40282347E+38f;
+    for (int dir = 0; dir < 3; dir++)
+        for (int c0 = 0; c0 < 2; c0++)
+            for (int c1 = 0; c1 < 2; c1++) {
+                f3 m0 = bpl;
+                vadd3i(m0, (dir + 1) % 3, c0 ? vget3(bs, (dir + 1) % 2) : 0.0f);
+                vadd3i(m0, (dir + 2) % 3, c1 ? vget3(bs, (dir + 2) % 3) : 0.0f);
+                f3 m1 = m0;
+                vadd3i(m1, dir, vget3(bs, dir));
+                sd = gmin(sd, sd_line_g(p, m0, m1) - lw);
+            }
+    return sd;
+}
+
+SDM_HD float sdf_program(f3 p, const SceneParams &sp) {
+    float acc = 3.40282347E+38f;
+    const uint32_t n = sp.ninstr < SDM_MAX_INSTR ? sp.ninstr : SDM_MAX_INSTR;
+    for (uint32_t i = 0; i < n; i++) {
+        const SdfInstr &in = sp.prog[i];
+        const f3 c = mk(in.a[0], in.a[1], in.a[2]);
+        float d;
+        switch (in.op) {
+        case OP_SPHERE: { f3 e = sub3(p, c); d = sqrtf(dot3(e, e)) - in.a[3]; } break;
+        case OP_BOX: d = sd_box(p, c, mk(in.a[3], in.a[4], in.a[5])); break;
+        case OP_BOX_SKELETON: d = sd_box_skeleton_g(p, c, mk(in.a[3], in.a[4], in.a[5]), in.a[6]); break;
+        case OP_CAPSULE: d = sd_line_g(p, c, mk(in.a[3], in.a[4], in.a[5])) - in.a[6]; break;
+        case OP_TORUS_Y: {
+            f3 e = sub3(p, c);
+            float qx = sqrtf(e.x * e.x + e.z * e.z) - in.a[3];
+            d = sqrtf(qx * qx + e.y * e.y) - in.a[4];
+        } break;
+        default: d = 3.40282347E+38f; break;
+        }
+        switch (in.combine) {
+        case CB_SET: acc = d; break;
+        case CB_MIN: acc = gmin(acc, d); break;
+        case CB_MAX: acc = gmax(acc, d); break;
+        case CB_SMOOTH_MIN: acc = smooth_min(acc, d, in.k); break;
+        case CB_SUBTRACT: acc = gmax(acc, -d); break;
+        default: break;
+        }
+    }
+    return acc;
+}
+
 template <int SCENE>
 SDM_HD float sdf(float px, float py, float pz, const SceneParams &sp) {
-    if (SCENE == SCENE_SPHERE) {
+    if (SCENE == SCENE_PROGRAM) {
+        return sdf_program(mk(px, py, pz), sp);
+    } else if (SCENE == SCENE_SPHERE) {
         return sqrtf((px * px + py * py) + pz * pz) - 1.0f;
     } else if (SCENE == SCENE_CSG3) {
         // build-defined scene; mirrors oracle sdf_eval SCENE_CSG3

@@ -134,6 +134,13 @@ class CudaHandler:
         self._chk(self._lib.sdmesh_set_scene(self._h, SCENES[scene] if isinstance(scene, str) else int(scene),
                                               p.ctypes.data, n))
 
+    def set_program(self, program):
+        """Runtime SDF program: [(op, args, combine[, k]), ...], e.g. the reference scene is
+        [("box_skeleton", [0, 0, 0, 3, 1, .5, .1], "set"), ("sphere", [0, 0, 0, 1], "smooth_min", .5)]."""
+        arr = _abi.pack_program(program)
+        self.scene = "program"
+        self._chk(self._lib.sdmesh_set_program(self._h, arr.ctypes.data, len(arr)))
+
     def set_animation_time(self, t):
         """sphere centre (0, 0.5*sin t, 0); sin is evaluated on the host."""
         self.set_scene("anim", [np.float32(0.5) * np.float32(math.sin(t))])

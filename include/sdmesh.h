@@ -76,6 +76,27 @@ const char *sdmesh_last_error(const sdmesh_handle *h);
 
 /* The reference compiles its scene in; here it is a runtime choice. */
 int sdmesh_set_scene(sdmesh_handle *h, int scene, const float *params, int nparams);
+/* Runtime SDF programs (the reference has exactly one compiled-in function).  A program is a
+ * linear CSG chain: acc = combine_i(acc, primitive_i(p)), i = 0..n-1, the first combine must be SET.
+ *   SPHERE        a = {cx, cy, cz, r}                      length(p - c) - r
+ *   BOX           a = {bpx, bpy, bpz, bsx, bsy, bsz}       sd_box            (cuda/includes/signed_distance.cu:86-91)
+ *   BOX_SKELETON  a = {bp xyz, bs xyz, lw}                 sd_box_skeleton   (signed_distance.cu:93-113, bug included)
+ *   CAPSULE       a = {b0 xyz, b1 xyz, lw}                 sd_line - lw      (signed_distance.cu:77-80)
+ *   TORUS_Y       a = {cx, cy, cz, R, r}                   build-defined
+ *   combine: SET, MIN (union), MAX (intersection), SMOOTH_MIN with radius k (signed_distance.cu:20-23), SUBTRACT
+ * The reference scene is {BOX_SKELETON (0,0,0) (3,1,.5) .1 SET; SPHERE (0,0,0) 1 SMOOTH_MIN k=.5} and gives results
+ * bit-identical to SDMESH_SCENE_SDOBJ. */
+enum { SDMESH_OP_SPHERE = 1, SDMESH_OP_BOX = 2, SDMESH_OP_BOX_SKELETON = 3, SDMESH_OP_CAPSULE = 4, SDMESH_OP_TORUS_Y = 5 };
+enum { SDMESH_CB_SET = 0, SDMESH_CB_MIN = 1, SDMESH_CB_MAX = 2, SDMESH_CB_SMOOTH_MIN = 3, SDMESH_CB_SUBTRACT = 4 };
+#define SDMESH_MAX_INSTR 16
+typedef struct sdmesh_instr {
+    uint32_t op;
+    uint32_t combine;
+    float k;
+    float a[7];
+} sdmesh_instr;
+int sdmesh_set_program(sdmesh_handle *h, const sdmesh_instr *instrs, int n);
+
 /* Run on a caller-owned hipStream_t (e.g. torch's current stream); NULL = the handle's own. */
 int sdmesh_set_stream(sdmesh_handle *h, void *hip_stream);
 /* Options: "direct" = 1 forces the per-corner projection path (no edge sharing) for A/B runs;

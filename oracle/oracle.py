@@ -16,7 +16,10 @@ import numpy as np
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _LIB = None
 
-SCENES = {"sdobj": 0, "sphere": 1, "csg3": 2, "anim": 3}
+SCENES = {"sdobj": 0, "sphere": 1, "csg3": 2, "anim": 3, "program": 4}
+OPS = {"sphere": 1, "box": 2, "box_skeleton": 3, "capsule": 4, "torus_y": 5}
+COMBINES = {"set": 0, "min": 1, "max": 2, "smooth_min": 3, "subtract": 4}
+INSTR = np.dtype([("op", "<u4"), ("combine", "<u4"), ("k", "<f4"), ("a", "<f4", (7,))])
 
 POINT = np.dtype([("x", "<f4"), ("y", "<f4"), ("z", "<f4")])
 VERTEX = np.dtype([("position", POINT), ("normal", POINT)])
@@ -58,6 +61,7 @@ def lib():
         L.orc_eval_points.argtypes = [ctypes.c_int, vp, vp, ctypes.c_long, vp, vp, vp, vp]
         L.orc_weld_quant.restype = ctypes.c_longlong
         L.orc_weld_quant.argtypes = [fp]
+        L.orc_set_program.argtypes = [vp, ctypes.c_int]
         L.orc_dense_mc_count.restype = u64
         L.orc_dense_mc_count.argtypes = [ctypes.c_int, vp, u32]
         _LIB = L
@@ -78,6 +82,19 @@ def _params(params):
 
 def _pt(a):
     return _PointC(float(a[0]), float(a[1]), float(a[2]))
+
+
+def set_program(program):
+    """[(op, args, combine[, k]), ...] -> the program evaluated by scene "program" (global in the oracle lib)."""
+    arr = np.zeros(len(program), INSTR)
+    for i, ins in enumerate(program):
+        arr[i]["op"] = OPS[ins[0]]
+        arr[i]["combine"] = COMBINES[ins[2]]
+        arr[i]["k"] = np.float32(ins[3]) if len(ins) > 3 else np.float32(0)
+        a = np.asarray(ins[1], np.float32).ravel()
+        arr[i]["a"][: a.size] = a
+    lib().orc_set_program(arr.ctypes.data, len(arr))
+    return arr
 
 
 def set_threads(n):

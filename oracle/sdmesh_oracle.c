@@ -60,7 +60,19 @@ _Static_assert(sizeof(Triangle) == 72, "Triangle");
  * 3 ANIM   : build-defined: sd_obj with the sphere centre at
  *            (0, params[0], 0); the host passes params[0] = 0.5*sin(t)
  */
-enum { SCENE_SDOBJ = 0, SCENE_SPHERE = 1, SCENE_CSG3 = 2, SCENE_ANIM = 3 };
+enum { SCENE_SDOBJ = 0, SCENE_SPHERE = 1, SCENE_CSG3 = 2, SCENE_ANIM = 3, SCENE_PROGRAM = 4 };
+
+/* 4 PROGRAM: build-defined runtime SDF program, a linear CSG chain of the reference's
+ * primitives: acc = combine_i(acc, primitive_i(p)).  Same instruction layout as include/sdmesh.h sdmesh_instr. */
+enum { OP_SPHERE = 1, OP_BOX = 2, OP_BOX_SKELETON = 3, OP_CAPSULE = 4, OP_TORUS_Y = 5 };
+enum { CB_SET = 0, CB_MIN = 1, CB_MAX = 2, CB_SMOOTH_MIN = 3, CB_SUBTRACT = 4 };
+typedef struct { uint32_t op, combine; float k; float a[7]; } OrcInstr;
+static OrcInstr g_prog[16];
+static int g_nprog;
+void orc_set_program(const void *instrs, int n) {
+    g_nprog = n < 0 ? 0 : (n > 16 ? 16 : n);
+    memcpy(g_prog, instrs, sizeof(OrcInstr) * (size_t) g_nprog);
+}
 
 typedef struct { float x, y, z; } v3;
 
@@ -157,6 +169,31 @@ static float sdf_eval(int scene, const float *params, v3 p) {
         float b = sd_box(p, V(1.2f, 0.0f, 0.0f), V(1.2f, 1.2f, 1.2f));
         float c = sd_torus_y(p, 1.5f, 0.25f);
         return smooth_min(smooth_min(a, b, 0.3f), c, 0.3f);
+    }
+    case SCENE_PROGRAM: {
+        float acc = (float) 3.40282347E+38;
+        for (int i = 0; i < g_nprog; i++) {
+            const OrcInstr *in = &g_prog[i];
+            v3 c = V(in->a[0], in->a[1], in->a[2]);
+            float d;
+            switch (in->op) {
+            case OP_SPHERE: d = length3(vsub(p, c)) - in->a[3]; break;
+            case OP_BOX: d = sd_box(p, c, V(in->a[3], in->a[4], in->a[5])); break;
+            case OP_BOX_SKELETON: d = sd_box_skeleton(p, c, V(in->a[3], in->a[4], in->a[5]), in->a[6]); break;
+            case OP_CAPSULE: d = sd_line(p, c, V(in->a[3], in->a[4], in->a[5])) - in->a[6]; break;
+            case OP_TORUS_Y: d = sd_torus_y(vsub(p, c), in->a[3], in->a[4]); break;
+            default: d = (float) 3.40282347E+38; break;
+            }
+            switch (in->combine) {
+            case CB_SET: acc = d; break;
+            case CB_MIN: acc = gmin(acc, d); break;
+            case CB_MAX: acc = gmax(acc, d); break;
+            case CB_SMOOTH_MIN: acc = smooth_min(acc, d, in->k); break;
+            case CB_SUBTRACT: acc = gmax(acc, -d); break;
+            default: break;
+            }
+        }
+        return acc;
     }
     case SCENE_ANIM: {
         float a1 = sd_box_skeleton(p, V(0.0f, 0.0f, 0.0f), V(3.0f, 1.0f, 0.5f), 0.1f);

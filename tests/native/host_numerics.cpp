@@ -29,11 +29,19 @@ static void eval_all(const float *pts, long n, const SceneParams &sp, float *sd,
     }
 }
 
+static SceneParams g_sp;
+
+extern "C" void sdm_host_set_program(const void *instrs, int n) {
+    g_sp.ninstr = (uint32_t) n;
+    for (int i = 0; i < n && i < SDM_MAX_INSTR; i++) g_sp.prog[i] = ((const SdfInstr *) instrs)[i];
+}
+
 extern "C" int sdm_host_eval(int scene, const float *params, const float *pts, long n, float *sd, float *nrm,
                              float *proj, int *flip) {
-    SceneParams sp;
+    SceneParams &sp = g_sp;
     for (int i = 0; i < 4; i++) sp.p[i] = params ? params[i] : 0.0f;
     switch (scene) {
+    case SCENE_PROGRAM: eval_all<SCENE_PROGRAM>(pts, n, sp, sd, nrm, proj, flip); return 0;
     case SCENE_SDOBJ: eval_all<SCENE_SDOBJ>(pts, n, sp, sd, nrm, proj, flip); return 0;
     case SCENE_SPHERE: eval_all<SCENE_SPHERE>(pts, n, sp, sd, nrm, proj, flip); return 0;
     case SCENE_CSG3: eval_all<SCENE_CSG3>(pts, n, sp, sd, nrm, proj, flip); return 0;

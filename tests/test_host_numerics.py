@@ -10,7 +10,18 @@ import pytest
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 NATIVE = os.path.join(ROOT, "tests", "native")
-SCENES = {"sdobj": 0, "sphere": 1, "csg3": 2, "anim": 3}
+SCENES = {"sdobj": 0, "sphere": 1, "csg3": 2, "anim": 3, "program": 4}
+
+PROGRAMS = {
+    # the reference scene and the build's csg3 as programs: must reproduce the AOT scenes bit for bit
+    "sdobj": [("box_skeleton", [0, 0, 0, 3, 1, 0.5, 0.1], "set"), ("sphere", [0, 0, 0, 1], "smooth_min", 0.5)],
+    "csg3": [("sphere", [0, 0, 0, 1], "set"), ("box", [1.2, 0, 0, 1.2, 1.2, 1.2], "smooth_min", 0.3),
+             ("torus_y", [0, 0, 0, 1.5, 0.25], "smooth_min", 0.3)],
+    # something the AOT scenes do not cover: every op and every combine
+    "mix": [("box", [0, 0, 0, 2.2, 1.6, 1.2], "set"), ("sphere", [0.7, 0.3, 0.0, 0.8], "subtract"),
+            ("capsule", [-1.5, -0.2, 0.1, 1.6, 0.4, -0.3, 0.25], "min"), ("torus_y", [0, 0.1, 0, 1.3, 0.2], "smooth_min", 0.4),
+            ("box_skeleton", [0.1, 0, 0, 2.5, 2.0, 1.5, 0.08], "smooth_min", 0.2), ("sphere", [0, 0, 0, 2.3], "max")],
+}
 
 
 @pytest.fixture(scope="module")
@@ -24,6 +35,7 @@ def hostnum():
     L = ctypes.CDLL(so)
     vp = ctypes.c_void_p
     L.sdm_host_eval.argtypes = [ctypes.c_int, vp, vp, ctypes.c_long, vp, vp, vp, vp]
+    L.sdm_host_set_program.argtypes = [vp, ctypes.c_int]
     L.sdm_host_weld_quant.restype = ctypes.c_longlong
     L.sdm_host_weld_quant.argtypes = [ctypes.c_float]
     return L
@@ -63,6 +75,24 @@ def test_sdf_normal_projection_bit_exact(oracle, hostnum, scene, params):
         same = (a.view(np.uint32) == b.view(np.uint32)) | (np.isnan(a) & np.isnan(b))
         assert same.all()
     assert np.array_equal(flip, ref["flip"])
+
+
+@pytest.mark.parametrize("name", ["sdobj", "csg3", "mix"])
+def test_sdf_programs_bit_exact(oracle, hostnum, name):
+    """Runtime SDF programs: product interpreter == oracle interpreter, and the two programs that restate AOT scenes
+    reproduce those scenes exactly (the generic 12-bar loop equals the restructured one-sqrt sd_obj)."""
+    arr = oracle.set_program(PROGRAMS[name])
+    hostnum.sdm_host_set_program(arr.ctypes.data, len(arr))
+    pts = _points(99, 2000)
+    ref = oracle.eval_points("program", pts)
+    sd, nrm, proj, flip = _host(hostnum, "program", pts, None)
+    assert np.array_equal(sd.view(np.uint32), ref["sd"].view(np.uint32))
+    for a, b in ((nrm, ref["nrm"]), (proj, ref["proj"])):
+        assert ((a.view(np.uint32) == b.view(np.uint32)) | (np.isnan(a) & np.isnan(b))).all()
+    assert np.array_equal(flip, ref["flip"])
+    if name in ("sdobj", "csg3"):
+        aot = oracle.eval_points(name, pts)
+        assert np.array_equal(ref["sd"].view(np.uint32), aot["sd"].view(np.uint32))
 
 
 def test_weld_quant_matches(oracle, hostnum):
