@@ -58,7 +58,6 @@ struct sdmesh_handle {
     int force_direct = 0;
     int skip_weld = 0;         // regen stops after the orientation test (multi-GPU ranks: the root welds)
     bool welded = false;       // tri_e holds the final corner order
-    uint32_t min_chunk = 128;  // unique edges per wave queue in k_project
     int dense_grid = 16384;    // workgroups for k_sample_dense
     int dense_nt = 1;          // nontemporal stores in k_sample_dense
     int dense_rows = 2;        // P1 kernel: 0 = flat 16-B aligned quads, 1 = one wave per z-row, 2 = auto
@@ -701,11 +700,6 @@ int sdmesh_set_option(sdmesh_handle *h, const char *name, int value) {
     if (!strcmp(name, "grid")) {
         if (value < 1 || value > 65535) return fail(h, SDMESH_ERR_INVALID, "grid out of range");
         h->grid = value;
-        return SDMESH_OK;
-    }
-    if (!strcmp(name, "min_chunk")) {
-        if (value < 1) return fail(h, SDMESH_ERR_INVALID, "min_chunk out of range");
-        h->min_chunk = (uint32_t) value;
         return SDMESH_OK;
     }
     if (!strcmp(name, "dense_grid")) { h->dense_grid = value; return SDMESH_OK; }

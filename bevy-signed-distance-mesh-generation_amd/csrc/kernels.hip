@@ -632,14 +632,6 @@ __global__ __launch_bounds__(256) void k_flip(const Vertex *__restrict__ uverts,
     }
 }
 
-// first-seen ordinals for an arbitrary (tri_e) list -- used by the generic weld entry point
-__global__ __launch_bounds__(256) void k_first_ord(const uint32_t *__restrict__ tri_e, const uint32_t *__restrict__ ntri_ptr,
-                                                    uint32_t *__restrict__ first_ord) {
-    const uint32_t n3 = 3u * *ntri_ptr;
-    for (uint32_t o = blockIdx.x * blockDim.x + threadIdx.x; o < n3; o += gridDim.x * blockDim.x)
-        atomicMin(&first_ord[tri_e[o]], o);
-}
-
 // tile descriptors for a plain triangle list (generic weld): tiles of 256 triangles, every corner
 // its own vertex (tri_e = identity), no flips
 __global__ __launch_bounds__(256) void k_raw_desc(const uint32_t *__restrict__ ntri_ptr, uint4 *__restrict__ tdesc,
@@ -1104,7 +1096,6 @@ __global__ __launch_bounds__(256) void k_dense_classify(const uint32_t *__restri
 }
 
 __global__ void k_set_u32(uint32_t *p, uint32_t v) { *p = v; }
-__global__ void k_mul3_u32(const uint32_t *a, uint32_t *out) { *out = 3u * *a; }
 
 // ------------------------------------------------------------------------------------------
 // P1: dense SDF sample pass, (N+1)^3 f32, x outer / z inner, one float4 store per thread
@@ -1267,11 +1258,6 @@ hipError_t launch_raw_desc(hipStream_t st, int grid, const uint32_t *ntri_ptr, u
     return hipGetLastError();
 }
 
-hipError_t launch_first_ord(hipStream_t st, int grid, const uint32_t *tri_e, const uint32_t *ntri_ptr, uint32_t *first_ord) {
-    hipLaunchKernelGGL(k_first_ord, dim3(grid), dim3(256), 0, st, tri_e, ntri_ptr, first_ord);
-    return hipGetLastError();
-}
-
 hipError_t launch_tile_claim(hipStream_t st, int grid, const Vertex *uverts, const uint4 *tdesc, const uint32_t *ntiles_ptr,
                              uint64_t *wkeys, uint32_t wsize, uint32_t *vslot, uint32_t *status) {
     hipLaunchKernelGGL(k_tile_claim, dim3(grid), dim3(256), 0, st, uverts, tdesc, ntiles_ptr, wkeys, wsize, vslot, status);
@@ -1369,9 +1355,5 @@ hipError_t launch_set_u32(hipStream_t st, uint32_t *p, uint32_t v) {
     return hipGetLastError();
 }
 
-hipError_t launch_mul3_u32(hipStream_t st, const uint32_t *a, uint32_t *out) {
-    hipLaunchKernelGGL(k_mul3_u32, dim3(1), dim3(1), 0, st, a, out);
-    return hipGetLastError();
-}
 
 }  // namespace sdm

@@ -42,7 +42,6 @@ hipError_t launch_flip(hipStream_t st, int grid, int scene, const SceneParams *s
                        const uint32_t *ntri_ptr, uint8_t *flip);
 hipError_t launch_raw_desc(hipStream_t st, int grid, const uint32_t *ntri_ptr, uint4 *tdesc, uint8_t *flip, uint32_t *ntiles_out,
                            uint32_t *nu_out);
-hipError_t launch_first_ord(hipStream_t st, int grid, const uint32_t *tri_e, const uint32_t *ntri_ptr, uint32_t *first_ord);
 hipError_t launch_tile_claim(hipStream_t st, int grid, const Vertex *uverts, const uint4 *tdesc, const uint32_t *ntiles_ptr,
                              uint64_t *wkeys, uint32_t wsize, uint32_t *vslot, uint32_t *status);
 hipError_t launch_weld(hipStream_t st, int grid, const Vertex *uverts, const uint4 *tdesc, const uint32_t *ntiles_ptr,
@@ -68,6 +67,5 @@ hipError_t launch_sign_bits(hipStream_t st, int grid, const float *samples, uint
 hipError_t launch_dense_classify(hipStream_t st, int grid, bool emit, const uint32_t *bits, uint32_t k, uint32_t *cellcnt,
                                  Point *vox, uint8_t *cubeidx, uint32_t cap);
 hipError_t launch_set_u32(hipStream_t st, uint32_t *p, uint32_t v);
-hipError_t launch_mul3_u32(hipStream_t st, const uint32_t *a, uint32_t *out);
 
 }  // namespace sdm
