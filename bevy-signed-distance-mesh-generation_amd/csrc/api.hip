@@ -60,6 +60,7 @@ struct sdmesh_handle {
     bool welded = false;       // tri_e holds the final corner order
     int dense_grid = 16384;    // workgroups for k_sample_dense
     int dense_nt = 1;          // nontemporal stores in k_sample_dense
+    int dense_contig = 0;      // flat P1 kernel: every workgroup writes one contiguous run
     int dense_rows = 2;        // P1 kernel: 0 = flat 16-B aligned quads, 1 = one wave per z-row, 2 = auto
     char err[512] = {0};
     uint64_t buf_gen = 0;      // bumped whenever a device buffer is (re)allocated: invalidates a captured graph
@@ -705,6 +706,7 @@ int sdmesh_set_option(sdmesh_handle *h, const char *name, int value) {
     if (!strcmp(name, "dense_grid")) { h->dense_grid = value; return SDMESH_OK; }
     if (!strcmp(name, "dense_nt")) { h->dense_nt = value ? 1 : 0; return SDMESH_OK; }
     if (!strcmp(name, "dense_rows")) { h->dense_rows = value; return SDMESH_OK; }
+    if (!strcmp(name, "dense_contig")) { h->dense_contig = value ? 1 : 0; return SDMESH_OK; }
     if (!strcmp(name, "forget_plan")) { h->plan_valid = false; return SDMESH_OK; }
     return fail(h, SDMESH_ERR_INVALID, "unknown option %s", name);
 }
@@ -973,7 +975,7 @@ static hipError_t launch_p1(sdmesh_handle *h, float *d_out, uint32_t N) {
     // quads, 5.5 TB/s vs 3.9 with dword-aligned row stores); the VALU-bound scenes want the leaner row kernel
     const bool rows = h->dense_rows == 2 ? (h->scene != SDMESH_SCENE_SPHERE) : (h->dense_rows != 0);
     return rows ? launch_sample_dense_rows(h->stream, grid, h->scene, h->d_sp, d_out, N, h->dense_nt != 0)
-                         : launch_sample_dense(h->stream, grid, h->scene, h->d_sp, d_out, N, h->dense_nt != 0);
+                         : launch_sample_dense(h->stream, grid, h->scene, h->d_sp, d_out, N, h->dense_nt != 0, h->dense_contig != 0);
 }
 
 int sdmesh_regen_dense(sdmesh_handle *h, int levels, sdmesh_regen_info *info) {

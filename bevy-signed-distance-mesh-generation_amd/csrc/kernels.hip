@@ -1101,40 +1101,67 @@ __global__ void k_set_u32(uint32_t *p, uint32_t v) { *p = v; }
 // P1: dense SDF sample pass, (N+1)^3 f32, x outer / z inner, one float4 store per thread
 // ------------------------------------------------------------------------------------------
 template <int SCENE, bool NT>
-__global__ __launch_bounds__(256) void k_sample_dense(float *__restrict__ out, uint32_t N, uint64_t total, const SceneParams *__restrict__ spp) {
+__global__ __launch_bounds__(256) void k_sample_dense(float *__restrict__ out, uint32_t N, uint64_t total, const SceneParams *__restrict__ spp,
+                                                       uint32_t contig) {
     const SceneParams &sp = *spp;  // scene uniform in device memory (a captured graph replays with new values)
     // Flat quads (4 consecutive samples, 16-B aligned float4 store) over the x-outer / z-inner volume.
     // (x, y, z) of a thread's first quad comes from one division; every further grid-stride step adds
-    // the stride decomposed in base S, so the loop body has no division.  The (x, y)-only part of the
-    // SDF is hoisted into a RowCtx and rebuilt only when a quad crosses a row end (1 quad in ~S/4).
+    // the stride decomposed in base S, so the loop body has no division.
+    typedef float v4f __attribute__((ext_vector_type(4)));
     const float h = 5.0f / (float) N;
     const uint32_t S = N + 1u;
     const uint64_t nquads = (total + 3ull) >> 2;
-    const uint64_t stride = (uint64_t) gridDim.x * blockDim.x;
+    // contig = 0: grid-stride (consecutive workgroups write consecutive 4 KiB pieces, each workgroup strides by the
+    // whole grid); contig = 1: every workgroup owns one contiguous run of quads
+    uint64_t stride = (uint64_t) gridDim.x * blockDim.x;
     uint64_t qd = (uint64_t) blockIdx.x * blockDim.x + threadIdx.x;
-    if (qd >= nquads) return;
+    uint64_t qlim = nquads;
+    if (contig) {
+        const uint64_t per = ((nquads + gridDim.x - 1) / gridDim.x + blockDim.x - 1) / blockDim.x * blockDim.x;
+        qd = (uint64_t) blockIdx.x * per + threadIdx.x;
+        qlim = (uint64_t) (blockIdx.x + 1) * per < nquads ? (uint64_t) (blockIdx.x + 1) * per : nquads;
+        stride = blockDim.x;
+    }
+    if (qd >= qlim) return;
     uint64_t i0 = qd << 2;
     uint32_t z = (uint32_t) (i0 % S);
     uint64_t r = i0 / S;
     uint32_t y = (uint32_t) (r % S), x = (uint32_t) (r / S);
     const uint64_t st4 = stride << 2;
     const uint32_t sz = (uint32_t) (st4 % S), sy = (uint32_t) ((st4 / S) % S), sx = (uint32_t) (st4 / S / S);
-    for (; qd < nquads; qd += stride) {
-        uint32_t cx = x, cy = y, cz = z;
-        RowCtx<SCENE> row;
-        row.init((float) cx * h - 2.5f, (float) cy * h - 2.5f, sp);
+    for (; qd < qlim; qd += stride) {
         float v[4];
+        if (SCENE == SCENE_SPHERE) {
+            // Sphere: the row context is one float (x^2 + y^2), so a quad that crosses a row end is handled with
+            // selects instead of branches: samples k >= rem belong to the next row.  |p|^2 is 0 or a normal float
+            // on the lattice, hence the lean sqrt.  (Same operations in the same order as sdf<SCENE_SPHERE>.)
+            const uint32_t rem = S - z;                                          // samples left in this row (>= 1)
+            const bool ywrap = (y + 1u == S);
+            const float px = (float) x * h - 2.5f, py = (float) y * h - 2.5f;
+            const float nx = (float) (ywrap ? x + 1u : x) * h - 2.5f, ny = (float) (ywrap ? 0u : y + 1u) * h - 2.5f;
+            const float a_cur = px * px + py * py, a_nxt = nx * nx + ny * ny;
 #pragma unroll
-        for (int k = 0; k < 4; k++) {
-            v[k] = row.eval((float) cz * h - 2.5f, sp);
-            if (++cz == S) {
-                cz = 0;
-                if (++cy == S) { cy = 0; ++cx; }
-                row.init((float) cx * h - 2.5f, (float) cy * h - 2.5f, sp);
+            for (uint32_t k = 0; k < 4; k++) {
+                const bool nxt = k >= rem;
+                const float pz = (float) (nxt ? k - rem : z + k) * h - 2.5f;
+                v[k] = sqrt_rn_normal((nxt ? a_nxt : a_cur) + pz * pz) - 1.0f;
+            }
+        } else {
+            // generic: the (x, y)-only part of the SDF is hoisted into a RowCtx, rebuilt when the quad crosses a row end
+            uint32_t cx = x, cy = y, cz = z;
+            RowCtx<SCENE> row;
+            row.init((float) cx * h - 2.5f, (float) cy * h - 2.5f, sp);
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                v[k] = row.eval((float) cz * h - 2.5f, sp);
+                if (++cz == S) {
+                    cz = 0;
+                    if (++cy == S) { cy = 0; ++cx; }
+                    row.init((float) cx * h - 2.5f, (float) cy * h - 2.5f, sp);
+                }
             }
         }
         if (i0 + 3 < total) {
-            typedef float v4f __attribute__((ext_vector_type(4)));
             v4f q = {v[0], v[1], v[2], v[3]};
             if (NT) __builtin_nontemporal_store(q, reinterpret_cast<v4f *>(out + i0));   // write-once stream
             else *reinterpret_cast<v4f *>(out + i0) = q;
@@ -1304,10 +1331,12 @@ hipError_t launch_sample_dense_rows(hipStream_t st, int grid, int scene, const S
     return hipGetLastError();
 }
 
-hipError_t launch_sample_dense(hipStream_t st, int grid, int scene, const SceneParams *sp, float *out, uint32_t N, bool nt) {
+hipError_t launch_sample_dense(hipStream_t st, int grid, int scene, const SceneParams *sp, float *out, uint32_t N, bool nt,
+                               bool contig) {
     const uint64_t total = (uint64_t) (N + 1) * (N + 1) * (N + 1);
-    if (nt) { SDM_DISPATCH(scene, hipLaunchKernelGGL((k_sample_dense<S, true>), dim3(grid), dim3(256), 0, st, out, N, total, sp)); }
-    else { SDM_DISPATCH(scene, hipLaunchKernelGGL((k_sample_dense<S, false>), dim3(grid), dim3(256), 0, st, out, N, total, sp)); }
+    const uint32_t cg = contig ? 1u : 0u;
+    if (nt) { SDM_DISPATCH(scene, hipLaunchKernelGGL((k_sample_dense<S, true>), dim3(grid), dim3(256), 0, st, out, N, total, sp, cg)); }
+    else { SDM_DISPATCH(scene, hipLaunchKernelGGL((k_sample_dense<S, false>), dim3(grid), dim3(256), 0, st, out, N, total, sp, cg)); }
     return hipGetLastError();
 }
 

@@ -55,7 +55,8 @@ hipError_t launch_expand_raw(hipStream_t st, int grid, const Vertex *uverts, con
 hipError_t launch_triangles_direct(hipStream_t st, int scene, const SceneParams *sp, const Point *vox, uint32_t n, Point vs,
                                    Triangle *out);
 hipError_t launch_sample_dense_rows(hipStream_t st, int grid, int scene, const SceneParams *sp, float *out, uint32_t N, bool nt);
-hipError_t launch_sample_dense(hipStream_t st, int grid, int scene, const SceneParams *sp, float *out, uint32_t N, bool nt);
+hipError_t launch_sample_dense(hipStream_t st, int grid, int scene, const SceneParams *sp, float *out, uint32_t N, bool nt,
+                               bool contig);
 hipError_t launch_create_field(hipStream_t st, Point *vox, uint32_t z0, uint32_t z1, uint32_t *n_out);
 hipError_t launch_raw_count(hipStream_t st, int grid, const Triangle *raw, const uint32_t *n_ptr, uint32_t *tilecnt);
 hipError_t launch_raw_compact(hipStream_t st, int grid, const Triangle *raw, const uint32_t *n_ptr, const uint32_t *tileoff,

@@ -233,6 +233,25 @@ SDM_HD float sdf(float px, float py, float pz, const SceneParams &sp) {
     }
 }
 
+// Correctly rounded sqrt for x == 0 or x a NORMAL positive float (no denormal, inf or NaN input): the same
+// v_sqrt_f32 + two-sided fma residual correction hipcc emits for sqrtf, minus the denormal pre-scaling and the
+// class test.  x == 0 falls through correctly (both residual tests fail).  Used only where the argument is a sum
+// of squares of lattice coordinates (the dense sphere pass), so the precondition holds by construction.
+SDM_HD float sqrt_rn_normal(float x) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    const float y = __builtin_amdgcn_sqrtf(x);
+    const float ydn = __builtin_bit_cast(float, __builtin_bit_cast(int, y) - 1);
+    const float yup = __builtin_bit_cast(float, __builtin_bit_cast(int, y) + 1);
+    const float rdn = __builtin_fmaf(-ydn, y, x);
+    const float rup = __builtin_fmaf(-yup, y, x);
+    float r = rdn <= 0.0f ? ydn : y;
+    r = rup > 0.0f ? yup : r;
+    return r;
+#else
+    return sqrtf(x);
+#endif
+}
+
 // ---------------------------------------------------------------------------------------------
 // Row context for dense sampling along z (k_sample_dense): everything that depends only on
 // (x, y) is computed once per row; eval(z) performs the remaining operations in exactly the
