@@ -152,6 +152,7 @@ def main():
     ap.add_argument("--levels", type=int, default=4)          # N = 32 * 2^levels = 512
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-anim", action="store_true")
+    ap.add_argument("--no-pipelined", action="store_true")
     ap.add_argument("--no-sharded", action="store_true")
     ap.add_argument("--no-graph", action="store_true", help="launch the planned chain eagerly instead of replaying a hipGraph")
     ap.add_argument("--sharded-selftest", action="store_true", help="run the sharded leg on 1 GPU (degenerate, for testing)")
@@ -213,6 +214,30 @@ def main():
         "triangles": int(info.triangles), "vertices": int(info.vertices), "active_voxels": int(info.voxel_count[args.levels]),
         "device_ms_per_step": round(float(np.median(dev_ms)), 4),
     }
+
+    # --- several regens in flight (one handle each): most kernels of the chain are latency-bound, so they overlap
+    if rank == 0 and world == 1 and not args.no_pipelined:
+        depth = 4
+        hs = [pkg.CudaHandler(local_rank, args.scene, params) for _ in range(depth)]
+        for hh in hs:
+            hh.regen(args.levels); hh.set_option("graph", 0 if args.no_graph else 1); hh.regen(args.levels); hh.regen(args.levels)
+        torch.cuda.synchronize()
+        psteps = max(args.steps, depth)
+        tp = time.perf_counter()
+        for hh in hs:
+            hh.regen_begin(args.levels)
+        for i in range(psteps):
+            hh = hs[i % depth]
+            pinfo = hh.regen_end()
+            if i + depth < psteps:
+                hh.regen_begin(args.levels)
+        torch.cuda.synchronize()
+        dp = time.perf_counter() - tp
+        out["pipelined"] = {"what": f"{depth} regens in flight on one GPU (one handle each, sdmesh_regen_begin/_end)",
+                            "ms_per_regen": round(dp / psteps * 1e3, 4), "mvoxels_per_s": round(n_grid ** 3 * psteps / dp / 1e6, 1),
+                            "mtris_per_s": round(pinfo.triangles * psteps / dp / 1e6, 1)}
+        for hh in hs:
+            hh.close()
 
     # --- BASELINE config 5: per-frame animated SDF (sphere centre (0, 0.5 sin t, 0), t = frame / 60), same grid
     if rank == 0 and not args.no_anim:

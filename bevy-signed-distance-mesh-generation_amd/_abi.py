@@ -85,6 +85,8 @@ SYMBOLS = {
     "sdmesh_weld_triangles": (_i, [_vp, _vp, _sz, _vp, _sz, _psz, _vp, _sz, _psz]),
     "sdmesh_regen": (_i, [_vp, _i, ctypes.POINTER(RegenInfo)]),
     "sdmesh_regen_part": (_i, [_vp, _i, _i, _i, _i, ctypes.POINTER(RegenInfo)]),
+    "sdmesh_regen_begin": (_i, [_vp, _i, _i, _i, _i]),
+    "sdmesh_regen_end": (_i, [_vp, ctypes.POINTER(RegenInfo)]),
     "sdmesh_device_mesh": (_i, [_vp, ctypes.POINTER(Mesh), ctypes.POINTER(_u32)]),
     "sdmesh_device_voxels": (_i, [_vp, ctypes.POINTER(VoxelField)]),
     "sdmesh_device_triangles": (_i, [_vp, _vp, _sz, _psz]),

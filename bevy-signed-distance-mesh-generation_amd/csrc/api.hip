@@ -60,7 +60,7 @@ struct sdmesh_handle {
     bool welded = false;       // tri_e holds the final corner order
     int dense_grid = 16384;    // workgroups for k_sample_dense
     int dense_nt = 1;          // nontemporal stores in k_sample_dense
-    int dense_contig = 0;      // flat P1 kernel: every workgroup writes one contiguous run
+    int dense_contig = 1;      // flat P1 kernel: every workgroup writes one contiguous run (measured best)
     int dense_rows = 2;        // P1 kernel: 0 = flat 16-B aligned quads, 1 = one wave per z-row, 2 = auto
     char err[512] = {0};
     uint64_t buf_gen = 0;      // bumped whenever a device buffer is (re)allocated: invalidates a captured graph
@@ -70,6 +70,11 @@ struct sdmesh_handle {
     uint64_t graph_key[8] = {0};
     int graph_cur = 0;
     Point graph_vs{0, 0, 0};
+    // regen_begin / regen_end: a planned chain that has been enqueued but not yet waited for
+    bool pend_active = false, pend_async = false;
+    int pend_levels = 0, pend_mode = 0, pend_part = 0, pend_nparts = 1;
+    Point pend_vs{0, 0, 0};
+    uint32_t pend_ncap = 0;
 
     // voxel lists (ping-pong), refine scratch
     DevBuf vox[2];
@@ -411,8 +416,17 @@ void drop_graph(sdmesh_handle *h) {
     h->graph = nullptr;
 }
 
-int regen_impl(sdmesh_handle *h, int levels, int mode, int part, int nparts, sdmesh_regen_info *info) {
+// phase 0: whole regen; 1: begin (enqueue the planned chain and return without waiting; without a plan only the request
+// is recorded); 2: end (wait, validate, fall back to the synchronous path if a capacity was exceeded)
+int regen_impl(sdmesh_handle *h, int levels, int mode, int part, int nparts, sdmesh_regen_info *info, int phase = 0) {
     if (!h) return SDMESH_ERR_INVALID;
+    if (phase == 2) {
+        if (!h->pend_active) return fail(h, SDMESH_ERR_INVALID, "sdmesh_regen_end without sdmesh_regen_begin");
+        levels = h->pend_levels; mode = h->pend_mode; part = h->pend_part; nparts = h->pend_nparts;
+        h->pend_active = false;
+    } else if (h->pend_active) {
+        return fail(h, SDMESH_ERR_INVALID, "a regen is pending: call sdmesh_regen_end first");
+    }
     if (levels < 0 || levels > SDMESH_MAX_LEVELS) return fail(h, SDMESH_ERR_INVALID, "levels must be 0..%d", SDMESH_MAX_LEVELS);
     if (mode != SDMESH_PART_NONE && mode != SDMESH_PART_ZSLAB) return fail(h, SDMESH_ERR_INVALID, "bad partition mode");
     if (mode == SDMESH_PART_NONE) { part = 0; nparts = 1; }
@@ -425,15 +439,27 @@ int regen_impl(sdmesh_handle *h, int levels, int mode, int part, int nparts, sdm
     const uint32_t n0 = F * F * (z1 - z0);
 
     for (int attempt = 0; attempt < 2; attempt++) {
-        const bool async = h->plan_valid && h->plan_scene == h->scene && h->plan_levels == levels && h->plan_mode == mode &&
-                           h->plan_part == part && h->plan_nparts == nparts && attempt == 0;
+        const bool resumed = phase == 2 && attempt == 0 && h->pend_async;
+        const bool async = resumed || (h->plan_valid && h->plan_scene == h->scene && h->plan_levels == levels && h->plan_mode == mode &&
+                                       h->plan_part == part && h->plan_nparts == nparts && attempt == 0);
         h->mesh_valid = h->vox_valid = false;
-        h->cur = 0;
         Point vs;
         vs.x = vs.y = vs.z = MESH_GENERATION_BB_SIZE / (float) MESH_GENERATION_INIT_FACTOR;
         uint32_t n_cap = n0;
         bool direct = h->force_direct != 0;
-        if (async && !direct) {
+        if (resumed) {
+            // the planned chain (and its read-back) were enqueued by regen_begin: just wait for them
+            vs = h->pend_vs;
+            n_cap = h->pend_ncap;
+            direct = false;
+            HIPCHK(hipStreamSynchronize(st));
+        } else if (phase == 1 && !(async && !direct)) {
+            // no capacity plan yet: nothing can be enqueued blindly; regen_end will run the discovery path
+            h->pend_active = true; h->pend_async = false;
+            h->pend_levels = levels; h->pend_mode = mode; h->pend_part = part; h->pend_nparts = nparts;
+            return SDMESH_OK;
+        } else if (async && !direct) {
+            h->cur = 0;
             // ---- planned path: no host round trip until the final read-back; optionally replayed as a hipGraph
             uint32_t lvl_words = 0;
             SDCHK(presize_planned_chain(h, levels, n0, &lvl_words));
@@ -464,15 +490,22 @@ int regen_impl(sdmesh_handle *h, int levels, int mode, int part, int nparts, sdm
                 HIPCHK(hipEventRecord(h->ev0, st));
                 HIPCHK(hipGraphLaunch(h->graph_exec, st));
                 HIPCHK(hipEventRecord(h->ev1, st));
-                HIPCHK(hipStreamSynchronize(st));
             } else {
                 HIPCHK(hipEventRecord(h->ev0, st));
                 SDCHK(enqueue_planned_chain(h, levels, z0, z1, n0, lvl_words, &vs));
                 HIPCHK(hipEventRecord(h->ev1, st));
-                SDCHK(read_back(h));
+                SDCHK(read_back_enqueue(h));
             }
+            if (phase == 1) {
+                h->pend_active = true; h->pend_async = true;
+                h->pend_levels = levels; h->pend_mode = mode; h->pend_part = part; h->pend_nparts = nparts;
+                h->pend_vs = vs; h->pend_ncap = n_cap;
+                return SDMESH_OK;
+            }
+            HIPCHK(hipStreamSynchronize(st));
         } else {
             // ---- discovery path: sizes become known level by level (one host sync per level)
+            h->cur = 0;
             SDCHK(ensure(h, h->vox[0], sizeof(Point) * (size_t) std::max<uint32_t>(n0, 64)));
             HIPCHK(hipEventRecord(h->ev0, st));
             SDCHK(zero_ctl(h, 0));
@@ -608,7 +641,7 @@ int sdmesh_create(int device, sdmesh_handle **out) {
         return SDMESH_ERR_NO_DEVICE;
     }
     h->grid = 4 * prop.multiProcessorCount;
-    h->dense_grid = 64 * prop.multiProcessorCount;   // measured best for the write-only P1 stream
+    h->dense_grid = 48 * prop.multiProcessorCount;   // measured best for the write-only P1 stream (tools/dense_sweep.py)
     if ((e = hipStreamCreateWithFlags(&h->own_stream, hipStreamNonBlocking)) != hipSuccess) return bail(e, "hipStreamCreate");
     h->stream = h->own_stream;
     if ((e = hipEventCreate(&h->ev0)) != hipSuccess) return bail(e, "hipEventCreate");
@@ -895,6 +928,14 @@ int sdmesh_regen(sdmesh_handle *h, int levels, sdmesh_regen_info *info) {
 
 int sdmesh_regen_part(sdmesh_handle *h, int levels, int mode, int part, int nparts, sdmesh_regen_info *info) {
     return regen_impl(h, levels, mode, part, nparts, info);
+}
+
+int sdmesh_regen_begin(sdmesh_handle *h, int levels, int mode, int part, int nparts) {
+    return regen_impl(h, levels, mode, part, nparts, nullptr, 1);
+}
+
+int sdmesh_regen_end(sdmesh_handle *h, sdmesh_regen_info *info) {
+    return regen_impl(h, 0, 0, 0, 1, info, 2);
 }
 
 int sdmesh_device_mesh(sdmesh_handle *h, struct Mesh *mesh, uint32_t *n_tris) {

@@ -211,6 +211,15 @@ class CudaHandler:
                                                ctypes.byref(info)))
         return info
 
+    def regen_begin(self, levels, mode=PART_NONE, part=0, nparts=1):
+        """Enqueue a regen without waiting (pair with regen_end; keeps several handles in flight)."""
+        self._chk(self._lib.sdmesh_regen_begin(self._h, int(levels), int(mode), int(part), int(nparts)))
+
+    def regen_end(self):
+        info = RegenInfo()
+        self._chk(self._lib.sdmesh_regen_end(self._h, ctypes.byref(info)))
+        return info
+
     def regen_dense(self, levels):
         """Same result as regen(levels) via the dense lattice (sample -> sign bits -> LDS-tiled classify)."""
         info = RegenInfo()

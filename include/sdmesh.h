@@ -146,6 +146,14 @@ int sdmesh_weld_triangles(sdmesh_handle *h, const struct Triangle *raw, size_t n
 int sdmesh_regen(sdmesh_handle *h, int levels, sdmesh_regen_info *info);
 int sdmesh_regen_part(sdmesh_handle *h, int levels, int mode, int part, int nparts, sdmesh_regen_info *info);
 
+/* Split form for keeping several regens in flight (one handle each): _begin enqueues the planned device chain on the
+ * handle's streams and returns without waiting (with no capacity plan yet it only records the request); _end waits,
+ * validates and returns the counts -- or falls back to the synchronous path if a capacity was exceeded.  Most kernels of
+ * the chain are latency-bound at low occupancy, so two handles in flight overlap well (bench.py).  The handle must not
+ * be touched between the two calls. */
+int sdmesh_regen_begin(sdmesh_handle *h, int levels, int mode, int part, int nparts);
+int sdmesh_regen_end(sdmesh_handle *h, sdmesh_regen_info *info);
+
 /* Borrow the results of the last regen / mesh call (device pointers owned by the handle, valid
  * until the next call).  Fills the reference's otherwise unused `struct Mesh` (bindings.h:70-75). */
 int sdmesh_device_mesh(sdmesh_handle *h, struct Mesh *mesh, uint32_t *n_tris);
