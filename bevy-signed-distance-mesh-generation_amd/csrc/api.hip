@@ -56,6 +56,8 @@ struct sdmesh_handle {
     bool sp_dirty = true;
     int grid = 1024;           // workgroups per grid-stride launch (4 per CU)
     int force_direct = 0;
+    int project_mult = 3;      // k_project grid = project_mult * grid: more, shorter waves tighten the tail (measured: -8 %)
+    int flip_mult = 1;         // same knob for k_flip
     int skip_weld = 0;         // regen stops after the orientation test (multi-GPU ranks: the root welds)
     bool welded = false;       // tri_e holds the final corner order
     int dense_grid = 16384;    // workgroups for k_sample_dense
@@ -209,7 +211,7 @@ int mesh_front(sdmesh_handle *h, const Point *d_vox, const uint32_t *n_ptr, Poin
                               (uint32_t *) h->trioff.p, (uint32_t *) h->tri_e.p, (Vertex *) h->uverts.p, (uint4 *) h->tdesc.p,
                               h->ucap, h->tcap, h->d_ctr + CTR_NTRI, h->d_ctr + CTR_NTILES, h->d_status));
     HIPCHK(launch_tile_prefix(st, (const uint4 *) h->tdesc.p, h->d_ctr + CTR_NTILES, (uint32_t *) h->tpre.p, h->d_ctr + CTR_NUNIQ));
-    HIPCHK(launch_project(st, h->grid, h->scene, h->d_sp, (Vertex *) h->uverts.p, (const uint4 *) h->tdesc.p,
+    HIPCHK(launch_project(st, h->grid * h->project_mult, h->scene, h->d_sp, (Vertex *) h->uverts.p, (const uint4 *) h->tdesc.p,
                           (const uint32_t *) h->tpre.p, h->d_ctr + CTR_NTILES, h->d_status));
     // fork: the weld claim (scattered CAS, latency-bound) runs beside the orientation test (VALU-bound)
     HIPCHK(hipEventRecord(h->ev_fork, st));
@@ -217,7 +219,7 @@ int mesh_front(sdmesh_handle *h, const Point *d_vox, const uint32_t *n_ptr, Poin
     HIPCHK(launch_tile_claim(h->side, h->grid, (const Vertex *) h->uverts.p, (const uint4 *) h->tdesc.p, h->d_ctr + CTR_NTILES,
                              h->wkeys, h->wsize, (uint32_t *) h->vslot.p, h->d_status));
     HIPCHK(hipEventRecord(h->ev_join, h->side));
-    HIPCHK(launch_flip(st, h->grid, h->scene, h->d_sp, (const Vertex *) h->uverts.p, (const uint32_t *) h->tri_e.p,
+    HIPCHK(launch_flip(st, h->grid * h->flip_mult, h->scene, h->d_sp, (const Vertex *) h->uverts.p, (const uint32_t *) h->tri_e.p,
                        h->d_ctr + CTR_NTRI, (uint8_t *) h->flip.p));
     HIPCHK(hipStreamWaitEvent(st, h->ev_join, 0));
     return SDMESH_OK;
@@ -729,6 +731,8 @@ int sdmesh_set_stream(sdmesh_handle *h, void *hip_stream) {
 int sdmesh_set_option(sdmesh_handle *h, const char *name, int value) {
     if (!h || !name) return SDMESH_ERR_INVALID;
     if (!strcmp(name, "direct")) { h->force_direct = value ? 1 : 0; h->plan_valid = false; return SDMESH_OK; }
+    if (!strcmp(name, "project_mult")) { if (value < 1 || value > 16) return fail(h, SDMESH_ERR_INVALID, "project_mult 1..16"); h->project_mult = value; drop_graph(h); return SDMESH_OK; }
+    if (!strcmp(name, "flip_mult")) { if (value < 1 || value > 16) return fail(h, SDMESH_ERR_INVALID, "flip_mult 1..16"); h->flip_mult = value; drop_graph(h); return SDMESH_OK; }
     if (!strcmp(name, "skip_weld")) { h->skip_weld = value ? 1 : 0; return SDMESH_OK; }
     if (!strcmp(name, "graph")) { h->use_graph = value ? 1 : 0; if (!value) drop_graph(h); return SDMESH_OK; }
     if (!strcmp(name, "grid")) {

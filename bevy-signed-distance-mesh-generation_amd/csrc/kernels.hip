@@ -97,11 +97,12 @@ __device__ __forceinline__ bool lattice_coord(float b, float h, int &m) {
     return ok && (lat(m, h) == b) && (lat(m + 1, h) == b + h);
 }
 
+// key of cube edge e of the voxel at lattice (mx, my, mz): the doubled-lattice coordinate of the edge midpoint, i.e.
+// 2 m + (corner offsets of the edge's two ends).  The offset sums (0, 1 or 2 per axis) of the 12 edges are packed two
+// bits each into immediates (derived from MC_EDGE_CORNERS: cox/coy/coz of both ends) -- no table load per corner.
 __device__ __forceinline__ uint64_t edge_key(int mx, int my, int mz, int e) {
-    const int c0 = MC_EDGE_CORNERS[e] & 0xF, c1 = MC_EDGE_CORNERS[e] >> 4;
-    const uint64_t kx = (uint64_t) (2 * mx + cox(c0) + cox(c1));
-    const uint64_t ky = (uint64_t) (2 * my + coy(c0) + coy(c1));
-    const uint64_t kz = (uint64_t) (2 * mz + coz(c0) + coz(c1));
+    const uint32_t ox = (0x281919u >> (2 * e)) & 3u, oy = (0xa06464u >> (2 * e)) & 3u, oz = (0x55aa00u >> (2 * e)) & 3u;
+    const uint64_t kx = (uint64_t) (2 * mx) + ox, ky = (uint64_t) (2 * my) + oy, kz = (uint64_t) (2 * mz) + oz;
     return kx | (ky << 21) | (kz << 42);
 }
 
@@ -389,23 +390,22 @@ __global__ __launch_bounds__(256) void k_tile_dedupe(const Point *__restrict__ v
         if (n == 0) *ntri_out = 0;
     }
     for (uint32_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        // issue every independent global load before the first barrier so their latencies overlap
+        const uint32_t v = tile * TILE + tid;
+        const uint32_t ci = v < n ? cubeidx[v] : 0u;
+        const Point b = vox[v < n ? v : (n - 1)];
         uint32_t part = 0;
         for (uint32_t i = tid; i < tile; i += 256) part += tilecnt[i];
+        const uint32_t ntri = v < n ? (uint32_t) MC_TRI_COUNT[ci] : 0u;
+        const uint64_t tri_row = MC_TRI_PACKED[ci];
         uint32_t tbase;
         (void) block_excl_scan(part, tbase, s_scan);
 
-        const uint32_t v = tile * TILE + tid;
-        uint32_t ci = 0, ntri = 0;
         int mx = 0, my = 0, mz = 0;
         bool lat_ok = true;
-        if (v < n) {
-            ci = cubeidx[v];
-            ntri = MC_TRI_COUNT[ci];
-            if (ntri) {
-                const Point b = vox[v];
-                const bool okx = lattice_coord(b.x, vs.x, mx), oky = lattice_coord(b.y, vs.y, my), okz = lattice_coord(b.z, vs.z, mz);
-                lat_ok = okx && oky && okz;
-            }
+        if (ntri) {
+            const bool okx = lattice_coord(b.x, vs.x, mx), oky = lattice_coord(b.y, vs.y, my), okz = lattice_coord(b.z, vs.z, mz);
+            lat_ok = okx && oky && okz;
         }
         uint32_t ttri;
         const uint32_t lo = block_excl_scan(ntri, ttri, s_scan);
@@ -422,7 +422,7 @@ __global__ __launch_bounds__(256) void k_tile_dedupe(const Point *__restrict__ v
 
         // insert every triangle corner's edge key; remember the slot per corner
         if (ntri && lat_ok) {
-            uint64_t row = MC_TRI_PACKED[ci];
+            uint64_t row = tri_row;
             for (uint32_t c = 0; c < 3 * ntri; c++) {
                 const uint64_t key = edge_key(mx, my, mz, (int) (row & 0xF));
                 row >>= 4;
