@@ -54,10 +54,13 @@ struct sdmesh_handle {
     SceneParams *d_sp = nullptr;   // device copy of sp (kernels read the scene uniform through this pointer)
     SceneParams *h_sp = nullptr;   // pinned staging for it
     bool sp_dirty = true;
-    int grid = 1024;           // workgroups per grid-stride launch (4 per CU)
+    int grid = 1024;           // workgroups per grid-stride launch of the item-parallel kernels (4 per CU)
+    int tgrid = 4096;          // workgroups of the per-tile kernels.  With 4 per CU a 512^3 field (1037 tiles on 1024
+                               // workgroups) made every tile kernel take TWO tile latencies; the grid now covers the tile
+                               // count up to the residency limit and beyond
     int force_direct = 0;
     int project_mult = 3;      // k_project grid = project_mult * grid: more, shorter waves tighten the tail (measured: -8 %)
-    int flip_mult = 1;         // same knob for k_flip
+    int flip_mult = 2;         // same knob for k_flip (measured: -3 %)
     int skip_weld = 0;         // regen stops after the orientation test (multi-GPU ranks: the root welds)
     bool welded = false;       // tri_e holds the final corner order
     int dense_grid = 16384;    // workgroups for k_sample_dense
@@ -205,9 +208,9 @@ int mesh_front(sdmesh_handle *h, const Point *d_vox, const uint32_t *n_ptr, Poin
     if (!ff_done) HIPCHK(hipMemsetAsync(h->ff_arena.p, 0xFF, ff_bytes(h), st));
     else HIPCHK(hipStreamWaitEvent(st, h->ev_ff, 0));          // table was cleared on the side stream during the refine
     if (zero_counters) HIPCHK(hipMemsetAsync(h->d_ctr + CTR_NUNIQ, 0, 4 * sizeof(uint32_t), st));
-    if (have_cubeidx) HIPCHK(launch_tile_tricount(st, h->grid, (const uint8_t *) h->cubeidx.p, n_ptr, (uint32_t *) h->tilecnt.p));
-    else HIPCHK(launch_classify(st, h->grid, h->scene, h->d_sp, d_vox, n_ptr, vs, (uint8_t *) h->cubeidx.p, (uint32_t *) h->tilecnt.p));
-    HIPCHK(launch_tile_dedupe(st, h->grid, d_vox, n_ptr, vs, (const uint8_t *) h->cubeidx.p, (const uint32_t *) h->tilecnt.p,
+    if (have_cubeidx) HIPCHK(launch_tile_tricount(st, h->tgrid, (const uint8_t *) h->cubeidx.p, n_ptr, (uint32_t *) h->tilecnt.p));
+    else HIPCHK(launch_classify(st, h->tgrid, h->scene, h->d_sp, d_vox, n_ptr, vs, (uint8_t *) h->cubeidx.p, (uint32_t *) h->tilecnt.p));
+    HIPCHK(launch_tile_dedupe(st, h->tgrid, d_vox, n_ptr, vs, (const uint8_t *) h->cubeidx.p, (const uint32_t *) h->tilecnt.p,
                               (uint32_t *) h->trioff.p, (uint32_t *) h->tri_e.p, (Vertex *) h->uverts.p, (uint4 *) h->tdesc.p,
                               h->ucap, h->tcap, h->d_ctr + CTR_NTRI, h->d_ctr + CTR_NTILES, h->d_status));
     HIPCHK(launch_tile_prefix(st, (const uint4 *) h->tdesc.p, h->d_ctr + CTR_NTILES, (uint32_t *) h->tpre.p, h->d_ctr + CTR_NUNIQ));
@@ -216,7 +219,7 @@ int mesh_front(sdmesh_handle *h, const Point *d_vox, const uint32_t *n_ptr, Poin
     // fork: the weld claim (scattered CAS, latency-bound) runs beside the orientation test (VALU-bound)
     HIPCHK(hipEventRecord(h->ev_fork, st));
     HIPCHK(hipStreamWaitEvent(h->side, h->ev_fork, 0));
-    HIPCHK(launch_tile_claim(h->side, h->grid, (const Vertex *) h->uverts.p, (const uint4 *) h->tdesc.p, h->d_ctr + CTR_NTILES,
+    HIPCHK(launch_tile_claim(h->side, h->tgrid, (const Vertex *) h->uverts.p, (const uint4 *) h->tdesc.p, h->d_ctr + CTR_NTILES,
                              h->wkeys, h->wsize, (uint32_t *) h->vslot.p, h->d_status));
     HIPCHK(hipEventRecord(h->ev_join, h->side));
     HIPCHK(launch_flip(st, h->grid * h->flip_mult, h->scene, h->d_sp, (const Vertex *) h->uverts.p, (const uint32_t *) h->tri_e.p,
@@ -228,7 +231,7 @@ int mesh_front(sdmesh_handle *h, const Point *d_vox, const uint32_t *n_ptr, Poin
 // per-tile weld of (uverts, tri_e, flip) described by tdesc[0..*NTILES) -> vertices / indices
 int mesh_weld(sdmesh_handle *h, const Vertex *uverts) {
     hipStream_t st = h->stream;
-    HIPCHK(launch_weld(st, h->grid, uverts, (const uint4 *) h->tdesc.p, h->d_ctr + CTR_NTILES, (uint32_t *) h->tri_e.p,
+    HIPCHK(launch_weld(st, h->tgrid, uverts, (const uint4 *) h->tdesc.p, h->d_ctr + CTR_NTILES, (uint32_t *) h->tri_e.p,
                        (const uint8_t *) h->flip.p, h->first_ord, h->wmin, (uint32_t *) h->wfirst.p, (const uint32_t *) h->vslot.p,
                        (uint32_t *) h->wvidx.p, (uint32_t *) h->torder.p, (uint32_t *) h->tfirst.p, (uint32_t *) h->tfpre.p,
                        (Vertex *) h->vertices.p, (uint32_t) (h->vertices.cap / sizeof(Vertex)), h->d_ctr + CTR_NVERT,
@@ -308,13 +311,13 @@ int weld_raw_device(sdmesh_handle *h, const Triangle *d_raw, uint32_t nslots) {
     SDCHK(ensure(h, h->compact, sizeof(Triangle) * (size_t) nslots));
     HIPCHK(hipMemsetAsync(h->ff_arena.p, 0xFF, ff_bytes(h), st));
     HIPCHK(launch_set_u32(st, h->d_ctr + CTR_NSLOTS, nslots));
-    HIPCHK(launch_raw_count(st, h->grid, d_raw, h->d_ctr + CTR_NSLOTS, (uint32_t *) h->tilecnt.p));
+    HIPCHK(launch_raw_count(st, h->tgrid, d_raw, h->d_ctr + CTR_NSLOTS, (uint32_t *) h->tilecnt.p));
     HIPCHK(launch_scan_tiles(st, (uint32_t *) h->tilecnt.p, h->d_ctr + CTR_NSLOTS, 256, h->d_ctr + CTR_NTRI, nslots, h->d_status));
-    HIPCHK(launch_raw_compact(st, h->grid, d_raw, h->d_ctr + CTR_NSLOTS, (const uint32_t *) h->tilecnt.p,
+    HIPCHK(launch_raw_compact(st, h->tgrid, d_raw, h->d_ctr + CTR_NSLOTS, (const uint32_t *) h->tilecnt.p,
                               (Triangle *) h->compact.p, (uint32_t *) h->tri_e.p, nslots));
     HIPCHK(launch_raw_desc(st, h->grid, h->d_ctr + CTR_NTRI, (uint4 *) h->tdesc.p, (uint8_t *) h->flip.p, h->d_ctr + CTR_NTILES,
                            h->d_ctr + CTR_NUNIQ));
-    HIPCHK(launch_tile_claim(st, h->grid, (const Vertex *) h->compact.p, (const uint4 *) h->tdesc.p, h->d_ctr + CTR_NTILES,
+    HIPCHK(launch_tile_claim(st, h->tgrid, (const Vertex *) h->compact.p, (const uint4 *) h->tdesc.p, h->d_ctr + CTR_NTILES,
                              h->wkeys, h->wsize, (uint32_t *) h->vslot.p, h->d_status));
     SDCHK(mesh_weld(h, (const Vertex *) h->compact.p));
     return SDMESH_OK;
@@ -344,7 +347,7 @@ int refine_level(sdmesh_handle *h, int L, uint32_t n_cap_in, uint32_t out_cap, P
     SDCHK(ensure(h, h->mask, n_cap_in));
     const uint32_t *n_in = h->d_ctr + CTR_LEVEL0 + L;
     uint32_t *n_out = h->d_ctr + CTR_LEVEL0 + L + 1;
-    HIPCHK(launch_refine_mask(st, h->grid, h->scene, h->d_sp, (const Point *) h->vox[src].p, n_in, cs, (uint8_t *) h->mask.p,
+    HIPCHK(launch_refine_mask(st, h->tgrid, h->scene, h->d_sp, (const Point *) h->vox[src].p, n_in, cs, (uint8_t *) h->mask.p,
                               cnt_region));
     uint32_t cap = out_cap;
     if (out_cap == 0) {
@@ -356,7 +359,7 @@ int refine_level(sdmesh_handle *h, int L, uint32_t n_cap_in, uint32_t out_cap, P
         if (count_out) *count_out = cnt;
     }
     SDCHK(ensure(h, h->vox[dst], sizeof(Point) * (size_t) std::max<uint32_t>(cap, 64)));
-    HIPCHK(launch_refine_emit(st, h->grid, (const Point *) h->vox[src].p, n_in, cs, (const uint8_t *) h->mask.p, cnt_region,
+    HIPCHK(launch_refine_emit(st, h->tgrid, (const Point *) h->vox[src].p, n_in, cs, (const uint8_t *) h->mask.p, cnt_region,
                               (Point *) h->vox[dst].p, cap, n_out, h->d_status));
     h->cur = dst;
     return SDMESH_OK;
@@ -468,7 +471,7 @@ int regen_impl(sdmesh_handle *h, int levels, int mode, int part, int nparts, sdm
             n_cap = padded(h->plan_counts[levels]);
             if (h->use_graph) {
                 uint64_t key[8] = {h->buf_gen, (uint64_t) h->scene, (uint64_t) levels, ((uint64_t) mode << 40) | ((uint64_t) part << 20) | (uint64_t) nparts,
-                                   (uint64_t) h->skip_weld, (uint64_t) (uintptr_t) st, (uint64_t) h->grid, 0};
+                                   (uint64_t) h->skip_weld, (uint64_t) (uintptr_t) st, (uint64_t) h->grid | ((uint64_t) h->tgrid << 20) | ((uint64_t) h->project_mult << 40) | ((uint64_t) h->flip_mult << 48), 0};
                 for (int i = 0; i <= levels; i++) key[7] = key[7] * 1000003ull + h->plan_counts[i];
                 key[7] = key[7] * 1000003ull + h->plan_uniq;
                 if (!h->graph_exec || memcmp(key, h->graph_key, sizeof key) != 0) {
@@ -643,6 +646,7 @@ int sdmesh_create(int device, sdmesh_handle **out) {
         return SDMESH_ERR_NO_DEVICE;
     }
     h->grid = 4 * prop.multiProcessorCount;
+    h->tgrid = 16 * prop.multiProcessorCount;   // measured: 512^3 (1037 tiles) -7 % vs 4/CU, 1024^3 (4150 tiles) best at 16/CU
     h->dense_grid = 48 * prop.multiProcessorCount;   // measured best for the write-only P1 stream (tools/dense_sweep.py)
     if ((e = hipStreamCreateWithFlags(&h->own_stream, hipStreamNonBlocking)) != hipSuccess) return bail(e, "hipStreamCreate");
     h->stream = h->own_stream;
@@ -735,6 +739,11 @@ int sdmesh_set_option(sdmesh_handle *h, const char *name, int value) {
     if (!strcmp(name, "flip_mult")) { if (value < 1 || value > 16) return fail(h, SDMESH_ERR_INVALID, "flip_mult 1..16"); h->flip_mult = value; drop_graph(h); return SDMESH_OK; }
     if (!strcmp(name, "skip_weld")) { h->skip_weld = value ? 1 : 0; return SDMESH_OK; }
     if (!strcmp(name, "graph")) { h->use_graph = value ? 1 : 0; if (!value) drop_graph(h); return SDMESH_OK; }
+    if (!strcmp(name, "tgrid")) {
+        if (value < 1 || value > 65535) return fail(h, SDMESH_ERR_INVALID, "tgrid out of range");
+        h->tgrid = value; drop_graph(h);
+        return SDMESH_OK;
+    }
     if (!strcmp(name, "grid")) {
         if (value < 1 || value > 65535) return fail(h, SDMESH_ERR_INVALID, "grid out of range");
         h->grid = value;
@@ -775,7 +784,7 @@ static int refine_host_common(sdmesh_handle *h, const Point *in, size_t n, Point
     HIPCHK(hipMemcpyAsync(h->vox[0].p, in, sizeof(Point) * n, hipMemcpyHostToDevice, st));
     SDCHK(zero_ctl(h, tiles((uint32_t) n) + 16));
     HIPCHK(launch_set_u32(st, h->d_ctr + CTR_LEVEL0, (uint32_t) n));
-    HIPCHK(launch_refine_mask(st, h->grid, h->scene, h->d_sp, (const Point *) h->vox[0].p, h->d_ctr + CTR_LEVEL0, half_size(voxel_size),
+    HIPCHK(launch_refine_mask(st, h->tgrid, h->scene, h->d_sp, (const Point *) h->vox[0].p, h->d_ctr + CTR_LEVEL0, half_size(voxel_size),
                               (uint8_t *) h->mask.p, h->d_ctr + CTL_LVL0));
     return SDMESH_OK;
 }
@@ -796,7 +805,7 @@ int sdmesh_refine_voxel_field(sdmesh_handle *h, const struct Point *in, size_t n
     const uint32_t cnt = h->h_pinned[CTR_SCRATCH];
     if (cnt > out_cap) return fail(h, SDMESH_ERR_CAPACITY, "refine output needs %u points, caller gave %zu", cnt, out_cap);
     SDCHK(ensure(h, h->vox[1], sizeof(Point) * (size_t) std::max<uint32_t>(cnt, 64)));
-    HIPCHK(launch_refine_emit(st, h->grid, (const Point *) h->vox[0].p, h->d_ctr + CTR_LEVEL0, half_size(voxel_size),
+    HIPCHK(launch_refine_emit(st, h->tgrid, (const Point *) h->vox[0].p, h->d_ctr + CTR_LEVEL0, half_size(voxel_size),
                               (const uint8_t *) h->mask.p, h->d_ctr + CTL_LVL0, (Point *) h->vox[1].p, cnt,
                               h->d_ctr + CTR_LEVEL0 + 1, h->d_status));
     if (cnt) HIPCHK(hipMemcpyAsync(out, h->vox[1].p, sizeof(Point) * (size_t) cnt, hipMemcpyDeviceToHost, st));
