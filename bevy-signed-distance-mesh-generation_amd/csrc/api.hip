@@ -61,6 +61,7 @@ struct sdmesh_handle {
     int force_direct = 0;
     int project_mult = 3;      // k_project grid = project_mult * grid: more, shorter waves tighten the tail (measured: -8 %)
     int flip_mult = 2;         // same knob for k_flip (measured: -3 %)
+    int refine2 = 0;           // planned path: two refine levels per step (k_refine2_*): measured no faster, off by default
     int skip_weld = 0;         // regen stops after the orientation test (multi-GPU ranks: the root welds)
     bool welded = false;       // tri_e holds the final corner order
     int dense_grid = 16384;    // workgroups for k_sample_dense
@@ -84,7 +85,7 @@ struct sdmesh_handle {
     // voxel lists (ping-pong), refine scratch
     DevBuf vox[2];
     int cur = 0;
-    DevBuf mask, tilecnt, ctl;             // ctl: counters + status + pre-zeroed per-level tile counters
+    DevBuf mask, mask2x, tilecnt, ctl;             // ctl: counters + status + pre-zeroed per-level tile counters
     uint32_t lvl_off[SDMESH_MAX_LEVELS + 2] = {0};
     // counters / status
     uint32_t *d_ctr = nullptr;     // CTR_WORDS
@@ -382,12 +383,30 @@ int enqueue_planned_chain(sdmesh_handle *h, int levels, uint32_t z0, uint32_t z1
     if (n0) HIPCHK(launch_create_field(st, (Point *) h->vox[0].p, z0, z1, h->d_ctr + CTR_LEVEL0));
     uint32_t n_cap = n0;
     h->cur = 0;
-    for (int L = 0; L < levels; L++) {
+    for (int L = 0; L < levels;) {
         const Point cs = half_size(vs);
+        if (h->refine2 && L + 2 <= levels) {
+            // two levels in one step: the level L+1 list is never materialised, only counted
+            const Point cs2 = half_size(cs);
+            const uint32_t out_cap = padded(h->plan_counts[L + 2]);
+            const int src = h->cur, dst = 1 - h->cur;
+            uint32_t *cnt_region = h->d_ctr + CTL_LVL0 + h->lvl_off[L];
+            HIPCHK(launch_refine2_mask(st, h->tgrid, h->scene, h->d_sp, (const Point *) h->vox[src].p, h->d_ctr + CTR_LEVEL0 + L, cs,
+                                       (uint8_t *) h->mask.p, (uint64_t *) h->mask2x.p, cnt_region, h->d_ctr + CTR_LEVEL0 + L + 1));
+            HIPCHK(launch_refine2_emit(st, h->tgrid, (const Point *) h->vox[src].p, h->d_ctr + CTR_LEVEL0 + L, cs,
+                                       (const uint8_t *) h->mask.p, (const uint64_t *) h->mask2x.p, cnt_region,
+                                       (Point *) h->vox[dst].p, out_cap, h->d_ctr + CTR_LEVEL0 + L + 2, h->d_status));
+            h->cur = dst;
+            vs = cs2;
+            n_cap = out_cap;
+            L += 2;
+            continue;
+        }
         const uint32_t out_cap = padded(h->plan_counts[L + 1]);
         SDCHK(refine_level(h, L, std::max<uint32_t>(n_cap, 64), out_cap, cs, h->d_ctr + CTL_LVL0 + h->lvl_off[L], nullptr));
         vs = cs;
         n_cap = out_cap;
+        L++;
     }
     SDCHK(mesh_front(h, (const Point *) h->vox[h->cur].p, h->d_ctr + CTR_LEVEL0 + levels, vs, false, true));
     if (!h->skip_weld) SDCHK(mesh_weld(h, (const Vertex *) h->uverts.p));
@@ -401,13 +420,16 @@ int presize_planned_chain(sdmesh_handle *h, int levels, uint32_t n0, uint32_t *l
     SDCHK(layout_mesh(h, padded(h->plan_counts[levels]), padded(h->plan_uniq)));
     uint32_t lvl_words = 0, n_cap = n0;
     int cur = 0;
-    for (int L = 0; L < levels; L++) {
+    for (int L = 0; L < levels;) {
+        const int step = (h->refine2 && L + 2 <= levels) ? 2 : 1;
         h->lvl_off[L] = lvl_words;
         lvl_words += tiles(L == 0 ? n0 : padded(h->plan_counts[L])) + 16;
         SDCHK(ensure(h, h->mask, std::max<uint32_t>(n_cap, 64)));
-        n_cap = padded(h->plan_counts[L + 1]);
+        if (step == 2) SDCHK(ensure(h, h->mask2x, 8ull * std::max<uint32_t>(n_cap, 64)));
+        n_cap = padded(h->plan_counts[L + step]);
         SDCHK(ensure(h, h->vox[1 - cur], sizeof(Point) * (size_t) std::max<uint32_t>(n_cap, 64)));
         cur = 1 - cur;
+        L += step;
     }
     SDCHK(ensure_ctl(h, lvl_words));
     *lvl_words_out = lvl_words;
@@ -471,7 +493,7 @@ int regen_impl(sdmesh_handle *h, int levels, int mode, int part, int nparts, sdm
             n_cap = padded(h->plan_counts[levels]);
             if (h->use_graph) {
                 uint64_t key[8] = {h->buf_gen, (uint64_t) h->scene, (uint64_t) levels, ((uint64_t) mode << 40) | ((uint64_t) part << 20) | (uint64_t) nparts,
-                                   (uint64_t) h->skip_weld, (uint64_t) (uintptr_t) st, (uint64_t) h->grid | ((uint64_t) h->tgrid << 20) | ((uint64_t) h->project_mult << 40) | ((uint64_t) h->flip_mult << 48), 0};
+                                   (uint64_t) h->skip_weld, (uint64_t) (uintptr_t) st, (uint64_t) h->grid | ((uint64_t) h->tgrid << 20) | ((uint64_t) h->project_mult << 40) | ((uint64_t) h->flip_mult << 48) | ((uint64_t) h->refine2 << 56), 0};
                 for (int i = 0; i <= levels; i++) key[7] = key[7] * 1000003ull + h->plan_counts[i];
                 key[7] = key[7] * 1000003ull + h->plan_uniq;
                 if (!h->graph_exec || memcmp(key, h->graph_key, sizeof key) != 0) {
@@ -675,7 +697,7 @@ void sdmesh_destroy(sdmesh_handle *h) {
     (void) hipSetDevice(h->device);
     if (h->stream) (void) hipStreamSynchronize(h->stream);
     drop_graph(h);
-    DevBuf *bufs[] = {&h->vox[0], &h->vox[1], &h->mask, &h->tilecnt, &h->ctl, &h->cubeidx, &h->trioff, &h->ff_arena,
+    DevBuf *bufs[] = {&h->vox[0], &h->vox[1], &h->mask, &h->mask2x, &h->tilecnt, &h->ctl, &h->cubeidx, &h->trioff, &h->ff_arena,
                       &h->first_ord_buf, &h->wfirst, &h->uverts, &h->tri_e, &h->vslot, &h->tdesc, &h->tfirst, &h->tfpre, &h->tpre, &h->flip, &h->wvidx, &h->torder,
                       &h->vertices, &h->indices, &h->raw, &h->compact, &h->staging, &h->dense_samples, &h->dense_bits,
                       &h->cellcnt};
@@ -737,6 +759,7 @@ int sdmesh_set_option(sdmesh_handle *h, const char *name, int value) {
     if (!strcmp(name, "direct")) { h->force_direct = value ? 1 : 0; h->plan_valid = false; return SDMESH_OK; }
     if (!strcmp(name, "project_mult")) { if (value < 1 || value > 16) return fail(h, SDMESH_ERR_INVALID, "project_mult 1..16"); h->project_mult = value; drop_graph(h); return SDMESH_OK; }
     if (!strcmp(name, "flip_mult")) { if (value < 1 || value > 16) return fail(h, SDMESH_ERR_INVALID, "flip_mult 1..16"); h->flip_mult = value; drop_graph(h); return SDMESH_OK; }
+    if (!strcmp(name, "refine2")) { h->refine2 = value ? 1 : 0; drop_graph(h); return SDMESH_OK; }
     if (!strcmp(name, "skip_weld")) { h->skip_weld = value ? 1 : 0; return SDMESH_OK; }
     if (!strcmp(name, "graph")) { h->use_graph = value ? 1 : 0; if (!value) drop_graph(h); return SDMESH_OK; }
     if (!strcmp(name, "tgrid")) {

@@ -132,6 +132,18 @@ __device__ __forceinline__ uint32_t hash_find(const uint64_t *__restrict__ keys,
 // ------------------------------------------------------------------------------------------
 static constexpr uint32_t MASK_CHUNK = 32;
 
+// child (i,j,k) of a parent is a border voxel iff its 8 corner signs (bits of the 27-sample field) are not all equal
+__device__ __forceinline__ uint32_t child_mask_from_bits(uint32_t bits) {
+    uint32_t m = 0;
+#pragma unroll
+    for (int c = 0; c < 8; c++) {
+        const int i = c >> 2, j = (c >> 1) & 1, k = c & 1;
+        const uint32_t cnt = __popc(bits & (0x361Bu << (i * 9 + j * 3 + k)));
+        if (cnt != 0 && cnt != 8) m |= 1u << c;
+    }
+    return m;
+}
+
 template <int SCENE>
 __global__ __launch_bounds__(256) void k_refine_mask(const Point *__restrict__ vox, const uint32_t *__restrict__ n_ptr,
                                                       Point cs /* child size = parent size / 2 */, const SceneParams *__restrict__ spp,
@@ -257,6 +269,122 @@ __global__ __launch_bounds__(1024) void k_sum_tiles(const uint32_t *__restrict__
     uint32_t total;
     (void) block_excl_scan(part, total, lds);
     if (threadIdx.x == 0) *total_out = total;
+}
+
+// ------------------------------------------------------------------------------------------
+// A2 refine, two levels per step (planned path).  The refine chain is latency-bound (every tiny kernel sits on a
+// ~5 us floor), so the level L+1 list is never materialised: one mask kernel evaluates, per level-L parent, its 8
+// children (27 samples) and then the 8 children of every KEPT child (27 samples each, at the kept child's own float
+// position, exactly as a second refine launch would), one emit kernel writes the level-(L+2) voxels in the
+// reference's order (parent-major, child slot, grandchild slot).  mask2[p] packs the 8 grandchild masks of parent p.
+// ------------------------------------------------------------------------------------------
+template <int SCENE>
+__global__ __launch_bounds__(256) void k_refine2_mask(const Point *__restrict__ vox, const uint32_t *__restrict__ n_ptr, Point cs1,
+                                                       const SceneParams *__restrict__ spp, uint8_t *__restrict__ mask1,
+                                                       uint64_t *__restrict__ mask2, uint32_t *__restrict__ tilecnt,
+                                                       uint32_t *__restrict__ n_mid) {
+    const SceneParams &sp = *spp;
+    __shared__ uint32_t s_cnt1, s_cnt2;
+    const uint32_t n = *n_ptr;
+    const uint32_t nchunks = (n + MASK_CHUNK - 1) / MASK_CHUNK;
+    const uint32_t grp = threadIdx.x >> 5, s = threadIdx.x & 31u;
+    const int ix = (int) (s / 9u), iy = (int) ((s / 3u) % 3u), iz = (int) (s % 3u);
+    const Point cs2 = Point{cs1.x / 2.0f, cs1.y / 2.0f, cs1.z / 2.0f};      // src/cuda/mod.rs:126-130
+    for (uint32_t chunk = blockIdx.x; chunk < nchunks; chunk += gridDim.x) {
+        if (threadIdx.x == 0) { s_cnt1 = 0; s_cnt2 = 0; }
+        __syncthreads();
+        uint32_t local1 = 0, local2 = 0;
+#pragma unroll 1
+        for (uint32_t it = 0; it < MASK_CHUNK / 8; it++) {
+            const uint32_t p = chunk * MASK_CHUNK + it * 8 + grp;
+            const Point b = vox[p < n ? p : (n - 1)];
+            bool in = false;
+            if (p < n && s < 27)
+                in = sdf<SCENE>(b.x + (float) ix * cs1.x, b.y + (float) iy * cs1.y, b.z + (float) iz * cs1.z, sp) <= 0.0f;
+            const uint64_t bal = __ballot(in);
+            const uint32_t m1 = p < n ? child_mask_from_bits((uint32_t) (bal >> (threadIdx.x & 32u)) & 0x7FFFFFFu) : 0u;
+            const uint32_t mu = m1 | (uint32_t) __shfl_xor((int) m1, 32, 64);          // children either half-wave needs
+            uint64_t packed = 0;
+#pragma unroll 1
+            for (uint32_t c = 0; c < 8; c++) {
+                if (!((mu >> c) & 1u)) continue;                                        // wave-uniform
+                const bool kept = (m1 >> c) & 1u;
+                const float cx = b.x + (float) (c >> 2) * cs1.x, cy = b.y + (float) ((c >> 1) & 1u) * cs1.y, cz = b.z + (float) (c & 1u) * cs1.z;
+                bool in2 = false;
+                if (kept && s < 27)
+                    in2 = sdf<SCENE>(cx + (float) ix * cs2.x, cy + (float) iy * cs2.y, cz + (float) iz * cs2.z, sp) <= 0.0f;
+                const uint64_t bal2 = __ballot(in2);
+                if (kept) {
+                    const uint32_t m2 = child_mask_from_bits((uint32_t) (bal2 >> (threadIdx.x & 32u)) & 0x7FFFFFFu);
+                    packed |= (uint64_t) m2 << (8u * c);
+                }
+            }
+            if (s == 0 && p < n) {
+                mask1[p] = (uint8_t) m1;
+                mask2[p] = packed;
+                local1 += __popc(m1);
+                local2 += __popcll(packed);
+            }
+        }
+        if (local1) atomicAdd(&s_cnt1, local1);
+        if (local2) atomicAdd(&s_cnt2, local2);
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            if (s_cnt2) atomicAdd(&tilecnt[(chunk * MASK_CHUNK) / TILE], s_cnt2);
+            if (s_cnt1) atomicAdd(n_mid, s_cnt1);
+        }
+        __syncthreads();
+    }
+}
+
+__global__ __launch_bounds__(256) void k_refine2_emit(const Point *__restrict__ vox, const uint32_t *__restrict__ n_ptr, Point cs1,
+                                                       const uint8_t *__restrict__ mask1, const uint64_t *__restrict__ mask2,
+                                                       const uint32_t *__restrict__ tilecnt, Point *__restrict__ out, uint32_t cap,
+                                                       uint32_t *__restrict__ n_out, uint32_t *__restrict__ status) {
+    __shared__ uint32_t lds[17];
+    const uint32_t n = *n_ptr;
+    const uint32_t ntiles = (n + TILE - 1) / TILE;
+    const Point cs2 = Point{cs1.x / 2.0f, cs1.y / 2.0f, cs1.z / 2.0f};
+    if (n == 0 && blockIdx.x == 0 && threadIdx.x == 0) *n_out = 0;
+    for (uint32_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        const uint32_t p = tile * TILE + threadIdx.x;
+        const uint32_t m1 = p < n ? mask1[p] : 0u;
+        const uint64_t m2 = p < n ? mask2[p] : 0ull;
+        const Point b = vox[p < n ? p : (n - 1)];
+        uint32_t part = 0;
+        for (uint32_t i = threadIdx.x; i < tile; i += 256) part += tilecnt[i];
+        uint32_t tbase;
+        (void) block_excl_scan(part, tbase, lds);
+        uint32_t total;
+        uint32_t o = tbase + block_excl_scan((uint32_t) __popcll(m2), total, lds);
+        if (tile == ntiles - 1 && threadIdx.x == 0) {
+            uint32_t tot = tbase + total;
+            if (tot > cap) { atomicOr(&status[ST_OVERFLOW], 1u); tot = cap; }
+            *n_out = tot;
+        }
+        if (m2) {
+#pragma unroll 1
+            for (uint32_t c = 0; c < 8; c++) {
+                const uint32_t mc = (uint32_t) (m2 >> (8u * c)) & 0xFFu;
+                if (!mc) continue;
+                const float cx = b.x + (float) (c >> 2) * cs1.x, cy = b.y + (float) ((c >> 1) & 1u) * cs1.y, cz = b.z + (float) (c & 1u) * cs1.z;
+#pragma unroll
+                for (uint32_t g = 0; g < 8; g++) {
+                    if (mc & (1u << g)) {
+                        if (o < cap) {
+                            Point q;
+                            q.x = cx + (float) (g >> 2) * cs2.x;
+                            q.y = cy + (float) ((g >> 1) & 1u) * cs2.y;
+                            q.z = cz + (float) (g & 1u) * cs2.z;
+                            out[o] = q;
+                        }
+                        o++;
+                    }
+                }
+            }
+        }
+        (void) m1;
+    }
 }
 
 // Raw 8n layout of the reference kernel (INFINITY for non-border children)
@@ -1239,6 +1367,19 @@ hipError_t launch_refine_emit(hipStream_t st, int grid, const Point *vox, const 
 
 hipError_t launch_sum_tiles(hipStream_t st, const uint32_t *tilecnt, const uint32_t *n_ptr, uint32_t *total_out) {
     hipLaunchKernelGGL(k_sum_tiles, dim3(1), dim3(1024), 0, st, tilecnt, n_ptr, total_out);
+    return hipGetLastError();
+}
+
+hipError_t launch_refine2_mask(hipStream_t st, int grid, int scene, const SceneParams *sp, const Point *vox, const uint32_t *n_ptr,
+                               Point cs1, uint8_t *mask1, uint64_t *mask2, uint32_t *tilecnt, uint32_t *n_mid) {
+    SDM_DISPATCH(scene, hipLaunchKernelGGL(k_refine2_mask<S>, dim3(grid), dim3(256), 0, st, vox, n_ptr, cs1, sp, mask1, mask2, tilecnt, n_mid));
+    return hipGetLastError();
+}
+
+hipError_t launch_refine2_emit(hipStream_t st, int grid, const Point *vox, const uint32_t *n_ptr, Point cs1, const uint8_t *mask1,
+                               const uint64_t *mask2, const uint32_t *tilecnt, Point *out, uint32_t cap, uint32_t *n_out,
+                               uint32_t *status) {
+    hipLaunchKernelGGL(k_refine2_emit, dim3(grid), dim3(256), 0, st, vox, n_ptr, cs1, mask1, mask2, tilecnt, out, cap, n_out, status);
     return hipGetLastError();
 }
 

@@ -28,6 +28,11 @@ hipError_t launch_refine_emit(hipStream_t st, int grid, const Point *vox, const 
                               const uint8_t *mask, const uint32_t *tilecnt, Point *out, uint32_t cap, uint32_t *n_out,
                               uint32_t *status);
 hipError_t launch_sum_tiles(hipStream_t st, const uint32_t *tilecnt, const uint32_t *n_ptr, uint32_t *total_out);
+hipError_t launch_refine2_mask(hipStream_t st, int grid, int scene, const SceneParams *sp, const Point *vox, const uint32_t *n_ptr,
+                               Point cs1, uint8_t *mask1, uint64_t *mask2, uint32_t *tilecnt, uint32_t *n_mid);
+hipError_t launch_refine2_emit(hipStream_t st, int grid, const Point *vox, const uint32_t *n_ptr, Point cs1, const uint8_t *mask1,
+                               const uint64_t *mask2, const uint32_t *tilecnt, Point *out, uint32_t cap, uint32_t *n_out,
+                               uint32_t *status);
 hipError_t launch_refine_expand_raw(hipStream_t st, int grid, const Point *vox, uint32_t n, Point cs, const uint8_t *mask,
                                     Point *out);
 hipError_t launch_classify(hipStream_t st, int grid, int scene, const SceneParams *sp, const Point *vox,
