@@ -61,6 +61,7 @@ struct sdmesh_handle {
     int force_direct = 0;
     int project_mult = 3;      // k_project grid = project_mult * grid: more, shorter waves tighten the tail (measured: -8 %)
     int flip_mult = 2;         // same knob for k_flip (measured: -3 %)
+    int mask_chunk = 32;       // parents per workgroup pass in k_refine_mask (8, 16 or 32)
     int refine2 = 0;           // planned path: two refine levels per step (k_refine2_*): measured no faster, off by default
     int skip_weld = 0;         // regen stops after the orientation test (multi-GPU ranks: the root welds)
     bool welded = false;       // tri_e holds the final corner order
@@ -349,7 +350,7 @@ int refine_level(sdmesh_handle *h, int L, uint32_t n_cap_in, uint32_t out_cap, P
     const uint32_t *n_in = h->d_ctr + CTR_LEVEL0 + L;
     uint32_t *n_out = h->d_ctr + CTR_LEVEL0 + L + 1;
     HIPCHK(launch_refine_mask(st, h->tgrid, h->scene, h->d_sp, (const Point *) h->vox[src].p, n_in, cs, (uint8_t *) h->mask.p,
-                              cnt_region));
+                              cnt_region, h->mask_chunk));
     uint32_t cap = out_cap;
     if (out_cap == 0) {
         HIPCHK(launch_sum_tiles(st, cnt_region, n_in, h->d_ctr + CTR_SCRATCH));
@@ -759,6 +760,7 @@ int sdmesh_set_option(sdmesh_handle *h, const char *name, int value) {
     if (!strcmp(name, "direct")) { h->force_direct = value ? 1 : 0; h->plan_valid = false; return SDMESH_OK; }
     if (!strcmp(name, "project_mult")) { if (value < 1 || value > 16) return fail(h, SDMESH_ERR_INVALID, "project_mult 1..16"); h->project_mult = value; drop_graph(h); return SDMESH_OK; }
     if (!strcmp(name, "flip_mult")) { if (value < 1 || value > 16) return fail(h, SDMESH_ERR_INVALID, "flip_mult 1..16"); h->flip_mult = value; drop_graph(h); return SDMESH_OK; }
+    if (!strcmp(name, "mask_chunk")) { if (value != 8 && value != 16 && value != 32) return fail(h, SDMESH_ERR_INVALID, "mask_chunk 8|16|32"); h->mask_chunk = value; drop_graph(h); return SDMESH_OK; }
     if (!strcmp(name, "refine2")) { h->refine2 = value ? 1 : 0; drop_graph(h); return SDMESH_OK; }
     if (!strcmp(name, "skip_weld")) { h->skip_weld = value ? 1 : 0; return SDMESH_OK; }
     if (!strcmp(name, "graph")) { h->use_graph = value ? 1 : 0; if (!value) drop_graph(h); return SDMESH_OK; }

@@ -144,29 +144,29 @@ __device__ __forceinline__ uint32_t child_mask_from_bits(uint32_t bits) {
     return m;
 }
 
-template <int SCENE>
+template <int SCENE, uint32_t CH>
 __global__ __launch_bounds__(256) void k_refine_mask(const Point *__restrict__ vox, const uint32_t *__restrict__ n_ptr,
                                                       Point cs /* child size = parent size / 2 */, const SceneParams *__restrict__ spp,
                                                       uint8_t *__restrict__ mask, uint32_t *__restrict__ tilecnt) {
     const SceneParams &sp = *spp;  // scene uniform in device memory (a captured graph replays with new values)
     __shared__ uint32_t s_cnt;
     const uint32_t n = *n_ptr;
-    const uint32_t nchunks = (n + MASK_CHUNK - 1) / MASK_CHUNK;
+    const uint32_t nchunks = (n + CH - 1) / CH;
     const uint32_t grp = threadIdx.x >> 5, s = threadIdx.x & 31u;     // 8 parents per pass, sample id
     const int ix = (int) (s / 9u), iy = (int) ((s / 3u) % 3u), iz = (int) (s % 3u);
     for (uint32_t chunk = blockIdx.x; chunk < nchunks; chunk += gridDim.x) {
         if (threadIdx.x == 0) s_cnt = 0;
         __syncthreads();
         uint32_t local = 0;
-        Point pb[MASK_CHUNK / 8];
+        Point pb[CH / 8];
 #pragma unroll
-        for (uint32_t it = 0; it < MASK_CHUNK / 8; it++) {        // all loads in flight before the first eval
-            const uint32_t p = chunk * MASK_CHUNK + it * 8 + grp;
+        for (uint32_t it = 0; it < CH / 8; it++) {        // all loads in flight before the first eval
+            const uint32_t p = chunk * CH + it * 8 + grp;
             pb[it] = vox[p < n ? p : (n - 1)];
         }
 #pragma unroll
-        for (uint32_t it = 0; it < MASK_CHUNK / 8; it++) {
-            const uint32_t p = chunk * MASK_CHUNK + it * 8 + grp;
+        for (uint32_t it = 0; it < CH / 8; it++) {
+            const uint32_t p = chunk * CH + it * 8 + grp;
             bool in = false;
             if (p < n && s < 27) {
                 const Point b = pb[it];
@@ -188,7 +188,7 @@ __global__ __launch_bounds__(256) void k_refine_mask(const Point *__restrict__ v
         }
         if (local) atomicAdd(&s_cnt, local);
         __syncthreads();
-        if (threadIdx.x == 0 && s_cnt) atomicAdd(&tilecnt[(chunk * MASK_CHUNK) / TILE], s_cnt);
+        if (threadIdx.x == 0 && s_cnt) atomicAdd(&tilecnt[(chunk * CH) / TILE], s_cnt);
         __syncthreads();
     }
 }
@@ -1347,8 +1347,10 @@ __global__ __launch_bounds__(256) void k_sample_dense_rows(float *__restrict__ o
     }
 
 hipError_t launch_refine_mask(hipStream_t st, int grid, int scene, const SceneParams *sp, const Point *vox,
-                              const uint32_t *n_ptr, Point cs, uint8_t *mask, uint32_t *tilecnt) {
-    SDM_DISPATCH(scene, hipLaunchKernelGGL(k_refine_mask<S>, dim3(grid), dim3(256), 0, st, vox, n_ptr, cs, sp, mask, tilecnt));
+                              const uint32_t *n_ptr, Point cs, uint8_t *mask, uint32_t *tilecnt, int chunk) {
+    if (chunk == 8) { SDM_DISPATCH(scene, hipLaunchKernelGGL((k_refine_mask<S, 8>), dim3(grid), dim3(256), 0, st, vox, n_ptr, cs, sp, mask, tilecnt)); }
+    else if (chunk == 16) { SDM_DISPATCH(scene, hipLaunchKernelGGL((k_refine_mask<S, 16>), dim3(grid), dim3(256), 0, st, vox, n_ptr, cs, sp, mask, tilecnt)); }
+    else { SDM_DISPATCH(scene, hipLaunchKernelGGL((k_refine_mask<S, 32>), dim3(grid), dim3(256), 0, st, vox, n_ptr, cs, sp, mask, tilecnt)); }
     return hipGetLastError();
 }
 

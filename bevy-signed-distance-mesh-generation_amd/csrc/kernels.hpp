@@ -21,7 +21,7 @@ enum StatusWord : int {
 };
 
 hipError_t launch_refine_mask(hipStream_t st, int grid, int scene, const SceneParams *sp, const Point *vox,
-                              const uint32_t *n_ptr, Point cs, uint8_t *mask, uint32_t *tilecnt);
+                              const uint32_t *n_ptr, Point cs, uint8_t *mask, uint32_t *tilecnt, int chunk = 32);
 hipError_t launch_scan_tiles(hipStream_t st, uint32_t *cnt, const uint32_t *n_ptr, uint32_t items_per_tile,
                              uint32_t *total_out, uint32_t cap, uint32_t *status);
 hipError_t launch_refine_emit(hipStream_t st, int grid, const Point *vox, const uint32_t *n_ptr, Point cs,

@@ -12,5 +12,5 @@ def run(k, tag):
     ms = [h.regen(k).device_ms for _ in range(30)]
     print(f"N={32 << k} {tag}: device_ms med={np.median(ms):.4f} min={min(ms):.4f}", flush=True)
 for k in (3, 4, 5):
-    for r2 in (0, 1, 0, 1):
-        h.set_option("refine2", r2); run(k, f"refine2={r2}")
+    for mc in (32, 16, 8, 32):
+        h.set_option("mask_chunk", mc); run(k, f"mask_chunk={mc}")
