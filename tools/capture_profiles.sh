@@ -1,0 +1,19 @@
+#!/bin/bash
+# Captures every rocprofv3 pass profiles/README.md lists, on the GPU box, into gpurun_out/prof/.
+# usage (from the repo root on the box): bash tools/capture_profiles.sh
+# PMC passes are separate runs with --kernel-trace only (no sys/hip trace domains), one counter group per pass.
+set -u
+R=$(pwd); O=$R/gpurun_out/prof; rm -rf $O; mkdir -p $O
+cd /tmp && export TMPDIR=/tmp
+P=python3
+run() { name=$1; shift; echo "== $name"; timeout -k 10 300 rocprofv3 "$@" > $O/$name.stdout 2> $O/$name.stderr; echo "rc=$?"; }
+run regen_trace --kernel-trace --stats --output-format csv -d $O/regen_trace -- $P $R/tools/prof_regen.py sdobj 4 20 || exit 1
+run regen_pmc_sq --kernel-trace --pmc SQ_INSTS_VALU SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_WAIT_INST_ANY GRBM_GUI_ACTIVE --output-format csv -d $O/regen_pmc_sq -- $P $R/tools/prof_regen.py sdobj 4 3 || exit 1
+run dense_write --kernel-trace --pmc WRITE_SIZE --output-format csv -d $O/dense_write -- $P $R/tools/dense_once.py || exit 1
+run dense_fetch --kernel-trace --pmc FETCH_SIZE --output-format csv -d $O/dense_fetch -- $P $R/tools/dense_once.py || exit 1
+run bench_trace --kernel-trace --stats --output-format csv -d $O/bench_trace -- $P $R/bench.py --steps 100 --warmup 10 --no-cpu-baseline || exit 1
+cd $R && echo "== plain bench" && timeout -k 10 400 $P bench.py > $O/bench_plain.json 2> $O/bench_plain.stderr; echo "rc=$?"
+# keep only the small summaries (the raw traces are large)
+find $O -name '*_kernel_trace.csv' -size +4M -delete
+find $O -name '*_counter_collection.csv' -size +8M -delete
+du -sh $O
