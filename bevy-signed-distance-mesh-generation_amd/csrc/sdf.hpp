@@ -211,32 +211,12 @@ SDM_HD float sdf_program(f3 p, const SceneParams &sp) {
     return acc;
 }
 
-template <int SCENE>
-SDM_HD float sdf(float px, float py, float pz, const SceneParams &sp) {
-    if (SCENE == SCENE_PROGRAM) {
-        return sdf_program(mk(px, py, pz), sp);
-    } else if (SCENE == SCENE_SPHERE) {
-        return sqrtf((px * px + py * py) + pz * pz) - 1.0f;
-    } else if (SCENE == SCENE_CSG3) {
-        // build-defined scene (SURVEY 8(d).3); mirrors oracle sdf_eval SCENE_CSG3
-        float a = sqrtf((px * px + py * py) + pz * pz) - 1.0f;
-        float b = sd_box(mk(px, py, pz), mk(1.2f, 0.0f, 0.0f), mk(1.2f, 1.2f, 1.2f));
-        float qx = sqrtf(px * px + pz * pz) - 1.5f;
-        float c = sqrtf(qx * qx + py * py) - 0.25f;
-        return smooth_min(smooth_min(a, b, 0.3f), c, 0.3f);
-    } else {
-        const float a1 = sqrtf(skeleton_min_d2(px, py, pz)) - 0.1f;
-        float sy = py;
-        if (SCENE == SCENE_ANIM) sy = py - sp.p[0];
-        const float a2 = sqrtf((px * px + sy * sy) + pz * pz) - 1.0f;
-        return smooth_min(a1, a2, 0.5f);
-    }
-}
-
-// Correctly rounded sqrt for x == 0 or x a NORMAL positive float (no denormal, inf or NaN input): the same
-// v_sqrt_f32 + two-sided fma residual correction hipcc emits for sqrtf, minus the denormal pre-scaling and the
-// class test.  x == 0 falls through correctly (both residual tests fail).  Used only where the argument is a sum
-// of squares of lattice coordinates (the dense sphere pass), so the precondition holds by construction.
+// Correctly rounded sqrt for x == 0 or x a NORMAL positive float: the same v_sqrt_f32 + two-sided fma residual
+// correction hipcc emits for sqrtf, minus the denormal pre-scaling and the class test (9 instructions instead of
+// 16).  x == 0 falls through correctly (both residual tests fail).  For a DENORMAL x the result is some value in
+// [0, 2^-63] (v_sqrt_f32 sees zero or a tiny number; at most one ulp step is added), as is the exact root, so
+// the only callers are expressions of the form  sqrt(x) - c  with |c| >= 0.1: there any root below 2^-30 is
+// absorbed by the subtraction and the two forms agree bit for bit.  (x = +inf returns +inf, NaN returns NaN.)
 SDM_HD float sqrt_rn_normal(float x) {
 #if defined(__HIP_DEVICE_COMPILE__)
     const float y = __builtin_amdgcn_sqrtf(x);
@@ -250,6 +230,28 @@ SDM_HD float sqrt_rn_normal(float x) {
 #else
     return sqrtf(x);
 #endif
+}
+
+template <int SCENE>
+SDM_HD float sdf(float px, float py, float pz, const SceneParams &sp) {
+    if (SCENE == SCENE_PROGRAM) {
+        return sdf_program(mk(px, py, pz), sp);
+    } else if (SCENE == SCENE_SPHERE) {
+        return sqrt_rn_normal((px * px + py * py) + pz * pz) - 1.0f;
+    } else if (SCENE == SCENE_CSG3) {
+        // build-defined scene (SURVEY 8(d).3); mirrors oracle sdf_eval SCENE_CSG3
+        float a = sqrtf((px * px + py * py) + pz * pz) - 1.0f;
+        float b = sd_box(mk(px, py, pz), mk(1.2f, 0.0f, 0.0f), mk(1.2f, 1.2f, 1.2f));
+        float qx = sqrtf(px * px + pz * pz) - 1.5f;
+        float c = sqrtf(qx * qx + py * py) - 0.25f;
+        return smooth_min(smooth_min(a, b, 0.3f), c, 0.3f);
+    } else {
+        const float a1 = sqrt_rn_normal(skeleton_min_d2(px, py, pz)) - 0.1f;
+        float sy = py;
+        if (SCENE == SCENE_ANIM) sy = py - sp.p[0];
+        const float a2 = sqrt_rn_normal((px * px + sy * sy) + pz * pz) - 1.0f;
+        return smooth_min(a1, a2, 0.5f);
+    }
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -277,7 +279,7 @@ struct RowCtx {
     }
     SDM_HDM float eval(float pz, const SceneParams &sp) const {
         if (SCENE == SCENE_SPHERE) {
-            return sqrtf(a[0] + pz * pz) - 1.0f;
+            return sqrt_rn_normal(a[0] + pz * pz) - 1.0f;
         } else if (SCENE == SCENE_SDOBJ || SCENE == SCENE_ANIM) {
             const float az = along_sq(pz, -0.25f, 0.5f);
             const float zm025 = sq(pz - (-0.25f)), zp025 = sq(pz - 0.25f), zp275 = sq(pz - 2.75f);
@@ -287,10 +289,10 @@ struct RowCtx {
             m = fmin1(m, fmin1(a[3] + zm025, a[3] + zp275));
             m = fmin1(m, fmin1(a[4] + az, a[5] + az));
             m = fmin1(m, fmin1(a[6] + az, a[7] + az));
-            const float a1 = sqrtf(m) - 0.1f;
+            const float a1 = sqrt_rn_normal(m) - 0.1f;
             float sy = py;
             if (SCENE == SCENE_ANIM) sy = py - sp.p[0];
-            const float a2 = sqrtf((px * px + sy * sy) + pz * pz) - 1.0f;
+            const float a2 = sqrt_rn_normal((px * px + sy * sy) + pz * pz) - 1.0f;
             return smooth_min(a1, a2, 0.5f);
         } else {
             return sdf<SCENE>(px, py, pz, sp);
