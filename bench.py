@@ -312,9 +312,15 @@ def main():
         out["roofline_p2_sign_bits"] = {"bound": "hbm", "kernel": "k_sign_bits", "achieved": round(gb2, 1), "peak": HBM_PEAK_GBPS,
                                         "unit": "GB/s", "frac": round(gb2 / HBM_PEAK_GBPS, 4), "traffic": None,
                                         "bytes_per_launch": alg_bytes + alg_bytes / 32, "avg_launch_ms": round(ms2, 5)}
+        # write ceiling on THIS box: P1's store stream (same bytes, same launch shape) with no arithmetic in front
+        ms3 = h.time_kernel(2, n_grid, buf.data_ptr(), 50)
+        gb3 = alg_bytes / (ms3 * 1e-3) / 1e9
         h.set_scene(args.scene, params)
         del buf
         out["roofline"] = roofs["sphere"]
+        out["roofline"]["write_ceiling"] = {"kernel": "k_stream_fill", "achieved": round(gb3, 1), "unit": "GB/s",
+                                            "avg_launch_ms": round(ms3, 5),
+                                            "p1_frac_of_ceiling": round(roofs["sphere"]["achieved"] / gb3, 4)}
         out["roofline"]["note"] = ("P1 dense (N+1)^3 f32 SDF-sample pass, the HBM pass the north star names; claimed on the "
                                    "sphere scene (SURVEY 8(d) caveat i); the regen itself is O(surface) and VALU/atomic "
                                    "bound, see DESIGN.md")

@@ -1131,7 +1131,7 @@ int sdmesh_sample_dense(sdmesh_handle *h, uint32_t N, float *d_out, float *kerne
 }
 
 int sdmesh_time_kernel(sdmesh_handle *h, int which, uint32_t N, float *d_buf, int iters, float *avg_ms) {
-    if (!h || !avg_ms || iters < 1 || which < 0 || which > 1 || !d_buf || N == 0 || N > 4096) return SDMESH_ERR_INVALID;
+    if (!h || !avg_ms || iters < 1 || which < 0 || which > 2 || !d_buf || N == 0 || N > 4096) return SDMESH_ERR_INVALID;
     HIPCHK(hipSetDevice(h->device));
     SDCHK(sync_scene(h));
     if (which == 1) {     // P2a: sign bits of the dense lattice in d_buf (fills it first)
@@ -1146,6 +1146,19 @@ int sdmesh_time_kernel(sdmesh_handle *h, int which, uint32_t N, float *d_buf, in
         float ms1 = 0.0f;
         HIPCHK(hipEventElapsedTime(&ms1, h->ev0, h->ev1));
         *avg_ms = ms1 / (float) iters;
+        return SDMESH_OK;
+    }
+    if (which == 2) {     // write ceiling: P1's store stream without the arithmetic
+        const uint64_t total = (uint64_t) (N + 1) * (N + 1) * (N + 1);
+        const int grid = h->dense_grid > 0 ? h->dense_grid : 8 * h->grid;
+        HIPCHK(launch_stream_fill(h->stream, grid, d_buf, total, 1.0f));
+        HIPCHK(hipEventRecord(h->ev0, h->stream));
+        for (int i = 0; i < iters; i++) HIPCHK(launch_stream_fill(h->stream, grid, d_buf, total, 1.0f));
+        HIPCHK(hipEventRecord(h->ev1, h->stream));
+        HIPCHK(hipStreamSynchronize(h->stream));
+        float ms2 = 0.0f;
+        HIPCHK(hipEventElapsedTime(&ms2, h->ev0, h->ev1));
+        *avg_ms = ms2 / (float) iters;
         return SDMESH_OK;
     }
     HIPCHK(launch_p1(h, d_buf, N));   // warm-up

@@ -1303,6 +1303,19 @@ __global__ __launch_bounds__(256) void k_sample_dense(float *__restrict__ out, u
     }
 }
 
+// Write ceiling for P1: the same store stream (contiguous run of float4 per workgroup, nontemporal) with no
+// arithmetic in front of it.  bench.py times it beside P1 to show how much of the achievable write rate P1 reaches.
+__global__ __launch_bounds__(256) void k_stream_fill(float *__restrict__ out, uint64_t total, float value) {
+    typedef float v4f __attribute__((ext_vector_type(4)));
+    const uint64_t nquads = total >> 2;
+    const uint64_t per = ((nquads + gridDim.x - 1) / gridDim.x + blockDim.x - 1) / blockDim.x * blockDim.x;
+    uint64_t qd = (uint64_t) blockIdx.x * per + threadIdx.x;
+    const uint64_t qlim = (uint64_t) (blockIdx.x + 1) * per < nquads ? (uint64_t) (blockIdx.x + 1) * per : nquads;
+    const v4f q = {value, value, value, value};
+    for (; qd < qlim; qd += blockDim.x) __builtin_nontemporal_store(q, reinterpret_cast<v4f *>(out) + qd);
+    if (blockIdx.x == 0 && threadIdx.x < (total & 3ull)) out[(nquads << 2) + threadIdx.x] = value;
+}
+
 // P1, row-structured variant: one wave per z-row of S = N + 1 samples.  Lane l evaluates the quads l, l + 64, ...
 // of its row and stores them as dword-aligned float4 (a row starts at byte 4 * S * row, S odd), the S % 4 tail samples
 // go out as scalars.  No div/mod or row-wrap logic in the sample loop; the (x, y) terms are computed once per row.
@@ -1480,6 +1493,11 @@ hipError_t launch_sample_dense(hipStream_t st, int grid, int scene, const SceneP
     const uint32_t cg = contig ? 1u : 0u;
     if (nt) { SDM_DISPATCH(scene, hipLaunchKernelGGL((k_sample_dense<S, true>), dim3(grid), dim3(256), 0, st, out, N, total, sp, cg)); }
     else { SDM_DISPATCH(scene, hipLaunchKernelGGL((k_sample_dense<S, false>), dim3(grid), dim3(256), 0, st, out, N, total, sp, cg)); }
+    return hipGetLastError();
+}
+
+hipError_t launch_stream_fill(hipStream_t st, int grid, float *out, uint64_t total, float value) {
+    hipLaunchKernelGGL(k_stream_fill, dim3(grid), dim3(256), 0, st, out, total, value);
     return hipGetLastError();
 }
 

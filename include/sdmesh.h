@@ -183,7 +183,8 @@ int sdmesh_regen_dense(sdmesh_handle *h, int levels, sdmesh_regen_info *info);
 int sdmesh_sample_dense(sdmesh_handle *h, uint32_t N, float *d_out, float *kernel_ms);
 
 /* Time `iters` back-to-back launches of one internal kernel with HIP events on the handle's stream
- * (bench.py's live roofline measurement).  which: 0 = P1 sample_dense(N) into d_buf; 1 = P2a sign bits of d_buf. */
+ * (bench.py's live roofline measurement).  which: 0 = P1 sample_dense(N) into d_buf; 1 = P2a sign bits of d_buf;
+ * 2 = write ceiling (P1's store stream over the same 4 (N+1)^3 bytes with no arithmetic). */
 int sdmesh_time_kernel(sdmesh_handle *h, int which, uint32_t N, float *d_buf, int iters, float *avg_ms);
 
 #ifdef __cplusplus
