@@ -62,6 +62,7 @@ struct sdmesh_handle {
     int project_mult = 3;      // k_project grid = project_mult * grid: more, shorter waves tighten the tail (measured: -8 %)
     int flip_mult = 2;         // same knob for k_flip (measured: -3 %)
     int mask_chunk = 32;       // parents per workgroup pass in k_refine_mask (8, 16 or 32)
+    int emit_ci = 1;           // planned path: the last refine level also writes the cube indices + tile triangle counts (no k_classify)
     int refine2 = 0;           // planned path: two refine levels per step (k_refine2_*): measured no faster, off by default
     int skip_weld = 0;         // regen stops after the orientation test (multi-GPU ranks: the root welds)
     bool welded = false;       // tri_e holds the final corner order
@@ -86,7 +87,7 @@ struct sdmesh_handle {
     // voxel lists (ping-pong), refine scratch
     DevBuf vox[2];
     int cur = 0;
-    DevBuf mask, mask2x, tilecnt, ctl;             // ctl: counters + status + pre-zeroed per-level tile counters
+    DevBuf mask, mask2x, signs, tilecnt, ctl;             // ctl: counters + status + pre-zeroed per-level tile counters
     uint32_t lvl_off[SDMESH_MAX_LEVELS + 2] = {0};
     // counters / status
     uint32_t *d_ctr = nullptr;     // CTR_WORDS
@@ -205,14 +206,17 @@ size_t ff_bytes(const sdmesh_handle *h) {
 // classify -> tile dedupe -> project -> flip for the voxel list d_vox (count at *n_ptr, at most cap_vox):
 // leaves (uverts, tri_e, flip, trioff, tdesc) and the counters NUNIQ / NTRI / NTILES on the device
 int mesh_front(sdmesh_handle *h, const Point *d_vox, const uint32_t *n_ptr, Point vs, bool zero_counters, bool ff_done = false,
-               bool have_cubeidx = false) {
+               bool have_cubeidx = false, uint32_t *have_tilecnt = nullptr) {
     hipStream_t st = h->stream;
+    // have_tilecnt: the last refine level already wrote cubeidx and the per-tile triangle counts (k_refine_emit)
+    uint32_t *tilecnt = have_tilecnt ? have_tilecnt : (uint32_t *) h->tilecnt.p;
     if (!ff_done) HIPCHK(hipMemsetAsync(h->ff_arena.p, 0xFF, ff_bytes(h), st));
     else HIPCHK(hipStreamWaitEvent(st, h->ev_ff, 0));          // table was cleared on the side stream during the refine
     if (zero_counters) HIPCHK(hipMemsetAsync(h->d_ctr + CTR_NUNIQ, 0, 4 * sizeof(uint32_t), st));
-    if (have_cubeidx) HIPCHK(launch_tile_tricount(st, h->tgrid, (const uint8_t *) h->cubeidx.p, n_ptr, (uint32_t *) h->tilecnt.p));
-    else HIPCHK(launch_classify(st, h->tgrid, h->scene, h->d_sp, d_vox, n_ptr, vs, (uint8_t *) h->cubeidx.p, (uint32_t *) h->tilecnt.p));
-    HIPCHK(launch_tile_dedupe(st, h->tgrid, d_vox, n_ptr, vs, (const uint8_t *) h->cubeidx.p, (const uint32_t *) h->tilecnt.p,
+    if (have_tilecnt) { /* nothing to launch */ }
+    else if (have_cubeidx) HIPCHK(launch_tile_tricount(st, h->tgrid, (const uint8_t *) h->cubeidx.p, n_ptr, tilecnt));
+    else HIPCHK(launch_classify(st, h->tgrid, h->scene, h->d_sp, d_vox, n_ptr, vs, (uint8_t *) h->cubeidx.p, tilecnt));
+    HIPCHK(launch_tile_dedupe(st, h->tgrid, d_vox, n_ptr, vs, (const uint8_t *) h->cubeidx.p, (const uint32_t *) tilecnt,
                               (uint32_t *) h->trioff.p, (uint32_t *) h->tri_e.p, (Vertex *) h->uverts.p, (uint4 *) h->tdesc.p,
                               h->ucap, h->tcap, h->d_ctr + CTR_NTRI, h->d_ctr + CTR_NTILES, h->d_status));
     HIPCHK(launch_tile_prefix(st, (const uint4 *) h->tdesc.p, h->d_ctr + CTR_NTILES, (uint32_t *) h->tpre.p, h->d_ctr + CTR_NUNIQ));
@@ -343,14 +347,19 @@ void fill_info(sdmesh_handle *h, sdmesh_regen_info *info, int levels, bool direc
 // cnt_region = this level's pre-zeroed tile counters.  If out_cap == 0 the output size is discovered
 // with a host sync between the two kernels (exact allocation); otherwise nothing synchronises.
 int refine_level(sdmesh_handle *h, int L, uint32_t n_cap_in, uint32_t out_cap, Point cs, uint32_t *cnt_region,
-                 uint32_t *count_out) {
+                 uint32_t *count_out, uint32_t *mesh_tilecnt = nullptr) {
     hipStream_t st = h->stream;
     const int src = h->cur, dst = 1 - h->cur;
     SDCHK(ensure(h, h->mask, n_cap_in));
     const uint32_t *n_in = h->d_ctr + CTR_LEVEL0 + L;
     uint32_t *n_out = h->d_ctr + CTR_LEVEL0 + L + 1;
+    uint32_t *signs = nullptr;
+    if (mesh_tilecnt) {                 // last level of a planned chain: emit the cube indices too (buffers presized)
+        SDCHK(ensure(h, h->signs, 4ull * n_cap_in));
+        signs = (uint32_t *) h->signs.p;
+    }
     HIPCHK(launch_refine_mask(st, h->tgrid, h->scene, h->d_sp, (const Point *) h->vox[src].p, n_in, cs, (uint8_t *) h->mask.p,
-                              cnt_region, h->mask_chunk));
+                              cnt_region, h->mask_chunk, signs));
     uint32_t cap = out_cap;
     if (out_cap == 0) {
         HIPCHK(launch_sum_tiles(st, cnt_region, n_in, h->d_ctr + CTR_SCRATCH));
@@ -362,7 +371,8 @@ int refine_level(sdmesh_handle *h, int L, uint32_t n_cap_in, uint32_t out_cap, P
     }
     SDCHK(ensure(h, h->vox[dst], sizeof(Point) * (size_t) std::max<uint32_t>(cap, 64)));
     HIPCHK(launch_refine_emit(st, h->tgrid, (const Point *) h->vox[src].p, n_in, cs, (const uint8_t *) h->mask.p, cnt_region,
-                              (Point *) h->vox[dst].p, cap, n_out, h->d_status));
+                              (Point *) h->vox[dst].p, cap, n_out, h->d_status, signs, signs ? (uint8_t *) h->cubeidx.p : nullptr,
+                              mesh_tilecnt));
     h->cur = dst;
     return SDMESH_OK;
 }
@@ -383,6 +393,7 @@ int enqueue_planned_chain(sdmesh_handle *h, int levels, uint32_t z0, uint32_t z1
     vs.x = vs.y = vs.z = MESH_GENERATION_BB_SIZE / (float) MESH_GENERATION_INIT_FACTOR;
     if (n0) HIPCHK(launch_create_field(st, (Point *) h->vox[0].p, z0, z1, h->d_ctr + CTR_LEVEL0));
     uint32_t n_cap = n0;
+    uint32_t *mesh_tc = nullptr;        // set when the last refine level also classifies (k_classify is then skipped)
     h->cur = 0;
     for (int L = 0; L < levels;) {
         const Point cs = half_size(vs);
@@ -404,12 +415,13 @@ int enqueue_planned_chain(sdmesh_handle *h, int levels, uint32_t z0, uint32_t z1
             continue;
         }
         const uint32_t out_cap = padded(h->plan_counts[L + 1]);
-        SDCHK(refine_level(h, L, std::max<uint32_t>(n_cap, 64), out_cap, cs, h->d_ctr + CTL_LVL0 + h->lvl_off[L], nullptr));
+        if (h->emit_ci && L + 1 == levels) mesh_tc = h->d_ctr + CTL_LVL0 + h->lvl_off[levels];
+        SDCHK(refine_level(h, L, std::max<uint32_t>(n_cap, 64), out_cap, cs, h->d_ctr + CTL_LVL0 + h->lvl_off[L], nullptr, mesh_tc));
         vs = cs;
         n_cap = out_cap;
         L++;
     }
-    SDCHK(mesh_front(h, (const Point *) h->vox[h->cur].p, h->d_ctr + CTR_LEVEL0 + levels, vs, false, true));
+    SDCHK(mesh_front(h, (const Point *) h->vox[h->cur].p, h->d_ctr + CTR_LEVEL0 + levels, vs, false, true, mesh_tc != nullptr, mesh_tc));
     if (!h->skip_weld) SDCHK(mesh_weld(h, (const Vertex *) h->uverts.p));
     *vs_out = vs;
     return SDMESH_OK;
@@ -427,11 +439,14 @@ int presize_planned_chain(sdmesh_handle *h, int levels, uint32_t n0, uint32_t *l
         lvl_words += tiles(L == 0 ? n0 : padded(h->plan_counts[L])) + 16;
         SDCHK(ensure(h, h->mask, std::max<uint32_t>(n_cap, 64)));
         if (step == 2) SDCHK(ensure(h, h->mask2x, 8ull * std::max<uint32_t>(n_cap, 64)));
+        if (step == 1 && L + 1 == levels && h->emit_ci) SDCHK(ensure(h, h->signs, 4ull * std::max<uint32_t>(n_cap, 64)));
         n_cap = padded(h->plan_counts[L + step]);
         SDCHK(ensure(h, h->vox[1 - cur], sizeof(Point) * (size_t) std::max<uint32_t>(n_cap, 64)));
         cur = 1 - cur;
         L += step;
     }
+    h->lvl_off[levels] = lvl_words;                          // mesh-tile triangle counters (fused classification)
+    lvl_words += tiles(padded(h->plan_counts[levels])) + 16;
     SDCHK(ensure_ctl(h, lvl_words));
     *lvl_words_out = lvl_words;
     return SDMESH_OK;
@@ -494,7 +509,7 @@ int regen_impl(sdmesh_handle *h, int levels, int mode, int part, int nparts, sdm
             n_cap = padded(h->plan_counts[levels]);
             if (h->use_graph) {
                 uint64_t key[8] = {h->buf_gen, (uint64_t) h->scene, (uint64_t) levels, ((uint64_t) mode << 40) | ((uint64_t) part << 20) | (uint64_t) nparts,
-                                   (uint64_t) h->skip_weld, (uint64_t) (uintptr_t) st, (uint64_t) h->grid | ((uint64_t) h->tgrid << 20) | ((uint64_t) h->project_mult << 40) | ((uint64_t) h->flip_mult << 48) | ((uint64_t) h->refine2 << 56), 0};
+                                   (uint64_t) h->skip_weld, (uint64_t) (uintptr_t) st, (uint64_t) h->grid | ((uint64_t) h->tgrid << 20) | ((uint64_t) h->project_mult << 40) | ((uint64_t) h->flip_mult << 48) | ((uint64_t) h->refine2 << 56) | ((uint64_t) h->emit_ci << 57), 0};
                 for (int i = 0; i <= levels; i++) key[7] = key[7] * 1000003ull + h->plan_counts[i];
                 key[7] = key[7] * 1000003ull + h->plan_uniq;
                 if (!h->graph_exec || memcmp(key, h->graph_key, sizeof key) != 0) {
@@ -698,7 +713,7 @@ void sdmesh_destroy(sdmesh_handle *h) {
     (void) hipSetDevice(h->device);
     if (h->stream) (void) hipStreamSynchronize(h->stream);
     drop_graph(h);
-    DevBuf *bufs[] = {&h->vox[0], &h->vox[1], &h->mask, &h->mask2x, &h->tilecnt, &h->ctl, &h->cubeidx, &h->trioff, &h->ff_arena,
+    DevBuf *bufs[] = {&h->vox[0], &h->vox[1], &h->mask, &h->mask2x, &h->signs, &h->tilecnt, &h->ctl, &h->cubeidx, &h->trioff, &h->ff_arena,
                       &h->first_ord_buf, &h->wfirst, &h->uverts, &h->tri_e, &h->vslot, &h->tdesc, &h->tfirst, &h->tfpre, &h->tpre, &h->flip, &h->wvidx, &h->torder,
                       &h->vertices, &h->indices, &h->raw, &h->compact, &h->staging, &h->dense_samples, &h->dense_bits,
                       &h->cellcnt};
@@ -762,6 +777,7 @@ int sdmesh_set_option(sdmesh_handle *h, const char *name, int value) {
     if (!strcmp(name, "flip_mult")) { if (value < 1 || value > 16) return fail(h, SDMESH_ERR_INVALID, "flip_mult 1..16"); h->flip_mult = value; drop_graph(h); return SDMESH_OK; }
     if (!strcmp(name, "mask_chunk")) { if (value != 8 && value != 16 && value != 32) return fail(h, SDMESH_ERR_INVALID, "mask_chunk 8|16|32"); h->mask_chunk = value; drop_graph(h); return SDMESH_OK; }
     if (!strcmp(name, "refine2")) { h->refine2 = value ? 1 : 0; drop_graph(h); return SDMESH_OK; }
+    if (!strcmp(name, "emit_ci")) { h->emit_ci = value ? 1 : 0; drop_graph(h); return SDMESH_OK; }
     if (!strcmp(name, "skip_weld")) { h->skip_weld = value ? 1 : 0; return SDMESH_OK; }
     if (!strcmp(name, "graph")) { h->use_graph = value ? 1 : 0; if (!value) drop_graph(h); return SDMESH_OK; }
     if (!strcmp(name, "tgrid")) {

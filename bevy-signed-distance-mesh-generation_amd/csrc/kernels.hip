@@ -147,7 +147,8 @@ __device__ __forceinline__ uint32_t child_mask_from_bits(uint32_t bits) {
 template <int SCENE, uint32_t CH>
 __global__ __launch_bounds__(256) void k_refine_mask(const Point *__restrict__ vox, const uint32_t *__restrict__ n_ptr,
                                                       Point cs /* child size = parent size / 2 */, const SceneParams *__restrict__ spp,
-                                                      uint8_t *__restrict__ mask, uint32_t *__restrict__ tilecnt) {
+                                                      uint8_t *__restrict__ mask, uint32_t *__restrict__ tilecnt,
+                                                      uint32_t *__restrict__ signs /* optional: the 27 sign bits per parent */) {
     const SceneParams &sp = *spp;  // scene uniform in device memory (a captured graph replays with new values)
     __shared__ uint32_t s_cnt;
     const uint32_t n = *n_ptr;
@@ -183,6 +184,7 @@ __global__ __launch_bounds__(256) void k_refine_mask(const Point *__restrict__ v
                     if (cnt != 0 && cnt != 8) m |= 1u << c;
                 }
                 mask[p] = (uint8_t) m;
+                if (signs) signs[p] = bits;
                 local += __popc(m);
             }
         }
@@ -221,8 +223,15 @@ __global__ __launch_bounds__(1024) void k_scan_tiles(uint32_t *__restrict__ cnt,
 __global__ __launch_bounds__(256) void k_refine_emit(const Point *__restrict__ vox, const uint32_t *__restrict__ n_ptr,
                                                       Point cs, const uint8_t *__restrict__ mask,
                                                       const uint32_t *__restrict__ tilecnt, Point *__restrict__ out,
-                                                      uint32_t cap, uint32_t *__restrict__ n_out, uint32_t *__restrict__ status) {
+                                                      uint32_t cap, uint32_t *__restrict__ n_out, uint32_t *__restrict__ status,
+                                                      const uint32_t *__restrict__ signs, uint8_t *__restrict__ cubeidx,
+                                                      uint32_t *__restrict__ mtilecnt) {
+    // signs != nullptr (last level of a device-resident regen): the parent's 27 lattice signs already hold the 8 corner
+    // signs of every child (same sample positions on an exact lattice, same `sd <= 0` test as k_classify), so the
+    // marching-cubes index of each child and the triangle count of each 256-voxel MESH tile (pre-zeroed mtilecnt) are
+    // written here and k_classify is not launched.
     __shared__ uint32_t lds[17];
+    __shared__ uint32_t s_mt[12];       // <= 2048 children per pass -> at most 9 mesh tiles touched
     const uint32_t n = *n_ptr;
     const uint32_t ntiles = (n + TILE - 1) / TILE;
     if (n == 0 && blockIdx.x == 0 && threadIdx.x == 0) *n_out = 0;
@@ -231,6 +240,7 @@ __global__ __launch_bounds__(256) void k_refine_emit(const Point *__restrict__ v
         for (uint32_t i = threadIdx.x; i < tile; i += 256) part += tilecnt[i];
         uint32_t tbase;
         (void) block_excl_scan(part, tbase, lds);
+        if (signs && threadIdx.x < 12) s_mt[threadIdx.x] = 0;      // (block_excl_scan below synchronises)
         const uint32_t p = tile * TILE + threadIdx.x;
         const uint32_t m = p < n ? mask[p] : 0u;
         uint32_t total;
@@ -242,6 +252,9 @@ __global__ __launch_bounds__(256) void k_refine_emit(const Point *__restrict__ v
         }
         if (m) {
             const Point b = vox[p];
+            const uint32_t sg = signs ? signs[p] : 0u;
+            uint32_t tri_lo = 0, tri_hi = 0;                        // a parent's <= 8 children span at most 2 mesh tiles
+            const uint32_t t_lo = o / TILE;
 #pragma unroll
             for (int c = 0; c < 8; c++) {
                 if (m & (1u << c)) {
@@ -251,10 +264,32 @@ __global__ __launch_bounds__(256) void k_refine_emit(const Point *__restrict__ v
                         q.y = b.y + (float) ((c >> 1) & 1) * cs.y;
                         q.z = b.z + (float) (c & 1) * cs.z;
                         out[o] = q;
+                        if (signs) {
+                            const uint32_t w = sg >> ((c >> 2) * 9 + ((c >> 1) & 1) * 3 + (c & 1));   // child's 2x2x2 corner of the 3^3
+                            uint32_t ci = 0;
+#pragma unroll
+                            for (int cz = 0; cz < 2; cz++)
+#pragma unroll
+                                for (int cq = 0; cq < 4; cq++)
+                                    ci |= ((w >> (cox(cq) * 9 + coy(cq) * 3 + cz)) & 1u) << (cz * 4 + cq);
+                            cubeidx[o] = (uint8_t) ci;
+                            const uint32_t nt = MC_TRI_COUNT[ci];
+                            if (o / TILE == t_lo) tri_lo += nt; else tri_hi += nt;
+                        }
                     }
                     o++;
                 }
             }
+            if (signs) {
+                const uint32_t t0 = tbase / TILE;
+                if (tri_lo) atomicAdd(&s_mt[t_lo - t0], tri_lo);
+                if (tri_hi) atomicAdd(&s_mt[t_lo + 1 - t0], tri_hi);
+            }
+        }
+        if (signs) {
+            __syncthreads();
+            if (threadIdx.x < 12 && s_mt[threadIdx.x]) atomicAdd(&mtilecnt[tbase / TILE + threadIdx.x], s_mt[threadIdx.x]);
+            __syncthreads();
         }
     }
 }
@@ -1360,10 +1395,10 @@ __global__ __launch_bounds__(256) void k_sample_dense_rows(float *__restrict__ o
     }
 
 hipError_t launch_refine_mask(hipStream_t st, int grid, int scene, const SceneParams *sp, const Point *vox,
-                              const uint32_t *n_ptr, Point cs, uint8_t *mask, uint32_t *tilecnt, int chunk) {
-    if (chunk == 8) { SDM_DISPATCH(scene, hipLaunchKernelGGL((k_refine_mask<S, 8>), dim3(grid), dim3(256), 0, st, vox, n_ptr, cs, sp, mask, tilecnt)); }
-    else if (chunk == 16) { SDM_DISPATCH(scene, hipLaunchKernelGGL((k_refine_mask<S, 16>), dim3(grid), dim3(256), 0, st, vox, n_ptr, cs, sp, mask, tilecnt)); }
-    else { SDM_DISPATCH(scene, hipLaunchKernelGGL((k_refine_mask<S, 32>), dim3(grid), dim3(256), 0, st, vox, n_ptr, cs, sp, mask, tilecnt)); }
+                              const uint32_t *n_ptr, Point cs, uint8_t *mask, uint32_t *tilecnt, int chunk, uint32_t *signs) {
+    if (chunk == 8) { SDM_DISPATCH(scene, hipLaunchKernelGGL((k_refine_mask<S, 8>), dim3(grid), dim3(256), 0, st, vox, n_ptr, cs, sp, mask, tilecnt, signs)); }
+    else if (chunk == 16) { SDM_DISPATCH(scene, hipLaunchKernelGGL((k_refine_mask<S, 16>), dim3(grid), dim3(256), 0, st, vox, n_ptr, cs, sp, mask, tilecnt, signs)); }
+    else { SDM_DISPATCH(scene, hipLaunchKernelGGL((k_refine_mask<S, 32>), dim3(grid), dim3(256), 0, st, vox, n_ptr, cs, sp, mask, tilecnt, signs)); }
     return hipGetLastError();
 }
 
@@ -1375,8 +1410,9 @@ hipError_t launch_scan_tiles(hipStream_t st, uint32_t *cnt, const uint32_t *n_pt
 
 hipError_t launch_refine_emit(hipStream_t st, int grid, const Point *vox, const uint32_t *n_ptr, Point cs,
                               const uint8_t *mask, const uint32_t *tilecnt, Point *out, uint32_t cap, uint32_t *n_out,
-                              uint32_t *status) {
-    hipLaunchKernelGGL(k_refine_emit, dim3(grid), dim3(256), 0, st, vox, n_ptr, cs, mask, tilecnt, out, cap, n_out, status);
+                              uint32_t *status, const uint32_t *signs, uint8_t *cubeidx, uint32_t *mtilecnt) {
+    hipLaunchKernelGGL(k_refine_emit, dim3(grid), dim3(256), 0, st, vox, n_ptr, cs, mask, tilecnt, out, cap, n_out, status, signs,
+                       cubeidx, mtilecnt);
     return hipGetLastError();
 }
 

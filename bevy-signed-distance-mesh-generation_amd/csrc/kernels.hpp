@@ -21,12 +21,13 @@ enum StatusWord : int {
 };
 
 hipError_t launch_refine_mask(hipStream_t st, int grid, int scene, const SceneParams *sp, const Point *vox,
-                              const uint32_t *n_ptr, Point cs, uint8_t *mask, uint32_t *tilecnt, int chunk = 32);
+                              const uint32_t *n_ptr, Point cs, uint8_t *mask, uint32_t *tilecnt, int chunk = 32, uint32_t *signs = nullptr);
 hipError_t launch_scan_tiles(hipStream_t st, uint32_t *cnt, const uint32_t *n_ptr, uint32_t items_per_tile,
                              uint32_t *total_out, uint32_t cap, uint32_t *status);
 hipError_t launch_refine_emit(hipStream_t st, int grid, const Point *vox, const uint32_t *n_ptr, Point cs,
                               const uint8_t *mask, const uint32_t *tilecnt, Point *out, uint32_t cap, uint32_t *n_out,
-                              uint32_t *status);
+                              uint32_t *status, const uint32_t *signs = nullptr, uint8_t *cubeidx = nullptr,
+                              uint32_t *mtilecnt = nullptr);
 hipError_t launch_sum_tiles(hipStream_t st, const uint32_t *tilecnt, const uint32_t *n_ptr, uint32_t *total_out);
 hipError_t launch_refine2_mask(hipStream_t st, int grid, int scene, const SceneParams *sp, const Point *vox, const uint32_t *n_ptr,
                                Point cs1, uint8_t *mask1, uint64_t *mask2, uint32_t *tilecnt, uint32_t *n_mid);
