@@ -6,7 +6,8 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libsdmesh.so")
+# SDMESH_LIB: development override (A/B timing of two builds of this same library on one box, tools/ab_perf.py)
+LIB_PATH = os.environ.get("SDMESH_LIB") or os.path.join(_HERE, "libsdmesh.so")
 HSACO_PATH = os.path.join(_HERE, "compute_mesh_generation.hsaco")
 
 # numpy views of the boundary structs (include/sdmesh/bindings.h)

@@ -61,6 +61,13 @@ struct sdmesh_handle {
     int force_direct = 0;
     int project_mult = 3;      // k_project grid = project_mult * grid: more, shorter waves tighten the tail (measured: -8 %)
     int flip_mult = 2;         // same knob for k_flip (measured: -3 %)
+    // lanes per vertex / triangle in the projection / orientation kernels: 4 (one stencil offset per lane), 1 (the
+    // whole Newton round in one lane: ~40 % fewer instructions per item, but 4x fewer items in flight, so it only pays
+    // when there are enough items to keep every lane refilled) or 0 = by the planned item count (measured crossover
+    // between 82 k and 323 k vertices: 256^3 0.158 vs 0.168 ms, 512^3 0.247 vs 0.234 ms, 1024^3 0.669 vs 0.561 ms)
+    int project_lanes = 0;
+    int flip_lanes = 0;
+    uint32_t lane_hint = 0;    // planned pre-weld vertex count of the chain being enqueued (0 = unknown)
     int mask_chunk = 32;       // parents per workgroup pass in k_refine_mask (8, 16 or 32)
     int emit_ci = 1;           // planned path: the last refine level also writes the cube indices + tile triangle counts (no k_classify)
     int refine2 = 0;           // planned path: two refine levels per step (k_refine2_*): measured no faster, off by default
@@ -220,16 +227,19 @@ int mesh_front(sdmesh_handle *h, const Point *d_vox, const uint32_t *n_ptr, Poin
                               (uint32_t *) h->trioff.p, (uint32_t *) h->tri_e.p, (Vertex *) h->uverts.p, (uint4 *) h->tdesc.p,
                               h->ucap, h->tcap, h->d_ctr + CTR_NTRI, h->d_ctr + CTR_NTILES, h->d_status));
     HIPCHK(launch_tile_prefix(st, (const uint4 *) h->tdesc.p, h->d_ctr + CTR_NTILES, (uint32_t *) h->tpre.p, h->d_ctr + CTR_NUNIQ));
+    const int plan_lanes = h->lane_hint >= 160000u ? 1 : 4;
+    const int p_lanes = h->project_lanes ? h->project_lanes : plan_lanes;
+    const int f_lanes = h->flip_lanes ? h->flip_lanes : plan_lanes;
     HIPCHK(launch_project(st, h->grid * h->project_mult, h->scene, h->d_sp, (Vertex *) h->uverts.p, (const uint4 *) h->tdesc.p,
-                          (const uint32_t *) h->tpre.p, h->d_ctr + CTR_NTILES, h->d_status));
+                          (const uint32_t *) h->tpre.p, h->d_ctr + CTR_NTILES, h->d_status, p_lanes));
     // fork: the weld claim (scattered CAS, latency-bound) runs beside the orientation test (VALU-bound)
     HIPCHK(hipEventRecord(h->ev_fork, st));
     HIPCHK(hipStreamWaitEvent(h->side, h->ev_fork, 0));
     HIPCHK(launch_tile_claim(h->side, h->tgrid, (const Vertex *) h->uverts.p, (const uint4 *) h->tdesc.p, h->d_ctr + CTR_NTILES,
                              h->wkeys, h->wsize, (uint32_t *) h->vslot.p, h->d_status));
     HIPCHK(hipEventRecord(h->ev_join, h->side));
-    HIPCHK(launch_flip(st, h->grid * h->flip_mult, h->scene, h->d_sp, (const Vertex *) h->uverts.p, (const uint32_t *) h->tri_e.p,
-                       h->d_ctr + CTR_NTRI, (uint8_t *) h->flip.p));
+    HIPCHK(launch_flip(st, h->grid * (f_lanes == 1 ? 1 : h->flip_mult), h->scene, h->d_sp, (const Vertex *) h->uverts.p, (const uint32_t *) h->tri_e.p,
+                       h->d_ctr + CTR_NTRI, (uint8_t *) h->flip.p, f_lanes));
     HIPCHK(hipStreamWaitEvent(st, h->ev_join, 0));
     return SDMESH_OK;
 }
@@ -421,7 +431,10 @@ int enqueue_planned_chain(sdmesh_handle *h, int levels, uint32_t z0, uint32_t z1
         n_cap = out_cap;
         L++;
     }
-    SDCHK(mesh_front(h, (const Point *) h->vox[h->cur].p, h->d_ctr + CTR_LEVEL0 + levels, vs, false, true, mesh_tc != nullptr, mesh_tc));
+    h->lane_hint = h->plan_uniq;
+    const int rc_front = mesh_front(h, (const Point *) h->vox[h->cur].p, h->d_ctr + CTR_LEVEL0 + levels, vs, false, true, mesh_tc != nullptr, mesh_tc);
+    h->lane_hint = 0;
+    SDCHK(rc_front);
     if (!h->skip_weld) SDCHK(mesh_weld(h, (const Vertex *) h->uverts.p));
     *vs_out = vs;
     return SDMESH_OK;
@@ -509,7 +522,7 @@ int regen_impl(sdmesh_handle *h, int levels, int mode, int part, int nparts, sdm
             n_cap = padded(h->plan_counts[levels]);
             if (h->use_graph) {
                 uint64_t key[8] = {h->buf_gen, (uint64_t) h->scene, (uint64_t) levels, ((uint64_t) mode << 40) | ((uint64_t) part << 20) | (uint64_t) nparts,
-                                   (uint64_t) h->skip_weld, (uint64_t) (uintptr_t) st, (uint64_t) h->grid | ((uint64_t) h->tgrid << 20) | ((uint64_t) h->project_mult << 40) | ((uint64_t) h->flip_mult << 48) | ((uint64_t) h->refine2 << 56) | ((uint64_t) h->emit_ci << 57), 0};
+                                   (uint64_t) h->skip_weld, (uint64_t) (uintptr_t) st, (uint64_t) h->grid | ((uint64_t) h->tgrid << 20) | ((uint64_t) h->project_mult << 40) | ((uint64_t) h->flip_mult << 48) | ((uint64_t) h->refine2 << 56) | ((uint64_t) h->emit_ci << 57) | ((uint64_t) h->project_lanes << 58) | ((uint64_t) h->flip_lanes << 61), 0};
                 for (int i = 0; i <= levels; i++) key[7] = key[7] * 1000003ull + h->plan_counts[i];
                 key[7] = key[7] * 1000003ull + h->plan_uniq;
                 if (!h->graph_exec || memcmp(key, h->graph_key, sizeof key) != 0) {
@@ -774,6 +787,8 @@ int sdmesh_set_option(sdmesh_handle *h, const char *name, int value) {
     if (!h || !name) return SDMESH_ERR_INVALID;
     if (!strcmp(name, "direct")) { h->force_direct = value ? 1 : 0; h->plan_valid = false; return SDMESH_OK; }
     if (!strcmp(name, "project_mult")) { if (value < 1 || value > 16) return fail(h, SDMESH_ERR_INVALID, "project_mult 1..16"); h->project_mult = value; drop_graph(h); return SDMESH_OK; }
+    if (!strcmp(name, "project_lanes")) { if (value != 0 && value != 1 && value != 4) return fail(h, SDMESH_ERR_INVALID, "project_lanes 0|1|4"); h->project_lanes = value; drop_graph(h); return SDMESH_OK; }
+    if (!strcmp(name, "flip_lanes")) { if (value != 0 && value != 1 && value != 4) return fail(h, SDMESH_ERR_INVALID, "flip_lanes 0|1|4"); h->flip_lanes = value; drop_graph(h); return SDMESH_OK; }
     if (!strcmp(name, "flip_mult")) { if (value < 1 || value > 16) return fail(h, SDMESH_ERR_INVALID, "flip_mult 1..16"); h->flip_mult = value; drop_graph(h); return SDMESH_OK; }
     if (!strcmp(name, "mask_chunk")) { if (value != 8 && value != 16 && value != 32) return fail(h, SDMESH_ERR_INVALID, "mask_chunk 8|16|32"); h->mask_chunk = value; drop_graph(h); return SDMESH_OK; }
     if (!strcmp(name, "refine2")) { h->refine2 = value ? 1 : 0; drop_graph(h); return SDMESH_OK; }

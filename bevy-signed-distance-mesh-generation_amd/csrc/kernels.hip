@@ -515,21 +515,31 @@ static constexpr uint32_t T_HASH = 2048;     // LDS hash slots; a tile with more
 static constexpr uint32_t T_UMAX = 1536;     // (a 256-voxel surface patch has ~300; 3072 is the theoretical maximum)
 static constexpr uint32_t T_TRI = 1280;      // 5 triangles x 256 voxels
 
-template <int SCENE>
-__device__ __forceinline__ float stencil_lane(const f3 g, uint32_t sub, const SceneParams &sp, float &centre) {
-    // lane sub<3: ((-f(+2e) + 8 f(+e)) - 8 f(-e)) + f(-2e) along axis `sub`; lane 3: f(g) in `centre`
+// value of lane (quad base + K) of the caller's 4-lane group (DPP quad_perm broadcast, no LDS traffic)
+template <int K>
+__device__ __forceinline__ float quad_bcast(float v) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, v), K * 0x55, 0xf, 0xf, true));
+}
+
+// 4th-order stencil of empirical_normal over a 4-lane group: lane `sub` owns ONE stencil offset (+2e, +e, -e, -2e)
+// and evaluates it along x, then y, then z.  Every sample differs from the centre g in one coordinate only and all
+// 64 lanes vary the SAME coordinate at a time, so after inlining the compiler shares the per-axis terms of the other
+// two coordinates between the centre sample and the axis samples (sd_obj: 302 instead of 372 instructions per Newton
+// round).  Sample positions (g.x + off ...) and the combination order ((-f(+2e) + 8 f(+e)) - 8 f(-e)) + f(-2e) are
+// those of empirical_normal (signed_distance.cu:179-202).  `centre` = f(g) when WANT_CENTRE.
+template <int SCENE, bool WANT_CENTRE>
+__device__ __forceinline__ f3 stencil_quad(const f3 g, uint32_t sub, const SceneParams &sp, float &centre) {
     const float e1 = SDM_NORMAL_EPS, e2 = 2.0f * SDM_NORMAL_EPS;
-    float f[4];
-#pragma unroll
-    for (int k = 0; k < 4; k++) {
-        const float off = k == 0 ? e2 : (k == 1 ? e1 : (k == 2 ? -e1 : -e2));
-        const float x = sub == 0 ? g.x + off : g.x;
-        const float y = sub == 1 ? g.y + off : g.y;
-        const float z = sub == 2 ? g.z + off : g.z;
-        f[k] = sdf<SCENE>(x, y, z, sp);
-    }
-    centre = f[0];
-    return (-f[0] + 8.0f * f[1] - 8.0f * f[2] + f[3]);
+    const float off = sub == 0 ? e2 : (sub == 1 ? e1 : (sub == 2 ? -e1 : -e2));
+    if (WANT_CENTRE) centre = sdf<SCENE>(g.x, g.y, g.z, sp);
+    const float fx = sdf<SCENE>(g.x + off, g.y, g.z, sp);
+    const float fy = sdf<SCENE>(g.x, g.y + off, g.z, sp);
+    const float fz = sdf<SCENE>(g.x, g.y, g.z + off, sp);
+    f3 d;
+    d.x = (-quad_bcast<0>(fx) + 8.0f * quad_bcast<1>(fx) - 8.0f * quad_bcast<2>(fx) + quad_bcast<3>(fx));
+    d.y = (-quad_bcast<0>(fy) + 8.0f * quad_bcast<1>(fy) - 8.0f * quad_bcast<2>(fy) + quad_bcast<3>(fy));
+    d.z = (-quad_bcast<0>(fz) + 8.0f * quad_bcast<1>(fz) - 8.0f * quad_bcast<2>(fz) + quad_bcast<3>(fz));
+    return d;
 }
 
 // tile descriptor: x = first vertex id, y = vertex count, z = first triangle, w = triangle count
@@ -740,11 +750,8 @@ __global__ __launch_bounds__(256) void k_project(Vertex *__restrict__ uverts, co
         }
         if (__ballot(have) == 0ull) break;
         if (have) {
-            float centre;
-            const float d = stencil_lane<SCENE>(g, sub, sp, centre);
-            const float dx = __shfl(d, (int) gbase, 64), dy = __shfl(d, (int) gbase + 1, 64), dz = __shfl(d, (int) gbase + 2, 64);
-            const float sd = __shfl(centre, (int) gbase + 3, 64);
-            const f3 nn = normalize3(mk(dx, dy, dz));
+            float sd;
+            const f3 nn = normalize3(stencil_quad<SCENE, true>(g, sub, sp, sd));
             if (!finalize) {
                 g = sub3(g, scale3(nn, sd));
                 it++;
@@ -763,19 +770,19 @@ __global__ __launch_bounds__(256) void k_project(Vertex *__restrict__ uverts, co
     }
 }
 
-// A7 orientation test (compute_mesh_generation.cu:102-105) for every triangle: 3 lanes per triangle
-// (lane a = 4-point stencil of axis a at the centroid), 21 triangles per wave
+// A7 orientation test (compute_mesh_generation.cu:102-105) for every triangle: 4 lanes per triangle
+// (lane k = stencil offset k of the centroid normal, evaluated along x, y, z), 16 triangles per wave
 template <int SCENE>
 __global__ __launch_bounds__(256) void k_flip(const Vertex *__restrict__ uverts, const uint32_t *__restrict__ tri_e,
                                                const uint32_t *__restrict__ ntri_ptr, const SceneParams *__restrict__ spp, uint8_t *__restrict__ flip) {
     const SceneParams &sp = *spp;  // scene uniform in device memory (a captured graph replays with new values)
     const uint32_t T = *ntri_ptr;
-    const uint32_t lane = lane_id(), g3 = lane / 3u, sub = lane - 3u * g3, gbase = 3u * g3;   // lane 63: g3 = 21, unused
+    const uint32_t lane = lane_id(), g4 = lane >> 2, sub = lane & 3u;
     const uint32_t nwaves = gridDim.x * (blockDim.x >> 6);
     const uint32_t wave = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
-    for (uint32_t t0 = wave * 21u; t0 < T; t0 += nwaves * 21u) {
-        const uint32_t t = t0 + g3;
-        const bool act = (g3 < 21u) && (t < T);
+    for (uint32_t t0 = wave * 16u; t0 < T; t0 += nwaves * 16u) {
+        const uint32_t t = t0 + g4;
+        const bool act = t < T;
         f3 v0 = mk(0, 0, 0), v1 = v0, v2 = v0, c = v0;
         if (act) {
             const Point p0 = uverts[tri_e[3 * t]].position, p1 = uverts[tri_e[3 * t + 1]].position, p2 = uverts[tri_e[3 * t + 2]].position;
@@ -783,14 +790,91 @@ __global__ __launch_bounds__(256) void k_flip(const Vertex *__restrict__ uverts,
             const f3 s = add3(add3(v0, v1), v2);
             c = mk(s.x / 3.0f, s.y / 3.0f, s.z / 3.0f);
         }
-        float centre;
-        const float d = act ? stencil_lane<SCENE>(c, sub, sp, centre) : 0.0f;
-        const int gb = (int) (gbase < 61u ? gbase : 60u);
-        const float dx = __shfl(d, gb, 64), dy = __shfl(d, gb + 1, 64), dz = __shfl(d, gb + 2, 64);
+        float unused;
+        const f3 d = stencil_quad<SCENE, false>(c, sub, sp, unused);     // whole quads are active or idle together
         if (act && sub == 0) {
-            const f3 an = normalize3(mk(dx, dy, dz));
+            const f3 an = normalize3(d);
             const f3 tn = normalize3(cross3(sub3(v1, v0), sub3(v2, v0)));
             flip[t] = dot3(tn, an) <= 0.0f ? 1 : 0;
+        }
+    }
+}
+
+// One lane per triangle: all 12 stencil samples of the centroid normal in one lane.  The 4 samples of an axis differ
+// from the centroid in that coordinate only, so the compiler shares the other two coordinates' terms across them
+// (sd_obj: ~70 instead of 93 instructions per sample), there are no cross-lane operations and the triangle set-up is
+// not replicated over a lane group.
+template <int SCENE>
+__global__ __launch_bounds__(256) void k_flip1(const Vertex *__restrict__ uverts, const uint32_t *__restrict__ tri_e,
+                                                const uint32_t *__restrict__ ntri_ptr, const SceneParams *__restrict__ spp, uint8_t *__restrict__ flip) {
+    const SceneParams &sp = *spp;
+    const uint32_t T = *ntri_ptr;
+    for (uint32_t t = blockIdx.x * blockDim.x + threadIdx.x; t < T; t += gridDim.x * blockDim.x) {
+        const Point p0 = uverts[tri_e[3 * t]].position, p1 = uverts[tri_e[3 * t + 1]].position, p2 = uverts[tri_e[3 * t + 2]].position;
+        flip[t] = change_orientation<SCENE>(mk(p0.x, p0.y, p0.z), mk(p1.x, p1.y, p1.z), mk(p2.x, p2.y, p2.z), sp) ? 1 : 0;
+    }
+}
+
+// One lane per pre-weld vertex: the whole Newton round (centre sample + 12 stencil samples, terms shared as in
+// k_flip1) in one lane, 64 vertices in flight per wave, finished lanes refill from the wave's round-robin share.
+template <int SCENE>
+__global__ __launch_bounds__(256) void k_project1(Vertex *__restrict__ uverts, const uint4 *__restrict__ tdesc,
+                                                   const uint32_t *__restrict__ tpre, const uint32_t *__restrict__ ntiles_ptr,
+                                                   const SceneParams *__restrict__ spp, uint32_t *__restrict__ status) {
+    const SceneParams &sp = *spp;
+    const uint32_t ntiles = *ntiles_ptr;
+    const uint32_t U = ntiles ? tpre[ntiles] : 0u;
+    const uint32_t lane = lane_id();
+    const uint32_t nwaves = gridDim.x * (blockDim.x >> 6);
+    const uint32_t wave = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    // batches of 64 items dealt round robin to the waves: the wave's j-th item is ((j / 64) * nwaves + wave) * 64 + j % 64
+    const uint32_t nbatch = (U + 63u) >> 6;
+    if (wave >= nbatch) return;
+    const uint32_t myb = (nbatch - wave - 1u) / nwaves + 1u;
+    uint32_t qhead = 0;
+    const uint32_t qend = myb * 64u;
+    const uint64_t lt_mask = (1ull << lane) - 1ull;
+    bool have = false, finalize = false;
+    uint32_t slot = 0;
+    int it = 0;
+    f3 g = mk(0.0f, 0.0f, 0.0f);
+    for (;;) {
+        const uint64_t need = __ballot(!have);
+        const uint32_t avail = qend - qhead;
+        if (need != 0ull && avail != 0u) {
+            const uint32_t rank = __popcll(need & lt_mask);
+            const uint32_t j = qhead + rank;
+            const uint32_t item = ((j >> 6) * nwaves + wave) * 64u + (j & 63u);
+            if (!have && rank < avail && item < U) {
+                uint32_t lo = 0, hi = ntiles;                          // last tile with tpre[tile] <= item
+                while (hi - lo > 1u) {
+                    const uint32_t mid = (lo + hi) >> 1;
+                    if (tpre[mid] <= item) lo = mid; else hi = mid;
+                }
+                slot = tdesc[lo].x + (item - tpre[lo]);
+                const Point p = uverts[slot].position;
+                g = mk(p.x, p.y, p.z);
+                have = true; finalize = false; it = 0;
+            }
+            const uint32_t want = __popcll(need);
+            qhead += want < avail ? want : avail;
+        }
+        if (__ballot(have) == 0ull) break;
+        if (have) {
+            const float sd = sdf<SCENE>(g.x, g.y, g.z, sp);
+            const f3 nn = empirical_normal<SCENE>(g, sp);
+            if (!finalize) {
+                g = sub3(g, scale3(nn, sd));
+                it++;
+                if (fabsf(sd) <= 0.00001f) finalize = true;
+                else if (it >= SDM_MAX_NEWTON) { finalize = true; atomicOr(&status[ST_NEWTON_CAPPED], 1u); }
+            } else {
+                Vertex o;
+                o.position.x = g.x; o.position.y = g.y; o.position.z = g.z;
+                o.normal.x = nn.x; o.normal.y = nn.y; o.normal.z = nn.z;
+                uverts[slot] = o;
+                have = false;
+            }
         }
     }
 }
@@ -1460,14 +1544,16 @@ hipError_t launch_tile_prefix(hipStream_t st, const uint4 *tdesc, const uint32_t
 }
 
 hipError_t launch_project(hipStream_t st, int grid, int scene, const SceneParams *sp, Vertex *uverts, const uint4 *tdesc,
-                          const uint32_t *tpre, const uint32_t *ntiles_ptr, uint32_t *status) {
-    SDM_DISPATCH(scene, hipLaunchKernelGGL(k_project<S>, dim3(grid), dim3(256), 0, st, uverts, tdesc, tpre, ntiles_ptr, sp, status));
+                          const uint32_t *tpre, const uint32_t *ntiles_ptr, uint32_t *status, int lanes) {
+    if (lanes == 1) { SDM_DISPATCH(scene, hipLaunchKernelGGL(k_project1<S>, dim3(grid), dim3(256), 0, st, uverts, tdesc, tpre, ntiles_ptr, sp, status)); }
+    else { SDM_DISPATCH(scene, hipLaunchKernelGGL(k_project<S>, dim3(grid), dim3(256), 0, st, uverts, tdesc, tpre, ntiles_ptr, sp, status)); }
     return hipGetLastError();
 }
 
 hipError_t launch_flip(hipStream_t st, int grid, int scene, const SceneParams *sp, const Vertex *uverts, const uint32_t *tri_e,
-                       const uint32_t *ntri_ptr, uint8_t *flip) {
-    SDM_DISPATCH(scene, hipLaunchKernelGGL(k_flip<S>, dim3(grid), dim3(256), 0, st, uverts, tri_e, ntri_ptr, sp, flip));
+                       const uint32_t *ntri_ptr, uint8_t *flip, int lanes) {
+    if (lanes == 1) { SDM_DISPATCH(scene, hipLaunchKernelGGL(k_flip1<S>, dim3(grid), dim3(256), 0, st, uverts, tri_e, ntri_ptr, sp, flip)); }
+    else { SDM_DISPATCH(scene, hipLaunchKernelGGL(k_flip<S>, dim3(grid), dim3(256), 0, st, uverts, tri_e, ntri_ptr, sp, flip)); }
     return hipGetLastError();
 }
 
