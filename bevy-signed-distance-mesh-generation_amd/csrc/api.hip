@@ -67,6 +67,7 @@ struct sdmesh_handle {
     // between 82 k and 323 k vertices: 256^3 0.158 vs 0.168 ms, 512^3 0.247 vs 0.234 ms, 1024^3 0.669 vs 0.561 ms)
     int project_lanes = 0;
     int flip_lanes = 0;
+    uint32_t tp_cap = 0;       // words of h->tpre before the coarse index
     uint32_t lane_hint = 0;    // planned pre-weld vertex count of the chain being enqueued (0 = unknown)
     int mask_chunk = 32;       // parents per workgroup pass in k_refine_mask (8, 16 or 32)
     int emit_ci = 1;           // planned path: the last refine level also writes the cube indices + tile triangle counts (no k_classify)
@@ -187,7 +188,8 @@ int layout_mesh(sdmesh_handle *h, uint32_t n_cap, uint32_t u_cap_hint) {
     SDCHK(ensure(h, h->vslot, 4ull * ucap));
     SDCHK(ensure(h, h->tdesc, 16ull * (tiles(n_cap) + tiles(tcap) + 16)));
     SDCHK(ensure(h, h->tfirst, 4ull * (tiles(n_cap) + tiles(tcap) + 16)));
-    SDCHK(ensure(h, h->tpre, 4ull * (tiles(n_cap) + tiles(tcap) + 16)));
+    h->tp_cap = tiles(n_cap) + tiles(tcap) + 16;          // tile prefix entries, then the coarse item -> tile index
+    SDCHK(ensure(h, h->tpre, 4ull * ((size_t) h->tp_cap + (ucap >> 6) + 8)));
     SDCHK(ensure(h, h->tfpre, 4ull * (tiles(n_cap) + tiles(tcap) + 16)));
     SDCHK(ensure(h, h->torder, 4ull * ucap));
     SDCHK(ensure(h, h->flip, (size_t) tcap + 64));
@@ -226,12 +228,13 @@ int mesh_front(sdmesh_handle *h, const Point *d_vox, const uint32_t *n_ptr, Poin
     HIPCHK(launch_tile_dedupe(st, h->tgrid, d_vox, n_ptr, vs, (const uint8_t *) h->cubeidx.p, (const uint32_t *) tilecnt,
                               (uint32_t *) h->trioff.p, (uint32_t *) h->tri_e.p, (Vertex *) h->uverts.p, (uint4 *) h->tdesc.p,
                               h->ucap, h->tcap, h->d_ctr + CTR_NTRI, h->d_ctr + CTR_NTILES, h->d_status));
-    HIPCHK(launch_tile_prefix(st, (const uint4 *) h->tdesc.p, h->d_ctr + CTR_NTILES, (uint32_t *) h->tpre.p, h->d_ctr + CTR_NUNIQ));
+    uint32_t *coarse = (uint32_t *) h->tpre.p + h->tp_cap;
+    HIPCHK(launch_tile_prefix(st, (const uint4 *) h->tdesc.p, h->d_ctr + CTR_NTILES, (uint32_t *) h->tpre.p, h->d_ctr + CTR_NUNIQ, coarse));
     const int plan_lanes = h->lane_hint >= 160000u ? 1 : 4;
     const int p_lanes = h->project_lanes ? h->project_lanes : plan_lanes;
     const int f_lanes = h->flip_lanes ? h->flip_lanes : plan_lanes;
     HIPCHK(launch_project(st, h->grid * h->project_mult, h->scene, h->d_sp, (Vertex *) h->uverts.p, (const uint4 *) h->tdesc.p,
-                          (const uint32_t *) h->tpre.p, h->d_ctr + CTR_NTILES, h->d_status, p_lanes));
+                          (const uint32_t *) h->tpre.p, coarse, h->d_ctr + CTR_NTILES, h->d_status, p_lanes));
     // fork: the weld claim (scattered CAS, latency-bound) runs beside the orientation test (VALU-bound)
     HIPCHK(hipEventRecord(h->ev_fork, st));
     HIPCHK(hipStreamWaitEvent(h->side, h->ev_fork, 0));

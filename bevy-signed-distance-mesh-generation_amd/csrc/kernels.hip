@@ -684,7 +684,10 @@ __device__ __forceinline__ uint32_t weld_claim(const Point p, uint64_t *__restri
 
 // exclusive prefix of the per-tile unique-vertex counts (dense work index for k_project); total -> *nu_out
 __global__ __launch_bounds__(1024) void k_tile_prefix(const uint4 *__restrict__ tdesc, const uint32_t *__restrict__ ntiles_ptr,
-                                                       uint32_t *__restrict__ tpre, uint32_t *__restrict__ nu_out) {
+                                                       uint32_t *__restrict__ tpre, uint32_t *__restrict__ nu_out,
+                                                       uint32_t *__restrict__ coarse) {
+    // coarse[b] = tile that holds work item 64 b: k_project finds an item's tile by walking forward from there (0..2
+    // steps) instead of a 10-12 step binary search of dependent loads on every refill
     __shared__ uint32_t lds[17];
     const uint32_t ntiles = *ntiles_ptr;
     uint32_t carry = 0;
@@ -693,7 +696,11 @@ __global__ __launch_bounds__(1024) void k_tile_prefix(const uint4 *__restrict__ 
         const uint32_t v = i < ntiles ? tdesc[i].y : 0u;
         uint32_t total;
         const uint32_t ex = block_excl_scan(v, total, lds);
-        if (i < ntiles) tpre[i] = carry + ex;
+        if (i < ntiles) {
+            const uint32_t start = carry + ex, end = start + v;
+            tpre[i] = start;
+            for (uint32_t b = (start + 63u) >> 6; (b << 6) < end; b++) coarse[b] = i;
+        }
         carry += total;
     }
     if (threadIdx.x == 0) { tpre[ntiles] = carry; *nu_out = carry; }
@@ -705,7 +712,7 @@ __global__ __launch_bounds__(1024) void k_tile_prefix(const uint4 *__restrict__ 
 // search in the tile prefix.
 template <int SCENE>
 __global__ __launch_bounds__(256) void k_project(Vertex *__restrict__ uverts, const uint4 *__restrict__ tdesc,
-                                                  const uint32_t *__restrict__ tpre, const uint32_t *__restrict__ ntiles_ptr,
+                                                  const uint32_t *__restrict__ tpre, const uint32_t *__restrict__ coarse, const uint32_t *__restrict__ ntiles_ptr,
                                                   const SceneParams *__restrict__ spp, uint32_t *__restrict__ status) {
     const SceneParams &sp = *spp;  // scene uniform in device memory (a captured graph replays with new values)
     const uint32_t ntiles = *ntiles_ptr;
@@ -735,11 +742,8 @@ __global__ __launch_bounds__(256) void k_project(Vertex *__restrict__ uverts, co
             const uint32_t j = qhead + rank;
             const uint32_t item = ((j >> 4) * nwaves + wave) * 16u + (j & 15u);
             if (!have && rank < avail && item < U) {
-                uint32_t lo = 0, hi = ntiles;                          // last tile with tpre[tile] <= item
-                while (hi - lo > 1u) {
-                    const uint32_t mid = (lo + hi) >> 1;
-                    if (tpre[mid] <= item) lo = mid; else hi = mid;
-                }
+                uint32_t lo = coarse[item >> 6];                       // tile of item 64 * (item / 64): at or before ours
+                while (tpre[lo + 1u] <= item) lo++;                    // (tpre[ntiles] = U > item ends the walk)
                 slot = tdesc[lo].x + (item - tpre[lo]);
                 const Point p = uverts[slot].position;
                 g = mk(p.x, p.y, p.z);
@@ -819,7 +823,7 @@ __global__ __launch_bounds__(256) void k_flip1(const Vertex *__restrict__ uverts
 // k_flip1) in one lane, 64 vertices in flight per wave, finished lanes refill from the wave's round-robin share.
 template <int SCENE>
 __global__ __launch_bounds__(256) void k_project1(Vertex *__restrict__ uverts, const uint4 *__restrict__ tdesc,
-                                                   const uint32_t *__restrict__ tpre, const uint32_t *__restrict__ ntiles_ptr,
+                                                   const uint32_t *__restrict__ tpre, const uint32_t *__restrict__ coarse, const uint32_t *__restrict__ ntiles_ptr,
                                                    const SceneParams *__restrict__ spp, uint32_t *__restrict__ status) {
     const SceneParams &sp = *spp;
     const uint32_t ntiles = *ntiles_ptr;
@@ -846,11 +850,8 @@ __global__ __launch_bounds__(256) void k_project1(Vertex *__restrict__ uverts, c
             const uint32_t j = qhead + rank;
             const uint32_t item = ((j >> 6) * nwaves + wave) * 64u + (j & 63u);
             if (!have && rank < avail && item < U) {
-                uint32_t lo = 0, hi = ntiles;                          // last tile with tpre[tile] <= item
-                while (hi - lo > 1u) {
-                    const uint32_t mid = (lo + hi) >> 1;
-                    if (tpre[mid] <= item) lo = mid; else hi = mid;
-                }
+                uint32_t lo = coarse[item >> 6];                       // tile of item 64 * (item / 64): at or before ours
+                while (tpre[lo + 1u] <= item) lo++;                    // (tpre[ntiles] = U > item ends the walk)
                 slot = tdesc[lo].x + (item - tpre[lo]);
                 const Point p = uverts[slot].position;
                 g = mk(p.x, p.y, p.z);
@@ -1538,15 +1539,16 @@ hipError_t launch_tile_dedupe(hipStream_t st, int grid, const Point *vox, const 
     return hipGetLastError();
 }
 
-hipError_t launch_tile_prefix(hipStream_t st, const uint4 *tdesc, const uint32_t *ntiles_ptr, uint32_t *tpre, uint32_t *nu_out) {
-    hipLaunchKernelGGL(k_tile_prefix, dim3(1), dim3(1024), 0, st, tdesc, ntiles_ptr, tpre, nu_out);
+hipError_t launch_tile_prefix(hipStream_t st, const uint4 *tdesc, const uint32_t *ntiles_ptr, uint32_t *tpre, uint32_t *nu_out,
+                              uint32_t *coarse) {
+    hipLaunchKernelGGL(k_tile_prefix, dim3(1), dim3(1024), 0, st, tdesc, ntiles_ptr, tpre, nu_out, coarse);
     return hipGetLastError();
 }
 
 hipError_t launch_project(hipStream_t st, int grid, int scene, const SceneParams *sp, Vertex *uverts, const uint4 *tdesc,
-                          const uint32_t *tpre, const uint32_t *ntiles_ptr, uint32_t *status, int lanes) {
-    if (lanes == 1) { SDM_DISPATCH(scene, hipLaunchKernelGGL(k_project1<S>, dim3(grid), dim3(256), 0, st, uverts, tdesc, tpre, ntiles_ptr, sp, status)); }
-    else { SDM_DISPATCH(scene, hipLaunchKernelGGL(k_project<S>, dim3(grid), dim3(256), 0, st, uverts, tdesc, tpre, ntiles_ptr, sp, status)); }
+                          const uint32_t *tpre, const uint32_t *coarse, const uint32_t *ntiles_ptr, uint32_t *status, int lanes) {
+    if (lanes == 1) { SDM_DISPATCH(scene, hipLaunchKernelGGL(k_project1<S>, dim3(grid), dim3(256), 0, st, uverts, tdesc, tpre, coarse, ntiles_ptr, sp, status)); }
+    else { SDM_DISPATCH(scene, hipLaunchKernelGGL(k_project<S>, dim3(grid), dim3(256), 0, st, uverts, tdesc, tpre, coarse, ntiles_ptr, sp, status)); }
     return hipGetLastError();
 }
 

@@ -41,9 +41,10 @@ hipError_t launch_classify(hipStream_t st, int grid, int scene, const SceneParam
 hipError_t launch_tile_dedupe(hipStream_t st, int grid, const Point *vox, const uint32_t *n_ptr, Point vs, const uint8_t *cubeidx,
                               const uint32_t *tilecnt, uint32_t *trioff, uint32_t *tri_e, Vertex *uverts, uint4 *tdesc,
                               uint32_t ucap, uint32_t tcap, uint32_t *ntri_out, uint32_t *ntiles_out, uint32_t *status);
-hipError_t launch_tile_prefix(hipStream_t st, const uint4 *tdesc, const uint32_t *ntiles_ptr, uint32_t *tpre, uint32_t *nu_out);
+hipError_t launch_tile_prefix(hipStream_t st, const uint4 *tdesc, const uint32_t *ntiles_ptr, uint32_t *tpre, uint32_t *nu_out,
+                              uint32_t *coarse);
 hipError_t launch_project(hipStream_t st, int grid, int scene, const SceneParams *sp, Vertex *uverts, const uint4 *tdesc,
-                          const uint32_t *tpre, const uint32_t *ntiles_ptr, uint32_t *status, int lanes = 4);
+                          const uint32_t *tpre, const uint32_t *coarse, const uint32_t *ntiles_ptr, uint32_t *status, int lanes = 4);
 hipError_t launch_flip(hipStream_t st, int grid, int scene, const SceneParams *sp, const Vertex *uverts, const uint32_t *tri_e,
                        const uint32_t *ntri_ptr, uint8_t *flip, int lanes = 4);
 hipError_t launch_raw_desc(hipStream_t st, int grid, const uint32_t *ntri_ptr, uint4 *tdesc, uint8_t *flip, uint32_t *ntiles_out,
