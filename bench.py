@@ -153,6 +153,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-anim", action="store_true")
     ap.add_argument("--no-pipelined", action="store_true")
+    ap.add_argument("--no-sizes", action="store_true")
     ap.add_argument("--no-sharded", action="store_true")
     ap.add_argument("--no-graph", action="store_true", help="launch the planned chain eagerly instead of replaying a hipGraph")
     ap.add_argument("--sharded-selftest", action="store_true", help="run the sharded leg on 1 GPU (degenerate, for testing)")
@@ -214,6 +215,31 @@ def main():
         "triangles": int(info.triangles), "vertices": int(info.vertices), "active_voxels": int(info.voxel_count[args.levels]),
         "device_ms_per_step": round(float(np.median(dev_ms)), 4),
     }
+
+    # --- the other grid sizes the north star names (256^3 / 1024^3 of the workload scene, and BASELINE configs[1]: the
+    #     single sphere at 256^3); same measurement as the primary metric, fewer steps
+    if rank == 0 and world == 1 and not args.no_sizes:
+        sizes = {}
+        for label, sc, lv in ((f"{args.scene}_256", args.scene, 3), (f"{args.scene}_1024", args.scene, 5), ("sphere_256", "sphere", 3)):
+            if sc == args.scene and lv == args.levels:
+                continue
+            hz = pkg.CudaHandler(local_rank, sc, params if sc == args.scene else None)
+            hz.regen(lv); hz.set_option("graph", 0 if args.no_graph else 1)
+            for _ in range(5):
+                zi = hz.regen(lv)
+            torch.cuda.synchronize()
+            tz = time.perf_counter()
+            zdev = []
+            for _ in range(50):
+                zi = hz.regen(lv); zdev.append(zi.device_ms)
+            torch.cuda.synchronize()
+            dz = (time.perf_counter() - tz) / 50
+            ng = 32 << lv
+            sizes[label] = {"grid": ng, "ms_per_step": round(dz * 1e3, 4), "device_ms_per_step": round(float(np.median(zdev)), 4),
+                            "mvoxels_per_s": round(ng ** 3 / dz / 1e6, 1), "mtris_per_s": round(zi.triangles / dz / 1e6, 1),
+                            "triangles": int(zi.triangles), "vertices": int(zi.vertices)}
+            hz.close()
+        out["sizes"] = sizes
 
     # --- several regens in flight (one handle each): most kernels of the chain are latency-bound, so they overlap
     if rank == 0 and world == 1 and not args.no_pipelined:
