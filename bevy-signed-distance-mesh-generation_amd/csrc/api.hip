@@ -401,10 +401,12 @@ int enqueue_planned_chain(sdmesh_handle *h, int levels, uint32_t z0, uint32_t z1
     HIPCHK(hipStreamWaitEvent(h->side, h->ev_fork, 0));
     HIPCHK(hipMemsetAsync(h->ff_arena.p, 0xFF, ff_bytes(h), h->side));
     HIPCHK(hipEventRecord(h->ev_ff, h->side));
-    SDCHK(zero_ctl(h, lvl_words));
     Point vs;
     vs.x = vs.y = vs.z = MESH_GENERATION_BB_SIZE / (float) MESH_GENERATION_INIT_FACTOR;
-    if (n0) HIPCHK(launch_create_field(st, (Point *) h->vox[0].p, z0, z1, h->d_ctr + CTR_LEVEL0));
+    // (the control block is cleared by the field kernel itself: one graph node less in front of the chain)
+    if (n0) HIPCHK(launch_create_field(st, (Point *) h->vox[0].p, z0, z1, h->d_ctr + CTR_LEVEL0, (uint32_t *) h->ctl.p,
+                                       (uint32_t) (CTL_LVL0 + lvl_words)));
+    else SDCHK(zero_ctl(h, lvl_words));
     uint32_t n_cap = n0;
     uint32_t *mesh_tc = nullptr;        // set when the last refine level also classifies (k_classify is then skipped)
     h->cur = 0;
