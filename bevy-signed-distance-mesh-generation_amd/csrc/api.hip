@@ -67,6 +67,7 @@ struct sdmesh_handle {
     // between 82 k and 323 k vertices: 256^3 0.158 vs 0.168 ms, 512^3 0.247 vs 0.234 ms, 1024^3 0.669 vs 0.561 ms)
     int project_lanes = 0;
     int flip_lanes = 0;
+    int fork = 2;              // weld claim and orientation test: 2 = one dispatch, 1 = two streams, 0 = one after the other
     uint32_t tp_cap = 0;       // words of h->tpre before the coarse index
     uint32_t lane_hint = 0;    // planned pre-weld vertex count of the chain being enqueued (0 = unknown)
     int mask_chunk = 32;       // parents per workgroup pass in k_refine_mask (8, 16 or 32)
@@ -236,14 +237,25 @@ int mesh_front(sdmesh_handle *h, const Point *d_vox, const uint32_t *n_ptr, Poin
     HIPCHK(launch_project(st, h->grid * h->project_mult, h->scene, h->d_sp, (Vertex *) h->uverts.p, (const uint4 *) h->tdesc.p,
                           (const uint32_t *) h->tpre.p, coarse, h->d_ctr + CTR_NTILES, h->d_status, p_lanes));
     // fork: the weld claim (scattered CAS, latency-bound) runs beside the orientation test (VALU-bound)
-    HIPCHK(hipEventRecord(h->ev_fork, st));
-    HIPCHK(hipStreamWaitEvent(h->side, h->ev_fork, 0));
-    HIPCHK(launch_tile_claim(h->side, h->tgrid, (const Vertex *) h->uverts.p, (const uint4 *) h->tdesc.p, h->d_ctr + CTR_NTILES,
+    const int f_grid = h->grid * (f_lanes == 1 ? 1 : h->flip_mult);
+    if (h->fork == 2) {
+        // one dispatch: claim workgroups first (latency-bound, resident early), orientation-test workgroups behind them
+        HIPCHK(launch_flip_claim(st, f_grid, h->tgrid, h->scene, h->d_sp, (const Vertex *) h->uverts.p, (const uint32_t *) h->tri_e.p,
+                                 h->d_ctr + CTR_NTRI, (uint8_t *) h->flip.p, f_lanes, (const uint4 *) h->tdesc.p, h->d_ctr + CTR_NTILES,
+                                 h->wkeys, h->wsize, (uint32_t *) h->vslot.p, h->d_status));
+        return SDMESH_OK;
+    }
+    hipStream_t cst = h->fork ? h->side : st;
+    if (h->fork) {
+        HIPCHK(hipEventRecord(h->ev_fork, st));
+        HIPCHK(hipStreamWaitEvent(h->side, h->ev_fork, 0));
+    }
+    HIPCHK(launch_tile_claim(cst, h->tgrid, (const Vertex *) h->uverts.p, (const uint4 *) h->tdesc.p, h->d_ctr + CTR_NTILES,
                              h->wkeys, h->wsize, (uint32_t *) h->vslot.p, h->d_status));
-    HIPCHK(hipEventRecord(h->ev_join, h->side));
-    HIPCHK(launch_flip(st, h->grid * (f_lanes == 1 ? 1 : h->flip_mult), h->scene, h->d_sp, (const Vertex *) h->uverts.p, (const uint32_t *) h->tri_e.p,
+    if (h->fork) HIPCHK(hipEventRecord(h->ev_join, h->side));
+    HIPCHK(launch_flip(st, f_grid, h->scene, h->d_sp, (const Vertex *) h->uverts.p, (const uint32_t *) h->tri_e.p,
                        h->d_ctr + CTR_NTRI, (uint8_t *) h->flip.p, f_lanes));
-    HIPCHK(hipStreamWaitEvent(st, h->ev_join, 0));
+    if (h->fork) HIPCHK(hipStreamWaitEvent(st, h->ev_join, 0));
     return SDMESH_OK;
 }
 
@@ -794,6 +806,7 @@ int sdmesh_set_option(sdmesh_handle *h, const char *name, int value) {
     if (!strcmp(name, "project_mult")) { if (value < 1 || value > 16) return fail(h, SDMESH_ERR_INVALID, "project_mult 1..16"); h->project_mult = value; drop_graph(h); return SDMESH_OK; }
     if (!strcmp(name, "project_lanes")) { if (value != 0 && value != 1 && value != 4) return fail(h, SDMESH_ERR_INVALID, "project_lanes 0|1|4"); h->project_lanes = value; drop_graph(h); return SDMESH_OK; }
     if (!strcmp(name, "flip_lanes")) { if (value != 0 && value != 1 && value != 4) return fail(h, SDMESH_ERR_INVALID, "flip_lanes 0|1|4"); h->flip_lanes = value; drop_graph(h); return SDMESH_OK; }
+    if (!strcmp(name, "fork")) { if (value < 0 || value > 2) return fail(h, SDMESH_ERR_INVALID, "fork 0|1|2"); h->fork = value; drop_graph(h); return SDMESH_OK; }
     if (!strcmp(name, "flip_mult")) { if (value < 1 || value > 16) return fail(h, SDMESH_ERR_INVALID, "flip_mult 1..16"); h->flip_mult = value; drop_graph(h); return SDMESH_OK; }
     if (!strcmp(name, "mask_chunk")) { if (value != 8 && value != 16 && value != 32) return fail(h, SDMESH_ERR_INVALID, "mask_chunk 8|16|32"); h->mask_chunk = value; drop_graph(h); return SDMESH_OK; }
     if (!strcmp(name, "refine2")) { h->refine2 = value ? 1 : 0; drop_graph(h); return SDMESH_OK; }

@@ -777,13 +777,12 @@ __global__ __launch_bounds__(256) void k_project(Vertex *__restrict__ uverts, co
 // A7 orientation test (compute_mesh_generation.cu:102-105) for every triangle: 4 lanes per triangle
 // (lane k = stencil offset k of the centroid normal, evaluated along x, y, z), 16 triangles per wave
 template <int SCENE>
-__global__ __launch_bounds__(256) void k_flip(const Vertex *__restrict__ uverts, const uint32_t *__restrict__ tri_e,
-                                               const uint32_t *__restrict__ ntri_ptr, const SceneParams *__restrict__ spp, uint8_t *__restrict__ flip) {
-    const SceneParams &sp = *spp;  // scene uniform in device memory (a captured graph replays with new values)
-    const uint32_t T = *ntri_ptr;
+__device__ __forceinline__ void flip_body4(uint32_t bid, uint32_t nblocks, const Vertex *__restrict__ uverts,
+                                           const uint32_t *__restrict__ tri_e, uint32_t T, const SceneParams &sp,
+                                           uint8_t *__restrict__ flip) {
     const uint32_t lane = lane_id(), g4 = lane >> 2, sub = lane & 3u;
-    const uint32_t nwaves = gridDim.x * (blockDim.x >> 6);
-    const uint32_t wave = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    const uint32_t nwaves = nblocks * (blockDim.x >> 6);
+    const uint32_t wave = bid * (blockDim.x >> 6) + (threadIdx.x >> 6);
     for (uint32_t t0 = wave * 16u; t0 < T; t0 += nwaves * 16u) {
         const uint32_t t = t0 + g4;
         const bool act = t < T;
@@ -809,14 +808,25 @@ __global__ __launch_bounds__(256) void k_flip(const Vertex *__restrict__ uverts,
 // (sd_obj: ~70 instead of 93 instructions per sample), there are no cross-lane operations and the triangle set-up is
 // not replicated over a lane group.
 template <int SCENE>
-__global__ __launch_bounds__(256) void k_flip1(const Vertex *__restrict__ uverts, const uint32_t *__restrict__ tri_e,
-                                                const uint32_t *__restrict__ ntri_ptr, const SceneParams *__restrict__ spp, uint8_t *__restrict__ flip) {
-    const SceneParams &sp = *spp;
-    const uint32_t T = *ntri_ptr;
-    for (uint32_t t = blockIdx.x * blockDim.x + threadIdx.x; t < T; t += gridDim.x * blockDim.x) {
+__device__ __forceinline__ void flip_body1(uint32_t bid, uint32_t nblocks, const Vertex *__restrict__ uverts,
+                                           const uint32_t *__restrict__ tri_e, uint32_t T, const SceneParams &sp,
+                                           uint8_t *__restrict__ flip) {
+    for (uint32_t t = bid * blockDim.x + threadIdx.x; t < T; t += nblocks * blockDim.x) {
         const Point p0 = uverts[tri_e[3 * t]].position, p1 = uverts[tri_e[3 * t + 1]].position, p2 = uverts[tri_e[3 * t + 2]].position;
         flip[t] = change_orientation<SCENE>(mk(p0.x, p0.y, p0.z), mk(p1.x, p1.y, p1.z), mk(p2.x, p2.y, p2.z), sp) ? 1 : 0;
     }
+}
+
+template <int SCENE>
+__global__ __launch_bounds__(256) void k_flip(const Vertex *__restrict__ uverts, const uint32_t *__restrict__ tri_e,
+                                               const uint32_t *__restrict__ ntri_ptr, const SceneParams *__restrict__ spp, uint8_t *__restrict__ flip) {
+    flip_body4<SCENE>(blockIdx.x, gridDim.x, uverts, tri_e, *ntri_ptr, *spp, flip);
+}
+
+template <int SCENE>
+__global__ __launch_bounds__(256) void k_flip1(const Vertex *__restrict__ uverts, const uint32_t *__restrict__ tri_e,
+                                                const uint32_t *__restrict__ ntri_ptr, const SceneParams *__restrict__ spp, uint8_t *__restrict__ flip) {
+    flip_body1<SCENE>(blockIdx.x, gridDim.x, uverts, tri_e, *ntri_ptr, *spp, flip);
 }
 
 // One lane per pre-weld vertex: the whole Newton round (centre sample + 12 stencil samples, terms shared as in
@@ -896,15 +906,43 @@ __global__ __launch_bounds__(256) void k_raw_desc(const uint32_t *__restrict__ n
 
 // claim pass: one CAS per pre-weld vertex, per tile.  Latency-bound on scattered L2 atomics and independent of
 // the orientation test, so the host runs it on a side stream concurrently with the VALU-bound k_flip.
-__global__ __launch_bounds__(256) void k_tile_claim(const Vertex *__restrict__ uverts, const uint4 *__restrict__ tdesc,
-                                                     const uint32_t *__restrict__ ntiles_ptr, uint64_t *__restrict__ wkeys,
-                                                     uint32_t wsize, uint32_t *__restrict__ vslot, uint32_t *__restrict__ status) {
-    const uint32_t ntiles = *ntiles_ptr;
-    for (uint32_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+__device__ __forceinline__ void claim_body(uint32_t bid, uint32_t nblocks, const Vertex *__restrict__ uverts,
+                                           const uint4 *__restrict__ tdesc, uint32_t ntiles, uint64_t *__restrict__ wkeys,
+                                           uint32_t wsize, uint32_t *__restrict__ vslot, uint32_t *__restrict__ status) {
+    for (uint32_t tile = bid; tile < ntiles; tile += nblocks) {
         const uint4 d = tdesc[tile];
         for (uint32_t i = threadIdx.x; i < d.y; i += 256) vslot[d.x + i] = weld_claim(uverts[d.x + i].position, wkeys, wsize, status);
     }
 }
+
+__global__ __launch_bounds__(256) void k_tile_claim(const Vertex *__restrict__ uverts, const uint4 *__restrict__ tdesc,
+                                                     const uint32_t *__restrict__ ntiles_ptr, uint64_t *__restrict__ wkeys,
+                                                     uint32_t wsize, uint32_t *__restrict__ vslot, uint32_t *__restrict__ status) {
+    claim_body(blockIdx.x, gridDim.x, uverts, tdesc, *ntiles_ptr, wkeys, wsize, vslot, status);
+}
+
+// Orientation test and weld claim in ONE dispatch: the LAST `claim_blocks` workgroups claim weld-table slots for the
+// projected vertices (scattered CAS, latency-bound), the first ones run the orientation test (VALU-bound; few, long
+// workgroups that take one wave slot per SIMD, dispatched first so the many short claim workgroups fill the rest).  Both only
+// read the projection's output and write disjoint arrays.  Running them as two kernels on two streams costs a
+// cross-queue fork and join (measured ~20 us of dependency latency at 512^3, more than the overlap wins); one
+// dispatch overlaps them with no synchronisation at all, and the claim's workgroups are resident first.
+template <int SCENE, int LANES>
+__global__ __launch_bounds__(256) void k_flip_claim(const Vertex *__restrict__ uverts, const uint32_t *__restrict__ tri_e,
+                                                     const uint32_t *__restrict__ ntri_ptr, const SceneParams *__restrict__ spp,
+                                                     uint8_t *__restrict__ flip, uint32_t claim_blocks, const uint4 *__restrict__ tdesc,
+                                                     const uint32_t *__restrict__ ntiles_ptr, uint64_t *__restrict__ wkeys, uint32_t wsize,
+                                                     uint32_t *__restrict__ vslot, uint32_t *__restrict__ status) {
+    const uint32_t flip_blocks = gridDim.x - claim_blocks;
+    if (blockIdx.x >= flip_blocks) {
+        claim_body(blockIdx.x - flip_blocks, claim_blocks, uverts, tdesc, *ntiles_ptr, wkeys, wsize, vslot, status);
+    } else if (LANES == 1) {
+        flip_body1<SCENE>(blockIdx.x, flip_blocks, uverts, tri_e, *ntri_ptr, *spp, flip);
+    } else {
+        flip_body4<SCENE>(blockIdx.x, flip_blocks, uverts, tri_e, *ntri_ptr, *spp, flip);
+    }
+}
+
 
 static constexpr uint32_t T_VMAX = 3072;
 
@@ -1561,6 +1599,15 @@ hipError_t launch_flip(hipStream_t st, int grid, int scene, const SceneParams *s
                        const uint32_t *ntri_ptr, uint8_t *flip, int lanes) {
     if (lanes == 1) { SDM_DISPATCH(scene, hipLaunchKernelGGL(k_flip1<S>, dim3(grid), dim3(256), 0, st, uverts, tri_e, ntri_ptr, sp, flip)); }
     else { SDM_DISPATCH(scene, hipLaunchKernelGGL(k_flip<S>, dim3(grid), dim3(256), 0, st, uverts, tri_e, ntri_ptr, sp, flip)); }
+    return hipGetLastError();
+}
+
+hipError_t launch_flip_claim(hipStream_t st, int flip_grid, int claim_grid, int scene, const SceneParams *sp, const Vertex *uverts,
+                            const uint32_t *tri_e, const uint32_t *ntri_ptr, uint8_t *flip, int lanes, const uint4 *tdesc,
+                            const uint32_t *ntiles_ptr, uint64_t *wkeys, uint32_t wsize, uint32_t *vslot, uint32_t *status) {
+    const dim3 grid(flip_grid + claim_grid);
+    if (lanes == 1) { SDM_DISPATCH(scene, hipLaunchKernelGGL((k_flip_claim<S, 1>), grid, dim3(256), 0, st, uverts, tri_e, ntri_ptr, sp, flip, (uint32_t) claim_grid, tdesc, ntiles_ptr, wkeys, wsize, vslot, status)); }
+    else { SDM_DISPATCH(scene, hipLaunchKernelGGL((k_flip_claim<S, 4>), grid, dim3(256), 0, st, uverts, tri_e, ntri_ptr, sp, flip, (uint32_t) claim_grid, tdesc, ntiles_ptr, wkeys, wsize, vslot, status)); }
     return hipGetLastError();
 }
 
