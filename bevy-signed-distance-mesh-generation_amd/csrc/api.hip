@@ -67,6 +67,8 @@ struct sdmesh_handle {
     // between 82 k and 323 k vertices: 256^3 0.158 vs 0.168 ms, 512^3 0.247 vs 0.234 ms, 1024^3 0.669 vs 0.561 ms)
     int project_lanes = 0;
     int flip_lanes = 0;
+    int ff_fork = 0;           // weld-table clear: 0 = inside k_create_field, 1 = memset on the side stream during the refine (measured:
+                               // the fork + join costs 8-12 us more than the whole clear), 2 = memset node on the main stream
     int fork = 2;              // weld claim and orientation test: 2 = one dispatch, 1 = two streams, 0 = one after the other
     uint32_t tp_cap = 0;       // words of h->tpre before the coarse index
     uint32_t lane_hint = 0;    // planned pre-weld vertex count of the chain being enqueued (0 = unknown)
@@ -221,7 +223,7 @@ int mesh_front(sdmesh_handle *h, const Point *d_vox, const uint32_t *n_ptr, Poin
     // have_tilecnt: the last refine level already wrote cubeidx and the per-tile triangle counts (k_refine_emit)
     uint32_t *tilecnt = have_tilecnt ? have_tilecnt : (uint32_t *) h->tilecnt.p;
     if (!ff_done) HIPCHK(hipMemsetAsync(h->ff_arena.p, 0xFF, ff_bytes(h), st));
-    else HIPCHK(hipStreamWaitEvent(st, h->ev_ff, 0));          // table was cleared on the side stream during the refine
+    else if (h->ff_fork == 1) HIPCHK(hipStreamWaitEvent(st, h->ev_ff, 0));   // table was cleared on the side stream during the refine
     if (zero_counters) HIPCHK(hipMemsetAsync(h->d_ctr + CTR_NUNIQ, 0, 4 * sizeof(uint32_t), st));
     if (have_tilecnt) { /* nothing to launch */ }
     else if (have_cubeidx) HIPCHK(launch_tile_tricount(st, h->tgrid, (const uint8_t *) h->cubeidx.p, n_ptr, tilecnt));
@@ -409,15 +411,21 @@ uint32_t padded(uint32_t n) { return n + n / 4 + 4096; }
 int enqueue_planned_chain(sdmesh_handle *h, int levels, uint32_t z0, uint32_t z1, uint32_t n0, uint32_t lvl_words, Point *vs_out) {
     hipStream_t st = h->stream;
     // fork: the weld table is cleared on the side stream while the refine runs
-    HIPCHK(hipEventRecord(h->ev_fork, st));
-    HIPCHK(hipStreamWaitEvent(h->side, h->ev_fork, 0));
-    HIPCHK(hipMemsetAsync(h->ff_arena.p, 0xFF, ff_bytes(h), h->side));
-    HIPCHK(hipEventRecord(h->ev_ff, h->side));
+    bool ff_in_kernel = h->ff_fork == 0;      // (the arena is allocated in 256-byte units, so rounding the clear up to 16 B stays inside it)
+    if (h->ff_fork == 1) {
+        HIPCHK(hipEventRecord(h->ev_fork, st));
+        HIPCHK(hipStreamWaitEvent(h->side, h->ev_fork, 0));
+        HIPCHK(hipMemsetAsync(h->ff_arena.p, 0xFF, ff_bytes(h), h->side));
+        HIPCHK(hipEventRecord(h->ev_ff, h->side));
+    } else if (h->ff_fork == 2 || n0 == 0) {
+        HIPCHK(hipMemsetAsync(h->ff_arena.p, 0xFF, ff_bytes(h), st));
+        ff_in_kernel = false;
+    }
     Point vs;
     vs.x = vs.y = vs.z = MESH_GENERATION_BB_SIZE / (float) MESH_GENERATION_INIT_FACTOR;
     // (the control block is cleared by the field kernel itself: one graph node less in front of the chain)
     if (n0) HIPCHK(launch_create_field(st, (Point *) h->vox[0].p, z0, z1, h->d_ctr + CTR_LEVEL0, (uint32_t *) h->ctl.p,
-                                       (uint32_t) (CTL_LVL0 + lvl_words)));
+                                       (uint32_t) (CTL_LVL0 + lvl_words), ff_in_kernel ? h->ff_arena.p : nullptr, (ff_bytes(h) + 15) & ~(size_t) 15));
     else SDCHK(zero_ctl(h, lvl_words));
     uint32_t n_cap = n0;
     uint32_t *mesh_tc = nullptr;        // set when the last refine level also classifies (k_classify is then skipped)
@@ -806,6 +814,7 @@ int sdmesh_set_option(sdmesh_handle *h, const char *name, int value) {
     if (!strcmp(name, "project_mult")) { if (value < 1 || value > 16) return fail(h, SDMESH_ERR_INVALID, "project_mult 1..16"); h->project_mult = value; drop_graph(h); return SDMESH_OK; }
     if (!strcmp(name, "project_lanes")) { if (value != 0 && value != 1 && value != 4) return fail(h, SDMESH_ERR_INVALID, "project_lanes 0|1|4"); h->project_lanes = value; drop_graph(h); return SDMESH_OK; }
     if (!strcmp(name, "flip_lanes")) { if (value != 0 && value != 1 && value != 4) return fail(h, SDMESH_ERR_INVALID, "flip_lanes 0|1|4"); h->flip_lanes = value; drop_graph(h); return SDMESH_OK; }
+    if (!strcmp(name, "ff_fork")) { if (value < 0 || value > 2) return fail(h, SDMESH_ERR_INVALID, "ff_fork 0|1|2"); h->ff_fork = value; drop_graph(h); return SDMESH_OK; }
     if (!strcmp(name, "fork")) { if (value < 0 || value > 2) return fail(h, SDMESH_ERR_INVALID, "fork 0|1|2"); h->fork = value; drop_graph(h); return SDMESH_OK; }
     if (!strcmp(name, "flip_mult")) { if (value < 1 || value > 16) return fail(h, SDMESH_ERR_INVALID, "flip_mult 1..16"); h->flip_mult = value; drop_graph(h); return SDMESH_OK; }
     if (!strcmp(name, "mask_chunk")) { if (value != 8 && value != 16 && value != 32) return fail(h, SDMESH_ERR_INVALID, "mask_chunk 8|16|32"); h->mask_chunk = value; drop_graph(h); return SDMESH_OK; }
