@@ -11,7 +11,7 @@ run regen_trace --kernel-trace --stats --output-format csv -d $O/regen_trace -- 
 run regen_pmc_sq --kernel-trace --pmc SQ_INSTS_VALU SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_WAIT_INST_ANY GRBM_GUI_ACTIVE --output-format csv -d $O/regen_pmc_sq -- $P $R/tools/prof_regen.py sdobj 4 3 || exit 1
 run dense_write --kernel-trace --pmc WRITE_SIZE --output-format csv -d $O/dense_write -- $P $R/tools/dense_once.py || exit 1
 run dense_fetch --kernel-trace --pmc FETCH_SIZE --output-format csv -d $O/dense_fetch -- $P $R/tools/dense_once.py || exit 1
-run bench_trace --kernel-trace --stats --output-format csv -d $O/bench_trace -- $P $R/bench.py --steps 100 --warmup 10 --no-cpu-baseline || exit 1
+run bench_trace --kernel-trace --stats --output-format csv -d $O/bench_trace -- $P $R/bench.py --steps 100 --warmup 10 --no-cpu-baseline --no-sizes --no-pipelined || exit 1
 cd $R && echo "== plain bench" && timeout -k 10 400 $P bench.py > $O/bench_plain.json 2> $O/bench_plain.stderr; echo "rc=$?"
 # keep only the small summaries (the raw traces are large)
 find $O -name '*_kernel_trace.csv' -size +4M -delete
