@@ -1,9 +1,9 @@
 #!/usr/bin/env python3
 """Copy the summaries tools/capture_profiles.sh left in gpurun_out/prof/ into profiles/ (round tag as argv[1])."""
-import collections, csv, glob, json, shutil, sys
+import collections, csv, glob, json, os, shutil, sys
 tag = sys.argv[1] if len(sys.argv) > 1 else "r01"
 P = "gpurun_out/prof"
-one = lambda pat: sorted(glob.glob(pat, recursive=True))[-1]          # noqa: E731
+one = lambda pat: max(glob.glob(pat, recursive=True), key=os.path.getmtime)   # noqa: E731 -- newest (gpurun merges, never deletes)
 shutil.copy(one(f"{P}/regen_trace/**/*_kernel_stats.csv"), f"profiles/{tag}_regen_sdobj512_kernel_stats.csv")
 shutil.copy(one(f"{P}/bench_trace/**/*_kernel_stats.csv"), f"profiles/{tag}_bench_kernel_stats.csv")
 shutil.copy(one(f"{P}/dense_write/**/*_counter_collection.csv"), f"profiles/{tag}_dense_pmc_write_size.csv")

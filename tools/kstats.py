@@ -2,7 +2,8 @@
 """Summarise a rocprofv3 --kernel-trace --stats CSV directory.  usage: kstats.py DIR [regens]"""
 import csv, glob, sys
 d = sys.argv[1]; regens = float(sys.argv[2]) if len(sys.argv) > 2 else 1.0
-f = sorted(glob.glob(d + '/**/*_kernel_stats.csv', recursive=True))[-1]
+import os
+f = max(glob.glob(d + '/**/*_kernel_stats.csv', recursive=True), key=os.path.getmtime)   # newest: gpurun merges, never deletes
 rows = list(csv.DictReader(open(f)))
 tot = sum(float(r['TotalDurationNs']) for r in rows)
 print("%-58s %6s %10s %7s" % ("kernel", "calls", "avg_us", "tot%"))
