@@ -155,9 +155,11 @@ def main():
     ap.add_argument("--no-pipelined", action="store_true")
     ap.add_argument("--no-sizes", action="store_true")
     ap.add_argument("--no-sharded", action="store_true")
-    ap.add_argument("--graph", action="store_true",
-                    help="replay the planned chain as a hipGraph for the primary metric (default: eager launches -- measured "
-                         "faster: the ~18 kernels are 5-50 us each and the graph executor adds ~8 us per replay on the device)")
+    ap.add_argument("--no-graph", dest="graph", action="store_false",
+                    help="drive the primary metric with eager launches instead of replaying the planned chain as a hipGraph "
+                         "(default: graph replay -- with the single-stream chain it is ~2 %% faster in wall time although ~4 us "
+                         "slower on the device; the other mode is reported beside it either way)")
+    ap.set_defaults(graph=True)
     ap.add_argument("--sharded-selftest", action="store_true", help="run the sharded leg on 1 GPU (degenerate, for testing)")
     args = ap.parse_args()
 
