@@ -99,9 +99,20 @@ int sdmesh_set_program(sdmesh_handle *h, const sdmesh_instr *instrs, int n);
 
 /* Run on a caller-owned hipStream_t (e.g. torch's current stream); NULL = the handle's own. */
 int sdmesh_set_stream(sdmesh_handle *h, void *hip_stream);
-/* Options: "direct" = 1 forces the per-corner projection path (no edge sharing) for A/B runs;
- * "grid" = workgroups per grid-stride launch; "skip_weld" = 1 makes sdmesh_regen* stop after the orientation
- * test (a multi-GPU rank exports sdmesh_device_triangles and the root welds). */
+/* Options (all have measured defaults; the others exist for A/B runs and are covered by the parity tests):
+ *   "direct" = 1        force the per-corner projection path (no edge sharing)
+ *   "skip_weld" = 1     sdmesh_regen* stops after the orientation test (a multi-GPU rank exports
+ *                       sdmesh_device_triangles and the root welds)
+ *   "graph" = 1         replay the planned chain as a hipGraph (default 0: eager launches)
+ *   "grid", "tgrid"     workgroups of the grid-stride kernels / of the per-tile kernels
+ *   "project_lanes", "flip_lanes" = 0|1|4   lanes per vertex / triangle (0 = by planned item count)
+ *   "project_mult", "flip_mult"             grid multipliers of those two kernels
+ *   "emit_ci" = 0       run k_classify instead of taking the MC cases from the last refine level
+ *   "fork" = 0|1|2      weld claim after / on a second stream beside / in one dispatch with the orientation test
+ *   "ff_fork" = 0|1|2   weld-table clear inside k_create_field / on a second stream / as a memset node
+ *   "refine2" = 1, "mask_chunk" = 8|16|32   refine variants
+ *   "dense_grid", "dense_nt", "dense_rows", "dense_contig"   launch shape of the dense sample pass (P1)
+ *   "forget_plan" = 1   drop the capacity plan (the next regen discovers sizes again) */
 int sdmesh_set_option(sdmesh_handle *h, const char *name, int value);
 
 /* ---- host-buffer API (B2) ----------------------------------------------------------------- */
