@@ -69,6 +69,7 @@ struct sdmesh_handle {
     int flip_lanes = 0;
     int ff_fork = 0;           // weld-table clear: 0 = inside k_create_field, 1 = memset on the side stream during the refine (measured:
                                // the fork + join costs 8-12 us more than the whole clear), 2 = memset node on the main stream
+    int mask_lanes = 0;        // k_refine_mask layout: 1 = one lane per parent, 32 = 32 lanes per parent, 0 = 1 for the compiled scenes
     int fork = 2;              // weld claim and orientation test: 2 = one dispatch, 1 = two streams, 0 = one after the other
     uint32_t tp_cap = 0;       // words of h->tpre before the coarse index
     uint32_t lane_hint = 0;    // planned pre-weld vertex count of the chain being enqueued (0 = unknown)
@@ -380,13 +381,15 @@ int refine_level(sdmesh_handle *h, int L, uint32_t n_cap_in, uint32_t out_cap, P
     SDCHK(ensure(h, h->mask, n_cap_in));
     const uint32_t *n_in = h->d_ctr + CTR_LEVEL0 + L;
     uint32_t *n_out = h->d_ctr + CTR_LEVEL0 + L + 1;
+    // 1 = one lane per parent (compiled scenes), else the 32-lane kernel with that parent chunk
+    const int mask_mode = (h->mask_lanes == 1 || (h->mask_lanes == 0 && h->scene != SCENE_PROGRAM)) ? 1 : h->mask_chunk;
     uint32_t *signs = nullptr;
     if (mesh_tilecnt) {                 // last level of a planned chain: emit the cube indices too (buffers presized)
         SDCHK(ensure(h, h->signs, 4ull * n_cap_in));
         signs = (uint32_t *) h->signs.p;
     }
     HIPCHK(launch_refine_mask(st, h->tgrid, h->scene, h->d_sp, (const Point *) h->vox[src].p, n_in, cs, (uint8_t *) h->mask.p,
-                              cnt_region, h->mask_chunk, signs));
+                              cnt_region, mask_mode, signs));
     uint32_t cap = out_cap;
     if (out_cap == 0) {
         HIPCHK(launch_sum_tiles(st, cnt_region, n_in, h->d_ctr + CTR_SCRATCH));
@@ -815,6 +818,7 @@ int sdmesh_set_option(sdmesh_handle *h, const char *name, int value) {
     if (!strcmp(name, "project_lanes")) { if (value != 0 && value != 1 && value != 4) return fail(h, SDMESH_ERR_INVALID, "project_lanes 0|1|4"); h->project_lanes = value; drop_graph(h); return SDMESH_OK; }
     if (!strcmp(name, "flip_lanes")) { if (value != 0 && value != 1 && value != 4) return fail(h, SDMESH_ERR_INVALID, "flip_lanes 0|1|4"); h->flip_lanes = value; drop_graph(h); return SDMESH_OK; }
     if (!strcmp(name, "ff_fork")) { if (value < 0 || value > 2) return fail(h, SDMESH_ERR_INVALID, "ff_fork 0|1|2"); h->ff_fork = value; drop_graph(h); return SDMESH_OK; }
+    if (!strcmp(name, "mask_lanes")) { if (value != 0 && value != 1 && value != 32) return fail(h, SDMESH_ERR_INVALID, "mask_lanes 0|1|32"); h->mask_lanes = value; drop_graph(h); return SDMESH_OK; }
     if (!strcmp(name, "fork")) { if (value < 0 || value > 2) return fail(h, SDMESH_ERR_INVALID, "fork 0|1|2"); h->fork = value; drop_graph(h); return SDMESH_OK; }
     if (!strcmp(name, "flip_mult")) { if (value < 1 || value > 16) return fail(h, SDMESH_ERR_INVALID, "flip_mult 1..16"); h->flip_mult = value; drop_graph(h); return SDMESH_OK; }
     if (!strcmp(name, "mask_chunk")) { if (value != 8 && value != 16 && value != 32) return fail(h, SDMESH_ERR_INVALID, "mask_chunk 8|16|32"); h->mask_chunk = value; drop_graph(h); return SDMESH_OK; }
