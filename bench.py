@@ -76,64 +76,29 @@ def cpu_baseline(scene, levels, params):
 
 
 def sharded_leg(pkg, h, levels, world, rank, steps, warmup):
-    """ONE mesh across all ranks (strong scaling): rank r meshes level-0 z-slab r with the weld
-    skipped, the 1024 per-column triangle counts are all-gathered (4 KB), the compact per-slab triangle lists go
-    straight to the root with NCCL send/recv (each peer on its own xGMI link), the root restores the single-GPU
-    order and welds.  Returns ms per regen (max over ranks) and the root's mesh counts."""
+    """ONE mesh across all ranks (strong scaling) -- partition.ShardedMesher: z-slab regen per rank,
+    all-gather of 1024 column counts, send/recv of the compact triangle lists to the root, order-restoring merge and
+    weld on the root.  Returns ms per regen (max over ranks) and the root's mesh counts."""
     from bevy_signed_distance_mesh_generation_amd import partition as P
     dev = torch.device("cuda", torch.cuda.current_device())
     h.set_option("graph", 0)
     h.set_stream(torch.cuda.current_stream().cuda_stream)      # one stream for kernels, merge and collectives
-    h.set_option("skip_weld", 1)
-    info = h.regen(levels, pkg.PART_ZSLAB, rank, world)        # capacity discovery
-    cap = int(info.triangles * 1.25) + 1024
-    mine = torch.empty((cap, 18), dtype=torch.float32, device=dev)
-    cc = torch.zeros(P.NCOLS, dtype=torch.int32, device=dev)
-    allc = torch.zeros((world, P.NCOLS), dtype=torch.int32, device=dev)
+    mesher = P.ShardedMesher(pkg, h, levels, rank, world, dev)
     result = {}
-
-    def step():
-        h.set_option("skip_weld", 1)
-        h.regen(levels, pkg.PART_ZSLAB, rank, world)
-        n = h.device_triangles_into(mine.data_ptr(), cap)
-        h.column_triangle_counts_into(cc.data_ptr())
-        if world > 1:
-            dist.all_gather_into_tensor(allc, cc)
-        else:
-            allc.copy_(cc.unsqueeze(0))
-        if rank == 0:
-            sizes = allc.sum(1).cpu().tolist()
-            lists = [mine[:n]]
-            ops, bufs = [], []
-            for r in range(1, world):
-                b = torch.empty((int(sizes[r]), 18), dtype=torch.float32, device=dev)
-                bufs.append(b)
-                if b.numel():
-                    ops.append(dist.P2POp(dist.irecv, b, r))
-            if ops:
-                for w in dist.batch_isend_irecv(ops):
-                    w.wait()
-            merged = P.merge_triangles(lists + bufs, allc.to(torch.int64))
-            torch.cuda.current_stream().synchronize()
-            h.set_option("skip_weld", 0)
-            winfo = h.weld_device_triangles(merged.data_ptr(), merged.shape[0])
-            result["triangles"], result["vertices"] = int(winfo.triangles), int(winfo.vertices)
-        elif n:
-            for w in dist.batch_isend_irecv([dist.P2POp(dist.isend, mine[:n], 0)]):
-                w.wait()
-
     for _ in range(warmup):
-        step()
+        mesher.step()
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(steps):
-        step()
+        winfo = mesher.step()
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
+    if winfo is not None:
+        result["triangles"], result["vertices"] = int(winfo.triangles), int(winfo.vertices)
     if world > 1:
         t = torch.tensor([dt], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)

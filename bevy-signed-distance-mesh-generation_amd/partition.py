@@ -53,3 +53,74 @@ def merge_triangles(tri_lists, counts):
         if t.shape[0]:
             out.index_copy_(0, d, t)
     return out
+
+
+class ShardedMesher:
+    """ONE mesh across all ranks (strong scaling): rank r meshes level-0 z-slab r with the weld
+    skipped, the 1024 per-column triangle counts are all-gathered (4 KB), the compact per-slab triangle lists go
+    straight to the root with point-to-point send/recv (RCCL: each peer on its own xGMI link), the root restores the
+    single-GPU order and welds.  The handler must run on torch's current stream (`set_stream`).
+
+    The transport is whatever process group is current: with "nccl" (= RCCL) the device buffers are exchanged
+    directly; with "gloo" (tests, CPU rehearsals) they are staged through host memory -- same code otherwise."""
+
+    def __init__(self, pkg, handler, levels, rank, world, device):
+        import torch.distributed as dist
+        self.pkg, self.h, self.levels, self.rank, self.world, self.dev = pkg, handler, levels, rank, world, device
+        self.dist = dist
+        self.staged = world > 1 and dist.get_backend() == "gloo"
+        handler.set_option("skip_weld", 1)
+        info = handler.regen(levels, pkg.PART_ZSLAB, rank, world)        # capacity discovery
+        handler.set_option("skip_weld", 0)
+        self.cap = int(info.triangles * 1.25) + 1024
+        self.mine = torch.empty((self.cap, 18), dtype=torch.float32, device=device)
+        self.cc = torch.zeros(NCOLS, dtype=torch.int32, device=device)
+        self.allc = torch.zeros((world, NCOLS), dtype=torch.int32, device=device)
+
+    def _all_gather_counts(self):
+        if self.world == 1:
+            self.allc.copy_(self.cc.unsqueeze(0))
+        elif self.staged:
+            mine = self.cc.cpu()
+            parts = [torch.zeros_like(mine) for _ in range(self.world)]
+            self.dist.all_gather(parts, mine)
+            self.allc.copy_(torch.stack(parts))
+        else:
+            self.dist.all_gather_into_tensor(self.allc, self.cc)
+
+    def step(self):
+        """One sharded regen.  Returns the root's sdmesh_regen_info of the welded mesh (None on the other ranks)."""
+        h, dist = self.h, self.dist
+        h.set_option("skip_weld", 1)
+        try:
+            h.regen(self.levels, self.pkg.PART_ZSLAB, self.rank, self.world)
+            n = h.device_triangles_into(self.mine.data_ptr(), self.cap)
+            h.column_triangle_counts_into(self.cc.data_ptr())
+        finally:
+            h.set_option("skip_weld", 0)
+        self._all_gather_counts()
+        if self.rank == 0:
+            sizes = self.allc.sum(1).cpu().tolist()
+            bufs, ops = [], []
+            for r in range(1, self.world):
+                b = torch.empty((int(sizes[r]), 18), dtype=torch.float32, device="cpu" if self.staged else self.dev)
+                bufs.append(b)
+                if b.numel():
+                    if self.staged:
+                        dist.recv(b, src=r)
+                    else:
+                        ops.append(dist.P2POp(dist.irecv, b, r))
+            if ops:
+                for w in dist.batch_isend_irecv(ops):
+                    w.wait()
+            lists = [self.mine[:n]] + [b.to(self.dev) for b in bufs]
+            merged = merge_triangles(lists, self.allc.to(torch.int64))
+            torch.cuda.current_stream().synchronize()
+            return h.weld_device_triangles(merged.data_ptr(), merged.shape[0])
+        if n:
+            if self.staged:
+                dist.send(self.mine[:n].cpu(), dst=0)
+            else:
+                for w in dist.batch_isend_irecv([dist.P2POp(dist.isend, self.mine[:n], 0)]):
+                    w.wait()
+        return None
