@@ -40,7 +40,7 @@ def pack_program(program):
         a = np.asarray(args, np.float32).ravel()
         out[i]["a"][: a.size] = a
     return out
-PART_NONE, PART_ZSLAB = 0, 1
+PART_NONE, PART_ZSLAB, PART_XSLAB = 0, 1, 2
 
 ERRORS = {1: "invalid argument", 2: "HIP runtime error", 3: "no gfx950 device", 4: "output buffer too small",
           5: "vertex outside the weld key range", 6: "internal device error"}

@@ -411,7 +411,8 @@ uint32_t padded(uint32_t n) { return n + n / 4 + 4096; }
 
 // The planned, synchronisation-free device chain of one regen (capacities from the plan).  Every buffer has
 // been sized by the caller, so nothing here allocates: the same code runs eagerly or under stream capture.
-int enqueue_planned_chain(sdmesh_handle *h, int levels, uint32_t z0, uint32_t z1, uint32_t n0, uint32_t lvl_words, Point *vs_out) {
+int enqueue_planned_chain(sdmesh_handle *h, int levels, const uint32_t *box, uint32_t n0, uint32_t lvl_words, Point *vs_out) {
+    const uint32_t x0 = box[0], x1 = box[1], z0 = box[2], z1 = box[3];      // level-0 cell range of this part
     hipStream_t st = h->stream;
     // fork: the weld table is cleared on the side stream while the refine runs
     bool ff_in_kernel = h->ff_fork == 0;      // (the arena is allocated in 256-byte units, so rounding the clear up to 16 B stays inside it)
@@ -427,7 +428,7 @@ int enqueue_planned_chain(sdmesh_handle *h, int levels, uint32_t z0, uint32_t z1
     Point vs;
     vs.x = vs.y = vs.z = MESH_GENERATION_BB_SIZE / (float) MESH_GENERATION_INIT_FACTOR;
     // (the control block is cleared by the field kernel itself: one graph node less in front of the chain)
-    if (n0) HIPCHK(launch_create_field(st, (Point *) h->vox[0].p, z0, z1, h->d_ctr + CTR_LEVEL0, (uint32_t *) h->ctl.p,
+    if (n0) HIPCHK(launch_create_field(st, (Point *) h->vox[0].p, x0, x1, z0, z1, h->d_ctr + CTR_LEVEL0, (uint32_t *) h->ctl.p,
                                        (uint32_t) (CTL_LVL0 + lvl_words), ff_in_kernel ? h->ff_arena.p : nullptr, (ff_bytes(h) + 15) & ~(size_t) 15));
     else SDCHK(zero_ctl(h, lvl_words));
     uint32_t n_cap = n0;
@@ -512,15 +513,19 @@ int regen_impl(sdmesh_handle *h, int levels, int mode, int part, int nparts, sdm
         return fail(h, SDMESH_ERR_INVALID, "a regen is pending: call sdmesh_regen_end first");
     }
     if (levels < 0 || levels > SDMESH_MAX_LEVELS) return fail(h, SDMESH_ERR_INVALID, "levels must be 0..%d", SDMESH_MAX_LEVELS);
-    if (mode != SDMESH_PART_NONE && mode != SDMESH_PART_ZSLAB) return fail(h, SDMESH_ERR_INVALID, "bad partition mode");
+    if (mode != SDMESH_PART_NONE && mode != SDMESH_PART_ZSLAB && mode != SDMESH_PART_XSLAB) return fail(h, SDMESH_ERR_INVALID, "bad partition mode");
     if (mode == SDMESH_PART_NONE) { part = 0; nparts = 1; }
     if (nparts < 1 || nparts > 32 || part < 0 || part >= nparts) return fail(h, SDMESH_ERR_INVALID, "bad partition %d/%d", part, nparts);
     HIPCHK(hipSetDevice(h->device));
     SDCHK(sync_scene(h));
     hipStream_t st = h->stream;
     const uint32_t F = MESH_GENERATION_INIT_FACTOR;
-    const uint32_t z0 = F * (uint32_t) part / (uint32_t) nparts, z1 = F * (uint32_t) (part + 1) / (uint32_t) nparts;
-    const uint32_t n0 = F * F * (z1 - z0);
+    const uint32_t p0 = F * (uint32_t) part / (uint32_t) nparts, p1 = F * (uint32_t) (part + 1) / (uint32_t) nparts;
+    // level-0 cell box {x0, x1, z0, z1} of this part: z layers (ZSLAB) or x layers (XSLAB: x is the outermost digit of
+    // the reference's order, so a part's voxel / triangle lists are contiguous ranges of the unpartitioned ones)
+    const uint32_t box[4] = {mode == SDMESH_PART_XSLAB ? p0 : 0u, mode == SDMESH_PART_XSLAB ? p1 : F,
+                             mode == SDMESH_PART_ZSLAB ? p0 : 0u, mode == SDMESH_PART_ZSLAB ? p1 : F};
+    const uint32_t n0 = (box[1] - box[0]) * F * (box[3] - box[2]);
 
     for (int attempt = 0; attempt < 2; attempt++) {
         const bool resumed = phase == 2 && attempt == 0 && h->pend_async;
@@ -557,7 +562,7 @@ int regen_impl(sdmesh_handle *h, int levels, int mode, int part, int nparts, sdm
                     drop_graph(h);
                     HIPCHK(hipStreamSynchronize(st));
                     HIPCHK(hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal));
-                    int rc = enqueue_planned_chain(h, levels, z0, z1, n0, lvl_words, &vs);
+                    int rc = enqueue_planned_chain(h, levels, box, n0, lvl_words, &vs);
                     if (rc == SDMESH_OK) rc = read_back_enqueue(h);
                     hipGraph_t g = nullptr;
                     hipError_t ce = hipStreamEndCapture(st, &g);
@@ -576,7 +581,7 @@ int regen_impl(sdmesh_handle *h, int levels, int mode, int part, int nparts, sdm
                 HIPCHK(hipEventRecord(h->ev1, st));
             } else {
                 HIPCHK(hipEventRecord(h->ev0, st));
-                SDCHK(enqueue_planned_chain(h, levels, z0, z1, n0, lvl_words, &vs));
+                SDCHK(enqueue_planned_chain(h, levels, box, n0, lvl_words, &vs));
                 HIPCHK(hipEventRecord(h->ev1, st));
                 SDCHK(read_back_enqueue(h));
             }
@@ -593,7 +598,7 @@ int regen_impl(sdmesh_handle *h, int levels, int mode, int part, int nparts, sdm
             SDCHK(ensure(h, h->vox[0], sizeof(Point) * (size_t) std::max<uint32_t>(n0, 64)));
             HIPCHK(hipEventRecord(h->ev0, st));
             SDCHK(zero_ctl(h, 0));
-            if (n0) HIPCHK(launch_create_field(st, (Point *) h->vox[0].p, z0, z1, h->d_ctr + CTR_LEVEL0));
+            if (n0) HIPCHK(launch_create_field(st, (Point *) h->vox[0].p, box[0], box[1], box[2], box[3], h->d_ctr + CTR_LEVEL0));
             for (int L = 0; L < levels; L++) {
                 const Point cs = half_size(vs);
                 uint32_t cnt = 0;

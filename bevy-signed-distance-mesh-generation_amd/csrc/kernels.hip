@@ -1210,13 +1210,14 @@ __global__ __launch_bounds__(128) void k_triangles_direct(const Point *__restric
 // A1 level-0 field on the device (src/cuda/mod.rs:105-122): x outer, y, z inner; optional
 // z-slab [z0, z1) for the multi-GPU partition (same order, slab cells only)
 // ------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_create_field(Point *__restrict__ vox, uint32_t z0, uint32_t z1, uint32_t *__restrict__ n_out,
+__global__ __launch_bounds__(256) void k_create_field(Point *__restrict__ vox, uint32_t x0, uint32_t x1, uint32_t z0, uint32_t z1,
+                                                       uint32_t *__restrict__ n_out,
                                                        uint32_t *__restrict__ zero, uint32_t nzero, uint4 *__restrict__ ff,
                                                        uint32_t nff16) {
     // zero[0 .. nzero) (optional): the regen's control block is cleared here instead of by a memset node in front of
     // this kernel; n_out (inside that block) is the one word this kernel writes, and it is skipped by the clear.
     const float SIZE = MESH_GENERATION_BB_SIZE / (float) MESH_GENERATION_INIT_FACTOR;
-    const uint32_t F = MESH_GENERATION_INIT_FACTOR, zs = z1 - z0, total = F * F * zs;
+    const uint32_t F = MESH_GENERATION_INIT_FACTOR, zs = z1 - z0, total = (x1 - x0) * F * zs;   // level-0 cells [x0,x1) x [0,F) x [z0,z1)
     for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < nzero; i += gridDim.x * blockDim.x)
         if (zero + i != n_out) zero[i] = 0u;
     // ff[0 .. nff16) (optional): the weld table (keys + loser minima) starts as all-ones; written here, consumed ten
@@ -1224,7 +1225,7 @@ __global__ __launch_bounds__(256) void k_create_field(Point *__restrict__ vox, u
     const uint4 ones = make_uint4(0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu);
     for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < nff16; i += gridDim.x * blockDim.x) ff[i] = ones;
     for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
-        const uint32_t z = z0 + i % zs, y = (i / zs) % F, x = i / (zs * F);
+        const uint32_t z = z0 + i % zs, y = (i / zs) % F, x = x0 + i / (zs * F);
         Point p;
         p.x = (float) x * SIZE - MESH_GENERATION_BB_SIZE / 2.0f;
         p.y = (float) y * SIZE - MESH_GENERATION_BB_SIZE / 2.0f;
@@ -1739,9 +1740,9 @@ hipError_t launch_stream_fill(hipStream_t st, int grid, float *out, uint64_t tot
     return hipGetLastError();
 }
 
-hipError_t launch_create_field(hipStream_t st, Point *vox, uint32_t z0, uint32_t z1, uint32_t *n_out, uint32_t *zero, uint32_t nzero,
-                               void *ff, size_t ff_bytes) {
-    hipLaunchKernelGGL(k_create_field, dim3(ff ? 1024 : 128), dim3(256), 0, st, vox, z0, z1, n_out, zero, nzero, (uint4 *) ff,
+hipError_t launch_create_field(hipStream_t st, Point *vox, uint32_t x0, uint32_t x1, uint32_t z0, uint32_t z1, uint32_t *n_out,
+                               uint32_t *zero, uint32_t nzero, void *ff, size_t ff_bytes) {
+    hipLaunchKernelGGL(k_create_field, dim3(ff ? 1024 : 128), dim3(256), 0, st, vox, x0, x1, z0, z1, n_out, zero, nzero, (uint4 *) ff,
                        ff ? (uint32_t) (ff_bytes / 16) : 0u);       // (no table pointer -> nothing to clear, whatever size was passed)
     return hipGetLastError();
 }

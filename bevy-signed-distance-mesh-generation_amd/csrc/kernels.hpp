@@ -68,8 +68,8 @@ hipError_t launch_stream_fill(hipStream_t st, int grid, float *out, uint64_t tot
 hipError_t launch_sample_dense_rows(hipStream_t st, int grid, int scene, const SceneParams *sp, float *out, uint32_t N, bool nt);
 hipError_t launch_sample_dense(hipStream_t st, int grid, int scene, const SceneParams *sp, float *out, uint32_t N, bool nt,
                                bool contig);
-hipError_t launch_create_field(hipStream_t st, Point *vox, uint32_t z0, uint32_t z1, uint32_t *n_out, uint32_t *zero = nullptr,
-                               uint32_t nzero = 0, void *ff = nullptr, size_t ff_bytes = 0);
+hipError_t launch_create_field(hipStream_t st, Point *vox, uint32_t x0, uint32_t x1, uint32_t z0, uint32_t z1, uint32_t *n_out,
+                               uint32_t *zero = nullptr, uint32_t nzero = 0, void *ff = nullptr, size_t ff_bytes = 0);
 hipError_t launch_raw_count(hipStream_t st, int grid, const Triangle *raw, const uint32_t *n_ptr, uint32_t *tilecnt);
 hipError_t launch_raw_compact(hipStream_t st, int grid, const Triangle *raw, const uint32_t *n_ptr, const uint32_t *tileoff,
                               Triangle *out, uint32_t *tri_e, uint32_t cap);

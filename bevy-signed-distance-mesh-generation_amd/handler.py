@@ -16,7 +16,7 @@ import math
 import numpy as np
 
 from . import _abi
-from ._abi import MAX_LEVELS, PART_NONE, PART_ZSLAB, SCENES, Mesh, Point, RegenInfo, VoxelField  # noqa: F401
+from ._abi import MAX_LEVELS, PART_NONE, PART_XSLAB, PART_ZSLAB, SCENES, Mesh, Point, RegenInfo, VoxelField  # noqa: F401
 
 
 class SdMeshError(RuntimeError):
@@ -245,6 +245,23 @@ class CudaHandler:
         nt = ctypes.c_uint32(0)
         self._chk(self._lib.sdmesh_device_mesh(self._h, ctypes.byref(m), ctypes.byref(nt)))
         return m, nt.value
+
+    def device_mesh_tensors(self, device):
+        """Zero-copy torch views of the welded mesh in HBM: vertices [V, 6] float32 (position, normal) and triangles
+        [T, 3] int32.  Valid until the next call that regenerates the mesh on this handle."""
+        import torch
+        m, nt = self.device_mesh()
+
+        class _View:          # CUDA array interface (version 2) over a raw device pointer
+            def __init__(self, ptr, shape, typestr):
+                self.__cuda_array_interface__ = {"shape": shape, "typestr": typestr, "data": (ptr, False), "version": 2}
+
+        nv = int(m.vertex_count)
+        verts = (torch.as_tensor(_View(m.vertices, (nv, 6), "<f4"), device=device) if nv
+                 else torch.empty((0, 6), dtype=torch.float32, device=device))
+        tris = (torch.as_tensor(_View(m.triangles, (nt, 3), "<i4"), device=device) if nt
+                else torch.empty((0, 3), dtype=torch.int32, device=device))
+        return verts, tris
 
     def device_triangles_into(self, dev_ptr, cap):
         n = ctypes.c_size_t(0)

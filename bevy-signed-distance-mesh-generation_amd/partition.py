@@ -124,3 +124,116 @@ class ShardedMesher:
                 for w in dist.batch_isend_irecv([dist.P2POp(dist.isend, self.mine[:n], 0)]):
                     w.wait()
         return None
+
+
+def weld_keys(pos):
+    """int64 weld keys of float32 positions [n, 3], exactly as the device weld forms them: q = roundf(x * 1e5f) per
+    axis (round half away from zero, src/cuda/mod.rs:270), 21 bits per axis."""
+    v = (pos * torch.tensor(100000.0, dtype=torch.float32, device=pos.device)).to(torch.float64)
+    q = (torch.sign(v) * torch.floor(torch.abs(v) + 0.5)).to(torch.int64) + 1048576
+    return q[:, 0] | (q[:, 1] << 21) | (q[:, 2] << 42)
+
+
+class DistributedMesher:
+    """ONE mesh across all ranks with a DISTRIBUTED weld (x-slab partition).
+
+    x is the outermost digit of the reference's order, so rank r's voxel and triangle lists are contiguous ranges of
+    the single-GPU lists and the global first-seen vertex order is: rank 0's vertices in its local first-seen order,
+    then rank 1's vertices that rank 0 does not already hold, and so on.  Every rank therefore runs the complete local
+    pipeline (its own weld included); the only exchange is with the x-neighbours, about the vertices within one voxel
+    of the shared face:
+      1. rank r sends the weld keys of its upper-face band to rank r + 1, which matches its lower-face band against them
+         (equal key = the same welded vertex in the single-GPU mesh: it keeps the lower rank's copy);
+      2. the counts of kept vertices are all-gathered (global offsets), rank r sends the new numbers of its upper band
+         to rank r + 1, and every rank rewrites its index buffer with the global numbers;
+      3. the mesh stays distributed (`step` returns this rank's kept vertices and global-index triangles); `gather`
+         concatenates the parts on the root -- no root-side weld, nothing proportional to the whole mesh is re-hashed.
+    Transport as in ShardedMesher: the current process group ("nccl" direct, "gloo" staged through host memory)."""
+
+    def __init__(self, pkg, handler, levels, rank, world, device):
+        import torch.distributed as dist
+        self.pkg, self.h, self.levels, self.rank, self.world, self.dev, self.dist = pkg, handler, levels, rank, world, device, dist
+        self.staged = world > 1 and dist.get_backend() == "gloo"
+        size = torch.tensor(5.0, dtype=torch.float32) / torch.tensor(float(INIT_FACTOR << levels), dtype=torch.float32)
+        lo, hi = slab_bounds(rank, world)
+        self.band = 2.5 * float(size)      # a projected vertex stays within ~a voxel diagonal of its lattice edge
+        self.x_lo = -2.5 + 5.0 * lo / INIT_FACTOR
+        self.x_hi = -2.5 + 5.0 * hi / INIT_FACTOR
+
+    # -- point-to-point helpers: variable-length vectors (length first, then the payload in its own dtype) ----------
+    def _send(self, t, dst):
+        t = t.contiguous().flatten()
+        n = torch.tensor([t.numel()], dtype=torch.int64, device="cpu" if self.staged else self.dev)
+        self.dist.send(n, dst=dst)
+        if t.numel():
+            self.dist.send(t.cpu() if self.staged else t, dst=dst)
+
+    def _recv(self, src, dtype=torch.int64):
+        n = torch.zeros(1, dtype=torch.int64, device="cpu" if self.staged else self.dev)
+        self.dist.recv(n, src=src)
+        t = torch.empty(int(n.item()), dtype=dtype, device="cpu" if self.staged else self.dev)
+        if t.numel():
+            self.dist.recv(t, src=src)
+        return t.to(self.dev)
+
+    def step(self):
+        """One distributed regen.  Returns (vertices [v, 6] float32 kept by this rank, triangles [t, 3] int64 with GLOBAL
+        vertex indices, global offset of this rank's vertices).  Concatenated over the ranks in order they are the
+        single-GPU mesh, bit for bit."""
+        h, dist, r, R, dev = self.h, self.dist, self.rank, self.world, self.dev
+        h.regen(self.levels, self.pkg.PART_XSLAB, r, R)
+        verts, tris = h.device_mesh_tensors(dev)
+        nv = verts.shape[0]
+        x = verts[:, 0]
+        up_ids = torch.nonzero(x >= self.x_hi - self.band).flatten() if r + 1 < R else torch.empty(0, dtype=torch.int64, device=dev)
+        lo_ids = torch.nonzero(x <= self.x_lo + self.band).flatten() if r > 0 else torch.empty(0, dtype=torch.int64, device=dev)
+        # 1. keys of my upper band -> rank r + 1; match my lower band against rank r - 1's upper band
+        if r + 1 < R:
+            self._send(weld_keys(verts[up_ids, :3]), r + 1)
+        dup_pos = torch.full((nv,), -1, dtype=torch.int64, device=dev)      # position in the neighbour's band, or -1
+        if r > 0:
+            prev_keys = self._recv(r - 1)
+            if prev_keys.numel() and lo_ids.numel():
+                order = torch.argsort(prev_keys)
+                sk = prev_keys[order]
+                mine = weld_keys(verts[lo_ids, :3])
+                pos = torch.searchsorted(sk, mine).clamp_(max=sk.numel() - 1)
+                hit = sk[pos] == mine
+                dup_pos[lo_ids[hit]] = order[pos[hit]]
+        keep = dup_pos < 0
+        newidx = torch.cumsum(keep.to(torch.int64), 0) - 1
+        n_keep = keep.sum().reshape(1)
+        # 2. global offsets; my upper band's new numbers -> rank r + 1
+        if R > 1:
+            counts = [torch.zeros(1, dtype=torch.int64, device="cpu" if self.staged else dev) for _ in range(R)]
+            dist.all_gather(counts, n_keep.cpu() if self.staged else n_keep)
+            counts = torch.cat(counts).to(dev)
+        else:
+            counts = n_keep
+        offsets = torch.cumsum(counts, 0) - counts
+        gidx = offsets[r] + newidx
+        if r + 1 < R:
+            # (an upper-band vertex is never itself a duplicate: the two faces of a slab are at least one level-0 cell apart)
+            self._send(gidx[up_ids], r + 1)
+        if r > 0:
+            prev_g = self._recv(r - 1)
+            dups = torch.nonzero(~keep).flatten()
+            if dups.numel():
+                gidx[dups] = prev_g[dup_pos[dups]]
+        return verts[keep], gidx[tris.to(torch.int64)], int(offsets[r].item())
+
+    def gather(self, part):
+        """Concatenate the ranks' parts on rank 0: (vertices [V, 6], triangles [T, 3] int64) there, None elsewhere."""
+        verts, tris, _ = part
+        dist, R = self.dist, self.world
+        if R == 1:
+            return verts, tris
+        if self.rank != 0:
+            self._send(verts, 0)
+            self._send(tris, 0)
+            return None
+        vs, ts = [verts], [tris]
+        for src in range(1, R):
+            vs.append(self._recv(src, torch.float32).reshape(-1, 6))
+            ts.append(self._recv(src, torch.int64).reshape(-1, 3))
+        return torch.cat(vs), torch.cat(ts)

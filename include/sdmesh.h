@@ -47,7 +47,8 @@ enum {
 /* Multi-GPU partition of the level-0 field. */
 enum {
     SDMESH_PART_NONE = 0,
-    SDMESH_PART_ZSLAB = 1        /* level-0 z layers [32*part/nparts, 32*(part+1)/nparts) */
+    SDMESH_PART_ZSLAB = 1,       /* level-0 z layers [32*part/nparts, 32*(part+1)/nparts) */
+    SDMESH_PART_XSLAB = 2        /* level-0 x layers, same bounds: a contiguous range of the unpartitioned order */
 };
 
 typedef struct sdmesh_handle sdmesh_handle;
