@@ -180,9 +180,14 @@ class DistributedMesher:
         """One distributed regen.  Returns (vertices [v, 6] float32 kept by this rank, triangles [t, 3] int64 with GLOBAL
         vertex indices, global offset of this rank's vertices).  Concatenated over the ranks in order they are the
         single-GPU mesh, bit for bit."""
-        h, dist, r, R, dev = self.h, self.dist, self.rank, self.world, self.dev
-        h.regen(self.levels, self.pkg.PART_XSLAB, r, R)
-        verts, tris = h.device_mesh_tensors(dev)
+        self.h.regen(self.levels, self.pkg.PART_XSLAB, self.rank, self.world)
+        verts, tris = self.h.device_mesh_tensors(self.dev)
+        return self.exchange(verts, tris)
+
+    def exchange(self, verts, tris):
+        """The weld across the slab faces, given this rank's locally welded slab mesh (vertices [v, 6] float32, triangles
+        [t, 3] with local indices) on `self.dev` -- a GPU in the product, the CPU in the gloo tests."""
+        dist, r, R, dev = self.dist, self.rank, self.world, self.dev
         nv = verts.shape[0]
         x = verts[:, 0]
         up_ids = torch.nonzero(x >= self.x_hi - self.band).flatten() if r + 1 < R else torch.empty(0, dtype=torch.int64, device=dev)

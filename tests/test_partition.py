@@ -90,3 +90,57 @@ def test_gloo_slab_gather_merge_weld_equals_single(world, levels):
         assert p.exitcode == 0
     ok, nt, nref = q.get()
     assert ok and nt == nref
+
+
+def _dist_worker(rank, world, port, levels, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    sys.path.insert(0, ROOT)
+    from oracle import oracle as O
+    P = _partition()
+    O.set_threads(2)
+    F = 32
+    # this rank's x-slab with the oracle: level-0 cells with x index in [x0, x1), refined, meshed and welded locally
+    vox, size = O.create_voxel_field()
+    x0, x1 = P.slab_bounds(rank, world)
+    xi = np.arange(F ** 3) // (F * F)
+    vox = vox[(xi >= x0) & (xi < x1)].copy()
+    for _ in range(levels):
+        vox, size = O.refine("sdobj", vox, size)
+    if len(vox):
+        raw = O.triangles_raw("sdobj", vox, size).reshape(-1, 18)
+        raw = raw[np.isfinite(raw[:, 0])]
+        pos, nrm, idx = O.weld(raw.reshape(-1, 3, 2, 3))
+    else:
+        pos = nrm = np.zeros((0, 3), np.float32); idx = np.zeros((0, 3), np.uint32)
+    verts = torch.from_numpy(np.concatenate([pos, nrm], axis=1).astype(np.float32))
+    tris = torch.from_numpy(idx.astype(np.int64))
+    mesher = P.DistributedMesher(None, None, levels, rank, world, torch.device("cpu"))
+    full = mesher.gather(mesher.exchange(verts, tris))
+    if rank == 0:
+        v, t = full
+        ref = O.regen("sdobj", levels)
+        v = v.numpy()
+        ok = (np.array_equal(t.numpy().astype(np.uint32), ref["idx"])
+              and np.array_equal(np.ascontiguousarray(v[:, :3]).view(np.uint32), ref["pos"].view(np.uint32))
+              and np.array_equal(np.ascontiguousarray(v[:, 3:]).view(np.uint32), ref["nrm"].view(np.uint32)))
+        q.put((ok, len(t), len(ref["idx"]), len(v), len(ref["pos"])))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,levels", [(2, 1), (3, 2)])
+def test_gloo_distributed_weld_equals_single(world, levels):
+    """The distributed weld (x-slabs, DistributedMesher.exchange / gather) as a gloo job on CPU tensors, the oracle
+    standing in for each rank's kernels: the concatenated parts are the single-GPU mesh, bit for bit."""
+    ctx = mp.get_context("spawn")
+    q = ctx.SimpleQueue()
+    port = 29300 + (os.getpid() % 2000) + 10 * world + levels
+    procs = [ctx.Process(target=_dist_worker, args=(r, world, port, levels, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(300)
+        assert p.exitcode == 0
+    ok, nt, nref, nv, nvref = q.get()
+    assert ok and (nt, nv) == (nref, nvref)
