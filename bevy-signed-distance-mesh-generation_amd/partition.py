@@ -177,8 +177,8 @@ class DistributedMesher:
         return t.to(self.dev)
 
     def step(self):
-        """One distributed regen.  Returns (vertices [v, 6] float32 kept by this rank, triangles [t, 3] int64 with GLOBAL
-        vertex indices, global offset of this rank's vertices).  Concatenated over the ranks in order they are the
+        """One distributed regen.  Returns (vertices [v, 6] float32 kept by this rank, triangles [t, 3] int32 with GLOBAL
+        vertex indices, global offset of this rank's vertices as a 0-d tensor).  Concatenated over the ranks in order they are the
         single-GPU mesh, bit for bit."""
         self.h.regen(self.levels, self.pkg.PART_XSLAB, self.rank, self.world)
         verts, tris = self.h.device_mesh_tensors(self.dev)
@@ -206,7 +206,7 @@ class DistributedMesher:
                 hit = sk[pos] == mine
                 dup_pos[lo_ids[hit]] = order[pos[hit]]
         keep = dup_pos < 0
-        newidx = torch.cumsum(keep.to(torch.int64), 0) - 1
+        newidx = torch.cumsum(keep.to(torch.int32), 0, dtype=torch.int32) - 1
         n_keep = keep.sum().reshape(1)
         # 2. global offsets; my upper band's new numbers -> rank r + 1
         if R > 1:
@@ -216,16 +216,21 @@ class DistributedMesher:
         else:
             counts = n_keep
         offsets = torch.cumsum(counts, 0) - counts
-        gidx = offsets[r] + newidx
+        if r == 0:
+            # rank 0 keeps every vertex at its local number: nothing to rewrite, nothing to copy
+            if R > 1:
+                self._send(up_ids.to(torch.int64), 1)
+            return verts, tris.to(torch.int32), offsets[0]
+        gidx = offsets[r].to(torch.int32) + newidx
         if r + 1 < R:
             # (an upper-band vertex is never itself a duplicate: the two faces of a slab are at least one level-0 cell apart)
-            self._send(gidx[up_ids], r + 1)
-        if r > 0:
-            prev_g = self._recv(r - 1)
-            dups = torch.nonzero(~keep).flatten()
-            if dups.numel():
-                gidx[dups] = prev_g[dup_pos[dups]]
-        return verts[keep], gidx[tris.to(torch.int64)], int(offsets[r].item())
+            self._send(gidx[up_ids].to(torch.int64), r + 1)
+        prev_g = self._recv(r - 1)
+        dups = torch.nonzero(~keep).flatten()
+        if dups.numel():
+            gidx[dups] = prev_g[dup_pos[dups]].to(torch.int32)
+        out_tris = torch.index_select(gidx, 0, tris.reshape(-1).to(torch.int32)).reshape(-1, 3)
+        return verts[keep], out_tris, offsets[r]
 
     def gather(self, part):
         """Concatenate the ranks' parts on rank 0: (vertices [V, 6], triangles [T, 3] int64) there, None elsewhere."""
@@ -240,5 +245,5 @@ class DistributedMesher:
         vs, ts = [verts], [tris]
         for src in range(1, R):
             vs.append(self._recv(src, torch.float32).reshape(-1, 6))
-            ts.append(self._recv(src, torch.int64).reshape(-1, 3))
+            ts.append(self._recv(src, torch.int32).reshape(-1, 3))
         return torch.cat(vs), torch.cat(ts)
