@@ -69,10 +69,26 @@ def cpu_baseline(scene, levels, params):
     r = O.regen(scene, levels, params)
     dt = time.perf_counter() - t0
     n = 32 << levels
-    return {"value": round(n ** 3 / dt / 1e6, 3), "unit": "Mvoxels/s", "cores": cores, "kind": "port",
-            "sample": f"one full regen of {scene} {n}^3 (refine x{levels} + triangles + weld), OpenMP over voxels, "
-                      f"{dt:.2f} s wall, {len(r['idx'])} triangles",
-            "mtris_per_s": round(len(r["idx"]) / dt / 1e6, 4), "seconds": round(dt, 3)}
+    out = {"value": round(n ** 3 / dt / 1e6, 3), "unit": "Mvoxels/s", "cores": cores, "kind": "port",
+           "sample": f"one full regen of {scene} {n}^3 (refine x{levels} + triangles + weld), OpenMP over voxels, "
+                     f"{dt:.2f} s wall, {len(r['idx'])} triangles",
+           "mtris_per_s": round(len(r["idx"]) / dt / 1e6, 4), "seconds": round(dt, 3)}
+    # the same port on ONE thread (one level coarser, so it stays a ~10 s sample), and a conventional dense
+    # CPU marching cubes (sample every lattice point -> classify -> count triangles; no projection, no normals, no weld)
+    lv1 = max(levels - 1, 0)
+    n1 = 32 << lv1
+    O.set_threads(1)
+    t0 = time.perf_counter()
+    O.regen(scene, lv1, params)
+    d1 = time.perf_counter() - t0
+    out["single_thread"] = {"value": round(n1 ** 3 / d1 / 1e6, 3), "unit": "Mvoxels/s", "cores": 1, "grid": n1, "seconds": round(d1, 3)}
+    O.set_threads(cores)
+    t0 = time.perf_counter()
+    nt = O.dense_mc_count(scene, n, params)
+    dd = time.perf_counter() - t0
+    out["dense_mc"] = {"value": round(n ** 3 / dd / 1e6, 3), "unit": "Mvoxels/s", "cores": cores, "grid": n, "seconds": round(dd, 3),
+                       "triangles": int(nt), "what": "dense sample + classify + triangle count only"}
+    return out
 
 
 def sharded_leg(pkg, h, levels, world, rank, steps, warmup):
