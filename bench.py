@@ -253,7 +253,7 @@ def main():
 
     # --- the other grid sizes the north star names (256^3 / 1024^3 of the workload scene, and BASELINE configs[1]: the
     #     single sphere at 256^3); same measurement as the primary metric, fewer steps
-    if rank == 0 and world == 1 and not args.no_sizes:
+    if not args.no_sizes:                 # every rank runs it (N independent regens, like the primary metric); whole-job rates
         sizes = {}
         for label, sc, lv in ((f"{args.scene}_256", args.scene, 3), (f"{args.scene}_1024", args.scene, 5), ("sphere_256", "sphere", 3)):
             if sc == args.scene and lv == args.levels:
@@ -262,16 +262,21 @@ def main():
             hz.regen(lv); hz.set_option("graph", 1 if args.graph else 0)
             for _ in range(5):
                 zi = hz.regen(lv)
-            torch.cuda.synchronize()
+            sync_all()
             tz = time.perf_counter()
             zdev = []
             for _ in range(50):
                 zi = hz.regen(lv); zdev.append(zi.device_ms)
-            torch.cuda.synchronize()
-            dz = (time.perf_counter() - tz) / 50
+            sync_all()
+            dz = time.perf_counter() - tz
+            if world > 1:
+                tt = torch.tensor([dz], dtype=torch.float64, device="cuda")
+                dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+                dz = float(tt.item())
+            dz /= 50
             ng = 32 << lv
             sizes[label] = {"grid": ng, "ms_per_step": round(dz * 1e3, 4), "device_ms_per_step": round(float(np.median(zdev)), 4),
-                            "mvoxels_per_s": round(ng ** 3 / dz / 1e6, 1), "mtris_per_s": round(zi.triangles / dz / 1e6, 1),
+                            "mvoxels_per_s": round(world * ng ** 3 / dz / 1e6, 1), "mtris_per_s": round(world * zi.triangles / dz / 1e6, 1),
                             "triangles": int(zi.triangles), "vertices": int(zi.vertices)}
             hz.close()
         out["sizes"] = sizes
