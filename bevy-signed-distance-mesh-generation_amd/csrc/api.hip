@@ -106,12 +106,13 @@ struct sdmesh_handle {
     uint32_t *d_status = nullptr;  // ST_WORDS
     uint32_t *h_pinned = nullptr;  // CTR_WORDS + ST_WORDS, pinned
     // mesh stage
-    DevBuf cubeidx, trioff, ff_arena, first_ord_buf, wfirst, uverts, tri_e, vslot, tdesc, tfirst, tfpre, tpre, flip, wvidx, torder;
+    DevBuf cubeidx, trioff, ff_arena, first_ord_buf, uverts, tri_e, vslot, tdesc, tfirst, tfpre, tpre, flip, wvidx, torder;
     DevBuf vertices, indices, raw, compact, staging, dense_samples, dense_bits, cellcnt;
     // capacities the device chain was laid out for
     uint32_t cap_vox = 0, ucap = 0, tcap = 0, wsize = 0;
     uint64_t *wkeys = nullptr;
-    uint32_t *first_ord = nullptr, *wmin = nullptr;
+    uint32_t *first_ord = nullptr;
+    uint2 *wfm = nullptr;          // inside ff_arena: per slot {winner's first-seen ordinal, minimum loser ordinal} (one gather)
 
     // last results (host view)
     uint32_t n_vox = 0, n_tris = 0, n_verts = 0, n_unique = 0;
@@ -198,22 +199,21 @@ int layout_mesh(sdmesh_handle *h, uint32_t n_cap, uint32_t u_cap_hint) {
     SDCHK(ensure(h, h->torder, 4ull * ucap));
     SDCHK(ensure(h, h->flip, (size_t) tcap + 64));
     SDCHK(ensure(h, h->wvidx, 4ull * wsize));
-    SDCHK(ensure(h, h->wfirst, 4ull * wsize));
     SDCHK(ensure(h, h->vertices, sizeof(Vertex) * (size_t) uexp));
     SDCHK(ensure(h, h->indices, 12ull * tcap));
     // one arena for everything that must start as 0xFF (weld keys + loser minima): one memset per regen
-    const size_t o_wkeys = 0, o_wmin = align256(o_wkeys + 8ull * wsize), total = align256(o_wmin + 4ull * wsize);
+    const size_t o_wkeys = 0, o_wfm = align256(o_wkeys + 8ull * wsize), total = align256(o_wfm + 8ull * wsize);
     SDCHK(ensure(h, h->ff_arena, total));
     char *base = (char *) h->ff_arena.p;
     h->wkeys = (uint64_t *) (base + o_wkeys);
-    h->wmin = (uint32_t *) (base + o_wmin);
+    h->wfm = (uint2 *) (base + o_wfm);
     h->first_ord = (uint32_t *) h->first_ord_buf.p;
     h->wsize = wsize; h->ucap = ucap; h->tcap = tcap; h->cap_vox = n_cap;
     return SDMESH_OK;
 }
 
 size_t ff_bytes(const sdmesh_handle *h) {
-    return (size_t) ((char *) h->wmin - (char *) h->ff_arena.p) + 4ull * h->wsize;
+    return (size_t) ((char *) h->wfm - (char *) h->ff_arena.p) + 8ull * h->wsize;
 }
 
 // classify -> tile dedupe -> project -> flip for the voxel list d_vox (count at *n_ptr, at most cap_vox):
@@ -266,7 +266,7 @@ int mesh_front(sdmesh_handle *h, const Point *d_vox, const uint32_t *n_ptr, Poin
 int mesh_weld(sdmesh_handle *h, const Vertex *uverts) {
     hipStream_t st = h->stream;
     HIPCHK(launch_weld(st, h->tgrid, uverts, (const uint4 *) h->tdesc.p, h->d_ctr + CTR_NTILES, (uint32_t *) h->tri_e.p,
-                       (const uint8_t *) h->flip.p, h->first_ord, h->wmin, (uint32_t *) h->wfirst.p, (const uint32_t *) h->vslot.p,
+                       (const uint8_t *) h->flip.p, h->first_ord, h->wfm, (const uint32_t *) h->vslot.p,
                        (uint32_t *) h->wvidx.p, (uint32_t *) h->torder.p, (uint32_t *) h->tfirst.p, (uint32_t *) h->tfpre.p,
                        (Vertex *) h->vertices.p, (uint32_t) (h->vertices.cap / sizeof(Vertex)), h->d_ctr + CTR_NVERT,
                        (uint32_t *) h->indices.p, h->d_status));
@@ -760,7 +760,7 @@ void sdmesh_destroy(sdmesh_handle *h) {
     if (h->stream) (void) hipStreamSynchronize(h->stream);
     drop_graph(h);
     DevBuf *bufs[] = {&h->vox[0], &h->vox[1], &h->mask, &h->mask2x, &h->signs, &h->tilecnt, &h->ctl, &h->cubeidx, &h->trioff, &h->ff_arena,
-                      &h->first_ord_buf, &h->wfirst, &h->uverts, &h->tri_e, &h->vslot, &h->tdesc, &h->tfirst, &h->tfpre, &h->tpre, &h->flip, &h->wvidx, &h->torder,
+                      &h->first_ord_buf, &h->uverts, &h->tri_e, &h->vslot, &h->tdesc, &h->tfirst, &h->tfpre, &h->tpre, &h->flip, &h->wvidx, &h->torder,
                       &h->vertices, &h->indices, &h->raw, &h->compact, &h->staging, &h->dense_samples, &h->dense_bits,
                       &h->cellcnt};
     for (DevBuf *b : bufs) release(*b);

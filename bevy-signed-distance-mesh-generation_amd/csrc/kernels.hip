@@ -710,7 +710,7 @@ __global__ __launch_bounds__(256) void k_tile_dedupe(const Point *__restrict__ v
 //   key  = 3 x 21-bit biased round(x * 1e5)  (covers +-10.48 units; the bounding cube is +-2.5)
 //   claim: one CAS per pre-weld vertex; the claimer is the "winner" (bit 31 of its vslot entry), everyone
 //   else who finds the key present is a "loser".  Later the winner stores its first-seen ordinal with a
-//   plain store (wfirst) and only losers pay an atomicMin (wmin): min(wfirst, wmin) is the key's first-seen
+//   plain store (wfm[slot].x) and only losers pay an atomicMin (wfm[slot].y): min(x, y) is the key's first-seen
 //   ordinal whatever the arrival order.
 // ------------------------------------------------------------------------------------------
 static constexpr uint32_t VS_WINNER = 0x80000000u;
@@ -1004,7 +1004,7 @@ static constexpr uint32_t T_VMAX = 3072;
 __global__ __launch_bounds__(256) void k_tile_first(const uint4 *__restrict__ tdesc, const uint32_t *__restrict__ ntiles_ptr,
                                                      uint32_t *__restrict__ tri_e, const uint8_t *__restrict__ flip,
                                                      const uint32_t *__restrict__ vslot, uint32_t *__restrict__ first_ord,
-                                                     uint32_t *__restrict__ wmin, uint32_t *__restrict__ wfirst) {
+                                                     uint2 *__restrict__ wfm /* per slot: {winner's ordinal, minimum loser ordinal} */) {
     __shared__ uint32_t s_first[T_VMAX];
     const uint32_t ntiles = *ntiles_ptr, tid = threadIdx.x;
     for (uint32_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
@@ -1030,8 +1030,8 @@ __global__ __launch_bounds__(256) void k_tile_first(const uint4 *__restrict__ td
             first_ord[e] = fo;
             const uint32_t vs = vslot[e];
             if (vs != U32_NONE) {
-                if (vs & VS_WINNER) wfirst[vs & VS_SLOT] = fo;
-                else if (fo != U32_NONE) atomicMin(&wmin[vs & VS_SLOT], fo);
+                if (vs & VS_WINNER) wfm[vs & VS_SLOT].x = fo;
+                else if (fo != U32_NONE) atomicMin(&wfm[vs & VS_SLOT].y, fo);
             }
         }
         __syncthreads();
@@ -1041,8 +1041,8 @@ __global__ __launch_bounds__(256) void k_tile_first(const uint4 *__restrict__ td
 // per tile: which vertices are first-seen, their rank by ordinal inside the tile, the tile's count.
 // wv[slot] = tile * 4096 + rank for the key's first-seen vertex; torder[3 * tbase + rank] = that vertex.
 __global__ __launch_bounds__(256) void k_tile_rank(const uint4 *__restrict__ tdesc, const uint32_t *__restrict__ ntiles_ptr,
-                                                    const uint32_t *__restrict__ first_ord, const uint32_t *__restrict__ wmin,
-                                                    const uint32_t *__restrict__ wfirst, const uint32_t *__restrict__ vslot,
+                                                    const uint32_t *__restrict__ first_ord, const uint2 *__restrict__ wfm,
+                                                    const uint32_t *__restrict__ vslot,
                                                     uint32_t *__restrict__ wv, uint32_t *__restrict__ torder,
                                                     uint32_t *__restrict__ tfirst) {
     __shared__ uint32_t s_bits[3 * T_TRI / 32];      // 120 words: one bit per local ordinal
@@ -1063,7 +1063,7 @@ __global__ __launch_bounds__(256) void k_tile_rank(const uint4 *__restrict__ tde
             if (i < d.y) {
                 const uint32_t vs = vslot[d.x + i], fo = first_ord[d.x + i];
                 if (vs != U32_NONE && fo != U32_NONE) {
-                    const uint32_t s = vs & VS_SLOT, a = wfirst[s], b = wmin[s];
+                    const uint32_t s = vs & VS_SLOT; const uint2 fm = wfm[s]; const uint32_t a = fm.x, b = fm.y;   // one 8-byte gather
                     if ((a < b ? a : b) == fo) { lo_of[k] = fo - 3u * d.z; slot_of[k] = s; }
                 }
             }
@@ -1072,7 +1072,7 @@ __global__ __launch_bounds__(256) void k_tile_rank(const uint4 *__restrict__ tde
         for (uint32_t i = tid + 512; i < d.y; i += 256) {            // rare: tiles with > 512 vertices
             const uint32_t vs = vslot[d.x + i], fo = first_ord[d.x + i];
             if (vs != U32_NONE && fo != U32_NONE) {
-                const uint32_t s = vs & VS_SLOT, a = wfirst[s], b = wmin[s];
+                const uint32_t s = vs & VS_SLOT; const uint2 fm = wfm[s]; const uint32_t a = fm.x, b = fm.y;   // one 8-byte gather
                 if ((a < b ? a : b) == fo) { const uint32_t lo = fo - 3u * d.z; atomicOr(&s_bits[lo >> 5], 1u << (lo & 31u)); extra = 1; }
             }
         }
@@ -1096,7 +1096,7 @@ __global__ __launch_bounds__(256) void k_tile_rank(const uint4 *__restrict__ tde
             for (uint32_t i = tid + 512; i < d.y; i += 256) {
                 const uint32_t vs = vslot[d.x + i], fo = first_ord[d.x + i];
                 if (vs != U32_NONE && fo != U32_NONE) {
-                    const uint32_t s = vs & VS_SLOT, a = wfirst[s], b = wmin[s];
+                    const uint32_t s = vs & VS_SLOT; const uint2 fm = wfm[s]; const uint32_t a = fm.x, b = fm.y;   // one 8-byte gather
                     if ((a < b ? a : b) == fo) {
                         const uint32_t lo = fo - 3u * d.z;
                         const uint32_t r = s_pre[lo >> 5] + __popc(s_bits[lo >> 5] & ((1u << (lo & 31u)) - 1u));
@@ -1688,11 +1688,11 @@ hipError_t launch_tile_claim(hipStream_t st, int grid, const Vertex *uverts, con
 
 // first -> rank -> scan -> finish (the claim has already happened: in k_project or k_weld_claim)
 hipError_t launch_weld(hipStream_t st, int grid, const Vertex *uverts, const uint4 *tdesc, const uint32_t *ntiles_ptr,
-                       uint32_t *tri_e, const uint8_t *flip, uint32_t *first_ord, uint32_t *wmin, uint32_t *wfirst,
+                       uint32_t *tri_e, const uint8_t *flip, uint32_t *first_ord, uint2 *wfm,
                        const uint32_t *vslot, uint32_t *wv, uint32_t *torder, uint32_t *tfirst, uint32_t *tfpre,
                        Vertex *vertices, uint32_t vcap, uint32_t *nverts_out, uint32_t *indices, uint32_t *status) {
-    hipLaunchKernelGGL(k_tile_first, dim3(grid), dim3(256), 0, st, tdesc, ntiles_ptr, tri_e, flip, vslot, first_ord, wmin, wfirst);
-    hipLaunchKernelGGL(k_tile_rank, dim3(grid), dim3(256), 0, st, tdesc, ntiles_ptr, first_ord, wmin, wfirst, vslot, wv, torder,
+    hipLaunchKernelGGL(k_tile_first, dim3(grid), dim3(256), 0, st, tdesc, ntiles_ptr, tri_e, flip, vslot, first_ord, wfm);
+    hipLaunchKernelGGL(k_tile_rank, dim3(grid), dim3(256), 0, st, tdesc, ntiles_ptr, first_ord, wfm, vslot, wv, torder,
                        tfirst);
     hipLaunchKernelGGL(k_scan_u32, dim3(1), dim3(1024), 0, st, tfirst, ntiles_ptr, tfpre, nverts_out);
     hipLaunchKernelGGL(k_tile_finish, dim3(grid), dim3(256), 0, st, uverts, tdesc, ntiles_ptr, tfpre, tfirst, torder, tri_e, vslot,

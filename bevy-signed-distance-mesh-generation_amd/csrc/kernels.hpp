@@ -55,7 +55,7 @@ hipError_t launch_raw_desc(hipStream_t st, int grid, const uint32_t *ntri_ptr, u
 hipError_t launch_tile_claim(hipStream_t st, int grid, const Vertex *uverts, const uint4 *tdesc, const uint32_t *ntiles_ptr,
                              uint64_t *wkeys, uint32_t wsize, uint32_t *vslot, uint32_t *status);
 hipError_t launch_weld(hipStream_t st, int grid, const Vertex *uverts, const uint4 *tdesc, const uint32_t *ntiles_ptr,
-                       uint32_t *tri_e, const uint8_t *flip, uint32_t *first_ord, uint32_t *wmin, uint32_t *wfirst,
+                       uint32_t *tri_e, const uint8_t *flip, uint32_t *first_ord, uint2 *wfm,
                        const uint32_t *vslot, uint32_t *wv, uint32_t *torder, uint32_t *tfirst, uint32_t *tfpre,
                        Vertex *vertices, uint32_t vcap, uint32_t *nverts_out, uint32_t *indices, uint32_t *status);
 hipError_t launch_expand_compact(hipStream_t st, int grid, const Vertex *uverts, const uint32_t *tri_e, const uint8_t *flip,
