@@ -58,6 +58,16 @@ class Mesh(ctypes.Structure):
     _fields_ = [("vertices", ctypes.c_void_p), ("vertex_count", ctypes.c_uint), ("triangles", ctypes.c_void_p)]
 
 
+class GlobalsBuffer(ctypes.Structure):
+    _fields_ = [("tick", ctypes.c_ulonglong), ("time", ctypes.c_float), ("render_texture_size", ctypes.c_uint * 2),
+                ("render_screen_size", ctypes.c_float * 2)]
+
+
+class CameraBuffer(ctypes.Structure):
+    _fields_ = [("position", ctypes.c_float * 3), ("forward", ctypes.c_float * 3), ("up", ctypes.c_float * 3),
+                ("right", ctypes.c_float * 3), ("fov", ctypes.c_float)]
+
+
 class RegenInfo(ctypes.Structure):
     _fields_ = [("levels", ctypes.c_uint32), ("voxel_count", ctypes.c_uint32 * (MAX_LEVELS + 1)),
                 ("unique_edges", ctypes.c_uint32), ("triangles", ctypes.c_uint32), ("vertices", ctypes.c_uint32),
@@ -66,6 +76,7 @@ class RegenInfo(ctypes.Structure):
 
 
 assert ctypes.sizeof(VoxelField) == 32 and ctypes.sizeof(Mesh) == 24 and ctypes.sizeof(Point) == 12
+assert ctypes.sizeof(GlobalsBuffer) == 32 and ctypes.sizeof(CameraBuffer) == 52
 
 # every symbol include/sdmesh.h declares: name -> (restype, argtypes)
 _vp, _sz, _i, _u32 = ctypes.c_void_p, ctypes.c_size_t, ctypes.c_int, ctypes.c_uint32
@@ -98,6 +109,8 @@ SYMBOLS = {
     "sdmesh_regen_dense": (_i, [_vp, _i, ctypes.POINTER(RegenInfo)]),
     "sdmesh_sample_dense": (_i, [_vp, _u32, _vp, ctypes.POINTER(ctypes.c_float)]),
     "sdmesh_time_kernel": (_i, [_vp, _i, _u32, _vp, _i, ctypes.POINTER(ctypes.c_float)]),
+    "sdmesh_render": (_i, [_vp, _vp, _vp, _vp]),
+    "sdmesh_render_device": (_i, [_vp, _vp, _vp, _vp, ctypes.POINTER(ctypes.c_float)]),
 }
 
 _LIB = None

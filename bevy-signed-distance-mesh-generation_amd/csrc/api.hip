@@ -99,6 +99,7 @@ struct sdmesh_handle {
     // voxel lists (ping-pong), refine scratch
     DevBuf vox[2];
     int cur = 0;
+    DevBuf render_tex;                             // RGBA8 target of the ray-march preview
     DevBuf mask, mask2x, signs, tilecnt, ctl;             // ctl: counters + status + pre-zeroed per-level tile counters
     uint32_t lvl_off[SDMESH_MAX_LEVELS + 2] = {0};
     // counters / status
@@ -759,7 +760,7 @@ void sdmesh_destroy(sdmesh_handle *h) {
     (void) hipSetDevice(h->device);
     if (h->stream) (void) hipStreamSynchronize(h->stream);
     drop_graph(h);
-    DevBuf *bufs[] = {&h->vox[0], &h->vox[1], &h->mask, &h->mask2x, &h->signs, &h->tilecnt, &h->ctl, &h->cubeidx, &h->trioff, &h->ff_arena,
+    DevBuf *bufs[] = {&h->render_tex, &h->vox[0], &h->vox[1], &h->mask, &h->mask2x, &h->signs, &h->tilecnt, &h->ctl, &h->cubeidx, &h->trioff, &h->ff_arena,
                       &h->first_ord_buf, &h->uverts, &h->tri_e, &h->vslot, &h->tdesc, &h->tfirst, &h->tfpre, &h->tpre, &h->flip, &h->wvidx, &h->torder,
                       &h->vertices, &h->indices, &h->raw, &h->compact, &h->staging, &h->dense_samples, &h->dense_bits,
                       &h->cellcnt};
@@ -1236,6 +1237,38 @@ int sdmesh_time_kernel(sdmesh_handle *h, int which, uint32_t N, float *d_buf, in
     float ms = 0.0f;
     HIPCHK(hipEventElapsedTime(&ms, h->ev0, h->ev1));
     *avg_ms = ms / (float) iters;
+    return SDMESH_OK;
+}
+
+
+int sdmesh_render_device(sdmesh_handle *h, const GlobalsBuffer *globals, const CameraBuffer *camera, Rgba *d_target, float *kernel_ms) {
+    if (!h || !globals || !camera || !d_target) return SDMESH_ERR_INVALID;
+    const uint32_t w = globals->render_texture_size[0], ht = globals->render_texture_size[1];
+    if (w == 0 || ht == 0 || w > 16384 || ht > 16384) return fail(h, SDMESH_ERR_INVALID, "render size %u x %u out of range", w, ht);
+    HIPCHK(hipSetDevice(h->device));
+    SDCHK(sync_scene(h));
+    float cam13[12];
+    for (int i = 0; i < 3; i++) { cam13[i] = camera->position[i]; cam13[3 + i] = camera->forward[i]; cam13[6 + i] = camera->up[i]; cam13[9 + i] = camera->right[i]; }
+    const float fov_fac = tanf(camera->fov / 2);                 // common.cu:86, once per frame instead of once per pixel
+    HIPCHK(hipEventRecord(h->ev0, h->stream));
+    HIPCHK(launch_render(h->stream, h->scene, h->d_sp, cam13, fov_fac, globals->render_screen_size[0], globals->render_screen_size[1],
+                         (float) globals->render_texture_size[0], (float) globals->render_texture_size[1], w, ht, d_target));
+    HIPCHK(hipEventRecord(h->ev1, h->stream));
+    if (kernel_ms) {
+        HIPCHK(hipStreamSynchronize(h->stream));
+        HIPCHK(hipEventElapsedTime(kernel_ms, h->ev0, h->ev1));
+    }
+    return SDMESH_OK;
+}
+
+int sdmesh_render(sdmesh_handle *h, const GlobalsBuffer *globals, const CameraBuffer *camera, Rgba *target) {
+    if (!h || !globals || !camera || !target) return SDMESH_ERR_INVALID;
+    const size_t bytes = 4ull * globals->render_texture_size[0] * globals->render_texture_size[1];
+    HIPCHK(hipSetDevice(h->device));
+    SDCHK(ensure(h, h->render_tex, std::max<size_t>(bytes, 256)));          // grow-only, like render_texture_buffer (mod.rs:364-366)
+    SDCHK(sdmesh_render_device(h, globals, camera, (Rgba *) h->render_tex.p, nullptr));
+    HIPCHK(hipMemcpyAsync(target, h->render_tex.p, bytes, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(hipStreamSynchronize(h->stream));
     return SDMESH_OK;
 }
 

@@ -45,6 +45,8 @@ hipError_t launch_tile_prefix(hipStream_t st, const uint4 *tdesc, const uint32_t
                               uint32_t *coarse);
 hipError_t launch_project(hipStream_t st, int grid, int scene, const SceneParams *sp, Vertex *uverts, const uint4 *tdesc,
                           const uint32_t *tpre, const uint32_t *coarse, const uint32_t *ntiles_ptr, uint32_t *status, int lanes = 4);
+hipError_t launch_render(hipStream_t st, int scene, const SceneParams *sp, const float *cam13, float fov_fac, float screen_x,
+                         float screen_y, float gtex_x, float gtex_y, uint32_t width, uint32_t height, void *rgba);
 hipError_t launch_flip_claim(hipStream_t st, int flip_grid, int claim_grid, int scene, const SceneParams *sp, const Vertex *uverts,
                             const uint32_t *tri_e, const uint32_t *ntri_ptr, uint8_t *flip, int lanes, const uint4 *tdesc,
                             const uint32_t *ntiles_ptr, uint64_t *wkeys, uint32_t wsize, uint32_t *vslot, uint32_t *status);

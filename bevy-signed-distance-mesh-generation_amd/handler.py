@@ -246,6 +246,26 @@ class CudaHandler:
         self._chk(self._lib.sdmesh_device_mesh(self._h, ctypes.byref(m), ctypes.byref(nt)))
         return m, nt.value
 
+    def render(self, width, height, position, forward, up, right, fov, screen=None, dev_ptr=None):
+        """CudaHandler::render (src/cuda/mod.rs:348): ray-march preview of the current scene as an RGBA8 image
+        [height, width, 4].  With dev_ptr the image is written to that device buffer and the kernel time (ms) returned."""
+        from ._abi import CameraBuffer, GlobalsBuffer
+        g = GlobalsBuffer()
+        g.render_texture_size[0], g.render_texture_size[1] = int(width), int(height)
+        sw, sh = screen or (float(width), float(height))
+        g.render_screen_size[0], g.render_screen_size[1] = sw, sh
+        c = CameraBuffer()
+        for i in range(3):
+            c.position[i], c.forward[i], c.up[i], c.right[i] = position[i], forward[i], up[i], right[i]
+        c.fov = fov
+        if dev_ptr is not None:
+            ms = ctypes.c_float(0.0)
+            self._chk(self._lib.sdmesh_render_device(self._h, ctypes.byref(g), ctypes.byref(c), ctypes.c_void_p(dev_ptr), ctypes.byref(ms)))
+            return ms.value
+        img = np.empty((int(height), int(width), 4), np.uint8)
+        self._chk(self._lib.sdmesh_render(self._h, ctypes.byref(g), ctypes.byref(c), img.ctypes.data))
+        return img
+
     def device_mesh_tensors(self, device):
         """Zero-copy torch views of the welded mesh in HBM: vertices [V, 6] float32 (position, normal) and triangles
         [T, 3] int32.  Valid until the next call that regenerates the mesh on this handle."""

@@ -199,6 +199,17 @@ int sdmesh_sample_dense(sdmesh_handle *h, uint32_t N, float *d_out, float *kerne
  * 2 = write ceiling (P1's store stream over the same 4 (N+1)^3 bytes with no arithmetic). */
 int sdmesh_time_kernel(sdmesh_handle *h, int which, uint32_t N, float *d_buf, int iters, float *avg_ms);
 
+/* ---- ray-march preview ------------------------------------------------ */
+
+/* CudaHandler::render (src/cuda/mod.rs:348-420): sphere-traces the current scene (plus the bounding-cube wire frame of
+ * compute_render.cu:8-16) into an RGBA8 image of globals->render_texture_size, kernel compute_render
+ * (cuda/modules/compute_render.cu:21-97).  target: host buffer of 4 * width * height bytes, as the reference's
+ * target_image.  tan(fov / 2) is evaluated once on the host (the reference evaluates the same value per pixel). */
+int sdmesh_render(sdmesh_handle *h, const struct GlobalsBuffer *globals, const struct CameraBuffer *camera, struct Rgba *target);
+/* Same, into a DEVICE buffer (a renderer that keeps the image on the GPU); *kernel_ms (optional) = HIP-event time. */
+int sdmesh_render_device(sdmesh_handle *h, const struct GlobalsBuffer *globals, const struct CameraBuffer *camera,
+                         struct Rgba *d_target, float *kernel_ms);
+
 #ifdef __cplusplus
 }
 #endif

@@ -49,6 +49,36 @@ struct Mesh {                             /* bindings.h:70-75 (declared, unused 
     struct IndexTriangle *triangles;
 };
 
+/* ---- ray-march preview (row N4), cuda/includes/bindings.h:12-41 ---- */
+enum RayMarchHitOutcome { Collision, StepLimit, DepthLimit };
+
+struct GlobalsBuffer {                    /* bindings.h:16-21 */
+    unsigned long long tick;
+    float time;
+    unsigned int render_texture_size[2];
+    float render_screen_size[2];
+};
+
+struct CameraBuffer {                     /* bindings.h:23-29 */
+    float position[3];
+    float forward[3];
+    float up[3];
+    float right[3];
+    float fov;
+};
+
+struct Rgba {                             /* bindings.h:31-36 */
+    unsigned char r;
+    unsigned char g;
+    unsigned char b;
+    unsigned char a;
+};
+
+struct RenderTexture {                    /* bindings.h:38-41 */
+    unsigned int size[2];
+    struct Rgba *data;
+};
+
 #ifdef __cplusplus
 #define SDMESH_SA(c, m) static_assert(c, m)
 #else
@@ -62,6 +92,11 @@ SDMESH_SA(sizeof(struct Triangle) == 72, "Triangle");
 SDMESH_SA(sizeof(struct IndexTriangle) == 12, "IndexTriangle");
 SDMESH_SA(sizeof(struct Mesh) == 24 && offsetof(struct Mesh, vertex_count) == 8 &&
           offsetof(struct Mesh, triangles) == 16, "Mesh");
+SDMESH_SA(sizeof(struct GlobalsBuffer) == 32 && offsetof(struct GlobalsBuffer, render_texture_size) == 12 &&
+          offsetof(struct GlobalsBuffer, render_screen_size) == 20, "GlobalsBuffer");
+SDMESH_SA(sizeof(struct CameraBuffer) == 52 && offsetof(struct CameraBuffer, fov) == 48, "CameraBuffer");
+SDMESH_SA(sizeof(struct Rgba) == 4, "Rgba");
+SDMESH_SA(sizeof(struct RenderTexture) == 16 && offsetof(struct RenderTexture, data) == 8, "RenderTexture");
 #undef SDMESH_SA
 
 #endif /* SDMESH_BINDINGS_H */

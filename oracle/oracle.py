@@ -209,3 +209,23 @@ def regen(scene, levels, params=None):
 def dense_mc_count(scene, N, params=None):
     p = _params(params)
     return int(lib().orc_dense_mc_count(SCENES[scene], p.ctypes.data, int(N)))
+
+
+def render(scene, width, height, position, forward, up, right, fov, screen=None, params=None):
+    """Row N4: the ray-march preview (compute_render.cu) as an RGBA8 image [height, width, 4]."""
+    import ctypes as C
+    p = _params(params)
+    L = lib()
+    screen = screen or (float(width), float(height))
+    g = np.zeros(32, np.uint8)
+    g[12:20] = np.array([width, height], np.uint32).view(np.uint8)
+    g[20:28] = np.array(screen, np.float32).view(np.uint8)
+    cam = np.array(list(position) + list(forward) + list(up) + list(right) + [fov], np.float32)
+    L.orc_fov_fac.restype = C.c_float
+    L.orc_fov_fac.argtypes = [C.c_float]
+    fac = L.orc_fov_fac(C.c_float(fov))
+    out = np.zeros((height, width, 4), np.uint8)
+    L.orc_render.restype = None
+    L.orc_render.argtypes = [C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_float, C.c_uint32, C.c_uint32, C.c_void_p]
+    L.orc_render(SCENES[scene], p.ctypes.data, g.ctypes.data, cam.ctypes.data, C.c_float(fac), width, height, out.ctypes.data)
+    return out

@@ -564,3 +564,116 @@ void orc_eval_points(int scene, const float *params, const float *pts, long n, f
 }
 
 long long orc_weld_quant(float x) { return (long long) f32_discrete(x); }
+
+
+/* ===========================================================================================
+ * Row N4: the ray-march preview, cuda/modules/compute_render.cu:21-97 with
+ * common.cu:13-215 (coordinate helpers, pixel cone), ray_marching.cu:15-49 (sphere tracing) and
+ * color.cu:7-22 (ACES tone map).  One deliberate difference, stated in DESIGN.md: tan(fov / 2)
+ * (common.cu:86, the same value for every pixel) is evaluated ONCE by the caller and passed in as
+ * fov_fac, because libm's and the GPU's tanf are not bit-identical; everything else follows the
+ * reference's operation order.  "parity unpinned" like the rest of this file (no reference outputs).
+ * =========================================================================================== */
+typedef struct { unsigned long long tick; float time; unsigned int render_texture_size[2]; float render_screen_size[2]; } GlobalsBuffer;
+typedef struct { float position[3], forward[3], up[3], right[3]; float fov; } CameraBuffer;
+
+#define RAY_MARCH_STEP_LIMIT 256
+#define RAY_MARCH_DEPTH_LIMIT 500.0f
+#define RAY_MARCH_COLLISION_DISTANCE 0.001f
+#define SQRT_INV 0.7071067811865475f
+
+static float sd_scene(int scene, const float *params, v3 p) {          /* compute_render.cu:3-19 */
+    float sd = 3.40282347E+38f;
+    sd = gmin(sd, sdf_eval(scene, params, p));
+    sd = gmin(sd, sd_box_skeleton(p, V(0.0f, 0.0f, 0.0f), V(5.0f, 5.0f, 5.0f), 0.05f));
+    return sd;
+}
+
+static v3 scene_normal(int scene, const float *params, v3 p) {          /* signed_distance.cu:179-202 on sd_scene */
+#define F(dx, dy, dz) sd_scene(scene, params, vadd(p, V(dx, dy, dz)))
+    float dx = (-F(2.0f * NORMAL_EPSILON, 0.0f, 0.0f) + 8.0f * F(NORMAL_EPSILON, 0.0f, 0.0f) -
+                8.0f * F(-NORMAL_EPSILON, 0.0f, 0.0f) + F(-2.0f * NORMAL_EPSILON, 0.0f, 0.0f));
+    float dy = (-F(0.0f, 2.0f * NORMAL_EPSILON, 0.0f) + 8.0f * F(0.0f, NORMAL_EPSILON, 0.0f) -
+                8.0f * F(0.0f, -NORMAL_EPSILON, 0.0f) + F(0.0f, -2.0f * NORMAL_EPSILON, 0.0f));
+    float dz = (-F(0.0f, 0.0f, 2.0f * NORMAL_EPSILON) + 8.0f * F(0.0f, 0.0f, NORMAL_EPSILON) -
+                8.0f * F(0.0f, 0.0f, -NORMAL_EPSILON) + F(0.0f, 0.0f, -2.0f * NORMAL_EPSILON));
+#undef F
+    return normalize3(V(dx, dy, dz));
+}
+
+/* texture coordinate -> unit ray direction (common.cu:15-17, 73-92) */
+static v3 pixel_dir(float px, float py, float tw, float th, const GlobalsBuffer *g, const CameraBuffer *c, float fov_fac) {
+    const float nx = (px + 0.5f) / tw, ny = (py + 0.5f) / th;                       /* texture_to_ndc */
+    const float cx = (2.0f * nx - 1.0f) * (tw / th), cy = 1.0f - 2.0f * ny;         /* ndc_to_camera(p, texture size) */
+    const float sx = g->render_screen_size[0], sy = g->render_screen_size[1];
+    const float gx = (float) g->render_texture_size[0], gy = (float) g->render_texture_size[1];
+    const float width_factor = (sx / gx) * (gy / sy);
+    const v3 fw = V(c->forward[0], c->forward[1], c->forward[2]), up = V(c->up[0], c->up[1], c->up[2]),
+             rt = V(c->right[0], c->right[1], c->right[2]);
+    return normalize3(vadd(vadd(fw, vscale(up, cy * fov_fac)), vscale(rt, cx * fov_fac * width_factor)));
+}
+
+static v3 aces(v3 hdr) {                                                 /* color.cu:7-22, column-major mat3x3 */
+    const v3 v = V(0.59719f * hdr.x + 0.35458f * hdr.y + 0.04823f * hdr.z,
+                   0.07600f * hdr.x + 0.90834f * hdr.y + 0.01566f * hdr.z,
+                   0.02840f * hdr.x + 0.13383f * hdr.y + 0.83777f * hdr.z);
+    const v3 a = V(v.x * (v.x + 0.0245786f) - 0.000090537f, v.y * (v.y + 0.0245786f) - 0.000090537f,
+                   v.z * (v.z + 0.0245786f) - 0.000090537f);
+    const v3 b = V(v.x * (0.983729f * v.x + 0.4329510f) + 0.238081f, v.y * (0.983729f * v.y + 0.4329510f) + 0.238081f,
+                   v.z * (0.983729f * v.z + 0.4329510f) + 0.238081f);
+    const v3 q = V(a.x / b.x, a.y / b.y, a.z / b.z);
+    const v3 r = V(1.60475f * q.x + -0.53108f * q.y + -0.07367f * q.z,
+                   -0.10208f * q.x + 1.10813f * q.y + -0.00605f * q.z,
+                   -0.00327f * q.x + -0.07276f * q.y + 1.07602f * q.z);
+    return V(gmin(gmax(r.x, 0.0f), 1.0f), gmin(gmax(r.y, 0.0f), 1.0f), gmin(gmax(r.z, 0.0f), 1.0f));
+}
+
+float orc_fov_fac(float fov) { return tanf(fov / 2); }                   /* common.cu:86 */
+
+void orc_render(int scene, const float *params, const void *globals, const void *camera, float fov_fac,
+                uint32_t width, uint32_t height, uint8_t *rgba /* width * height * 4 */) {
+    const GlobalsBuffer *g = (const GlobalsBuffer *) globals;
+    const CameraBuffer *c = (const CameraBuffer *) camera;
+    const float tw = (float) width, th = (float) height;
+    const v3 light = normalize3(V(1.0f, 1.0f, 1.0f));
+#pragma omp parallel for schedule(dynamic, 4)
+    for (int64_t y = 0; y < (int64_t) height; y++)
+        for (uint32_t x = 0; x < width; x++) {
+            const v3 dir = pixel_dir((float) x, (float) y, tw, th, g, c, fov_fac);
+            /* get_pixel_cone_radius (common.cu:97-178) */
+            const v3 b0 = pixel_dir((float) x - SQRT_INV, (float) y - SQRT_INV, tw, th, g, c, fov_fac);
+            const v3 b1 = pixel_dir((float) x - SQRT_INV, (float) y + SQRT_INV, tw, th, g, c, fov_fac);
+            const v3 b2 = pixel_dir((float) x + SQRT_INV, (float) y - SQRT_INV, tw, th, g, c, fov_fac);
+            const v3 b3 = pixel_dir((float) x + SQRT_INV, (float) y + SQRT_INV, tw, th, g, c, fov_fac);
+            const float cone = gmax(gmax(length3(vsub(dir, b0)), length3(vsub(dir, b1))),
+                                    gmax(length3(vsub(dir, b2)), length3(vsub(dir, b3))));
+            /* ray_march (ray_marching.cu:15-49) */
+            v3 pos = V(c->position[0], c->position[1], c->position[2]);
+            float depth = 0.0f;
+            int outcome = 1;                                             /* StepLimit */
+            for (int steps = 0; steps < RAY_MARCH_STEP_LIMIT; steps++) {
+                const float cd = cone * depth;
+                const float d = sd_scene(scene, params, pos);
+                if (d <= cd + RAY_MARCH_COLLISION_DISTANCE) { outcome = 0; break; }
+                depth += (d - cd);
+                pos = vadd(pos, vscale(dir, d - cd));
+                if (depth > RAY_MARCH_DEPTH_LIMIT) { outcome = 2; break; }
+            }
+            v3 color = V(0.0f, 0.0f, 0.0f);
+            if (outcome == 0) {
+                const v3 n = scene_normal(scene, params, pos);
+                const float t = (dot3(n, light) + 1.0f) / 2.0f;
+                const v3 c1 = V(19.0f / 255.0f, 9.0f / 255.0f, 130.0f / 255.0f), c2 = V(240.0f / 255.0f, 103.0f / 255.0f, 24.0f / 255.0f);
+                color = vadd(vscale(c1, 1.0f - t), vscale(c2, t));       /* glm::mix */
+            } else if (outcome == 1) {
+                color = V(1.0f, 1.0f, 1.0f);
+            }
+            color = aces(color);
+            uint8_t *o = rgba + 4 * ((size_t) y * width + x);
+            o[0] = (uint8_t) (gmin(gmax(color.x, 0.0f), 1.0f) * 255.0f);
+            o[1] = (uint8_t) (gmin(gmax(color.y, 0.0f), 1.0f) * 255.0f);
+            o[2] = (uint8_t) (gmin(gmax(color.z, 0.0f), 1.0f) * 255.0f);
+            o[3] = 0xFF;
+        }
+    flush_evals();
+}

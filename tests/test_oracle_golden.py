@@ -113,3 +113,18 @@ def test_sd_obj_bug_is_preserved(oracle):
     assert abs(d[0] - (-0.1)) < 0.05 or d[0] < 0
     # close to the misplaced dir=1 bar at z=2.75, x=+1.5 (c1): a correct skeleton would be > 1 away
     assert oracle.sdf("sdobj", [[1.5, 0.0, 2.5]])[0] < 0.2
+
+
+def test_oracle_render_preview_is_sane_and_deterministic(oracle):
+    """Row N4 restatement (compute_render.cu): deterministic, opaque, centre pixel on the object, a ray that leaves the
+    scene is black, and the bounding-cube wire frame (compute_render.cu:8-16) shows up as step-limit / hit pixels."""
+    cam = dict(position=(0.0, 1.0, -6.0), forward=(0.0, -0.16439898, 0.98639392), up=(0.0, 0.98639392, 0.16439898),
+               right=(1.0, 0.0, 0.0), fov=1.0)
+    a = oracle.render("sdobj", 96, 64, **cam)
+    b = oracle.render("sdobj", 96, 64, **cam)
+    assert a.shape == (64, 96, 4) and (a == b).all() and (a[..., 3] == 255).all()
+    assert tuple(a[0, 0, :3]) == (0, 0, 0)                      # depth limit -> black
+    assert a[32, 48, :3].sum() > 0                              # the object
+    assert len(np.unique(a.reshape(-1, 4), axis=0)) > 50
+    s = oracle.render("sphere", 64, 64, **cam)
+    assert not np.array_equal(s, oracle.render("sdobj", 64, 64, **cam))
