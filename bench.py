@@ -324,6 +324,18 @@ def main():
         for hh in hs:
             hh.close()
 
+    # --- the ray-march preview of the same scene (pure VALU, one thread per pixel), 1080p
+    if rank == 0 and world == 1:
+        try:
+            tex = torch.empty((1080, 1920, 4), dtype=torch.uint8, device="cuda")
+            cam = ((0.0, 1.0, -6.0), (0.0, -0.16439898, 0.98639392), (0.0, 0.98639392, 0.16439898), (1.0, 0.0, 0.0))
+            rms = [h.render(1920, 1080, *cam, 1.0, None, dev_ptr=tex.data_ptr()) for _ in range(12)][2:]
+            out["render_preview"] = {"what": "sdmesh_render (compute_render.cu) of the workload scene, 1920x1080 RGBA8, kernel time",
+                                     "ms": round(float(np.median(rms)), 4), "mpixels_per_s": round(1920 * 1080 / float(np.median(rms)) / 1e3, 1)}
+            del tex
+        except Exception as e:          # noqa: BLE001
+            out["render_preview"] = {"error": f"{type(e).__name__}: {e}"[:200]}
+
     # --- BASELINE config 5: per-frame animated SDF (sphere centre (0, 0.5 sin t, 0), t = frame / 60), same grid
     if rank == 0 and not args.no_anim:
         ha = pkg.CudaHandler(local_rank, "anim", [0.5])
