@@ -1689,7 +1689,7 @@ template <int SCENE>
 __device__ __forceinline__ float sd_scene(f3 p, const SceneParams &sp) {          // compute_render.cu:3-19
     float sd = 3.40282347E+38f;
     sd = gmin(sd, sdf<SCENE>(p.x, p.y, p.z, sp));
-    sd = gmin(sd, sd_box_skeleton_g(p, mk(0.0f, 0.0f, 0.0f), mk(5.0f, 5.0f, 5.0f), 0.05f));
+    sd = gmin(sd, sqrtf(skeleton_cube5_min_d2(p.x, p.y, p.z)) - 0.05f);     // = sd_box_skeleton(p, 0, (5, 5, 5), 0.05), see sdf.hpp
     return sd;
 }
 

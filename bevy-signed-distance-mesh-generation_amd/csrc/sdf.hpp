@@ -133,6 +133,24 @@ SDM_HD float skeleton_min_d2(float px, float py, float pz) {
     return m;
 }
 
+// sd_box_skeleton(p, 0, (5, 5, 5), lw): the bounding-cube wire frame of the preview (compute_render.cu:8-16).  All
+// twelve bars are axis-aligned with ends at +-2.5 (with equal sides the `% 2` of signed_distance.cu:101 changes nothing),
+// so the same rewrite as skeleton_min_d2 applies: unit directions make sd_ray's dot / scale exact, the residual along
+// a bar is along_sq, across it a plain difference, and min_i(sqrt(d2_i) - lw) = sqrt(min_i d2_i) - lw.
+SDM_HD float skeleton_cube5_min_d2(float px, float py, float pz) {
+    const float ax = along_sq(px, -2.5f, 5.0f), ay = along_sq(py, -2.5f, 5.0f), az = along_sq(pz, -2.5f, 5.0f);
+    const float xm = sq(px - (-2.5f)), xp = sq(px - 2.5f);
+    const float ym = sq(py - (-2.5f)), yp = sq(py - 2.5f);
+    const float zm = sq(pz - (-2.5f)), zp = sq(pz - 2.5f);
+    // each d2 is (ex^2 + ey^2) + ez^2 in x, y, z order, as glm::dot evaluates it
+    const float x0 = ax + ym, x1 = ax + yp;
+    float m = fmin1(fmin1(x0 + zm, x0 + zp), fmin1(x1 + zm, x1 + zp));
+    const float y0 = xm + ay, y1 = xp + ay;
+    m = fmin1(m, fmin1(fmin1(y0 + zm, y0 + zp), fmin1(y1 + zm, y1 + zp)));
+    m = fmin1(m, fmin1(fmin1((xm + ym) + az, (xm + yp) + az), fmin1((xp + ym) + az, (xp + yp) + az)));
+    return m;
+}
+
 SDM_HD float sd_box(f3 p, f3 bp, f3 bs) {
     f3 d = sub3(p, bp);
     f3 hs = mk(bs.x / 2.0f, bs.y / 2.0f, bs.z / 2.0f);

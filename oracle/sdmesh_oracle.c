@@ -628,6 +628,12 @@ static v3 aces(v3 hdr) {                                                 /* colo
     return V(gmin(gmax(r.x, 0.0f), 1.0f), gmin(gmax(r.y, 0.0f), 1.0f), gmin(gmax(r.z, 0.0f), 1.0f));
 }
 
+/* probe for the host numerics test: the literal 12-bar loop on the preview's bounding-cube frame (compute_render.cu:8-16) */
+void orc_cube_frame(const float *pts, long n, float *out) {
+    for (long i = 0; i < n; i++)
+        out[i] = sd_box_skeleton(V(pts[3 * i], pts[3 * i + 1], pts[3 * i + 2]), V(0.0f, 0.0f, 0.0f), V(5.0f, 5.0f, 5.0f), 0.05f);
+}
+
 float orc_fov_fac(float fov) { return tanf(fov / 2); }                   /* common.cu:86 */
 
 void orc_render(int scene, const float *params, const void *globals, const void *camera, float fov_fac,

@@ -51,3 +51,8 @@ extern "C" int sdm_host_eval(int scene, const float *params, const float *pts, l
 }
 
 extern "C" long long sdm_host_weld_quant(float x) { return weld_quant(x); }
+
+// the preview's bounding-cube wire frame as rewritten in sdf.hpp (axis-aligned, sqrt of the minimum)
+extern "C" void sdm_host_cube_frame(const float *pts, long n, float *out) {
+    for (long i = 0; i < n; i++) out[i] = sqrtf(skeleton_cube5_min_d2(pts[3 * i], pts[3 * i + 1], pts[3 * i + 2])) - 0.05f;
+}

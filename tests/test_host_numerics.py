@@ -141,3 +141,22 @@ def test_random_programs_bit_exact_on_host(oracle, hostnum, seed):
     for a, b in ((nrm, ref["nrm"]), (proj, ref["proj"])):
         assert ((a.view(np.uint32) == b.view(np.uint32)) | (np.isnan(a) & np.isnan(b))).all()
     assert np.array_equal(flip, ref["flip"])
+
+
+def test_cube_frame_rewrite_bit_exact_on_host(oracle, hostnum):
+    """The preview's bounding-cube wire frame: sdf.hpp's axis-aligned rewrite (skeleton_cube5_min_d2) against the
+    oracle's literal 12-bar sd_box_skeleton(p, 0, (5, 5, 5), 0.05) -- random points, points on the bars, their ends,
+    the face planes and far outside."""
+    rng = np.random.default_rng(77)
+    special = np.array([-2.5, 2.5, 0.0, -0.0, 2.45, -2.55, 1e-30, 7.5, -7.5, 2.5000002, -2.4999998])
+    pts = np.concatenate([_points(78, 3000), rng.choice(special, (4000, 3)), rng.uniform(-9, 9, (3000, 3)),
+                          rng.choice(special, (3000, 3)) + rng.uniform(-0.06, 0.06, (3000, 3))]).astype(np.float32)
+    n = len(pts)
+    a = np.zeros(n, np.float32); b = np.zeros(n, np.float32)
+    hostnum.sdm_host_cube_frame.argtypes = [ctypes.c_void_p, ctypes.c_long, ctypes.c_void_p]
+    hostnum.sdm_host_cube_frame(pts.ctypes.data, n, a.ctypes.data)
+    L = oracle.lib()
+    L.orc_cube_frame.argtypes = [ctypes.c_void_p, ctypes.c_long, ctypes.c_void_p]
+    L.orc_cube_frame.restype = None
+    L.orc_cube_frame(pts.ctypes.data, n, b.ctypes.data)
+    assert np.array_equal(a.view(np.uint32), b.view(np.uint32))
