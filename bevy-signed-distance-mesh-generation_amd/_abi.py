@@ -9,6 +9,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 # SDMESH_LIB: development override (A/B timing of two builds of this same library on one box, tools/ab_perf.py)
 LIB_PATH = os.environ.get("SDMESH_LIB") or os.path.join(_HERE, "libsdmesh.so")
 HSACO_PATH = os.path.join(_HERE, "compute_mesh_generation.hsaco")
+RENDER_HSACO_PATH = os.path.join(_HERE, "compute_render.hsaco")
 
 # numpy views of the boundary structs (include/sdmesh/bindings.h)
 POINT = np.dtype([("x", "<f4"), ("y", "<f4"), ("z", "<f4")])

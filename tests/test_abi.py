@@ -83,3 +83,6 @@ def test_code_object_has_reference_kernel_symbols(pkg):
             sizes = dict(re.findall(r"\.name:\s+(compute_\w+)[\s\S]*?\.kernarg_segment_size:\s+(\d+)", out))
             # (VoxelField, VoxelField) = 64 B; (VoxelField, Triangle*) = 40 B (+ hidden args)
             assert int(sizes.get("compute_refine_voxel_field_by_sdf", 64)) >= 64
+    # the preview's module: compute_render(RenderTexture 16 B, GlobalsBuffer 32 B, CameraBuffer 52 B) by value
+    assert os.path.exists(pkg.RENDER_HSACO_PATH)
+    assert b"compute_render" in open(pkg.RENDER_HSACO_PATH, "rb").read()
