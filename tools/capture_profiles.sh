@@ -13,6 +13,7 @@ run dense_write --kernel-trace --pmc WRITE_SIZE --output-format csv -d $O/dense_
 run dense_fetch --kernel-trace --pmc FETCH_SIZE --output-format csv -d $O/dense_fetch -- $P $R/tools/dense_once.py || exit 1
 run bench_trace --kernel-trace --stats --output-format csv -d $O/bench_trace -- $P $R/bench.py --steps 100 --warmup 10 --no-cpu-baseline --no-sizes --no-pipelined || exit 1
 cd $R && echo "== plain bench" && timeout -k 10 400 $P bench.py > $O/bench_plain.json 2> $O/bench_plain.stderr; echo "rc=$?"
+python3 $R/tools/streaming_window.py $O/bench_trace $O/streaming_window.csv
 # keep only the small summaries (the raw traces are large)
 find $O -name '*_kernel_trace.csv' -size +4M -delete
 find $O -name '*_counter_collection.csv' -size +8M -delete

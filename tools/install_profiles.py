@@ -11,6 +11,8 @@ shutil.copy(one(f"{P}/dense_fetch/**/*_counter_collection.csv"), f"profiles/{tag
 open(f"profiles/{tag}_bench_under_rocprof.json", "w").write(
     "".join(l for l in open(f"{P}/bench_trace.stdout") if l.startswith("{")))
 shutil.copy(f"{P}/bench_plain.json", f"profiles/{tag}_bench_plain.json")
+if os.path.exists(f"{P}/streaming_window.csv"):
+    shutil.copy(f"{P}/streaming_window.csv", f"profiles/{tag}_bench_streaming_kernels_timed_window.csv")
 rows = list(csv.DictReader(open(one(f"{P}/regen_pmc_sq/**/*_counter_collection.csv"))))
 agg = collections.defaultdict(lambda: collections.defaultdict(list))
 for r in rows:
