@@ -410,7 +410,6 @@ def main():
         roofs = {}
         for sc in ("sphere", args.scene):
             h.set_scene(sc, [0.25] if sc == "anim" else None)
-            h.time_kernel(0, n_grid, buf.data_ptr(), 150)          # untimed warm-up: the memory clocks take a few ms of streaming to settle
             ms = h.time_kernel(0, n_grid, buf.data_ptr(), 50)
             gbps = alg_bytes / (ms * 1e-3) / 1e9
             roofs[sc] = {"bound": "hbm", "kernel": f"k_sample_dense<{sc}>", "achieved": round(gbps, 1), "peak": HBM_PEAK_GBPS,
@@ -420,14 +419,12 @@ def main():
                          "gsamples_per_s": round((n_grid + 1) ** 3 / (ms * 1e-3) / 1e9, 1)}
         # P2a: sign bits of the dense lattice -- the streaming-READ pass (4 B x (N+1)^3 in, 1 bit per sample out)
         h.set_scene("sphere")
-        h.time_kernel(1, n_grid, buf.data_ptr(), 100)
         ms2 = h.time_kernel(1, n_grid, buf.data_ptr(), 50)
         gb2 = alg_bytes / (ms2 * 1e-3) / 1e9
         out["roofline_p2_sign_bits"] = {"bound": "hbm", "kernel": "k_sign_bits", "achieved": round(gb2, 1), "peak": HBM_PEAK_GBPS,
                                         "unit": "GB/s", "frac": round(gb2 / HBM_PEAK_GBPS, 4), "traffic": None,
                                         "bytes_per_launch": alg_bytes + alg_bytes / 32, "avg_launch_ms": round(ms2, 5)}
         # write ceiling on THIS box: P1's store stream (same bytes, same launch shape) with no arithmetic in front
-        h.time_kernel(2, n_grid, buf.data_ptr(), 100)
         ms3 = h.time_kernel(2, n_grid, buf.data_ptr(), 50)
         gb3 = alg_bytes / (ms3 * 1e-3) / 1e9
         h.set_scene(args.scene, params)
