@@ -410,6 +410,9 @@ def main():
         roofs = {}
         for sc in ("sphere", args.scene):
             h.set_scene(sc, [0.25] if sc == "anim" else None)
+            # untimed warm-up first: a burst of this kernel starts with a ~25 ms transient (per-launch 110 -> 143 -> 103 us on the
+            # sphere, tools/p1_burst.py + tools/window_avg.py) before it settles at the steady state the roofline is about
+            h.time_kernel(0, n_grid, buf.data_ptr(), 250)
             ms = h.time_kernel(0, n_grid, buf.data_ptr(), 50)
             gbps = alg_bytes / (ms * 1e-3) / 1e9
             roofs[sc] = {"bound": "hbm", "kernel": f"k_sample_dense<{sc}>", "achieved": round(gbps, 1), "peak": HBM_PEAK_GBPS,
