@@ -4,8 +4,11 @@
  * Layout-identical to the mesh-generation part of the reference's shared header
  * cuda/includes/bindings.h:7-10 (constants) and :43-75 (structs), which bindgen turns into
  * src/bindings/cuda.rs (build.rs:139-168).  Sizes/offsets are asserted below against the
- * table in SURVEY.md 8(b).  The render-only structs (GlobalsBuffer, CameraBuffer, Rgba,
- * RenderTexture, bindings.h:12-41) are out of scope and not declared.
+ * table in SURVEY.md 8(b).  The render structs (GlobalsBuffer, CameraBuffer, Rgba, RenderTexture,
+ * bindings.h:12-41) are declared too: they are the kernargs of the ray-march preview (row N4).
+ * Field names, C types, declaration order and the three constants are pinned against the reference's
+ * header by tests/test_reference_pins.py (fixture tests/golden/bindings_ref.json, made by
+ * tools/pin_mc_tables.py from the reference's own file).
  */
 #ifndef SDMESH_BINDINGS_H
 #define SDMESH_BINDINGS_H

@@ -1,0 +1,118 @@
+"""Pins against DATA the reference itself holds (tests/golden/*_ref.json, written by tools/pin_mc_tables.py from
+/root/reference/cuda/includes/marching_cubes_constants.cu:3-275 and cuda/includes/bindings.h:5-75).
+
+The reference ships no tests and no golden vectors; its marching-cubes tables and its FFI header are the only
+reference-held data on the hot path.  Product and oracle share one table generator, so without this pin a table
+error would be common-mode and invisible to HIP-vs-oracle parity."""
+import json
+import os
+import re
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "tools"))
+import gen_mc_tables as G  # noqa: E402
+
+GOLD = os.path.join(ROOT, "tests", "golden")
+
+
+def _ref_tables():
+    ref = json.load(open(os.path.join(GOLD, "mc_tables_ref.json")))
+    rows = []
+    for r in ref["triangle_table"]:
+        assert len(r) == 16
+        n = r.index(-1) if -1 in r else 16
+        assert all(v == -1 for v in r[n:]), "entries after the terminator"
+        rows.append(r[:n])
+    return [tuple(e) for e in ref["edge_table"]], rows
+
+
+def _decode_header(path):
+    """(rows, counts, edge corner pairs, edge masks) decoded from a generated header's packed arrays."""
+    txt = open(path).read()
+
+    def arr(name):
+        body = txt[txt.index(name):]
+        body = body[body.index("{") + 1: body.index("}")]
+        return [int(v.rstrip("ulUL"), 0) for v in re.findall(r"0x[0-9a-fA-F]+(?:ull)?|\d+", body)]
+
+    packed, counts, corners, masks = arr("MC_TRI_PACKED"), arr("MC_TRI_COUNT"), arr("MC_EDGE_CORNERS"), arr("MC_EDGE_MASK")
+    rows = []
+    for w in packed:
+        r = []
+        for i in range(16):
+            nib = (w >> (4 * i)) & 0xF
+            if nib == 0xF:
+                break
+            r.append(nib)
+        rows.append(r)
+    return rows, counts, [(c & 0xF, c >> 4) for c in corners], masks
+
+
+def test_generator_tables_equal_the_reference_tables():
+    edges, rows = _ref_tables()
+    assert [tuple(e) for e in G.EDGES] == edges
+    assert [list(r) for r in G.TRI] == rows
+
+
+def test_generated_headers_decode_to_the_reference_tables():
+    edges, rows = _ref_tables()
+    for rel in ("oracle/mc_tables.h", "bevy-signed-distance-mesh-generation_amd/csrc/mc_tables.hpp"):
+        h_rows, h_counts, h_edges, h_masks = _decode_header(os.path.join(ROOT, rel))
+        assert h_rows == rows, rel
+        assert h_counts == [len(r) // 3 for r in rows], rel
+        assert h_edges == edges, rel
+        assert h_masks == [sum(1 << e for e in set(r)) for r in rows], rel
+
+
+def test_edge_key_immediates_in_the_kernels_follow_the_reference_edge_table():
+    """kernels.hip edge_key() packs, per cube edge, the sum of its two corners' offsets (0, 1 or 2 per axis) two bits
+    each into three immediates; the corner offsets are compute_mesh_generation.cu:80-82 (+x iff c%4 in {1,2},
+    +y iff c%4 >= 2, +z iff c >= 4)."""
+    edges, _ = _ref_tables()
+    cox = lambda c: 1 if c % 4 in (1, 2) else 0   # noqa: E731
+    coy = lambda c: 1 if c % 4 >= 2 else 0        # noqa: E731
+    coz = lambda c: 1 if c >= 4 else 0            # noqa: E731
+    imm = [0, 0, 0]
+    for e, (a, b) in enumerate(edges):
+        for k, f in enumerate((cox, coy, coz)):
+            imm[k] |= (f(a) + f(b)) << (2 * e)
+    txt = open(os.path.join(ROOT, "bevy-signed-distance-mesh-generation_amd/csrc/kernels.hip")).read()
+    m = re.search(r"ox = \((0x[0-9a-f]+)u >> \(2 \* e\)\) & 3u, oy = \((0x[0-9a-f]+)u >> \(2 \* e\)\) & 3u, oz = \((0x[0-9a-f]+)u", txt)
+    assert m, "edge_key immediates not found"
+    assert [int(m.group(i), 16) for i in (1, 2, 3)] == imm
+
+
+def _our_header():
+    txt = open(os.path.join(ROOT, "include/sdmesh/bindings.h")).read()
+    txt = re.sub(r"/\*.*?\*/", " ", txt, flags=re.S)
+    return txt
+
+
+def test_bindings_constants_equal_the_reference_header():
+    ref = json.load(open(os.path.join(GOLD, "bindings_ref.json")))["constants"]
+    txt = _our_header()
+    for name in ("BLOCK_SIZE", "MESH_GENERATION_INIT_FACTOR", "MESH_GENERATION_BB_SIZE"):
+        m = re.search(r"#define\s+%s\s+(\S+)" % name, txt)
+        assert m and m.group(1) == ref[name], name
+
+
+def test_bindings_struct_fields_equal_the_reference_header():
+    """Same struct names, field names, C types, array extents and declaration order (=> same layout under the C ABI;
+    the numeric sizes/offsets are static-asserted in the header and checked in tests/test_abi.py)."""
+    ref = json.load(open(os.path.join(GOLD, "bindings_ref.json")))["structs"]
+    txt = _our_header()
+    ours = {}
+    for m in re.finditer(r"struct\s+(\w+)\s*\{(.*?)\}\s*;", txt, flags=re.S):
+        fields = []
+        for decl in m.group(2).split(";"):
+            decl = " ".join(decl.split())
+            if not decl:
+                continue
+            fm = re.match(r"(.+?)\s*(\**)\s*(\w+)\s*(\[\s*\d+\s*\])?$", decl)
+            ctype = (fm.group(1) + (" " + fm.group(2) if fm.group(2) else "")).strip()
+            fields.append({"name": fm.group(3), "type": ctype, "array": int(re.sub(r"\D", "", fm.group(4))) if fm.group(4) else 0})
+        ours[m.group(1)] = fields
+    assert set(ref) <= set(ours), set(ref) - set(ours)
+    for name, fields in ref.items():
+        assert ours[name] == fields, name

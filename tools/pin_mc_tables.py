@@ -1,0 +1,97 @@
+#!/usr/bin/env python3
+"""Pin the data the reference itself holds for the hot path into tests/golden/ (build container only).
+
+The reference ships no tests, so the only reference-held DATA on the path is
+  * the marching-cubes tables   cuda/includes/marching_cubes_constants.cu:3-16 (12 edge corner pairs),
+                                :18-275 (256 rows of 16 edge ids, -1 terminated)
+  * the three FFI constants     cuda/includes/bindings.h:7-10  (BLOCK_SIZE, MESH_GENERATION_INIT_FACTOR,
+                                MESH_GENERATION_BB_SIZE)
+  * the FFI struct field lists  cuda/includes/bindings.h:43-75 (names and C types in declaration order)
+This script parses those files as TEXT (no compilation, nothing executed) and writes the values -- a constant
+table and a handful of numbers, not source -- to tests/golden/mc_tables_ref.json and tests/golden/bindings_ref.json.
+tests/test_reference_pins.py then checks tools/gen_mc_tables.TRI/EDGES, oracle/mc_tables.h,
+csrc/mc_tables.hpp and include/sdmesh/bindings.h against them on every run (the reference itself does not travel).
+
+Usage: python tools/pin_mc_tables.py [/root/reference]
+"""
+import json
+import os
+import re
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def strip_comments(txt):
+    txt = re.sub(r"/\*.*?\*/", " ", txt, flags=re.S)
+    return re.sub(r"//[^\n]*", " ", txt)
+
+
+def braces_after(txt, name):
+    """The balanced {...} initialiser that follows `name` in txt."""
+    i = txt.index(name)
+    i = txt.index("{", i)
+    depth, j = 0, i
+    while True:
+        if txt[j] == "{":
+            depth += 1
+        elif txt[j] == "}":
+            depth -= 1
+            if depth == 0:
+                return txt[i:j + 1]
+        j += 1
+
+
+def int_rows(block):
+    inner = block.strip()[1:-1]
+    return [[int(v) for v in re.findall(r"-?\d+", row)] for row in re.findall(r"\{([^{}]*)\}", inner)]
+
+
+def pin_tables(ref):
+    path = os.path.join(ref, "cuda/includes/marching_cubes_constants.cu")
+    txt = strip_comments(open(path).read())
+    edges = int_rows(braces_after(txt, "MC_EDGE_TABLE"))
+    rows = int_rows(braces_after(txt, "MC_TRIANGLE_TABLE"))
+    assert len(edges) == 12 and all(len(e) == 2 for e in edges), "edge table shape"
+    assert len(rows) == 256 and all(len(r) == 16 for r in rows), "triangle table shape"
+    return {"source": "cuda/includes/marching_cubes_constants.cu:3-16 (MC_EDGE_TABLE), :18-275 (MC_TRIANGLE_TABLE)",
+            "edge_table": edges, "triangle_table": rows}
+
+
+def pin_bindings(ref):
+    path = os.path.join(ref, "cuda/includes/bindings.h")
+    txt = strip_comments(open(path).read())
+    consts = {}
+    for name in ("BLOCK_SIZE", "MESH_GENERATION_INIT_FACTOR", "MESH_GENERATION_BB_SIZE", "CUDA_DEBUG"):
+        m = re.search(r"#define\s+%s\s+(\S+)" % name, txt)
+        if m:
+            consts[name] = m.group(1)
+    structs = {}
+    for m in re.finditer(r"struct\s+(\w+)\s*\{(.*?)\}\s*;", txt, flags=re.S):
+        fields = []
+        for decl in m.group(2).split(";"):
+            decl = " ".join(decl.split())
+            if not decl:
+                continue
+            fm = re.match(r"(.+?)\s*(\**)\s*(\w+)\s*(\[\s*\d+\s*\])?$", decl)
+            ctype = (fm.group(1) + (" " + fm.group(2) if fm.group(2) else "")).strip()
+            fields.append({"name": fm.group(3), "type": ctype, "array": int(re.sub(r"\D", "", fm.group(4))) if fm.group(4) else 0})
+        structs[m.group(1)] = fields
+    return {"source": "cuda/includes/bindings.h:5-10 (constants), :12-75 (structs, declaration order)",
+            "constants": consts, "structs": structs}
+
+
+def main():
+    ref = sys.argv[1] if len(sys.argv) > 1 else "/root/reference"
+    out = os.path.join(ROOT, "tests", "golden")
+    with open(os.path.join(out, "mc_tables_ref.json"), "w") as f:
+        json.dump(pin_tables(ref), f, separators=(",", ":"))
+        f.write("\n")
+    with open(os.path.join(out, "bindings_ref.json"), "w") as f:
+        json.dump(pin_bindings(ref), f, indent=1)
+        f.write("\n")
+    print("pinned", out)
+
+
+if __name__ == "__main__":
+    main()
