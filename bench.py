@@ -9,13 +9,21 @@ One "step" = one full regen of the workload on the device: level-0 field -> 4 hi
 -> marching cubes -> Newton projection + normals -> orientation -> vertex weld, ending with the indexed
 mesh resident in HBM (SURVEY.md 8(d) t_regen).  Nothing is uploaded: the SDF is the input.
 
-metric   Mvoxels/s = N_grid^3 * steps * n_gpus / wall  (BASELINE.json: "Mvoxels/s + Mtris/s for 512^3 SDF
-         mesh extract"); Mtris/s rides along in "mtris_per_s".
-N > 1    every rank regenerates the same workload independently (the path shards by object/frame with no
-         data-path exchange) -> "scaling": "weak".  The single-mesh z-slab + RCCL-gather + root-weld path is
-         exercised and timed separately under "sharded" (strong scaling of ONE mesh, reported, not `value`).
+metric   Mvoxels/s = N_grid^3 * steps / wall  (BASELINE.json: "Mvoxels/s + Mtris/s for 512^3 SDF mesh extract;
+         1/2/4/8-GPU scaling"); Mtris/s rides along in "mtris_per_s".
+N = 1    the step runs on one GPU.
+N > 1    the step is ONE mesh over all N GPUs (`sdmesh_sharded_regen`): rank r meshes level-0 z-slab r,
+         RCCL all-gather of the per-column counts, RCCL send/recv of the per-slab triangle lists to rank 0, merge kernel,
+         weld on rank 0 -> "scaling": "strong".  `one_mesh` repeats that at 512^3 / 1024^3 (BASELINE configs[3]) /
+         2048^3 / 4096^3 with the same-size 1-rank time measured in the same invocation, for both one-mesh forms (z-slab
+         gather + root weld; x-slab distributed weld), plus `ranks_seen` from an RCCL all-reduce.  N independent regens
+         (no exchange at all) are reported as the extra `replicas`.  A failure or hang in any multi-rank leg is a failure
+         of the run: every rank exits non-zero.
 roofline the north-star HBM pass P1 = dense (N+1)^3 f32 SDF sample, timed live with HIP events on the
          stream the kernel runs on: algorithmic bytes 4*(N+1)^3 per launch / average launch time, vs 8 TB/s.
+roofline_step  the two throughput-bound kernels of the timed step itself (k_project1, k_flip_claim): VALU wave-instructions
+         per launch (SQ_INSTS_VALU from the committed PMC pass, profiles/constants.json) / live stage time (HIP events
+         between the stages, option "profile") vs the VALU issue peak and vs the measured micro-benchmark ceiling.
 cpu_baseline  the CPU oracle (oracle/, a port of the reference algorithm) on the host cores of this box,
          same workload, whole regen, all cores ("port").  Reported, not a target.
 """
@@ -23,6 +31,7 @@ import argparse
 import json
 import os
 import sys
+import threading
 import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
@@ -35,9 +44,18 @@ import torch.distributed as dist  # noqa: E402
 import sdmesh_pkg  # noqa: E402
 
 HBM_PEAK_GBPS = 8000.0          # MI355X_MICROARCH.md "HBM3E peak BW 8.0 TB/s spec"
-# HBM bytes per P1 launch at N = 512 from the PMC passes committed under profiles/ (WRITE_SIZE 527 366 KiB exact for
-# 16-B streaming stores + 2 x FETCH_SIZE ~0.1 MB, gfx950 correction): equal to the algorithmic 4 B x 513^3.
-P1_TRAFFIC_512 = 527366 * 1024 + 2 * 54 * 1024
+# VALU issue peak in wave64 instructions per second: 157.3 TFLOP/s f32 (MI355X_MICROARCH.md "Peak FP32 (vector)") / 2 flop
+# per FMA lane / 64 lanes = 1024 SIMDs x 2.4 GHz / 2 cycles per wave64 instruction
+VALU_PEAK_WAVE_INSTR_PER_S = 157.3e12 / 2 / 64
+
+
+def load_constants():
+    """Measured constants that cannot be collected from inside this process (PMC passes), committed under profiles/ by
+    tools/install_profiles.py together with the rocprofv3 files they come from."""
+    try:
+        return json.load(open(os.path.join(ROOT, "profiles", "constants.json")))
+    except Exception:                       # noqa: BLE001 -- the fields that need them become null
+        return {}
 
 
 def host_cores():
@@ -91,68 +109,226 @@ def cpu_baseline(scene, levels, params):
     return out
 
 
-def sharded_leg(pkg, h, levels, world, rank, steps, warmup):
-    """ONE mesh across all ranks (strong scaling) -- partition.ShardedMesher: z-slab regen per rank,
-    all-gather of 1024 column counts, send/recv of the compact triangle lists to the root, order-restoring merge and
-    weld on the root.  Returns ms per regen (max over ranks) and the root's mesh counts."""
-    from bevy_signed_distance_mesh_generation_amd import partition as P
-    dev = torch.device("cuda", torch.cuda.current_device())
-    h.set_option("graph", 0)
-    h.set_stream(torch.cuda.current_stream().cuda_stream)      # one stream for kernels, merge and collectives
-    mesher = P.ShardedMesher(pkg, h, levels, rank, world, dev)
-    result = {}
-    for _ in range(warmup):
-        mesher.step()
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(steps):
-        winfo = mesher.step()
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
-    dt = time.perf_counter() - t0
-    if winfo is not None:
-        result["triangles"], result["vertices"] = int(winfo.triangles), int(winfo.vertices)
-    if world > 1:
-        t = torch.tensor([dt], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
-    h.set_option("skip_weld", 0)
-    h.set_stream(None)
-    return dt / steps * 1e3, result
+class Job:
+    """Rank bookkeeping, barrier-bracketed timing (max over ranks) and the hang watchdog."""
+
+    def __init__(self, world, rank):
+        self.world, self.rank = world, rank
+        self.dog = None
+
+    def sync(self):
+        if self.world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    def timed(self, fn, steps, warmup):
+        """`warmup` untimed calls, then exactly `steps` timed ones bracketed by barrier + synchronize on both sides;
+        seconds for the timed region, max over ranks.  Returns (seconds, last result)."""
+        res = None
+        for _ in range(warmup):
+            res = fn()
+        self.sync()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            res = fn()
+        self.sync()
+        dt = time.perf_counter() - t0
+        if self.world > 1:
+            t = torch.tensor([dt], dtype=torch.float64, device="cuda")
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            dt = float(t.item())
+        return dt, res
+
+    def arm_watchdog(self, seconds, what):
+        """A hung collective or GPU must not look like a pass: after `seconds` every rank writes the reason to stderr and
+        exits with status 3."""
+        def bail():
+            sys.stderr.write(f"bench.py: rank {self.rank}: '{what}' did not finish within {seconds} s -- giving up (exit 3)\n")
+            sys.stderr.flush()
+            os._exit(3)
+        self.disarm_watchdog()
+        self.dog = threading.Timer(seconds, bail)
+        self.dog.daemon = True
+        self.dog.start()
+
+    def disarm_watchdog(self):
+        if self.dog is not None:
+            self.dog.cancel()
+            self.dog = None
 
 
-def distributed_leg(pkg, h, levels, world, rank, steps, warmup):
-    """ONE mesh across all ranks with the distributed weld (partition.DistributedMesher): x-slab regen + local weld per
-    rank, face vertices unified between x-neighbours, global indices; the mesh stays distributed.  Returns ms per regen
-    (max over ranks) and the global mesh counts."""
+def single_gpu_step_times(pkg, local_rank, scene, params, levels_list, graph, reps):
+    """ms per regen (wall, this rank alone, no barrier inside the loop) and mesh counts per level: the 1-rank same-size
+    reference of every one-mesh figure, measured in the same invocation on the same GPU."""
+    out = {}
+    for lv in levels_list:
+        h = pkg.CudaHandler(local_rank, scene, params)
+        h.regen(lv)
+        h.set_option("graph", 1 if graph else 0)
+        for _ in range(3):
+            info = h.regen(lv)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            info = h.regen(lv)
+        torch.cuda.synchronize()
+        out[lv] = {"ms": (time.perf_counter() - t0) / reps * 1e3, "triangles": int(info.triangles), "vertices": int(info.vertices)}
+        h.close()
+    return out
+
+
+def one_mesh_legs(pkg, job, local_rank, scene, params, levels_list, base_levels, steps, warmup, graph):
+    """ONE mesh over all ranks, both forms, every size; plus the primary timing (z-slab form at the workload size)."""
     from bevy_signed_distance_mesh_generation_amd import partition as P
-    dev = torch.device("cuda", torch.cuda.current_device())
-    h.set_option("graph", 0)
-    h.set_stream(torch.cuda.current_stream().cuda_stream)
-    mesher = P.DistributedMesher(pkg, h, levels, rank, world, dev)
-    for _ in range(warmup + 1):
-        verts, tris, off = mesher.step()
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(steps):
-        verts, tris, off = mesher.step()
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
-    dt = time.perf_counter() - t0
-    cnt = torch.tensor([verts.shape[0], tris.shape[0]], dtype=torch.int64, device=dev)
-    if world > 1:
-        t = torch.tensor([dt], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
-        dist.all_reduce(cnt)
+    world, rank = job.world, job.rank
+    dev = torch.device("cuda", local_rank)
+    t1 = single_gpu_step_times(pkg, local_rank, scene, params, levels_list, graph, 20)
+    if world > 1:                                    # rank 0's single-GPU times are the reference for everyone
+        box = [t1]
+        dist.broadcast_object_list(box, src=0)
+        t1 = box[0]
+    # --- z-slabs, RCCL gather to rank 0, merge + weld there: all inside sdmesh_sharded_regen
+    h = pkg.CudaHandler(local_rank, scene, params)
+    mesher = P.ShardedMesher(pkg, h, base_levels, rank, world, dev, transport="rccl")
+    ranks_seen = mesher.ranks_seen
+    zslab, primary = {}, None
+    for lv in levels_list:
+        mesher.levels = lv
+        mesher.step()                                # capacity discovery (synchronous), untimed
+        k, w = (steps, warmup) if lv == base_levels else (max(3, min(20, steps // 4)), 2)
+        dt, info = job.timed(mesher.step, k, w)
+        n = 32 << lv
+        tri = torch.tensor([int(info.triangles) if info is not None else 0, int(info.vertices) if info is not None else 0],
+                           dtype=torch.int64, device=dev)
+        if world > 1:
+            dist.all_reduce(tri, op=dist.ReduceOp.MAX)
+        ms = dt / k * 1e3
+        if (int(tri[0]), int(tri[1])) != (t1[lv]["triangles"], t1[lv]["vertices"]):
+            raise RuntimeError(f"sharded mesh at {n}^3 has {int(tri[0])} triangles / {int(tri[1])} vertices, the single-GPU mesh "
+                               f"{t1[lv]['triangles']} / {t1[lv]['vertices']}")
+        zslab[f"{n}^3"] = {"ms_per_regen": round(ms, 4), "t_1rank_ms": round(t1[lv]["ms"], 4),
+                           "speedup_vs_1rank": round(t1[lv]["ms"] / ms, 3), "mvoxels_per_s": round(n ** 3 / ms / 1e3, 1),
+                           "mtris_per_s": round(int(tri[0]) / ms / 1e3, 1), "triangles": int(tri[0]), "vertices": int(tri[1]), "steps": k}
+        if lv == base_levels:
+            primary = (dt, k, int(tri[0]), int(tri[1]))
+    mesher.close()
+    h.close()
+    # --- x-slabs, every rank welds its slab, neighbours unify the shared faces, the mesh stays distributed
+    h = pkg.CudaHandler(local_rank, scene, params)
+    h.set_stream(torch.cuda.current_stream().cuda_stream)          # torch's stream: kernels, torch ops and collectives in one order
+    xslab = {}
+    for lv in levels_list:
+        dm = P.DistributedMesher(pkg, h, lv, rank, world, dev)
+        dm.step()
+        k = max(3, min(20, steps // 4))
+        dt, part = job.timed(dm.step, k, 2)
+        cnt = torch.tensor([part[0].shape[0], part[1].shape[0]], dtype=torch.int64, device=dev)
+        if world > 1:
+            dist.all_reduce(cnt)
+        n = 32 << lv
+        ms = dt / k * 1e3
+        if (int(cnt[1]), int(cnt[0])) != (t1[lv]["triangles"], t1[lv]["vertices"]):
+            raise RuntimeError(f"distributed mesh at {n}^3 has {int(cnt[1])} triangles / {int(cnt[0])} vertices, expected "
+                               f"{t1[lv]['triangles']} / {t1[lv]['vertices']}")
+        xslab[f"{n}^3"] = {"ms_per_regen": round(ms, 4), "t_1rank_ms": round(t1[lv]["ms"], 4),
+                           "speedup_vs_1rank": round(t1[lv]["ms"] / ms, 3), "mvoxels_per_s": round(n ** 3 / ms / 1e3, 1),
+                           "triangles": int(cnt[1]), "vertices": int(cnt[0]), "steps": k}
     h.set_stream(None)
-    return dt / steps * 1e3, {"vertices": int(cnt[0]), "triangles": int(cnt[1])}
+    h.close()
+    return primary, {"n_gpus": world, "ranks_seen": ranks_seen,
+                     "zslab_gather_root_weld": {"what": "sdmesh_sharded_regen: level-0 z-slab per rank, ncclAllGather of 1024 column "
+                                                        "counts, ncclSend/ncclRecv of compact triangle lists to rank 0, merge kernel + "
+                                                        "first-seen weld there; mesh identical to 1 GPU (counts checked here, bits in tests)",
+                                                **zslab},
+                     "xslab_distributed_weld": {"what": "level-0 x-slab per rank, every rank welds its slab, x-neighbours unify the vertices "
+                                                        "of their shared face by weld key, indices become global, the mesh stays distributed",
+                                                **xslab}}
+
+
+def roofline_legs(h, out, n_grid, scene, params, consts):
+    """P1 / P2a / write ceiling, HIP-event timed on the handle's stream (N = 1 only)."""
+    buf = torch.empty((n_grid + 1) ** 3, dtype=torch.float32, device="cuda")
+    alg_bytes = 4.0 * (n_grid + 1) ** 3
+    traffic = (consts.get("p1_traffic_bytes") or {}).get(str(n_grid), {})
+    roofs = {}
+    for sc in ("sphere", scene):
+        h.set_scene(sc, [0.25] if sc == "anim" else None)
+        h.time_kernel(0, n_grid, buf.data_ptr(), 20)                 # warm-up launches (instruction cache, clocks)
+        ms_first = h.time_kernel(0, n_grid, buf.data_ptr(), 50)      # the first 50 of a burst ...
+        h.time_kernel(0, n_grid, buf.data_ptr(), 200)
+        ms = h.time_kernel(0, n_grid, buf.data_ptr(), 50)            # ... and 50 in steady state (the quoted figure)
+        gbps = alg_bytes / (ms * 1e-3) / 1e9
+        roofs[sc] = {"bound": "hbm", "kernel": f"k_sample_dense<{sc}>", "achieved": round(gbps, 1), "peak": HBM_PEAK_GBPS,
+                     "unit": "GB/s", "frac": round(gbps / HBM_PEAK_GBPS, 4),
+                     "traffic": traffic.get(sc),
+                     "bytes_per_launch": alg_bytes, "avg_launch_ms": round(ms, 5),
+                     "first_50_of_burst": {"avg_launch_ms": round(ms_first, 5), "frac": round(alg_bytes / (ms_first * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4)},
+                     "gsamples_per_s": round((n_grid + 1) ** 3 / (ms * 1e-3) / 1e9, 1)}
+    # P2a: sign bits of the dense lattice -- the streaming-READ pass (4 B x (N+1)^3 in, 1 bit per sample out)
+    h.set_scene("sphere")
+    ms2 = h.time_kernel(1, n_grid, buf.data_ptr(), 50)
+    gb2 = alg_bytes / (ms2 * 1e-3) / 1e9
+    out["roofline_p2_sign_bits"] = {"bound": "hbm", "kernel": "k_sign_bits", "achieved": round(gb2, 1), "peak": HBM_PEAK_GBPS,
+                                    "unit": "GB/s", "frac": round(gb2 / HBM_PEAK_GBPS, 4), "traffic": None,
+                                    "bytes_per_launch": alg_bytes + alg_bytes / 32, "avg_launch_ms": round(ms2, 5)}
+    # write ceiling on THIS box: P1's store stream (same bytes, same launch shape) with no arithmetic in front
+    ms3 = h.time_kernel(2, n_grid, buf.data_ptr(), 50)
+    gb3 = alg_bytes / (ms3 * 1e-3) / 1e9
+    h.set_scene(scene, params)
+    del buf
+    out["roofline"] = roofs["sphere"]
+    out["roofline"]["write_ceiling"] = {"kernel": "k_stream_fill", "achieved": round(gb3, 1), "unit": "GB/s",
+                                        "avg_launch_ms": round(ms3, 5),
+                                        "p1_frac_of_ceiling": round(roofs["sphere"]["achieved"] / gb3, 4)}
+    out["roofline"]["note"] = ("P1 dense (N+1)^3 f32 SDF-sample pass, the HBM pass the north star names; claimed on the "
+                               "sphere scene (SURVEY 8(d) caveat i); the regen itself is O(surface) and VALU/latency "
+                               "bound, see roofline_step and DESIGN.md")
+    if scene != "sphere":
+        out["roofline_workload_scene"] = roofs[scene]
+
+
+def roofline_step_leg(pkg, local_rank, scene, params, levels, consts, info):
+    """The throughput-bound kernels of the timed step, live: stage times from HIP events between the stages of the planned
+    chain (median of 30 regens), VALU wave-instructions per launch from the committed SQ PMC pass."""
+    h = pkg.CudaHandler(local_rank, scene, params)
+    h.regen(levels)
+    h.set_option("profile", 1)
+    acc = {}
+    for _ in range(32):
+        h.regen(levels)
+        per = {}
+        for name, ms in h.profile_stages():          # (refine_mask / refine_emit appear once per level: summed per regen)
+            per[name] = per.get(name, 0.0) + ms
+        for name, ms in per.items():
+            acc.setdefault(name, []).append(ms)
+    rounds = h.projection_rounds()
+    h.close()
+    stages = {k: round(float(np.median(v)) * 1e3, 2) for k, v in acc.items()}                              # us per regen
+    pmc = (consts.get("step_kernels") or {}).get(f"{scene}_{32 << levels}", {})
+    ceiling = consts.get("valu_ubench_wave_instr_per_s")
+    out = {"what": "VALU roofline of the step's throughput-bound kernels: wave64 VALU instructions per launch (SQ_INSTS_VALU, "
+                   "profiles/constants.json) / live stage time; peak = 157.3 TF / 2 / 64; ceiling_ubench = what a dependent-free "
+                   "f32 VALU stream sustains on this part (tools/ubench/pk_rate.hip)",
+           "peak": VALU_PEAK_WAVE_INSTR_PER_S, "ceiling_ubench": ceiling, "unit": "wave-instr/s",
+           "stage_us": stages, "stage_sum_us": round(sum(stages.values()), 2)}
+    evals = {"project": 13 * rounds if rounds else None, "flip_claim": 12 * int(info.triangles)}
+    for key, stage_prefix in (("project", "project"), ("flip_claim", "flip_claim")):
+        name = next((s for s in stages if s.startswith(stage_prefix)), None)
+        if name is None:
+            continue
+        us = stages[name]
+        k = pmc.get(name, {})
+        wi = k.get("wave_instr")
+        row = {"kernel": name, "avg_us": us, "trace_avg_us": k.get("avg_us"), "wave_instr": wi,
+               "vgpr": k.get("vgpr"), "waves_per_simd": k.get("waves_per_simd")}
+        if wi:
+            ach = wi / (us * 1e-6)
+            row.update({"achieved": round(ach, 1), "frac": round(ach / VALU_PEAK_WAVE_INSTR_PER_S, 4),
+                        "frac_of_ceiling": round(ach / ceiling, 4) if ceiling else None})
+        if evals[key]:
+            row.update({"sdf_evals": int(evals[key]), "sdf_evals_per_s": round(evals[key] / (us * 1e-6), 1)})
+        out[key] = row
+    return out
 
 
 def main():
@@ -166,13 +342,14 @@ def main():
     ap.add_argument("--no-anim", action="store_true")
     ap.add_argument("--no-pipelined", action="store_true")
     ap.add_argument("--no-sizes", action="store_true")
-    ap.add_argument("--no-sharded", action="store_true")
-    ap.add_argument("--no-graph", dest="graph", action="store_false",
-                    help="drive the primary metric with eager launches instead of replaying the planned chain as a hipGraph "
-                         "(default: graph replay -- with the single-stream chain it is ~2 %% faster in wall time although ~4 us "
-                         "slower on the device; the other mode is reported beside it either way)")
-    ap.set_defaults(graph=True)
-    ap.add_argument("--sharded-selftest", action="store_true", help="run the sharded leg on 1 GPU (degenerate, for testing)")
+    ap.add_argument("--no-replicas", action="store_true")
+    ap.add_argument("--max-levels", type=int, default=7, help="largest one-mesh size of the N > 1 legs: 32 * 2^L (7 = 4096^3)")
+    ap.add_argument("--graph", dest="graph", action="store_true",
+                    help="drive the single-GPU step by replaying the planned chain as a hipGraph (default: eager launches -- on "
+                         "the driver's box the graph executor costs ~4 us more on the device than it saves on the host; the "
+                         "other mode is reported beside it either way, and BASELINE configs[4] is reported with the graph)")
+    ap.set_defaults(graph=False)
+    ap.add_argument("--one-mesh-selftest", action="store_true", help="run the N > 1 one-mesh legs on 1 GPU (degenerate, for testing)")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -185,123 +362,129 @@ def main():
     if not torch.cuda.is_available():
         sys.exit("bench.py: no GPU visible -- the product path has no CPU fallback")
     torch.cuda.set_device(local_rank)
+    job = Job(world, rank)
     if world > 1:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        job.arm_watchdog(180, "process group initialisation")
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        job.disarm_watchdog()
 
     pkg = sdmesh_pkg.load()
     params = [0.25] if args.scene == "anim" else None
-    h = pkg.CudaHandler(local_rank, args.scene, params)
     n_grid = 32 << args.levels
+    consts = load_constants()
+    multi = world > 1 or args.one_mesh_selftest
 
-    def sync_all():
+    if multi:
+        # ---------------------------------------------------------------- N > 1: the step is ONE mesh over all ranks
+        levels_list = [lv for lv in range(args.levels, max(args.levels, args.max_levels) + 1)]
+        job.arm_watchdog(900, "one-mesh legs (z-slab RCCL gather / x-slab distributed weld)")
+        primary, one_mesh = one_mesh_legs(pkg, job, local_rank, args.scene, params, levels_list, args.levels, args.steps, args.warmup, args.graph)
+        job.disarm_watchdog()
+        dt, k, tris, verts = primary
+        out = {
+            "metric": "Mvoxels/s (512^3 SDF mesh extract: N^3 grid cells per full regen, whole job)",
+            "value": round(n_grid ** 3 * k / dt / 1e6, 1), "unit": "Mvoxels/s", "n_gpus": world, "steps": k, "warmup": args.warmup,
+            "ms_per_step": round(dt / k * 1e3, 4), "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
+            "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"{args.scene} {n_grid}^3 (BASELINE configs[2]: reference scene sd_obj, 32^3 level-0 cells refined "
+                                   f"x{args.levels}) as ONE mesh over {world} GPUs: level-0 z-slab per rank, RCCL gather of the per-slab "
+                                   "triangle lists to rank 0, merge + weld there; indexed mesh left in rank 0's HBM",
+                       "levels": args.levels, "grid": n_grid, "parallelism": f"{world} z-slabs, one per GPU (sdmesh_sharded_regen)"},
+            "mtris_per_s": round(tris * k / dt / 1e6, 2), "triangles": tris, "vertices": verts,
+            "ranks_seen": one_mesh["ranks_seen"], "one_mesh": one_mesh,
+        }
+        if not args.no_replicas:
+            # extra: N independent regens, one per GPU, no exchange (objects / frames shard trivially) -- not the judged figure
+            job.arm_watchdog(300, "replicas leg")
+            h = pkg.CudaHandler(local_rank, args.scene, params)
+            h.regen(args.levels)
+            h.set_option("graph", 1 if args.graph else 0)
+            rdt, rinfo = job.timed(lambda: h.regen(args.levels), args.steps, args.warmup)
+            h.close()
+            job.disarm_watchdog()
+            out["replicas"] = {"what": f"{world} independent regens of the workload, one per GPU, no data-path exchange (weak scaling of "
+                                       "independent objects / frames); an extra, not the scaling result",
+                               "ms_per_step": round(rdt / args.steps * 1e3, 4),
+                               "mvoxels_per_s": round(n_grid ** 3 * args.steps * world / rdt / 1e6, 1),
+                               "mtris_per_s": round(int(rinfo.triangles) * args.steps * world / rdt / 1e6, 2)}
+        if rank == 0:
+            print(json.dumps(out), flush=True)
         if world > 1:
+            job.arm_watchdog(120, "final barrier")
             dist.barrier()
-        torch.cuda.synchronize()
+            dist.destroy_process_group()
+            job.disarm_watchdog()
+        return
 
+    # -------------------------------------------------------------------- N = 1
+    h = pkg.CudaHandler(local_rank, args.scene, params)
     info = h.regen(args.levels)                      # capacity discovery pass (synchronous, untimed)
-    h.set_option("graph", 1 if args.graph else 0)    # --graph: planned chain captured once, replayed per step
-    for _ in range(args.warmup):
-        info = h.regen(args.levels)
-    sync_all()
-    t0 = time.perf_counter()
+    h.set_option("graph", 1 if args.graph else 0)
     dev_ms = []
-    for _ in range(args.steps):
-        info = h.regen(args.levels)
-        dev_ms.append(info.device_ms)
-    sync_all()
-    dt = time.perf_counter() - t0
-    if world > 1:
-        t = torch.tensor([dt], dtype=torch.float64, device="cuda")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
 
+    def step():
+        i = h.regen(args.levels)
+        dev_ms.append(i.device_ms)
+        return i
+
+    dt, info = job.timed(step, args.steps, args.warmup)
+    dev_ms = dev_ms[-args.steps:]
     ms_per_step = dt / args.steps * 1e3
-    value = n_grid ** 3 * args.steps * world / dt / 1e6
     out = {
         "metric": "Mvoxels/s (512^3 SDF mesh extract: N^3 grid cells per full regen, whole job)",
-        "value": round(value, 1), "unit": "Mvoxels/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-        "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "value": round(n_grid ** 3 * args.steps / dt / 1e6, 1), "unit": "Mvoxels/s", "n_gpus": 1, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
         "dtype": "f32", "data": "synthetic",
         "config": {"workload": f"{args.scene} {n_grid}^3 (BASELINE configs[2]: reference scene sd_obj, 32^3 level-0 "
                                f"cells refined x{args.levels}), device-resident regen, indexed mesh left in HBM, "
                                + ("hipGraph replay" if args.graph else "eager launches"),
-                   "levels": args.levels, "grid": n_grid,
-                   "parallelism": "1 GPU" if world == 1 else f"{world} independent regens (one per GPU, no exchange)"},
-        "mtris_per_s": round(info.triangles * args.steps * world / dt / 1e6, 2),
+                   "levels": args.levels, "grid": n_grid, "parallelism": "1 GPU"},
+        "mtris_per_s": round(info.triangles * args.steps / dt / 1e6, 2),
         "triangles": int(info.triangles), "vertices": int(info.vertices), "active_voxels": int(info.voxel_count[args.levels]),
         "device_ms_per_step": round(float(np.median(dev_ms)), 4),
+        "work_actually_done": {"active_gvoxels_per_s": round(int(info.voxel_count[args.levels]) / ms_per_step / 1e6, 3),
+                               "gtris_per_s": round(info.triangles / ms_per_step / 1e6, 3),
+                               "note": "`value` is the N^3-equivalent rate BASELINE defines; the hierarchical path touches O(surface) cells"},
     }
 
-    # With more than one rank every later leg that synchronises the ranks (sizes, sharded, distributed) runs under a
-    # watchdog: whatever happens there, rank 0 still prints the primary line and every rank leaves.
-    big_dog = None
-    if world > 1:
-        import threading
-
-        def bail_all():
-            if rank == 0:
-                out["watchdog"] = "a multi-rank extra leg did not finish within 300 s; primary metric above is complete"
-                print(json.dumps(out), flush=True)
-            os._exit(0)
-
-        big_dog = threading.Timer(300.0, bail_all)
-        big_dog.daemon = True
-        big_dog.start()
-
-    # --- the same step replayed as a hipGraph (or eagerly, if --graph made the graph the primary): both ways of driving the
-    #     identical kernel chain are reported, the primary is whichever the flags selected
-    if rank == 0 and world == 1:
-        h.set_option("graph", 0 if args.graph else 1)
-        for _ in range(10):
-            h.regen(args.levels)
-        torch.cuda.synchronize()
-        tg = time.perf_counter()
-        gdev = []
-        for _ in range(100):
-            gdev.append(h.regen(args.levels).device_ms)
-        torch.cuda.synchronize()
-        dg = (time.perf_counter() - tg) / 100
-        out["eager_launches" if args.graph else "hipgraph_replay"] = {
-            "ms_per_step": round(dg * 1e3, 4), "device_ms_per_step": round(float(np.median(gdev)), 4),
-            "mvoxels_per_s": round(n_grid ** 3 / dg / 1e6, 1)}
-        h.set_option("graph", 1 if args.graph else 0)
+    # --- the same step driven the other way (graph replay vs eager launches of the identical chain)
+    h.set_option("graph", 0 if args.graph else 1)
+    gdev = []
+    gdt, _ = job.timed(lambda: gdev.append(h.regen(args.levels).device_ms), 100, 10)
+    out["eager_launches" if args.graph else "hipgraph_replay"] = {
+        "ms_per_step": round(gdt / 100 * 1e3, 4), "device_ms_per_step": round(float(np.median(gdev[-100:])), 4),
+        "mvoxels_per_s": round(n_grid ** 3 * 100 / gdt / 1e6, 1)}
+    h.set_option("graph", 1 if args.graph else 0)
 
     # --- the other grid sizes the north star names (256^3 / 1024^3 of the workload scene, and BASELINE configs[1]: the
     #     single sphere at 256^3); same measurement as the primary metric, fewer steps
-    if not args.no_sizes:                 # every rank runs it (N independent regens, like the primary metric); whole-job rates
-        try:
-            sizes = {}
-            for label, sc, lv in ((f"{args.scene}_256", args.scene, 3), (f"{args.scene}_1024", args.scene, 5), ("sphere_256", "sphere", 3)):
-                if sc == args.scene and lv == args.levels:
-                    continue
-                hz = pkg.CudaHandler(local_rank, sc, params if sc == args.scene else None)
-                hz.regen(lv); hz.set_option("graph", 1 if args.graph else 0)
-                for _ in range(5):
-                    zi = hz.regen(lv)
-                sync_all()
-                tz = time.perf_counter()
-                zdev = []
-                for _ in range(50):
-                    zi = hz.regen(lv); zdev.append(zi.device_ms)
-                sync_all()
-                dz = time.perf_counter() - tz
-                if world > 1:
-                    tt = torch.tensor([dz], dtype=torch.float64, device="cuda")
-                    dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-                    dz = float(tt.item())
-                dz /= 50
-                ng = 32 << lv
-                sizes[label] = {"grid": ng, "ms_per_step": round(dz * 1e3, 4), "device_ms_per_step": round(float(np.median(zdev)), 4),
-                                "mvoxels_per_s": round(world * ng ** 3 / dz / 1e6, 1), "mtris_per_s": round(world * zi.triangles / dz / 1e6, 1),
-                                "triangles": int(zi.triangles), "vertices": int(zi.vertices)}
-                hz.close()
-            out["sizes"] = sizes
-        except Exception as e:              # noqa: BLE001 -- report, never lose the primary metric
-            out["sizes"] = {"error": f"{type(e).__name__}: {e}"[:300]}
+    if not args.no_sizes:
+        sizes = {}
+        for label, sc, lv in ((f"{args.scene}_256", args.scene, 3), (f"{args.scene}_1024", args.scene, 5), ("sphere_256", "sphere", 3)):
+            if sc == args.scene and lv == args.levels:
+                continue
+            hz = pkg.CudaHandler(local_rank, sc, params if sc == args.scene else None)
+            hz.regen(lv)
+            hz.set_option("graph", 1 if args.graph else 0)
+            zdev = []
+
+            def zstep():
+                zi = hz.regen(lv)
+                zdev.append(zi.device_ms)
+                return zi
+
+            dz, zi = job.timed(zstep, 50, 5)
+            dz /= 50
+            ng = 32 << lv
+            sizes[label] = {"grid": ng, "ms_per_step": round(dz * 1e3, 4), "device_ms_per_step": round(float(np.median(zdev[-50:])), 4),
+                            "mvoxels_per_s": round(ng ** 3 / dz / 1e6, 1), "mtris_per_s": round(zi.triangles / dz / 1e6, 1),
+                            "triangles": int(zi.triangles), "vertices": int(zi.vertices)}
+            hz.close()
+        out["sizes"] = sizes
 
     # --- several regens in flight (one handle each): most kernels of the chain are latency-bound, so they overlap
-    if rank == 0 and world == 1 and not args.no_pipelined:
+    if not args.no_pipelined:
         depth = 4
         hs = [pkg.CudaHandler(local_rank, args.scene, params) for _ in range(depth)]
         for hh in hs:
@@ -325,19 +508,15 @@ def main():
             hh.close()
 
     # --- the ray-march preview of the same scene (pure VALU, one thread per pixel), 1080p
-    if rank == 0 and world == 1:
-        try:
-            tex = torch.empty((1080, 1920, 4), dtype=torch.uint8, device="cuda")
-            cam = ((0.0, 1.0, -6.0), (0.0, -0.16439898, 0.98639392), (0.0, 0.98639392, 0.16439898), (1.0, 0.0, 0.0))
-            rms = [h.render(1920, 1080, *cam, 1.0, None, dev_ptr=tex.data_ptr()) for _ in range(12)][2:]
-            out["render_preview"] = {"what": "sdmesh_render (compute_render.cu) of the workload scene, 1920x1080 RGBA8, kernel time",
-                                     "ms": round(float(np.median(rms)), 4), "mpixels_per_s": round(1920 * 1080 / float(np.median(rms)) / 1e3, 1)}
-            del tex
-        except Exception as e:          # noqa: BLE001
-            out["render_preview"] = {"error": f"{type(e).__name__}: {e}"[:200]}
+    tex = torch.empty((1080, 1920, 4), dtype=torch.uint8, device="cuda")
+    cam = ((0.0, 1.0, -6.0), (0.0, -0.16439898, 0.98639392), (0.0, 0.98639392, 0.16439898), (1.0, 0.0, 0.0))
+    rms = [h.render(1920, 1080, *cam, 1.0, None, dev_ptr=tex.data_ptr()) for _ in range(12)][2:]
+    out["render_preview"] = {"what": "sdmesh_render (compute_render.cu) of the workload scene, 1920x1080 RGBA8, kernel time",
+                             "ms": round(float(np.median(rms)), 4), "mpixels_per_s": round(1920 * 1080 / float(np.median(rms)) / 1e3, 1)}
+    del tex
 
     # --- BASELINE config 5: per-frame animated SDF (sphere centre (0, 0.5 sin t, 0), t = frame / 60), same grid
-    if rank == 0 and not args.no_anim:
+    if not args.no_anim:
         ha = pkg.CudaHandler(local_rank, "anim", [0.5])
         for cy in (0.5, -0.5, 0.0):                  # widest frames first: one capacity plan covers the animation
             ha.set_scene("anim", [cy]); ha.regen(args.levels)
@@ -362,93 +541,12 @@ def main():
         out["animated"] = anim
         ha.close()
 
-    # --- ONE mesh sharded over the ranks (strong scaling; reported next to, never instead of, `value`).
-    # This leg is the only one with data-path collectives; a watchdog makes sure a stuck collective can never cost
-    # the primary line: after 120 s rank 0 prints what it has and every rank leaves.
-    if (world > 1 and not args.no_sharded) or args.sharded_selftest:
-        import threading
-
-        def bail():
-            if rank == 0:
-                out["sharded"] = {"error": "sharded leg did not finish within 120 s (watchdog)"}
-                print(json.dumps(out), flush=True)
-            os._exit(0)
-
-        dog = threading.Timer(120.0, bail)
-        dog.daemon = True
-        dog.start()
-        try:
-            shard = {}
-            for lv in (args.levels, args.levels + 1):
-                ms, res = sharded_leg(pkg, h, lv, world, rank, 20, 3)
-                n = 32 << lv
-                shard[f"{n}^3"] = {"ms_per_regen": round(ms, 4), "mvoxels_per_s": round(n ** 3 / ms / 1e3, 1), **res}
-            out["sharded"] = {"what": "one mesh, level-0 z-slabs over the ranks, all-gather of 1024 column counts + NCCL "
-                                      "send/recv of compact triangle lists to the root + root weld (strong scaling)",
-                              "n_gpus": world, **shard}
-            dshard = {}
-            for lv in (args.levels, args.levels + 1, args.levels + 2):
-                ms, res = distributed_leg(pkg, h, lv, world, rank, 20, 3)
-                n = 32 << lv
-                dshard[f"{n}^3"] = {"ms_per_regen": round(ms, 4), "mvoxels_per_s": round(n ** 3 / ms / 1e3, 1), **res}
-            out["distributed"] = {"what": "one mesh, level-0 x-slabs over the ranks, every rank welds its slab, x-neighbours unify "
-                                          "the vertices of their shared face by weld key (two small send/recv + one all-gather "
-                                          "of counts), indices become global, the mesh stays distributed (strong scaling)",
-                                  "n_gpus": world, **dshard}
-            h.regen(args.levels)        # back to the unpartitioned plan
-        except Exception as e:          # noqa: BLE001 -- report, never lose the primary metric
-            out["sharded"] = {"error": f"{type(e).__name__}: {e}"[:300]}
-        finally:
-            dog.cancel()
-
-    if big_dog is not None:
-        big_dog.cancel()
-    if rank == 0:
-        # --- roofline of the north-star HBM pass (P1 dense SDF sample), HIP-event timed on the handle's stream
-        buf = torch.empty((n_grid + 1) ** 3, dtype=torch.float32, device="cuda")
-        alg_bytes = 4.0 * (n_grid + 1) ** 3
-        roofs = {}
-        for sc in ("sphere", args.scene):
-            h.set_scene(sc, [0.25] if sc == "anim" else None)
-            # untimed warm-up first: a burst of this kernel starts with a ~25 ms transient (per-launch 110 -> 143 -> 103 us on the
-            # sphere, tools/p1_burst.py + tools/window_avg.py) before it settles at the steady state the roofline is about
-            h.time_kernel(0, n_grid, buf.data_ptr(), 250)
-            ms = h.time_kernel(0, n_grid, buf.data_ptr(), 50)
-            gbps = alg_bytes / (ms * 1e-3) / 1e9
-            roofs[sc] = {"bound": "hbm", "kernel": f"k_sample_dense<{sc}>", "achieved": round(gbps, 1), "peak": HBM_PEAK_GBPS,
-                         "unit": "GB/s", "frac": round(gbps / HBM_PEAK_GBPS, 4),
-                         "traffic": P1_TRAFFIC_512 if n_grid == 512 else None,
-                         "bytes_per_launch": alg_bytes, "avg_launch_ms": round(ms, 5),
-                         "gsamples_per_s": round((n_grid + 1) ** 3 / (ms * 1e-3) / 1e9, 1)}
-        # P2a: sign bits of the dense lattice -- the streaming-READ pass (4 B x (N+1)^3 in, 1 bit per sample out)
-        h.set_scene("sphere")
-        ms2 = h.time_kernel(1, n_grid, buf.data_ptr(), 50)
-        gb2 = alg_bytes / (ms2 * 1e-3) / 1e9
-        out["roofline_p2_sign_bits"] = {"bound": "hbm", "kernel": "k_sign_bits", "achieved": round(gb2, 1), "peak": HBM_PEAK_GBPS,
-                                        "unit": "GB/s", "frac": round(gb2 / HBM_PEAK_GBPS, 4), "traffic": None,
-                                        "bytes_per_launch": alg_bytes + alg_bytes / 32, "avg_launch_ms": round(ms2, 5)}
-        # write ceiling on THIS box: P1's store stream (same bytes, same launch shape) with no arithmetic in front
-        ms3 = h.time_kernel(2, n_grid, buf.data_ptr(), 50)
-        gb3 = alg_bytes / (ms3 * 1e-3) / 1e9
-        h.set_scene(args.scene, params)
-        del buf
-        out["roofline"] = roofs["sphere"]
-        out["roofline"]["write_ceiling"] = {"kernel": "k_stream_fill", "achieved": round(gb3, 1), "unit": "GB/s",
-                                            "avg_launch_ms": round(ms3, 5),
-                                            "p1_frac_of_ceiling": round(roofs["sphere"]["achieved"] / gb3, 4)}
-        out["roofline"]["note"] = ("P1 dense (N+1)^3 f32 SDF-sample pass, the HBM pass the north star names; claimed on the "
-                                   "sphere scene (SURVEY 8(d) caveat i); the regen itself is O(surface) and VALU/atomic "
-                                   "bound, see DESIGN.md")
-        if args.scene != "sphere":
-            out["roofline_workload_scene"] = roofs[args.scene]
-        if not args.no_cpu_baseline and world == 1:
-            out["cpu_baseline"] = cpu_baseline(args.scene, args.levels, params)
-        print(json.dumps(out), flush=True)
-
+    roofline_legs(h, out, n_grid, args.scene, params, consts)
+    out["roofline_step"] = roofline_step_leg(pkg, local_rank, args.scene, params, args.levels, consts, info)
+    if not args.no_cpu_baseline:
+        out["cpu_baseline"] = cpu_baseline(args.scene, args.levels, params)
+    print(json.dumps(out), flush=True)
     h.close()
-    if world > 1:
-        dist.barrier()
-        dist.destroy_process_group()
 
 
 if __name__ == "__main__":

@@ -44,7 +44,7 @@ def pack_program(program):
 PART_NONE, PART_ZSLAB, PART_XSLAB = 0, 1, 2
 
 ERRORS = {1: "invalid argument", 2: "HIP runtime error", 3: "no gfx950 device", 4: "output buffer too small",
-          5: "vertex outside the weld key range", 6: "internal device error"}
+          5: "vertex outside the weld key range", 6: "internal device error", 7: "RCCL error"}
 
 
 class Point(ctypes.Structure):
@@ -89,6 +89,7 @@ SYMBOLS = {
     "sdmesh_set_scene": (_i, [_vp, _i, _vp, _i]),
     "sdmesh_set_program": (_i, [_vp, _vp, _i]),
     "sdmesh_set_stream": (_i, [_vp, _vp]),
+    "sdmesh_use_own_stream": (_i, [_vp]),
     "sdmesh_set_option": (_i, [_vp, ctypes.c_char_p, _i]),
     "sdmesh_create_voxel_field": (_i, [_vp, _vp]),
     "sdmesh_refine_voxel_field": (_i, [_vp, _vp, _sz, Point, _vp, _sz, _psz, ctypes.POINTER(Point)]),
@@ -105,11 +106,20 @@ SYMBOLS = {
     "sdmesh_device_triangles": (_i, [_vp, _vp, _sz, _psz]),
     "sdmesh_weld_device_triangles": (_i, [_vp, _vp, _sz, ctypes.POINTER(RegenInfo)]),
     "sdmesh_column_triangle_counts": (_i, [_vp, _vp]),
+    "sdmesh_merge_by_column": (_i, [_vp, _vp, _vp, _i, _vp, _sz, _psz]),
+    "sdmesh_comm_unique_id": (_i, [_vp]),
+    "sdmesh_comm_init": (_i, [_vp, _vp, _i, _i]),
+    "sdmesh_comm_destroy": (_i, [_vp]),
+    "sdmesh_comm_ranks": (_i, [_vp, ctypes.POINTER(_i)]),
+    "sdmesh_sharded_regen": (_i, [_vp, _i, _i, ctypes.POINTER(RegenInfo)]),
     "sdmesh_download_mesh": (_i, [_vp, _vp, _vp]),
     "sdmesh_download_voxels": (_i, [_vp, _vp]),
     "sdmesh_regen_dense": (_i, [_vp, _i, ctypes.POINTER(RegenInfo)]),
     "sdmesh_sample_dense": (_i, [_vp, _u32, _vp, ctypes.POINTER(ctypes.c_float)]),
     "sdmesh_time_kernel": (_i, [_vp, _i, _u32, _vp, _i, ctypes.POINTER(ctypes.c_float)]),
+    "sdmesh_profile_stages": (_i, [_vp, _vp, _sz, _vp, _i, ctypes.POINTER(_i)]),
+    "sdmesh_profile_rounds": (_i, [_vp, ctypes.POINTER(ctypes.c_uint64)]),
+    "sdmesh_project_diag": (_i, [_vp, _vp, _sz, _psz]),
     "sdmesh_render": (_i, [_vp, _vp, _vp, _vp]),
     "sdmesh_render_device": (_i, [_vp, _vp, _vp, _vp, ctypes.POINTER(ctypes.c_float)]),
 }

@@ -8,13 +8,17 @@
 // synchronisation per regen (the final read-back of counters + status).
 #include <hip/hip_runtime.h>
 
+#include <dlfcn.h>
 #include <math.h>
 #include <stdarg.h>
 #include <stdio.h>
 #include <string.h>
 
 #include <algorithm>
+#include <string>
 #include <vector>
+
+#include <rccl/rccl.h>        // types only: the functions are resolved with dlsym when a communicator is first asked for
 
 #include "../../include/sdmesh.h"
 #include "kernels.hpp"
@@ -41,6 +45,22 @@ enum {
 };
 
 }  // namespace
+
+// RCCL entry points (librccl.so.1), bound at run time: a single-GPU host never loads the library, and inside a
+// PyTorch-ROCm process the copy torch already loaded (same SONAME) is reused instead of a second one.
+struct RcclApi {
+    void *lib = nullptr;
+    ncclResult_t (*GetUniqueId)(ncclUniqueId *) = nullptr;
+    ncclResult_t (*CommInitRank)(ncclComm_t *, int, ncclUniqueId, int) = nullptr;
+    ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+    ncclResult_t (*AllGather)(const void *, void *, size_t, ncclDataType_t, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*AllReduce)(const void *, void *, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*Send)(const void *, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*Recv)(void *, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*GroupStart)() = nullptr;
+    ncclResult_t (*GroupEnd)() = nullptr;
+    const char *(*GetErrorString)(ncclResult_t) = nullptr;
+};
 
 struct sdmesh_handle {
     int device = 0;
@@ -76,7 +96,12 @@ struct sdmesh_handle {
     int mask_chunk = 32;       // parents per workgroup pass in k_refine_mask (8, 16 or 32)
     int emit_ci = 1;           // planned path: the last refine level also writes the cube indices + tile triangle counts (no k_classify)
     int refine2 = 0;           // planned path: two refine levels per step (k_refine2_*): measured no faster, off by default
+    int col_refine = 1;        // levels 0 .. min(levels - 1, 3) fused per level-0 column (k_col_refine + k_col_emit: 2 launches
+                               // instead of 1 + 2 per level); 0 = level by level from the level-0 field
+    DevBuf col_list1, col_mask2, col_mask3, colinfo;
     int skip_weld = 0;         // regen stops after the orientation test (multi-GPU ranks: the root welds)
+    int weld_wide = 0;         // option: 1 = always weld with the unbounded [i64; 3] key form
+    bool wide_active = false;  // the wide form is in use (forced, or a vertex did not fit the packed 3 x 21-bit key)
     bool welded = false;       // tri_e holds the final corner order
     int dense_grid = 16384;    // workgroups for k_sample_dense
     int dense_nt = 1;          // nontemporal stores in k_sample_dense
@@ -119,6 +144,26 @@ struct sdmesh_handle {
     uint32_t n_vox = 0, n_tris = 0, n_verts = 0, n_unique = 0;
     Point voxel_size{0, 0, 0};
     bool mesh_valid = false, vox_valid = false, last_direct = false;
+
+    // option "profile": HIP events between the stages of the planned chain (live per-stage device times for bench.py)
+    int profile = 0;
+    DevBuf prof_rounds;            // 256 counters x 64 B: Newton rounds of the projection kernel (profile mode)
+    DevBuf proj_diag;              // option "project_diag": per-wave {start, end, rounds, hw id} of the projection kernel
+    int project_diag = 0;
+    uint32_t diag_waves = 0;
+    uint64_t last_rounds = 0;
+    std::vector<hipEvent_t> prof_ev;
+    std::vector<std::string> prof_names;
+    std::vector<float> prof_ms;
+    size_t prof_n = 0;
+
+    // multi-GPU: communicator + the buffers of the z-slab gather / merge
+    ncclComm_t comm = nullptr;
+    int comm_rank = 0, comm_nranks = 1;
+    DevBuf shard_mine, shard_counts, shard_recv, shard_lists, shard_plan, shard_merged;
+    uint32_t *h_counts = nullptr;      // pinned: nranks x 1024 column counts (root)
+    size_t h_counts_words = 0;
+    void **h_lists = nullptr;          // pinned: nranks device pointers
 
     // capacity plan learnt from the last synchronous run (async path)
     bool plan_valid = false;
@@ -171,6 +216,27 @@ void release(DevBuf &b) {
     if (b.p) (void) hipFree(b.p);
     b.p = nullptr;
     b.cap = 0;
+}
+
+// Stage markers of option "profile": an event BEHIND each stage of the chain; stage time = gap to the previous marker.
+int prof_mark(sdmesh_handle *h, const char *name) {
+    if (!h->profile) return SDMESH_OK;
+    if (h->prof_n >= h->prof_ev.size()) {
+        hipEvent_t e;
+        HIPCHK(hipEventCreate(&e));
+        h->prof_ev.push_back(e);
+        h->prof_names.emplace_back();
+    }
+    h->prof_names[h->prof_n] = name;
+    HIPCHK(hipEventRecord(h->prof_ev[h->prof_n], h->stream));
+    h->prof_n++;
+    return SDMESH_OK;
+}
+
+int prof_collect(sdmesh_handle *h) {      // after the stream has been synchronised
+    h->prof_ms.assign(h->prof_n, 0.0f);
+    for (size_t i = 1; i < h->prof_n; i++) HIPCHK(hipEventElapsedTime(&h->prof_ms[i], h->prof_ev[i - 1], h->prof_ev[i]));
+    return SDMESH_OK;
 }
 
 inline uint32_t tiles(uint32_t n) { return (n + 255u) / 256u; }
@@ -233,20 +299,37 @@ int mesh_front(sdmesh_handle *h, const Point *d_vox, const uint32_t *n_ptr, Poin
     HIPCHK(launch_tile_dedupe(st, h->tgrid, d_vox, n_ptr, vs, (const uint8_t *) h->cubeidx.p, (const uint32_t *) tilecnt,
                               (uint32_t *) h->trioff.p, (uint32_t *) h->tri_e.p, (Vertex *) h->uverts.p, (uint4 *) h->tdesc.p,
                               h->ucap, h->tcap, h->d_ctr + CTR_NTRI, h->d_ctr + CTR_NTILES, h->d_status));
+    SDCHK(prof_mark(h, "tile_dedupe"));
     uint32_t *coarse = (uint32_t *) h->tpre.p + h->tp_cap;
     HIPCHK(launch_tile_prefix(st, (const uint4 *) h->tdesc.p, h->d_ctr + CTR_NTILES, (uint32_t *) h->tpre.p, h->d_ctr + CTR_NUNIQ, coarse));
+    SDCHK(prof_mark(h, "tile_prefix"));
     const int plan_lanes = h->lane_hint >= 160000u ? 1 : 4;
     const int p_lanes = h->project_lanes ? h->project_lanes : plan_lanes;
     const int f_lanes = h->flip_lanes ? h->flip_lanes : plan_lanes;
+    uint32_t *d_prof = nullptr;
+    uint64_t *d_diag = nullptr;
+    if (h->profile) {                       // (profile / diag runs are eager and may allocate: never on the captured path)
+        SDCHK(ensure(h, h->prof_rounds, 256 * 64));
+        HIPCHK(hipMemsetAsync(h->prof_rounds.p, 0, 256 * 64, st));
+        d_prof = (uint32_t *) h->prof_rounds.p;
+    }
+    if (h->project_diag) {
+        h->diag_waves = (uint32_t) (h->grid * h->project_mult) * 4u;
+        SDCHK(ensure(h, h->proj_diag, 32ull * h->diag_waves));
+        HIPCHK(hipMemsetAsync(h->proj_diag.p, 0, 32ull * h->diag_waves, st));
+        d_diag = (uint64_t *) h->proj_diag.p;
+    }
     HIPCHK(launch_project(st, h->grid * h->project_mult, h->scene, h->d_sp, (Vertex *) h->uverts.p, (const uint4 *) h->tdesc.p,
-                          (const uint32_t *) h->tpre.p, coarse, h->d_ctr + CTR_NTILES, h->d_status, p_lanes));
+                          (const uint32_t *) h->tpre.p, coarse, h->d_ctr + CTR_NTILES, h->d_status, p_lanes, d_prof, d_diag));
+    SDCHK(prof_mark(h, p_lanes == 1 ? "project1" : "project4"));
     // fork: the weld claim (scattered CAS, latency-bound) runs beside the orientation test (VALU-bound)
     const int f_grid = h->grid * (f_lanes == 1 ? 1 : h->flip_mult);
     if (h->fork == 2) {
         // one dispatch: claim workgroups first (latency-bound, resident early), orientation-test workgroups behind them
         HIPCHK(launch_flip_claim(st, f_grid, h->tgrid, h->scene, h->d_sp, (const Vertex *) h->uverts.p, (const uint32_t *) h->tri_e.p,
                                  h->d_ctr + CTR_NTRI, (uint8_t *) h->flip.p, f_lanes, (const uint4 *) h->tdesc.p, h->d_ctr + CTR_NTILES,
-                                 h->wkeys, h->wsize, (uint32_t *) h->vslot.p, h->d_status));
+                                 h->wkeys, h->wsize, (uint32_t *) h->vslot.p, h->d_status, h->wide_active));
+        SDCHK(prof_mark(h, f_lanes == 1 ? "flip_claim1" : "flip_claim4"));
         return SDMESH_OK;
     }
     hipStream_t cst = h->fork ? h->side : st;
@@ -255,7 +338,7 @@ int mesh_front(sdmesh_handle *h, const Point *d_vox, const uint32_t *n_ptr, Poin
         HIPCHK(hipStreamWaitEvent(h->side, h->ev_fork, 0));
     }
     HIPCHK(launch_tile_claim(cst, h->tgrid, (const Vertex *) h->uverts.p, (const uint4 *) h->tdesc.p, h->d_ctr + CTR_NTILES,
-                             h->wkeys, h->wsize, (uint32_t *) h->vslot.p, h->d_status));
+                             h->wkeys, h->wsize, (uint32_t *) h->vslot.p, h->d_status, h->wide_active));
     if (h->fork) HIPCHK(hipEventRecord(h->ev_join, h->side));
     HIPCHK(launch_flip(st, f_grid, h->scene, h->d_sp, (const Vertex *) h->uverts.p, (const uint32_t *) h->tri_e.p,
                        h->d_ctr + CTR_NTRI, (uint8_t *) h->flip.p, f_lanes));
@@ -271,6 +354,7 @@ int mesh_weld(sdmesh_handle *h, const Vertex *uverts) {
                        (uint32_t *) h->wvidx.p, (uint32_t *) h->torder.p, (uint32_t *) h->tfirst.p, (uint32_t *) h->tfpre.p,
                        (Vertex *) h->vertices.p, (uint32_t) (h->vertices.cap / sizeof(Vertex)), h->d_ctr + CTR_NVERT,
                        (uint32_t *) h->indices.p, h->d_status));
+    SDCHK(prof_mark(h, "weld"));
     return SDMESH_OK;
 }
 
@@ -289,7 +373,7 @@ int read_back(sdmesh_handle *h) {
 int status_to_error(sdmesh_handle *h) {
     const uint32_t *s = h->h_pinned + CTR_WORDS;
     if (s[ST_INTERNAL]) return fail(h, SDMESH_ERR_INTERNAL, "device invariant violated (status %u)", s[ST_INTERNAL]);
-    if (s[ST_WELD_RANGE]) return fail(h, SDMESH_ERR_WELD_RANGE, "vertex outside the +-10.48 unit weld key range");
+    if (s[ST_WELD_RANGE]) return fail(h, SDMESH_ERR_WELD_RANGE, "vertex outside the packed weld key range although the wide key form was requested");
     return SDMESH_OK;
 }
 
@@ -353,7 +437,7 @@ int weld_raw_device(sdmesh_handle *h, const Triangle *d_raw, uint32_t nslots) {
     HIPCHK(launch_raw_desc(st, h->grid, h->d_ctr + CTR_NTRI, (uint4 *) h->tdesc.p, (uint8_t *) h->flip.p, h->d_ctr + CTR_NTILES,
                            h->d_ctr + CTR_NUNIQ));
     HIPCHK(launch_tile_claim(st, h->tgrid, (const Vertex *) h->compact.p, (const uint4 *) h->tdesc.p, h->d_ctr + CTR_NTILES,
-                             h->wkeys, h->wsize, (uint32_t *) h->vslot.p, h->d_status));
+                             h->wkeys, h->wsize, (uint32_t *) h->vslot.p, h->d_status, h->wide_active));
     SDCHK(mesh_weld(h, (const Vertex *) h->compact.p));
     return SDMESH_OK;
 }
@@ -391,6 +475,7 @@ int refine_level(sdmesh_handle *h, int L, uint32_t n_cap_in, uint32_t out_cap, P
     }
     HIPCHK(launch_refine_mask(st, h->tgrid, h->scene, h->d_sp, (const Point *) h->vox[src].p, n_in, cs, (uint8_t *) h->mask.p,
                               cnt_region, mask_mode, signs));
+    SDCHK(prof_mark(h, "refine_mask"));
     uint32_t cap = out_cap;
     if (out_cap == 0) {
         HIPCHK(launch_sum_tiles(st, cnt_region, n_in, h->d_ctr + CTR_SCRATCH));
@@ -404,11 +489,25 @@ int refine_level(sdmesh_handle *h, int L, uint32_t n_cap_in, uint32_t out_cap, P
     HIPCHK(launch_refine_emit(st, h->tgrid, (const Point *) h->vox[src].p, n_in, cs, (const uint8_t *) h->mask.p, cnt_region,
                               (Point *) h->vox[dst].p, cap, n_out, h->d_status, signs, signs ? (uint8_t *) h->cubeidx.p : nullptr,
                               mesh_tilecnt));
+    SDCHK(prof_mark(h, "refine_emit"));
     h->cur = dst;
     return SDMESH_OK;
 }
 
 uint32_t padded(uint32_t n) { return n + n / 4 + 4096; }
+
+// levels the column kernels take care of (0 = level-by-level chain from the level-0 field)
+int col_levels(const sdmesh_handle *h, int levels, uint32_t n0) {
+    return (h->col_refine && !h->refine2 && levels >= 2 && n0) ? std::min(levels - 1, 3) : 0;
+}
+
+int ensure_col_scratch(sdmesh_handle *h, uint32_t ncols) {
+    SDCHK(ensure(h, h->col_list1, 256ull * ncols));
+    SDCHK(ensure(h, h->col_mask2, 256ull * ncols));
+    SDCHK(ensure(h, h->col_mask3, 2048ull * ncols));
+    SDCHK(ensure(h, h->colinfo, 16ull * ncols));
+    return SDMESH_OK;
+}
 
 // The planned, synchronisation-free device chain of one regen (capacities from the plan).  Every buffer has
 // been sized by the caller, so nothing here allocates: the same code runs eagerly or under stream capture.
@@ -428,14 +527,32 @@ int enqueue_planned_chain(sdmesh_handle *h, int levels, const uint32_t *box, uin
     }
     Point vs;
     vs.x = vs.y = vs.z = MESH_GENERATION_BB_SIZE / (float) MESH_GENERATION_INIT_FACTOR;
-    // (the control block is cleared by the field kernel itself: one graph node less in front of the chain)
-    if (n0) HIPCHK(launch_create_field(st, (Point *) h->vox[0].p, x0, x1, z0, z1, h->d_ctr + CTR_LEVEL0, (uint32_t *) h->ctl.p,
-                                       (uint32_t) (CTL_LVL0 + lvl_words), ff_in_kernel ? h->ff_arena.p : nullptr, (ff_bytes(h) + 15) & ~(size_t) 15));
-    else SDCHK(zero_ctl(h, lvl_words));
+    h->prof_n = 0;
+    SDCHK(prof_mark(h, "begin"));
+    // (the control block is cleared by the first kernel itself: one graph node less in front of the chain)
+    const int J = col_levels(h, levels, n0);
     uint32_t n_cap = n0;
-    uint32_t *mesh_tc = nullptr;        // set when the last refine level also classifies (k_classify is then skipped)
     h->cur = 0;
-    for (int L = 0; L < levels;) {
+    if (J) {
+        // levels 0 .. J per level-0 column: two launches, whatever J is (the level-0 .. J-1 lists are never materialised)
+        HIPCHK(launch_col_refine(st, h->scene, h->d_sp, x0, x1, z0, z1, J, (uint8_t *) h->col_list1.p, (uint8_t *) h->col_mask2.p,
+                                 (uint8_t *) h->col_mask3.p, (uint4 *) h->colinfo.p, (uint32_t *) h->ctl.p, (uint32_t) (CTL_LVL0 + lvl_words),
+                                 ff_in_kernel ? h->ff_arena.p : nullptr, (ff_bytes(h) + 15) & ~(size_t) 15));
+        SDCHK(prof_mark(h, "col_refine"));
+        n_cap = padded(h->plan_counts[J]);
+        HIPCHK(launch_col_emit(st, x0, x1, z0, z1, J, (const uint8_t *) h->col_list1.p, (const uint8_t *) h->col_mask2.p,
+                               (const uint8_t *) h->col_mask3.p, (const uint4 *) h->colinfo.p, (Point *) h->vox[0].p, n_cap,
+                               h->d_ctr + CTR_LEVEL0, h->d_status));
+        SDCHK(prof_mark(h, "col_emit"));
+        for (int i = 0; i < J; i++) vs = half_size(vs);
+    } else {
+        if (n0) HIPCHK(launch_create_field(st, (Point *) h->vox[0].p, x0, x1, z0, z1, h->d_ctr + CTR_LEVEL0, (uint32_t *) h->ctl.p,
+                                           (uint32_t) (CTL_LVL0 + lvl_words), ff_in_kernel ? h->ff_arena.p : nullptr, (ff_bytes(h) + 15) & ~(size_t) 15));
+        else SDCHK(zero_ctl(h, lvl_words));
+        SDCHK(prof_mark(h, "create_field"));
+    }
+    uint32_t *mesh_tc = nullptr;        // set when the last refine level also classifies (k_classify is then skipped)
+    for (int L = J; L < levels;) {
         const Point cs = half_size(vs);
         if (h->refine2 && L + 2 <= levels) {
             // two levels in one step: the level L+1 list is never materialised, only counted
@@ -471,15 +588,18 @@ int enqueue_planned_chain(sdmesh_handle *h, int levels, const uint32_t *box, uin
 }
 
 // size every buffer the planned chain touches (idempotent; may allocate, so it runs before any capture)
-int presize_planned_chain(sdmesh_handle *h, int levels, uint32_t n0, uint32_t *lvl_words_out) {
-    SDCHK(ensure(h, h->vox[0], sizeof(Point) * (size_t) std::max<uint32_t>(n0, 64)));
+int presize_planned_chain(sdmesh_handle *h, int levels, uint32_t n0, uint32_t zs_of_box, uint32_t *lvl_words_out) {
+    const int J = col_levels(h, levels, n0);
+    SDCHK(ensure(h, h->vox[0], sizeof(Point) * (size_t) std::max<uint32_t>(J ? padded(h->plan_counts[J]) : n0, 64)));
+    if (J) SDCHK(ensure_col_scratch(h, n0 / std::max<uint32_t>(1u, zs_of_box)));
     SDCHK(layout_mesh(h, padded(h->plan_counts[levels]), padded(h->plan_uniq)));
-    uint32_t lvl_words = 0, n_cap = n0;
+    uint32_t lvl_words = 0, n_cap = J ? padded(h->plan_counts[J]) : n0;
     int cur = 0;
-    for (int L = 0; L < levels;) {
+    for (int L = 0; L < J; L++) h->lvl_off[L] = 0;
+    for (int L = J; L < levels;) {
         const int step = (h->refine2 && L + 2 <= levels) ? 2 : 1;
         h->lvl_off[L] = lvl_words;
-        lvl_words += tiles(L == 0 ? n0 : padded(h->plan_counts[L])) + 16;
+        lvl_words += tiles(L == 0 ? n0 : padded(h->plan_counts[L])) + 16;       // (L == 0 only without the column kernels)
         SDCHK(ensure(h, h->mask, std::max<uint32_t>(n_cap, 64)));
         if (step == 2) SDCHK(ensure(h, h->mask2x, 8ull * std::max<uint32_t>(n_cap, 64)));
         if (step == 1 && L + 1 == levels && h->emit_ci) SDCHK(ensure(h, h->signs, 4ull * std::max<uint32_t>(n_cap, 64)));
@@ -528,7 +648,8 @@ int regen_impl(sdmesh_handle *h, int levels, int mode, int part, int nparts, sdm
                              mode == SDMESH_PART_ZSLAB ? p0 : 0u, mode == SDMESH_PART_ZSLAB ? p1 : F};
     const uint32_t n0 = (box[1] - box[0]) * F * (box[3] - box[2]);
 
-    for (int attempt = 0; attempt < 2; attempt++) {
+    if (h->weld_wide) h->wide_active = true;
+    for (int attempt = 0; attempt < 3; attempt++) {
         const bool resumed = phase == 2 && attempt == 0 && h->pend_async;
         const bool async = resumed || (h->plan_valid && h->plan_scene == h->scene && h->plan_levels == levels && h->plan_mode == mode &&
                                        h->plan_part == part && h->plan_nparts == nparts && attempt == 0);
@@ -552,11 +673,11 @@ int regen_impl(sdmesh_handle *h, int levels, int mode, int part, int nparts, sdm
             h->cur = 0;
             // ---- planned path: no host round trip until the final read-back; optionally replayed as a hipGraph
             uint32_t lvl_words = 0;
-            SDCHK(presize_planned_chain(h, levels, n0, &lvl_words));
+            SDCHK(presize_planned_chain(h, levels, n0, box[3] - box[2], &lvl_words));
             n_cap = padded(h->plan_counts[levels]);
-            if (h->use_graph) {
+            if (h->use_graph && st != nullptr && !h->profile && !h->project_diag) {   // (the legacy null stream cannot be captured: eager launches there)
                 uint64_t key[8] = {h->buf_gen, (uint64_t) h->scene, (uint64_t) levels, ((uint64_t) mode << 40) | ((uint64_t) part << 20) | (uint64_t) nparts,
-                                   (uint64_t) h->skip_weld, (uint64_t) (uintptr_t) st, (uint64_t) h->grid | ((uint64_t) h->tgrid << 20) | ((uint64_t) h->project_mult << 40) | ((uint64_t) h->flip_mult << 48) | ((uint64_t) h->refine2 << 56) | ((uint64_t) h->emit_ci << 57) | ((uint64_t) h->project_lanes << 58) | ((uint64_t) h->flip_lanes << 61), 0};
+                                   (uint64_t) h->skip_weld | ((uint64_t) h->wide_active << 1) | ((uint64_t) h->col_refine << 2), (uint64_t) (uintptr_t) st, (uint64_t) h->grid | ((uint64_t) h->tgrid << 20) | ((uint64_t) h->project_mult << 40) | ((uint64_t) h->flip_mult << 48) | ((uint64_t) h->refine2 << 56) | ((uint64_t) h->emit_ci << 57) | ((uint64_t) h->project_lanes << 58) | ((uint64_t) h->flip_lanes << 61), 0};
                 for (int i = 0; i <= levels; i++) key[7] = key[7] * 1000003ull + h->plan_counts[i];
                 key[7] = key[7] * 1000003ull + h->plan_uniq;
                 if (!h->graph_exec || memcmp(key, h->graph_key, sizeof key) != 0) {
@@ -593,14 +714,36 @@ int regen_impl(sdmesh_handle *h, int levels, int mode, int part, int nparts, sdm
                 return SDMESH_OK;
             }
             HIPCHK(hipStreamSynchronize(st));
+            if (h->profile) SDCHK(prof_collect(h));
         } else {
             // ---- discovery path: sizes become known level by level (one host sync per level)
             h->cur = 0;
             SDCHK(ensure(h, h->vox[0], sizeof(Point) * (size_t) std::max<uint32_t>(n0, 64)));
+            n_cap = n0;
             HIPCHK(hipEventRecord(h->ev0, st));
             SDCHK(zero_ctl(h, 0));
-            if (n0) HIPCHK(launch_create_field(st, (Point *) h->vox[0].p, box[0], box[1], box[2], box[3], h->d_ctr + CTR_LEVEL0));
-            for (int L = 0; L < levels; L++) {
+            const int J = col_levels(h, levels, n0);
+            if (J) {
+                // column kernels: lists first, then the totals (count-only emit + one host sync), then the level-J voxel list
+                SDCHK(ensure_col_scratch(h, n0 / (box[3] - box[2])));
+                HIPCHK(launch_col_refine(st, h->scene, h->d_sp, box[0], box[1], box[2], box[3], J, (uint8_t *) h->col_list1.p,
+                                         (uint8_t *) h->col_mask2.p, (uint8_t *) h->col_mask3.p, (uint4 *) h->colinfo.p, nullptr, 0, nullptr, 0));
+                for (int pass = 0; pass < 2; pass++) {
+                    HIPCHK(launch_col_emit(st, box[0], box[1], box[2], box[3], J, (const uint8_t *) h->col_list1.p, (const uint8_t *) h->col_mask2.p,
+                                           (const uint8_t *) h->col_mask3.p, (const uint4 *) h->colinfo.p, pass ? (Point *) h->vox[0].p : nullptr,
+                                           n_cap, h->d_ctr + CTR_LEVEL0, h->d_status));
+                    if (pass) break;
+                    uint32_t cnt = 0;
+                    HIPCHK(hipMemcpyAsync(&cnt, h->d_ctr + CTR_LEVEL0 + J, 4, hipMemcpyDeviceToHost, st));
+                    HIPCHK(hipStreamSynchronize(st));
+                    n_cap = cnt;
+                    SDCHK(ensure(h, h->vox[0], sizeof(Point) * (size_t) std::max<uint32_t>(cnt, 64)));
+                }
+                for (int i = 0; i < J; i++) vs = half_size(vs);
+            } else if (n0) {
+                HIPCHK(launch_create_field(st, (Point *) h->vox[0].p, box[0], box[1], box[2], box[3], h->d_ctr + CTR_LEVEL0));
+            }
+            for (int L = J; L < levels; L++) {
                 const Point cs = half_size(vs);
                 uint32_t cnt = 0;
                 h->lvl_off[L] = 0;
@@ -621,6 +764,12 @@ int regen_impl(sdmesh_handle *h, int levels, int mode, int part, int nparts, sdm
         const Point *d_vox = (const Point *) h->vox[h->cur].p;
         const uint32_t *n_ptr = h->d_ctr + CTR_LEVEL0 + levels;
         const uint32_t *c = h->h_pinned, *s = h->h_pinned + CTR_WORDS;
+        if (s[ST_WELD_RANGE] && !h->wide_active) {
+            // a vertex does not fit the packed key: the reference's [i64; 3] key has no range (src/cuda/mod.rs:268-273),
+            // so run again with the wide key form (sticky for this handle)
+            h->wide_active = true; h->plan_valid = false; drop_graph(h);
+            continue;
+        }
         if (!direct && s[ST_OVERFLOW]) {
             if (async) { h->plan_valid = false; drop_graph(h); continue; }   // capacities were too tight: redo synchronously
             // synchronous path: voxel buffers are exact, so only the unique-edge estimate can be too
@@ -634,7 +783,10 @@ int regen_impl(sdmesh_handle *h, int levels, int mode, int part, int nparts, sdm
             SDCHK(read_back(h));
             if (s[ST_OVERFLOW]) return fail(h, SDMESH_ERR_INTERNAL, "capacity overflow persists (status %u)", s[ST_OVERFLOW]);
         }
-        if (!direct && (s[ST_NOT_LATTICE] || s[ST_TILE_OVERFLOW])) direct = true;   // not expected for create+refine fields; handled anyway
+        // not expected for create+refine fields of the compiled scenes; handled anyway.  ST_NONFINITE: a projected vertex
+        // with a non-finite x -- the reference drops a triangle whose (post-flip) first vertex is one (src/cuda/mod.rs:289),
+        // which the per-slot direct path reproduces literally
+        if (!direct && (s[ST_NOT_LATTICE] || s[ST_TILE_OVERFLOW] || s[ST_NONFINITE])) direct = true;
         const uint32_t n = c[CTR_LEVEL0 + levels];
         if (direct) {
             SDCHK(ensure(h, h->raw, sizeof(Triangle) * 5ull * std::max<uint32_t>(n, 1)));
@@ -644,6 +796,13 @@ int regen_impl(sdmesh_handle *h, int levels, int mode, int part, int nparts, sdm
             HIPCHK(hipEventRecord(h->ev1, st));
             // keep the level counters: weld_raw_device only touches the mesh counters
             SDCHK(read_back(h));
+            if (s[ST_WELD_RANGE] && !h->wide_active) {
+                h->wide_active = true; h->plan_valid = false; drop_graph(h);
+                SDCHK(zero_status(h));
+                SDCHK(weld_raw_device(h, (const Triangle *) h->raw.p, 5u * n));
+                HIPCHK(hipEventRecord(h->ev1, st));
+                SDCHK(read_back(h));
+            }
         }
         SDCHK(status_to_error(h));
         float ms = 0.0f;
@@ -687,7 +846,7 @@ int host_mesh_front(sdmesh_handle *h, const Point *voxels, uint32_t n, Point vs,
             SDCHK(mesh_front(h, (const Point *) h->vox[0].p, h->d_ctr + CTR_LEVEL0, vs, true));
             SDCHK(read_back(h));
             const uint32_t *s = h->h_pinned + CTR_WORDS;
-            if (s[ST_NOT_LATTICE] || s[ST_TILE_OVERFLOW]) { direct = true; break; }
+            if (s[ST_NOT_LATTICE] || s[ST_TILE_OVERFLOW] || s[ST_NONFINITE]) { direct = true; break; }
             if (!s[ST_OVERFLOW]) break;
             if (attempt == 1) return fail(h, SDMESH_ERR_INTERNAL, "capacity overflow persists");
             SDCHK(layout_mesh(h, n, h->h_pinned[CTR_NUNIQ] + 1024));
@@ -763,7 +922,10 @@ void sdmesh_destroy(sdmesh_handle *h) {
     DevBuf *bufs[] = {&h->render_tex, &h->vox[0], &h->vox[1], &h->mask, &h->mask2x, &h->signs, &h->tilecnt, &h->ctl, &h->cubeidx, &h->trioff, &h->ff_arena,
                       &h->first_ord_buf, &h->uverts, &h->tri_e, &h->vslot, &h->tdesc, &h->tfirst, &h->tfpre, &h->tpre, &h->flip, &h->wvidx, &h->torder,
                       &h->vertices, &h->indices, &h->raw, &h->compact, &h->staging, &h->dense_samples, &h->dense_bits,
-                      &h->cellcnt};
+                      &h->cellcnt, &h->col_list1, &h->col_mask2, &h->col_mask3, &h->colinfo, &h->prof_rounds, &h->proj_diag, &h->shard_mine, &h->shard_counts, &h->shard_recv, &h->shard_lists, &h->shard_plan, &h->shard_merged};
+    (void) sdmesh_comm_destroy(h);
+    if (h->h_counts) (void) hipHostFree(h->h_counts);
+    if (h->h_lists) (void) hipHostFree(h->h_lists);
     for (DevBuf *b : bufs) release(*b);
     if (h->h_pinned) (void) hipHostFree(h->h_pinned);
     if (h->d_sp) (void) hipFree(h->d_sp);
@@ -774,6 +936,7 @@ void sdmesh_destroy(sdmesh_handle *h) {
     if (h->ev_fork) (void) hipEventDestroy(h->ev_fork);
     if (h->ev_join) (void) hipEventDestroy(h->ev_join);
     if (h->ev_ff) (void) hipEventDestroy(h->ev_ff);
+    for (hipEvent_t e : h->prof_ev) (void) hipEventDestroy(e);
     if (h->own_stream) (void) hipStreamDestroy(h->own_stream);
     delete h;
 }
@@ -813,7 +976,15 @@ int sdmesh_set_stream(sdmesh_handle *h, void *hip_stream) {
     if (!h) return SDMESH_ERR_INVALID;
     HIPCHK(hipStreamSynchronize(h->stream));
     drop_graph(h);
-    h->stream = hip_stream ? (hipStream_t) hip_stream : h->own_stream;
+    h->stream = (hipStream_t) hip_stream;          // NULL = the legacy default stream, exactly as HIP itself reads it
+    return SDMESH_OK;
+}
+
+int sdmesh_use_own_stream(sdmesh_handle *h) {
+    if (!h) return SDMESH_ERR_INVALID;
+    HIPCHK(hipStreamSynchronize(h->stream));
+    drop_graph(h);
+    h->stream = h->own_stream;
     return SDMESH_OK;
 }
 
@@ -829,8 +1000,12 @@ int sdmesh_set_option(sdmesh_handle *h, const char *name, int value) {
     if (!strcmp(name, "flip_mult")) { if (value < 1 || value > 16) return fail(h, SDMESH_ERR_INVALID, "flip_mult 1..16"); h->flip_mult = value; drop_graph(h); return SDMESH_OK; }
     if (!strcmp(name, "mask_chunk")) { if (value != 8 && value != 16 && value != 32) return fail(h, SDMESH_ERR_INVALID, "mask_chunk 8|16|32"); h->mask_chunk = value; drop_graph(h); return SDMESH_OK; }
     if (!strcmp(name, "refine2")) { h->refine2 = value ? 1 : 0; drop_graph(h); return SDMESH_OK; }
+    if (!strcmp(name, "col_refine")) { h->col_refine = value ? 1 : 0; h->plan_valid = false; drop_graph(h); return SDMESH_OK; }
     if (!strcmp(name, "emit_ci")) { h->emit_ci = value ? 1 : 0; drop_graph(h); return SDMESH_OK; }
     if (!strcmp(name, "skip_weld")) { h->skip_weld = value ? 1 : 0; return SDMESH_OK; }
+    if (!strcmp(name, "profile")) { h->profile = value ? 1 : 0; h->prof_n = 0; h->prof_ms.clear(); return SDMESH_OK; }
+    if (!strcmp(name, "project_diag")) { h->project_diag = value ? 1 : 0; return SDMESH_OK; }
+    if (!strcmp(name, "weld_wide")) { h->weld_wide = value ? 1 : 0; h->wide_active = value != 0; drop_graph(h); return SDMESH_OK; }
     if (!strcmp(name, "graph")) { h->use_graph = value ? 1 : 0; if (!value) drop_graph(h); return SDMESH_OK; }
     if (!strcmp(name, "tgrid")) {
         if (value < 1 || value > 65535) return fail(h, SDMESH_ERR_INVALID, "tgrid out of range");
@@ -960,10 +1135,15 @@ int sdmesh_voxel_field_to_mesh(sdmesh_handle *h, const struct Point *voxels, siz
     HIPCHK(hipSetDevice(h->device));
     SDCHK(sync_scene(h));
     bool direct = false;
-    SDCHK(host_mesh_front(h, voxels, (uint32_t) n, voxel_size, direct));
-    if (direct) SDCHK(weld_raw_device(h, (const Triangle *) h->raw.p, 5u * (uint32_t) n));
-    else SDCHK(mesh_weld(h, (const Vertex *) h->uverts.p));
-    SDCHK(read_back(h));
+    if (h->weld_wide) h->wide_active = true;
+    for (int pass = 0; pass < 2; pass++) {
+        SDCHK(host_mesh_front(h, voxels, (uint32_t) n, voxel_size, direct));
+        if (direct) SDCHK(weld_raw_device(h, (const Triangle *) h->raw.p, 5u * (uint32_t) n));
+        else SDCHK(mesh_weld(h, (const Vertex *) h->uverts.p));
+        SDCHK(read_back(h));
+        if (!h->h_pinned[CTR_WORDS + ST_WELD_RANGE] || h->wide_active) break;
+        h->wide_active = true;               // a vertex outside the packed key range: weld again with [i64; 3]-equivalent keys
+    }
     SDCHK(status_to_error(h));
     h->n_unique = h->h_pinned[CTR_NUNIQ];
     h->n_tris = h->h_pinned[CTR_NTRI];
@@ -1009,12 +1189,17 @@ int sdmesh_weld_device_triangles(sdmesh_handle *h, const struct Triangle *d_raw,
     HIPCHK(hipSetDevice(h->device));
     SDCHK(sync_scene(h));
     h->mesh_valid = false;
-    HIPCHK(hipEventRecord(h->ev0, h->stream));
-    SDCHK(zero_status(h));
-    HIPCHK(hipMemsetAsync(h->d_ctr + CTR_NUNIQ, 0, 4 * sizeof(uint32_t), h->stream));
-    SDCHK(weld_raw_device(h, d_raw, (uint32_t) nslots));
-    HIPCHK(hipEventRecord(h->ev1, h->stream));
-    SDCHK(read_back(h));
+    if (h->weld_wide) h->wide_active = true;
+    for (int pass = 0; pass < 2; pass++) {
+        HIPCHK(hipEventRecord(h->ev0, h->stream));
+        SDCHK(zero_status(h));
+        HIPCHK(hipMemsetAsync(h->d_ctr + CTR_NUNIQ, 0, 4 * sizeof(uint32_t), h->stream));
+        SDCHK(weld_raw_device(h, d_raw, (uint32_t) nslots));
+        HIPCHK(hipEventRecord(h->ev1, h->stream));
+        SDCHK(read_back(h));
+        if (!h->h_pinned[CTR_WORDS + ST_WELD_RANGE] || h->wide_active) break;
+        h->wide_active = true;               // src/cuda/mod.rs:268-273: [i64; 3] keys have no range
+    }
     SDCHK(status_to_error(h));
     if (h->h_pinned[CTR_WORDS + ST_OVERFLOW]) return fail(h, SDMESH_ERR_INTERNAL, "weld overflow (status %u)", h->h_pinned[CTR_WORDS + ST_OVERFLOW]);
     h->n_unique = nslots ? h->h_pinned[CTR_NUNIQ] : 0;
@@ -1269,6 +1454,251 @@ int sdmesh_render(sdmesh_handle *h, const GlobalsBuffer *globals, const CameraBu
     SDCHK(sdmesh_render_device(h, globals, camera, (Rgba *) h->render_tex.p, nullptr));
     HIPCHK(hipMemcpyAsync(target, h->render_tex.p, bytes, hipMemcpyDeviceToHost, h->stream));
     HIPCHK(hipStreamSynchronize(h->stream));
+    return SDMESH_OK;
+}
+
+}  // extern "C"
+
+extern "C" int sdmesh_profile_rounds(sdmesh_handle *h, uint64_t *vertex_rounds) {
+    if (!h || !vertex_rounds) return SDMESH_ERR_INVALID;
+    if (!h->prof_rounds.p) return fail(h, SDMESH_ERR_INVALID, "no profiled regen yet (option \"profile\")");
+    uint32_t host[256 * 16];
+    HIPCHK(hipMemcpy(host, h->prof_rounds.p, sizeof host, hipMemcpyDeviceToHost));
+    uint64_t sum = 0;
+    for (int i = 0; i < 256; i++) sum += host[i * 16];
+    *vertex_rounds = sum;
+    return SDMESH_OK;
+}
+
+extern "C" int sdmesh_project_diag(sdmesh_handle *h, uint64_t *out, size_t cap_waves, size_t *n_waves) {
+    if (!h || !n_waves) return SDMESH_ERR_INVALID;
+    *n_waves = h->proj_diag.p ? h->diag_waves : 0;
+    if (!out) return SDMESH_OK;
+    if (cap_waves < *n_waves) return fail(h, SDMESH_ERR_CAPACITY, "need room for %zu waves", *n_waves);
+    if (*n_waves) HIPCHK(hipMemcpy(out, h->proj_diag.p, 32ull * *n_waves, hipMemcpyDeviceToHost));
+    return SDMESH_OK;
+}
+
+extern "C" int sdmesh_profile_stages(sdmesh_handle *h, char *names, size_t names_cap, float *ms, int cap, int *n_out) {
+    if (!h || !n_out) return SDMESH_ERR_INVALID;
+    const int n = h->prof_ms.size() > 1 ? (int) h->prof_ms.size() - 1 : 0;      // stage i = gap between markers i and i + 1
+    *n_out = n;
+    if (!names && !ms) return SDMESH_OK;
+    if (cap < n) return fail(h, SDMESH_ERR_CAPACITY, "need room for %d stages", n);
+    std::string joined;
+    for (int i = 0; i < n; i++) {
+        if (ms) ms[i] = h->prof_ms[(size_t) i + 1];
+        if (i) joined += ',';
+        joined += h->prof_names[(size_t) i + 1];
+    }
+    if (names) {
+        if (joined.size() + 1 > names_cap) return fail(h, SDMESH_ERR_CAPACITY, "need %zu bytes for the stage names", joined.size() + 1);
+        memcpy(names, joined.c_str(), joined.size() + 1);
+    }
+    return SDMESH_OK;
+}
+
+// ================================================================================================
+// Multi-GPU: ONE mesh over the ranks of an RCCL communicator
+// ================================================================================================
+namespace {
+
+RcclApi g_rccl;
+
+const char *load_rccl() {
+    if (g_rccl.lib) return nullptr;
+    void *lib = dlopen("librccl.so.1", RTLD_NOW | RTLD_NOLOAD);          // the copy already in the process (PyTorch-ROCm)
+    if (!lib) lib = dlopen("librccl.so.1", RTLD_NOW | RTLD_LOCAL);
+    if (!lib) lib = dlopen("/opt/rocm/lib/librccl.so.1", RTLD_NOW | RTLD_LOCAL);
+    if (!lib) return "librccl.so.1 not found";
+#define SDM_BIND(field, sym)                                                     \
+    g_rccl.field = reinterpret_cast<decltype(g_rccl.field)>(dlsym(lib, sym));    \
+    if (!g_rccl.field) return "librccl.so.1 lacks " sym
+    SDM_BIND(GetUniqueId, "ncclGetUniqueId");
+    SDM_BIND(CommInitRank, "ncclCommInitRank");
+    SDM_BIND(CommDestroy, "ncclCommDestroy");
+    SDM_BIND(AllGather, "ncclAllGather");
+    SDM_BIND(AllReduce, "ncclAllReduce");
+    SDM_BIND(Send, "ncclSend");
+    SDM_BIND(Recv, "ncclRecv");
+    SDM_BIND(GroupStart, "ncclGroupStart");
+    SDM_BIND(GroupEnd, "ncclGroupEnd");
+    SDM_BIND(GetErrorString, "ncclGetErrorString");
+#undef SDM_BIND
+    g_rccl.lib = lib;
+    return nullptr;
+}
+
+#define NCCLCHK(expr)                                                                                               \
+    do {                                                                                                            \
+        ncclResult_t r_ = (expr);                                                                                   \
+        if (r_ != ncclSuccess)                                                                                      \
+            return fail(h, SDMESH_ERR_RCCL, "%s failed: %s (%s:%d)", #expr, g_rccl.GetErrorString(r_), __FILE__, __LINE__); \
+    } while (0)
+
+int ensure_grow(sdmesh_handle *h, DevBuf &b, size_t bytes) {      // like ensure(), with 25 % head-room when it has to grow
+    if (b.p && b.cap >= bytes) return SDMESH_OK;
+    return ensure(h, b, bytes + bytes / 4 + 4096);
+}
+
+int ensure_shard_host(sdmesh_handle *h, int nranks) {
+    const size_t words = (size_t) nranks * 1024;
+    if (h->h_counts_words >= words) return SDMESH_OK;
+    if (h->h_counts) (void) hipHostFree(h->h_counts);
+    if (h->h_lists) (void) hipHostFree(h->h_lists);
+    h->h_counts = nullptr; h->h_lists = nullptr; h->h_counts_words = 0;
+    HIPCHK(hipHostMalloc((void **) &h->h_counts, 4 * words, hipHostMallocDefault));
+    HIPCHK(hipHostMalloc((void **) &h->h_lists, sizeof(void *) * (size_t) nranks, hipHostMallocDefault));
+    h->h_counts_words = words;
+    return SDMESH_OK;
+}
+
+// merged list of `nranks` device lists (pointers in h->h_lists, pinned) by the nranks x 1024 counts at d_counts
+int merge_lists(sdmesh_handle *h, const uint32_t *d_counts, int nranks, Triangle *d_out, size_t cap) {
+    SDCHK(ensure(h, h->shard_lists, sizeof(void *) * (size_t) nranks));
+    SDCHK(ensure(h, h->shard_plan, 8ull * (size_t) nranks * 1024));
+    HIPCHK(hipMemcpyAsync(h->shard_lists.p, h->h_lists, sizeof(void *) * (size_t) nranks, hipMemcpyHostToDevice, h->stream));
+    HIPCHK(launch_merge_by_column(h->stream, (const Triangle *const *) h->shard_lists.p, d_counts, nranks, (uint32_t *) h->shard_plan.p,
+                                  d_out, (uint32_t) std::min<size_t>(cap, 0xFFFFFFFFu), h->d_ctr + CTR_SCRATCH, h->d_status));
+    return SDMESH_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int sdmesh_comm_unique_id(sdmesh_unique_id *out) {
+    if (!out) return SDMESH_ERR_INVALID;
+    static_assert(sizeof(sdmesh_unique_id) == sizeof(ncclUniqueId), "sdmesh_unique_id must be an ncclUniqueId");
+    if (load_rccl()) return SDMESH_ERR_RCCL;
+    ncclUniqueId id;
+    if (g_rccl.GetUniqueId(&id) != ncclSuccess) return SDMESH_ERR_RCCL;
+    memcpy(out->bytes, &id, sizeof id);
+    return SDMESH_OK;
+}
+
+int sdmesh_comm_init(sdmesh_handle *h, const sdmesh_unique_id *id, int nranks, int rank) {
+    if (!h || !id || nranks < 1 || nranks > 32 || rank < 0 || rank >= nranks) return SDMESH_ERR_INVALID;
+    if (h->comm) return fail(h, SDMESH_ERR_INVALID, "the handle already has a communicator");
+    if (const char *why = load_rccl()) return fail(h, SDMESH_ERR_RCCL, "%s", why);
+    HIPCHK(hipSetDevice(h->device));
+    ncclUniqueId nid;
+    memcpy(&nid, id->bytes, sizeof nid);
+    NCCLCHK(g_rccl.CommInitRank(&h->comm, nranks, nid, rank));
+    h->comm_rank = rank;
+    h->comm_nranks = nranks;
+    return SDMESH_OK;
+}
+
+int sdmesh_comm_destroy(sdmesh_handle *h) {
+    if (!h) return SDMESH_ERR_INVALID;
+    if (h->comm) {
+        (void) hipStreamSynchronize(h->stream);
+        (void) g_rccl.CommDestroy(h->comm);
+        h->comm = nullptr;
+    }
+    h->comm_rank = 0;
+    h->comm_nranks = 1;
+    return SDMESH_OK;
+}
+
+int sdmesh_comm_ranks(sdmesh_handle *h, int *ranks_seen) {
+    if (!h || !ranks_seen) return SDMESH_ERR_INVALID;
+    if (!h->comm) return fail(h, SDMESH_ERR_INVALID, "no communicator (sdmesh_comm_init)");
+    HIPCHK(hipSetDevice(h->device));
+    HIPCHK(launch_set_u32(h->stream, h->d_ctr + CTR_SCRATCH, 1u));
+    NCCLCHK(g_rccl.AllReduce(h->d_ctr + CTR_SCRATCH, h->d_ctr + CTR_SCRATCH, 1, ncclUint32, ncclSum, h->comm, h->stream));
+    uint32_t v = 0;
+    HIPCHK(hipMemcpyAsync(&v, h->d_ctr + CTR_SCRATCH, 4, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    *ranks_seen = (int) v;
+    return SDMESH_OK;
+}
+
+int sdmesh_merge_by_column(sdmesh_handle *h, const struct Triangle *const *d_lists, const uint32_t *d_counts, int nranks,
+                           struct Triangle *d_out, size_t cap, size_t *n_out) {
+    if (!h || !d_lists || !d_counts || !n_out || nranks < 1 || nranks > 32 || (cap && !d_out)) return SDMESH_ERR_INVALID;
+    HIPCHK(hipSetDevice(h->device));
+    SDCHK(ensure_shard_host(h, nranks));
+    for (int r = 0; r < nranks; r++) h->h_lists[r] = (void *) d_lists[r];
+    SDCHK(zero_status(h));
+    SDCHK(merge_lists(h, d_counts, nranks, d_out, cap));
+    SDCHK(read_back(h));
+    *n_out = h->h_pinned[CTR_SCRATCH];
+    if (h->h_pinned[CTR_WORDS + ST_OVERFLOW]) return fail(h, SDMESH_ERR_CAPACITY, "merged list needs room for %u triangles", h->h_pinned[CTR_SCRATCH]);
+    return SDMESH_OK;
+}
+
+int sdmesh_sharded_regen(sdmesh_handle *h, int levels, int root, sdmesh_regen_info *info) {
+    if (!h) return SDMESH_ERR_INVALID;
+    if (!h->comm) return fail(h, SDMESH_ERR_INVALID, "no communicator (sdmesh_comm_init)");
+    const int R = h->comm_nranks, me = h->comm_rank;
+    if (root < 0 || root >= R) return fail(h, SDMESH_ERR_INVALID, "root %d outside the communicator", root);
+    hipStream_t st = h->stream;
+    // 1. this rank's level-0 z-slab: refine^levels, marching cubes, projection, orientation; no weld
+    const int saved_skip = h->skip_weld;
+    h->skip_weld = 1;
+    sdmesh_regen_info slab;
+    const int rc = regen_impl(h, levels, SDMESH_PART_ZSLAB, me, R, &slab);
+    h->skip_weld = saved_skip;
+    SDCHK(rc);
+    if (h->last_direct) return fail(h, SDMESH_ERR_INTERNAL, "a slab took the direct path: no column counts");
+    const uint32_t n_mine = h->n_tris;
+    // 2. compact triangle list of the slab + its per-column counts, then the 4 KB all-gather of the counts
+    SDCHK(ensure_grow(h, h->shard_mine, sizeof(Triangle) * (size_t) std::max<uint32_t>(n_mine, 1)));
+    SDCHK(ensure(h, h->shard_counts, 4ull * (size_t) R * 1024));
+    uint32_t *d_counts = (uint32_t *) h->shard_counts.p;
+    if (n_mine)
+        HIPCHK(launch_expand_compact(st, h->grid, (const Vertex *) h->uverts.p, (const uint32_t *) h->tri_e.p, (const uint8_t *) h->flip.p,
+                                     h->d_ctr + CTR_NTRI, (Triangle *) h->shard_mine.p, n_mine));
+    HIPCHK(hipMemsetAsync(d_counts + (size_t) me * 1024, 0, 4096, st));
+    if (h->n_vox) {
+        HIPCHK(launch_set_u32(st, h->d_ctr + CTR_SCRATCH, h->n_vox));
+        HIPCHK(launch_column_counts(st, std::min(h->grid, (int) tiles(h->n_vox)), (const Point *) h->vox[h->cur].p,
+                                    h->d_ctr + CTR_SCRATCH, (const uint8_t *) h->cubeidx.p, d_counts + (size_t) me * 1024));
+    }
+    NCCLCHK(g_rccl.AllGather(d_counts + (size_t) me * 1024, d_counts, 1024, ncclUint32, h->comm, st));   // in place
+    if (me != root) {
+        // 3a. peers: the slab's triangles go straight to the root (each peer on its own xGMI link)
+        if (n_mine) NCCLCHK(g_rccl.Send(h->shard_mine.p, (size_t) n_mine * 18, ncclFloat32, root, h->comm, st));
+        HIPCHK(hipStreamSynchronize(st));
+        if (info) *info = slab;
+        return SDMESH_OK;
+    }
+    // 3b. root: sizes from the gathered counts (the one extra host synchronisation of a sharded step), grouped receives
+    SDCHK(ensure_shard_host(h, R));
+    HIPCHK(hipMemcpyAsync(h->h_counts, d_counts, 4ull * (size_t) R * 1024, hipMemcpyDeviceToHost, st));
+    HIPCHK(hipStreamSynchronize(st));
+    std::vector<uint64_t> tr((size_t) R, 0);
+    uint64_t total = 0, foreign = 0;
+    for (int r = 0; r < R; r++) {
+        for (int c = 0; c < 1024; c++) tr[r] += h->h_counts[(size_t) r * 1024 + c];
+        total += tr[r];
+        if (r != root) foreign += tr[r];
+    }
+    if (tr[root] != n_mine) return fail(h, SDMESH_ERR_INTERNAL, "column counts (%llu) disagree with the slab's triangle count (%u)", (unsigned long long) tr[root], n_mine);
+    if (total > 0x0FFFFFFFull) return fail(h, SDMESH_ERR_INVALID, "too many triangles for one weld");
+    SDCHK(ensure_grow(h, h->shard_recv, sizeof(Triangle) * (size_t) std::max<uint64_t>(foreign, 1)));
+    SDCHK(ensure_grow(h, h->shard_merged, sizeof(Triangle) * (size_t) std::max<uint64_t>(total, 1)));
+    uint64_t off = 0;
+    for (int r = 0; r < R; r++) {
+        if (r == root) { h->h_lists[r] = h->shard_mine.p; continue; }
+        h->h_lists[r] = (Triangle *) h->shard_recv.p + off;
+        off += tr[r];
+    }
+    if (foreign) {
+        NCCLCHK(g_rccl.GroupStart());
+        for (int r = 0; r < R; r++)
+            if (r != root && tr[r]) NCCLCHK(g_rccl.Recv(h->h_lists[r], (size_t) tr[r] * 18, ncclFloat32, r, h->comm, st));
+        NCCLCHK(g_rccl.GroupEnd());
+    }
+    // 4. order-restoring merge (HIP kernel), then the first-seen weld of the merged list = the single-GPU mesh
+    SDCHK(merge_lists(h, d_counts, R, (Triangle *) h->shard_merged.p, (size_t) total));
+    SDCHK(sdmesh_weld_device_triangles(h, (const Triangle *) h->shard_merged.p, (size_t) total, info));
+    if (info) {
+        info->levels = (uint32_t) levels;
+        info->voxel_size = slab.voxel_size;
+    }
     return SDMESH_OK;
 }
 

@@ -476,6 +476,222 @@ __global__ __launch_bounds__(256) void k_refine2_emit(const Point *__restrict__ 
     }
 }
 
+
+// ------------------------------------------------------------------------------------------
+// A1 + A2, levels 0 .. J in ONE workgroup per level-0 (x0, y0) column ("column refine", J = 1..3).
+//
+// The refine chain is latency-bound: at 512^3 the first three levels hold 32 768 / 4 136 / 16 532 parents -- 17 to 128
+// workgroups on 256 CUs, two dependent launches per level.  A level-0 column (32 cells, z innermost) is a CONTIGUOUS
+// range of the reference's order at every level (src/cuda/mod.rs:105-122: x outer, y, z inner; children in slot order
+// compute_mesh_generation.cu:51), and all its descendants down to level 3 fit LDS, so one workgroup walks the levels
+// itself: level-1 lattice signs of the column -> kept level-1 children (ordered) -> their 27 level-2 samples each ->
+// kept level-2 cells (ordered) -> their 27 level-3 samples each -> per-cell child masks.  Same sample positions
+// (lattice point m of level l is (float) m * h_l - 2.5f, the value b + i * cs of the reference's float adds: all
+// dyadic, exact), same `sd <= 0` test, same "not all 8 corner signs equal" criterion as k_refine_mask.
+// k_col_refine writes the ordered lists / masks per column, k_col_emit (next launch: it needs every column's count)
+// writes the level-J voxel list in the reference's order.  The workgroups of k_col_refine also clear the regen's
+// control block and the weld table (what k_create_field does in the level-by-level chain).
+// ------------------------------------------------------------------------------------------
+static constexpr uint32_t COL_L1 = 256;      // level-1 children of a column (32 cells x 8)
+static constexpr uint32_t COL_L2 = 2048;     // level-2 cells of a column
+static constexpr uint32_t COL_S1 = 9 * 65;   // level-1 lattice samples of a column: 3 x 3 x (2 * 32 + 1)
+
+// lattice index (at the level of the entry) of list1 entry t = cell * 8 + slot of column (X0, Y0), slab start Z0
+__device__ __forceinline__ void col_l1_index(uint32_t t, uint32_t X0, uint32_t Y0, uint32_t Z0, uint32_t &lx, uint32_t &ly, uint32_t &lz) {
+    const uint32_t zc = t >> 3, c = t & 7u;
+    lx = 2u * X0 + (c >> 2); ly = 2u * Y0 + ((c >> 1) & 1u); lz = 2u * (Z0 + zc) + (c & 1u);
+}
+
+// 27 samples of the cell at lattice (lx, ly, lz) of spacing 2 * hc (children spacing hc): 32 lanes per cell, lane s < 27
+// evaluates sample (s / 9, (s / 3) % 3, s % 3); returns the 8-bit kept-children mask in the lane with s == 0
+template <int SCENE>
+__device__ __forceinline__ uint32_t col_cell_mask(bool valid, uint32_t lx, uint32_t ly, uint32_t lz, float hc, uint32_t s, const SceneParams &sp) {
+    bool in = false;
+    if (valid && s < 27u) {
+        const uint32_t ix = s / 9u, iy = (s / 3u) % 3u, iz = s % 3u;
+        in = sdf<SCENE>(lat((int) (2u * lx + ix), hc), lat((int) (2u * ly + iy), hc), lat((int) (2u * lz + iz), hc), sp) <= 0.0f;
+    }
+    const uint64_t bal = __ballot(in);
+    return child_mask_from_bits((uint32_t) (bal >> (threadIdx.x & 32u)) & 0x7FFFFFFu);
+}
+
+template <int SCENE>
+__global__ __launch_bounds__(256) void k_col_refine(uint32_t x0, uint32_t z0, uint32_t zs, uint32_t J, const SceneParams *__restrict__ spp,
+                                                     uint8_t *__restrict__ g_list1, uint8_t *__restrict__ g_mask2, uint8_t *__restrict__ g_mask3,
+                                                     uint4 *__restrict__ colinfo, uint32_t *__restrict__ zero, uint32_t nzero,
+                                                     uint4 *__restrict__ ff, uint32_t nff16) {
+    const SceneParams &sp = *spp;
+    __shared__ uint8_t s_sign[COL_S1];
+    __shared__ uint8_t s_list1[COL_L1];
+    __shared__ uint8_t s_mask2[COL_L1];
+    __shared__ uint16_t s_list2[COL_L2];
+    __shared__ uint32_t s_scan[17];
+    __shared__ uint32_t s_n3;
+    const uint32_t tid = threadIdx.x;
+    // the regen's clears (control block, weld table), spread over the grid
+    for (uint32_t i = blockIdx.x * 256u + tid; i < nzero; i += gridDim.x * 256u) zero[i] = 0u;
+    const uint4 ones = make_uint4(0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu);
+    for (uint32_t i = blockIdx.x * 256u + tid; i < nff16; i += gridDim.x * 256u) ff[i] = ones;
+
+    const uint32_t F = MESH_GENERATION_INIT_FACTOR;
+    const float h0 = MESH_GENERATION_BB_SIZE / (float) MESH_GENERATION_INIT_FACTOR;
+    const float h1 = h0 / 2.0f, h2 = h1 / 2.0f, h3 = h2 / 2.0f;                 // src/cuda/mod.rs:126-130, exact halvings
+    const uint32_t col = blockIdx.x, X0 = x0 + col / F, Y0 = col % F, Z0 = z0;
+    const uint32_t nz1 = 2u * zs + 1u;                                          // level-1 lattice points along z
+    if (tid == 0) s_n3 = 0;
+    // A. signs of the column's level-1 lattice: (ix, iy) in 0..2, iz in 0..2 zs
+    for (uint32_t i = tid; i < 9u * nz1; i += 256u) {
+        const uint32_t ix = i / (3u * nz1), iy = (i / nz1) % 3u, iz = i % nz1;
+        s_sign[i] = sdf<SCENE>(lat((int) (2u * X0 + ix), h1), lat((int) (2u * Y0 + iy), h1), lat((int) (2u * Z0 + iz), h1), sp) <= 0.0f ? 1 : 0;
+    }
+    __syncthreads();
+    // B. level-1 children in order: thread t = cell * 8 + slot; kept iff its 8 corner signs differ
+    bool act1 = false;
+    if (tid < 8u * zs) {
+        const uint32_t zc = tid >> 3, c = tid & 7u, i = c >> 2, j = (c >> 1) & 1u, k = c & 1u;
+        uint32_t cnt = 0;
+#pragma unroll
+        for (uint32_t q = 0; q < 8; q++)
+            cnt += s_sign[((i + (q >> 2)) * 3u + (j + ((q >> 1) & 1u))) * nz1 + 2u * zc + k + (q & 1u)];
+        act1 = cnt != 0 && cnt != 8;
+    }
+    uint32_t n1;
+    const uint32_t p1 = block_excl_scan(act1 ? 1u : 0u, n1, s_scan);
+    if (act1) s_list1[p1] = (uint8_t) tid;
+    __syncthreads();
+    uint32_t n2 = 0, n3 = 0;
+    const uint32_t grp = tid >> 5, s = tid & 31u;
+    if (J >= 2 && n1) {
+        // C. level-2: 27 samples per kept level-1 child, 8 children per pass
+        for (uint32_t a0 = 0; a0 < n1; a0 += 8u) {
+            const uint32_t a = a0 + grp;
+            uint32_t lx = 0, ly = 0, lz = 0;
+            if (a < n1) col_l1_index(s_list1[a], X0, Y0, Z0, lx, ly, lz);
+            const uint32_t m = col_cell_mask<SCENE>(a < n1, lx, ly, lz, h2, s, sp);
+            if (s == 0 && a < n1) s_mask2[a] = (uint8_t) m;
+        }
+        __syncthreads();
+        const uint32_t m2 = tid < n1 ? s_mask2[tid] : 0u;
+        uint32_t o2 = block_excl_scan(__popc(m2), n2, s_scan);
+        if (J >= 3) {
+            for (uint32_t c = 0; c < 8; c++)
+                if (m2 & (1u << c)) { if (o2 < COL_L2) s_list2[o2] = (uint16_t) (tid * 8u + c); o2++; }
+            __syncthreads();
+            // D. level-3: 27 samples per kept level-2 cell, 8 cells per pass
+            uint32_t local3 = 0;
+            for (uint32_t b0 = 0; b0 < n2; b0 += 8u) {
+                const uint32_t b = b0 + grp;
+                uint32_t lx = 0, ly = 0, lz = 0;
+                if (b < n2) {
+                    const uint32_t e = s_list2[b], c2 = e & 7u;
+                    col_l1_index(s_list1[e >> 3], X0, Y0, Z0, lx, ly, lz);
+                    lx = 2u * lx + (c2 >> 2); ly = 2u * ly + ((c2 >> 1) & 1u); lz = 2u * lz + (c2 & 1u);
+                }
+                const uint32_t m = col_cell_mask<SCENE>(b < n2, lx, ly, lz, h3, s, sp);
+                if (s == 0 && b < n2) { g_mask3[(size_t) col * COL_L2 + b] = (uint8_t) m; local3 += __popc(m); }
+            }
+            if (local3) atomicAdd(&s_n3, local3);
+            __syncthreads();
+            n3 = s_n3;
+        }
+    }
+    if (tid < n1) {
+        g_list1[(size_t) col * COL_L1 + tid] = s_list1[tid];
+        if (J >= 2) g_mask2[(size_t) col * COL_L1 + tid] = s_mask2[tid];
+    }
+    if (tid == 0) colinfo[col] = make_uint4(n1, n2, n3, 0u);
+}
+
+// Ordered emission of the level-J voxel list from the per-column lists (J = 1..3).  Every workgroup sums the counts of
+// the columns in front of it (<= 1024 words); block 0 also publishes the level totals.  out == nullptr: totals only.
+__global__ __launch_bounds__(256) void k_col_emit(uint32_t x0, uint32_t z0, uint32_t zs, uint32_t ncols, uint32_t J,
+                                                   const uint8_t *__restrict__ g_list1, const uint8_t *__restrict__ g_mask2,
+                                                   const uint8_t *__restrict__ g_mask3, const uint4 *__restrict__ colinfo,
+                                                   Point *__restrict__ out, uint32_t cap, uint32_t *__restrict__ level_ctr /* [0..J] */,
+                                                   uint32_t *__restrict__ status) {
+    __shared__ uint8_t s_list1[COL_L1];
+    __shared__ uint16_t s_list2[COL_L2];
+    __shared__ uint32_t s_scan[17];
+    const uint32_t F = MESH_GENERATION_INIT_FACTOR, tid = threadIdx.x;
+    const float h0 = MESH_GENERATION_BB_SIZE / (float) MESH_GENERATION_INIT_FACTOR;
+    const float hJ = J == 1 ? h0 / 2.0f : (J == 2 ? h0 / 4.0f : h0 / 8.0f);
+    const uint32_t col = blockIdx.x, X0 = x0 + col / F, Y0 = col % F, Z0 = z0;
+    // offset of this column in the level-J list; block 0 sums everything for the totals
+    uint32_t before = 0, t1 = 0, t2 = 0, t3 = 0;
+    for (uint32_t c = tid; c < ncols; c += 256u) {
+        const uint4 ci = colinfo[c];
+        const uint32_t nj = J == 1 ? ci.x : (J == 2 ? ci.y : ci.z);
+        if (c < col) before += nj;
+        t1 += ci.x; t2 += ci.y; t3 += ci.z;
+    }
+    uint32_t base, tot;
+    (void) block_excl_scan(before, base, s_scan);
+    if (blockIdx.x == 0) {
+        (void) block_excl_scan(t1, tot, s_scan); const uint32_t T1 = tot;
+        (void) block_excl_scan(t2, tot, s_scan); const uint32_t T2 = tot;
+        (void) block_excl_scan(t3, tot, s_scan); const uint32_t T3 = tot;
+        if (tid == 0) {
+            uint32_t tj = J == 1 ? T1 : (J == 2 ? T2 : T3);
+            if (out && tj > cap) { atomicOr(&status[ST_OVERFLOW], 1u); tj = cap; }
+            level_ctr[0] = ncols * zs;
+            level_ctr[1] = J == 1 ? tj : T1;
+            if (J >= 2) level_ctr[2] = J == 2 ? tj : T2;
+            if (J >= 3) level_ctr[3] = tj;
+        }
+    }
+    if (!out) return;
+    const uint4 me = colinfo[col];
+    const uint32_t n1 = me.x, n2 = me.y;
+    if (n1 == 0) return;
+    if (tid < n1) s_list1[tid] = g_list1[(size_t) col * COL_L1 + tid];
+    __syncthreads();
+    if (J == 1) {
+        if (tid < n1 && base + tid < cap) {
+            uint32_t lx, ly, lz;
+            col_l1_index(s_list1[tid], X0, Y0, Z0, lx, ly, lz);
+            out[base + tid] = Point{lat((int) lx, hJ), lat((int) ly, hJ), lat((int) lz, hJ)};
+        }
+        return;
+    }
+    const uint32_t m2 = tid < n1 ? g_mask2[(size_t) col * COL_L1 + tid] : 0u;
+    uint32_t tot2;
+    uint32_t o2 = block_excl_scan(__popc(m2), tot2, s_scan);
+    if (J == 2) {
+        if (m2) {
+            uint32_t lx, ly, lz;
+            col_l1_index(s_list1[tid], X0, Y0, Z0, lx, ly, lz);
+            for (uint32_t c = 0; c < 8; c++)
+                if (m2 & (1u << c)) {
+                    if (base + o2 < cap) out[base + o2] = Point{lat((int) (2u * lx + (c >> 2)), hJ), lat((int) (2u * ly + ((c >> 1) & 1u)), hJ), lat((int) (2u * lz + (c & 1u)), hJ)};
+                    o2++;
+                }
+        }
+        return;
+    }
+    for (uint32_t c = 0; c < 8; c++)
+        if (m2 & (1u << c)) { if (o2 < COL_L2) s_list2[o2] = (uint16_t) (tid * 8u + c); o2++; }
+    __syncthreads();
+    uint32_t run = base;
+    for (uint32_t b0 = 0; b0 < n2; b0 += 256u) {
+        const uint32_t b = b0 + tid;
+        const uint32_t m3 = b < n2 ? g_mask3[(size_t) col * COL_L2 + b] : 0u;
+        uint32_t tot3;
+        uint32_t o3 = run + block_excl_scan(__popc(m3), tot3, s_scan);
+        if (m3) {
+            const uint32_t e = s_list2[b], c2 = e & 7u;
+            uint32_t lx, ly, lz;
+            col_l1_index(s_list1[e >> 3], X0, Y0, Z0, lx, ly, lz);
+            lx = 2u * lx + (c2 >> 2); ly = 2u * ly + ((c2 >> 1) & 1u); lz = 2u * lz + (c2 & 1u);
+            for (uint32_t c = 0; c < 8; c++)
+                if (m3 & (1u << c)) {
+                    if (o3 < cap) out[o3] = Point{lat((int) (2u * lx + (c >> 2)), hJ), lat((int) (2u * ly + ((c >> 1) & 1u)), hJ), lat((int) (2u * lz + (c & 1u)), hJ)};
+                    o3++;
+                }
+        }
+        run += tot3;
+    }
+}
+
 // Raw 8n layout of the reference kernel (INFINITY for non-border children)
 __global__ __launch_bounds__(256) void k_refine_expand_raw(const Point *__restrict__ vox, uint32_t n, Point cs,
                                                             const uint8_t *__restrict__ mask, Point *__restrict__ out) {
@@ -736,6 +952,27 @@ __device__ __forceinline__ uint32_t weld_claim(const Point p, uint64_t *__restri
     return U32_NONE;
 }
 
+// The reference's key is [i64; 3] (src/cuda/mod.rs:268-273), unbounded.  When a vertex does not fit the packed 3 x 21-bit
+// key the host re-runs the weld in WIDE mode: a slot then holds the id of the vertex that claimed it (its "owner") and
+// two keys are equal iff the quantised triples of the two POSITIONS are (every position was written by an earlier
+// kernel).  Same first-seen semantics, any coordinate the i64 cast can express (NaN -> 0, +-inf saturate, as `as i64`).
+__device__ __forceinline__ uint32_t weld_claim_wide(const Vertex *__restrict__ uverts, uint32_t id, uint64_t *__restrict__ wkeys,
+                                                    uint32_t wsize, uint32_t *__restrict__ status) {
+    const Point p = uverts[id].position;
+    const long long qx = weld_quant(p.x), qy = weld_quant(p.y), qz = weld_quant(p.z);
+    const uint64_t hsh = mix64((uint64_t) qx * 0x9E3779B97F4A7C15ull ^ mix64((uint64_t) qy) ^ (mix64((uint64_t) qz) << 1));
+    uint32_t s = (uint32_t) (((hsh >> 32) * (uint64_t) wsize) >> 32);
+    for (uint32_t probe = 0; probe < wsize; probe++) {
+        const uint64_t prev = atomicCAS((unsigned long long *) &wkeys[s], (unsigned long long) KEY_EMPTY, (unsigned long long) id);
+        if (prev == KEY_EMPTY) return s | VS_WINNER;
+        const Point o = uverts[(uint32_t) prev].position;
+        if (weld_quant(o.x) == qx && weld_quant(o.y) == qy && weld_quant(o.z) == qz) return s;
+        s = hash_next(s, wsize);
+    }
+    atomicOr(&status[ST_OVERFLOW], 8u);
+    return U32_NONE;
+}
+
 // exclusive prefix of the per-tile unique-vertex counts (dense work index for k_project); total -> *nu_out
 __global__ __launch_bounds__(1024) void k_tile_prefix(const uint4 *__restrict__ tdesc, const uint32_t *__restrict__ ntiles_ptr,
                                                        uint32_t *__restrict__ tpre, uint32_t *__restrict__ nu_out,
@@ -760,6 +997,20 @@ __global__ __launch_bounds__(1024) void k_tile_prefix(const uint4 *__restrict__ 
     if (threadIdx.x == 0) { tpre[ntiles] = carry; *nu_out = carry; }
 }
 
+// optional bookkeeping of the projection kernels (option "profile" / tools): Newton rounds per wave into one of 256
+// counters on separate cache lines (a single address would serialise at ~88 atomics per us), and the wave's timeline
+__device__ __forceinline__ void project_epilogue(uint32_t wave, uint32_t rounds, uint64_t t_start, uint32_t *__restrict__ prof,
+                                                 uint64_t *__restrict__ diag) {
+    if (lane_id() != 0) return;
+    if (prof) atomicAdd(&prof[(wave & 255u) * 16u], rounds);
+    if (diag) {
+        diag[4ull * wave + 0] = t_start;
+        diag[4ull * wave + 1] = __builtin_amdgcn_s_memtime();
+        diag[4ull * wave + 2] = rounds;
+        diag[4ull * wave + 3] = (uint64_t) __builtin_amdgcn_s_getreg((31 << 11) | 4) | ((uint64_t) __builtin_amdgcn_s_getreg((31 << 11) | 20) << 32);   // HW_ID | XCC_ID
+    }
+}
+
 // A5/A6: closest_surface_point + vertex normal for every unique vertex; position read from and written
 // back to uverts[].position.  16 items in flight per wave (4 lanes each); finished groups refill from
 // the wave's round-robin share of the U work items; item i is mapped to its vertex slot with a binary
@@ -767,7 +1018,9 @@ __global__ __launch_bounds__(1024) void k_tile_prefix(const uint4 *__restrict__ 
 template <int SCENE>
 __global__ __launch_bounds__(256) void k_project(Vertex *__restrict__ uverts, const uint4 *__restrict__ tdesc,
                                                   const uint32_t *__restrict__ tpre, const uint32_t *__restrict__ coarse, const uint32_t *__restrict__ ntiles_ptr,
-                                                  const SceneParams *__restrict__ spp, uint32_t *__restrict__ status) {
+                                                  const SceneParams *__restrict__ spp, uint32_t *__restrict__ status,
+                                                  uint32_t *__restrict__ prof /* optional: 256 counters of Newton rounds, 64 B apart */,
+                                                  uint64_t *__restrict__ diag /* optional: per wave {start, end, rounds, hw id} */) {
     const SceneParams &sp = *spp;  // scene uniform in device memory (a captured graph replays with new values)
     const uint32_t ntiles = *ntiles_ptr;
     const uint32_t U = ntiles ? tpre[ntiles] : 0u;
@@ -780,6 +1033,8 @@ __global__ __launch_bounds__(256) void k_project(Vertex *__restrict__ uverts, co
     // The wave's j-th item is item ((j / 16) * nwaves + wave) * 16 + j % 16.
     const uint32_t nbatch = (U + 15u) >> 4;
     if (wave >= nbatch) return;
+    const uint64_t t_start = diag ? __builtin_amdgcn_s_memtime() : 0ull;
+    uint32_t rounds = 0;                                              // vertex-rounds this wave evaluated (scalar bookkeeping)
     const uint32_t myb = (nbatch - wave - 1u) / nwaves + 1u;          // batches owned by this wave
     uint32_t qhead = 0;                                               // items handed out so far
     const uint32_t qend = myb * 16u;
@@ -806,7 +1061,9 @@ __global__ __launch_bounds__(256) void k_project(Vertex *__restrict__ uverts, co
             const uint32_t want = __popcll(need);
             qhead += want < avail ? want : avail;
         }
-        if (__ballot(have) == 0ull) break;
+        const uint64_t act = __ballot(have && sub == 0);
+        if (act == 0ull) break;
+        rounds += __popcll(act);
         if (have) {
             float sd;
             const f3 nn = normalize3(stencil_quad<SCENE, true>(g, sub, sp, sd));
@@ -821,11 +1078,13 @@ __global__ __launch_bounds__(256) void k_project(Vertex *__restrict__ uverts, co
                     o.position.x = g.x; o.position.y = g.y; o.position.z = g.z;
                     o.normal.x = nn.x; o.normal.y = nn.y; o.normal.z = nn.z;
                     uverts[slot] = o;
+                    if (!((g.x - g.x) == 0.0f)) atomicOr(&status[ST_NONFINITE], 1u);   // src/cuda/mod.rs:289 needs the direct path
                 }
                 have = false;
             }
         }
     }
+    project_epilogue(wave, rounds, t_start, prof, diag);
 }
 
 // A7 orientation test (compute_mesh_generation.cu:102-105) for every triangle: 4 lanes per triangle
@@ -888,7 +1147,8 @@ __global__ __launch_bounds__(256) void k_flip1(const Vertex *__restrict__ uverts
 template <int SCENE>
 __global__ __launch_bounds__(256) void k_project1(Vertex *__restrict__ uverts, const uint4 *__restrict__ tdesc,
                                                    const uint32_t *__restrict__ tpre, const uint32_t *__restrict__ coarse, const uint32_t *__restrict__ ntiles_ptr,
-                                                   const SceneParams *__restrict__ spp, uint32_t *__restrict__ status) {
+                                                   const SceneParams *__restrict__ spp, uint32_t *__restrict__ status,
+                                                   uint32_t *__restrict__ prof, uint64_t *__restrict__ diag) {
     const SceneParams &sp = *spp;
     const uint32_t ntiles = *ntiles_ptr;
     const uint32_t U = ntiles ? tpre[ntiles] : 0u;
@@ -898,6 +1158,8 @@ __global__ __launch_bounds__(256) void k_project1(Vertex *__restrict__ uverts, c
     // batches of 64 items dealt round robin to the waves: the wave's j-th item is ((j / 64) * nwaves + wave) * 64 + j % 64
     const uint32_t nbatch = (U + 63u) >> 6;
     if (wave >= nbatch) return;
+    const uint64_t t_start = diag ? __builtin_amdgcn_s_memtime() : 0ull;
+    uint32_t rounds = 0;
     const uint32_t myb = (nbatch - wave - 1u) / nwaves + 1u;
     uint32_t qhead = 0;
     const uint32_t qend = myb * 64u;
@@ -924,7 +1186,52 @@ __global__ __launch_bounds__(256) void k_project1(Vertex *__restrict__ uverts, c
             const uint32_t want = __popcll(need);
             qhead += want < avail ? want : avail;
         }
-        if (__ballot(have) == 0ull) break;
+        const uint64_t act = __ballot(have);
+        if (act == 0ull) break;
+        if (qend == qhead && __popcll(act) <= 16) {
+            // Straggler mode.  Iteration counts are spatially correlated (slow convergence near the smooth-min blends), so a
+            // few waves are left with a handful of live lanes for many more rounds while a full one-lane round costs ~960
+            // instructions whatever the number of live lanes -- measured: the longest wave lives 2x the mean and sets the
+            // kernel time.  With <= 16 vertices left and nothing to refill from, each vertex moves to a 4-lane group (lane k
+            // = stencil offset k along x, y, z: k_project's layout, ~300 instructions per round).  Same sample positions,
+            // same combination order, same values.
+            const uint32_t sub = lane & 3u, grp = lane >> 2;
+            uint64_t mm = act;
+            for (uint32_t i = 0; i < 15u; i++) if (i < grp) mm &= mm - 1ull;          // drop the grp lowest live lanes
+            const bool ghave = mm != 0ull;
+            const int src = ghave ? (int) __builtin_ctzll(mm) : (int) lane;
+            g.x = __shfl(g.x, src, 64); g.y = __shfl(g.y, src, 64); g.z = __shfl(g.z, src, 64);
+            slot = (uint32_t) __shfl((int) slot, src, 64);
+            it = __shfl(it, src, 64);
+            finalize = __shfl((int) finalize, src, 64) != 0;
+            have = ghave;
+            for (;;) {
+                const uint64_t qact = __ballot(have && sub == 0);
+                if (qact == 0ull) break;
+                rounds += __popcll(qact);
+                if (have) {
+                    float sd;
+                    const f3 nn = normalize3(stencil_quad<SCENE, true>(g, sub, sp, sd));
+                    if (!finalize) {
+                        g = sub3(g, scale3(nn, sd));
+                        it++;
+                        if (fabsf(sd) <= 0.00001f) finalize = true;
+                        else if (it >= SDM_MAX_NEWTON) { finalize = true; if (sub == 0) atomicOr(&status[ST_NEWTON_CAPPED], 1u); }
+                    } else {
+                        if (sub == 0) {
+                            Vertex o;
+                            o.position.x = g.x; o.position.y = g.y; o.position.z = g.z;
+                            o.normal.x = nn.x; o.normal.y = nn.y; o.normal.z = nn.z;
+                            uverts[slot] = o;
+                            if (!((g.x - g.x) == 0.0f)) atomicOr(&status[ST_NONFINITE], 1u);
+                        }
+                        have = false;
+                    }
+                }
+            }
+            break;
+        }
+        rounds += __popcll(act);
         if (have) {
             const float sd = sdf<SCENE>(g.x, g.y, g.z, sp);
             const f3 nn = empirical_normal<SCENE>(g, sp);
@@ -938,10 +1245,12 @@ __global__ __launch_bounds__(256) void k_project1(Vertex *__restrict__ uverts, c
                 o.position.x = g.x; o.position.y = g.y; o.position.z = g.z;
                 o.normal.x = nn.x; o.normal.y = nn.y; o.normal.z = nn.z;
                 uverts[slot] = o;
+                if (!((g.x - g.x) == 0.0f)) atomicOr(&status[ST_NONFINITE], 1u);       // src/cuda/mod.rs:289 needs the direct path
                 have = false;
             }
         }
     }
+    project_epilogue(wave, rounds, t_start, prof, diag);
 }
 
 // tile descriptors for a plain triangle list (generic weld): tiles of 256 triangles, every corner
@@ -962,17 +1271,21 @@ __global__ __launch_bounds__(256) void k_raw_desc(const uint32_t *__restrict__ n
 // the orientation test, so the host runs it on a side stream concurrently with the VALU-bound k_flip.
 __device__ __forceinline__ void claim_body(uint32_t bid, uint32_t nblocks, const Vertex *__restrict__ uverts,
                                            const uint4 *__restrict__ tdesc, uint32_t ntiles, uint64_t *__restrict__ wkeys,
-                                           uint32_t wsize, uint32_t *__restrict__ vslot, uint32_t *__restrict__ status) {
+                                           uint32_t wsize, uint32_t *__restrict__ vslot, uint32_t *__restrict__ status, uint32_t wide) {
     for (uint32_t tile = bid; tile < ntiles; tile += nblocks) {
         const uint4 d = tdesc[tile];
-        for (uint32_t i = threadIdx.x; i < d.y; i += 256) vslot[d.x + i] = weld_claim(uverts[d.x + i].position, wkeys, wsize, status);
+        if (wide) {
+            for (uint32_t i = threadIdx.x; i < d.y; i += 256) vslot[d.x + i] = weld_claim_wide(uverts, d.x + i, wkeys, wsize, status);
+        } else {
+            for (uint32_t i = threadIdx.x; i < d.y; i += 256) vslot[d.x + i] = weld_claim(uverts[d.x + i].position, wkeys, wsize, status);
+        }
     }
 }
 
 __global__ __launch_bounds__(256) void k_tile_claim(const Vertex *__restrict__ uverts, const uint4 *__restrict__ tdesc,
                                                      const uint32_t *__restrict__ ntiles_ptr, uint64_t *__restrict__ wkeys,
-                                                     uint32_t wsize, uint32_t *__restrict__ vslot, uint32_t *__restrict__ status) {
-    claim_body(blockIdx.x, gridDim.x, uverts, tdesc, *ntiles_ptr, wkeys, wsize, vslot, status);
+                                                     uint32_t wsize, uint32_t *__restrict__ vslot, uint32_t *__restrict__ status, uint32_t wide) {
+    claim_body(blockIdx.x, gridDim.x, uverts, tdesc, *ntiles_ptr, wkeys, wsize, vslot, status, wide);
 }
 
 // Orientation test and weld claim in ONE dispatch: the LAST `claim_blocks` workgroups claim weld-table slots for the
@@ -986,10 +1299,10 @@ __global__ __launch_bounds__(256) void k_flip_claim(const Vertex *__restrict__ u
                                                      const uint32_t *__restrict__ ntri_ptr, const SceneParams *__restrict__ spp,
                                                      uint8_t *__restrict__ flip, uint32_t claim_blocks, const uint4 *__restrict__ tdesc,
                                                      const uint32_t *__restrict__ ntiles_ptr, uint64_t *__restrict__ wkeys, uint32_t wsize,
-                                                     uint32_t *__restrict__ vslot, uint32_t *__restrict__ status) {
+                                                     uint32_t *__restrict__ vslot, uint32_t *__restrict__ status, uint32_t wide) {
     const uint32_t flip_blocks = gridDim.x - claim_blocks;
     if (blockIdx.x >= flip_blocks) {
-        claim_body(blockIdx.x - flip_blocks, claim_blocks, uverts, tdesc, *ntiles_ptr, wkeys, wsize, vslot, status);
+        claim_body(blockIdx.x - flip_blocks, claim_blocks, uverts, tdesc, *ntiles_ptr, wkeys, wsize, vslot, status, wide);
     } else if (LANES == 1) {
         flip_body1<SCENE>(blockIdx.x, flip_blocks, uverts, tri_e, *ntri_ptr, *spp, flip);
     } else {
@@ -1307,6 +1620,57 @@ __global__ __launch_bounds__(256) void k_column_counts(const Point *__restrict__
         if (s_hist[i]) atomicAdd(&colcnt[i], s_hist[i]);
 }
 
+
+// ------------------------------------------------------------------------------------------
+// multi-GPU order restoration, part 2: merge R per-slab triangle lists into the single-GPU order.
+// counts[r][c] = triangles of rank r in level-0 column c (k_column_counts of every rank, all-gathered).  Every rank's
+// list is column-sorted, and inside a column the global order is rank 0's triangles, then rank 1's, ...:
+//     src_start[r][c] = sum_{c' < c} counts[r][c']                 (where the segment starts in rank r's list)
+//     dst_start[r][c] = sum_{c' < c} sum_r' counts[r'][c'] + sum_{r' < r} counts[r'][c]
+// k_merge_plan (one workgroup) writes both tables, k_merge_copy moves the segments: one workgroup per (rank, column)
+// segment, 72-byte triangles as nine 8-byte words (a Triangle is only 8-byte aligned in general), fully coalesced on
+// both sides.  HBM-bound: reads and writes 72 B x T once.
+// ------------------------------------------------------------------------------------------
+static constexpr uint32_t NCOL = MESH_GENERATION_INIT_FACTOR * MESH_GENERATION_INIT_FACTOR;     // 1024 columns = one per thread
+
+__global__ __launch_bounds__(1024) void k_merge_plan(const uint32_t *__restrict__ counts, uint32_t nranks, uint32_t *__restrict__ plan,
+                                                      uint32_t cap, uint32_t *__restrict__ total_out, uint32_t *__restrict__ status) {
+    __shared__ uint32_t lds[17];
+    const uint32_t c = threadIdx.x;
+    uint32_t col_total = 0;
+    for (uint32_t r = 0; r < nranks; r++) col_total += counts[r * NCOL + c];
+    uint32_t total;
+    const uint32_t col_base = block_excl_scan(col_total, total, lds);
+    uint32_t within = 0;
+    for (uint32_t r = 0; r < nranks; r++) {
+        const uint32_t n = counts[r * NCOL + c];
+        uint32_t rank_total;
+        const uint32_t src = block_excl_scan(n, rank_total, lds);
+        plan[(r * NCOL + c) * 2u] = src;
+        plan[(r * NCOL + c) * 2u + 1u] = col_base + within;
+        within += n;
+    }
+    if (c == 0) {
+        if (total > cap) { atomicOr(&status[ST_OVERFLOW], 32u); }
+        *total_out = total;
+    }
+}
+
+__global__ __launch_bounds__(256) void k_merge_copy(const Triangle *const *__restrict__ lists, const uint32_t *__restrict__ counts,
+                                                     const uint32_t *__restrict__ plan, uint32_t nranks, Triangle *__restrict__ out, uint32_t cap) {
+    const uint32_t nseg = nranks * NCOL;
+    for (uint32_t seg = blockIdx.x; seg < nseg; seg += gridDim.x) {
+        const uint32_t n = counts[seg];
+        if (n == 0) continue;
+        const uint32_t src = plan[2u * seg], dst = plan[2u * seg + 1u];
+        if (dst + n > cap) continue;                                  // flagged by k_merge_plan
+        const uint2 *__restrict__ s = reinterpret_cast<const uint2 *>(lists[seg / NCOL] + src);
+        uint2 *__restrict__ d = reinterpret_cast<uint2 *>(out + dst);
+        const uint32_t words = 9u * n;
+        for (uint32_t i = threadIdx.x; i < words; i += 256) d[i] = s[i];
+    }
+}
+
 // ------------------------------------------------------------------------------------------
 // Dense mode: the same voxel list as the hierarchical refine, derived from
 // the dense (N+1)^3 sample lattice.
@@ -1608,6 +1972,25 @@ hipError_t launch_refine_emit(hipStream_t st, int grid, const Point *vox, const 
     return hipGetLastError();
 }
 
+hipError_t launch_col_refine(hipStream_t st, int scene, const SceneParams *sp, uint32_t x0, uint32_t x1, uint32_t z0, uint32_t z1, int J,
+                             uint8_t *g_list1, uint8_t *g_mask2, uint8_t *g_mask3, uint4 *colinfo, uint32_t *zero, uint32_t nzero,
+                             void *ff, size_t ff_bytes) {
+    const uint32_t ncols = (x1 - x0) * MESH_GENERATION_INIT_FACTOR;
+    if (ncols == 0 || z1 <= z0) return hipErrorInvalidValue;
+    SDM_DISPATCH(scene, hipLaunchKernelGGL(k_col_refine<S>, dim3(ncols), dim3(256), 0, st, x0, z0, z1 - z0, (uint32_t) J, sp, g_list1, g_mask2, g_mask3,
+                                           colinfo, zero, nzero, (uint4 *) ff, ff ? (uint32_t) (ff_bytes / 16) : 0u));
+    return hipGetLastError();
+}
+
+hipError_t launch_col_emit(hipStream_t st, uint32_t x0, uint32_t x1, uint32_t z0, uint32_t z1, int J, const uint8_t *g_list1,
+                           const uint8_t *g_mask2, const uint8_t *g_mask3, const uint4 *colinfo, Point *out, uint32_t cap,
+                           uint32_t *level_ctr, uint32_t *status) {
+    const uint32_t ncols = (x1 - x0) * MESH_GENERATION_INIT_FACTOR;
+    hipLaunchKernelGGL(k_col_emit, dim3(ncols), dim3(256), 0, st, x0, z0, z1 - z0, ncols, (uint32_t) J, g_list1, g_mask2, g_mask3, colinfo, out, cap,
+                       level_ctr, status);
+    return hipGetLastError();
+}
+
 hipError_t launch_sum_tiles(hipStream_t st, const uint32_t *tilecnt, const uint32_t *n_ptr, uint32_t *total_out) {
     hipLaunchKernelGGL(k_sum_tiles, dim3(1), dim3(1024), 0, st, tilecnt, n_ptr, total_out);
     return hipGetLastError();
@@ -1653,9 +2036,10 @@ hipError_t launch_tile_prefix(hipStream_t st, const uint4 *tdesc, const uint32_t
 }
 
 hipError_t launch_project(hipStream_t st, int grid, int scene, const SceneParams *sp, Vertex *uverts, const uint4 *tdesc,
-                          const uint32_t *tpre, const uint32_t *coarse, const uint32_t *ntiles_ptr, uint32_t *status, int lanes) {
-    if (lanes == 1) { SDM_DISPATCH(scene, hipLaunchKernelGGL(k_project1<S>, dim3(grid), dim3(256), 0, st, uverts, tdesc, tpre, coarse, ntiles_ptr, sp, status)); }
-    else { SDM_DISPATCH(scene, hipLaunchKernelGGL(k_project<S>, dim3(grid), dim3(256), 0, st, uverts, tdesc, tpre, coarse, ntiles_ptr, sp, status)); }
+                          const uint32_t *tpre, const uint32_t *coarse, const uint32_t *ntiles_ptr, uint32_t *status, int lanes,
+                          uint32_t *prof, uint64_t *diag) {
+    if (lanes == 1) { SDM_DISPATCH(scene, hipLaunchKernelGGL(k_project1<S>, dim3(grid), dim3(256), 0, st, uverts, tdesc, tpre, coarse, ntiles_ptr, sp, status, prof, diag)); }
+    else { SDM_DISPATCH(scene, hipLaunchKernelGGL(k_project<S>, dim3(grid), dim3(256), 0, st, uverts, tdesc, tpre, coarse, ntiles_ptr, sp, status, prof, diag)); }
     return hipGetLastError();
 }
 
@@ -1668,10 +2052,11 @@ hipError_t launch_flip(hipStream_t st, int grid, int scene, const SceneParams *s
 
 hipError_t launch_flip_claim(hipStream_t st, int flip_grid, int claim_grid, int scene, const SceneParams *sp, const Vertex *uverts,
                             const uint32_t *tri_e, const uint32_t *ntri_ptr, uint8_t *flip, int lanes, const uint4 *tdesc,
-                            const uint32_t *ntiles_ptr, uint64_t *wkeys, uint32_t wsize, uint32_t *vslot, uint32_t *status) {
+                            const uint32_t *ntiles_ptr, uint64_t *wkeys, uint32_t wsize, uint32_t *vslot, uint32_t *status, bool wide) {
     const dim3 grid(flip_grid + claim_grid);
-    if (lanes == 1) { SDM_DISPATCH(scene, hipLaunchKernelGGL((k_flip_claim<S, 1>), grid, dim3(256), 0, st, uverts, tri_e, ntri_ptr, sp, flip, (uint32_t) claim_grid, tdesc, ntiles_ptr, wkeys, wsize, vslot, status)); }
-    else { SDM_DISPATCH(scene, hipLaunchKernelGGL((k_flip_claim<S, 4>), grid, dim3(256), 0, st, uverts, tri_e, ntri_ptr, sp, flip, (uint32_t) claim_grid, tdesc, ntiles_ptr, wkeys, wsize, vslot, status)); }
+    const uint32_t w = wide ? 1u : 0u;
+    if (lanes == 1) { SDM_DISPATCH(scene, hipLaunchKernelGGL((k_flip_claim<S, 1>), grid, dim3(256), 0, st, uverts, tri_e, ntri_ptr, sp, flip, (uint32_t) claim_grid, tdesc, ntiles_ptr, wkeys, wsize, vslot, status, w)); }
+    else { SDM_DISPATCH(scene, hipLaunchKernelGGL((k_flip_claim<S, 4>), grid, dim3(256), 0, st, uverts, tri_e, ntri_ptr, sp, flip, (uint32_t) claim_grid, tdesc, ntiles_ptr, wkeys, wsize, vslot, status, w)); }
     return hipGetLastError();
 }
 
@@ -1703,8 +2088,8 @@ hipError_t launch_raw_desc(hipStream_t st, int grid, const uint32_t *ntri_ptr, u
 }
 
 hipError_t launch_tile_claim(hipStream_t st, int grid, const Vertex *uverts, const uint4 *tdesc, const uint32_t *ntiles_ptr,
-                             uint64_t *wkeys, uint32_t wsize, uint32_t *vslot, uint32_t *status) {
-    hipLaunchKernelGGL(k_tile_claim, dim3(grid), dim3(256), 0, st, uverts, tdesc, ntiles_ptr, wkeys, wsize, vslot, status);
+                             uint64_t *wkeys, uint32_t wsize, uint32_t *vslot, uint32_t *status, bool wide) {
+    hipLaunchKernelGGL(k_tile_claim, dim3(grid), dim3(256), 0, st, uverts, tdesc, ntiles_ptr, wkeys, wsize, vslot, status, wide ? 1u : 0u);
     return hipGetLastError();
 }
 
@@ -1783,6 +2168,13 @@ hipError_t launch_raw_compact(hipStream_t st, int grid, const Triangle *raw, con
 hipError_t launch_column_counts(hipStream_t st, int grid, const Point *vox, const uint32_t *n_ptr, const uint8_t *cubeidx,
                                 uint32_t *colcnt) {
     hipLaunchKernelGGL(k_column_counts, dim3(grid), dim3(256), 0, st, vox, n_ptr, cubeidx, colcnt);
+    return hipGetLastError();
+}
+
+hipError_t launch_merge_by_column(hipStream_t st, const Triangle *const *d_lists, const uint32_t *d_counts, int nranks, uint32_t *d_plan,
+                                  Triangle *d_out, uint32_t cap, uint32_t *total_out, uint32_t *status) {
+    hipLaunchKernelGGL(k_merge_plan, dim3(1), dim3(1024), 0, st, d_counts, (uint32_t) nranks, d_plan, cap, total_out, status);
+    hipLaunchKernelGGL(k_merge_copy, dim3(nranks * 1024), dim3(256), 0, st, d_lists, d_counts, d_plan, (uint32_t) nranks, d_out, cap);
     return hipGetLastError();
 }
 

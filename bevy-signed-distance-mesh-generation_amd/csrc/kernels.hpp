@@ -17,6 +17,8 @@ enum StatusWord : int {
     ST_NEWTON_CAPPED = 3,   // informational: closest_surface_point hit the 10 000-iteration cap
     ST_INTERNAL = 4,        // invariant violated
     ST_TILE_OVERFLOW = 5,   // a 256-voxel tile has more unique edges than the LDS hash holds -> host takes the direct path
+    ST_NONFINITE = 6,       // a projected vertex has a non-finite x: the reference drops triangles whose first vertex is
+                            // such a vertex (src/cuda/mod.rs:289) -> host takes the direct path, which applies that test
     ST_WORDS = 8
 };
 
@@ -29,6 +31,12 @@ hipError_t launch_refine_emit(hipStream_t st, int grid, const Point *vox, const 
                               uint32_t *status, const uint32_t *signs = nullptr, uint8_t *cubeidx = nullptr,
                               uint32_t *mtilecnt = nullptr);
 hipError_t launch_sum_tiles(hipStream_t st, const uint32_t *tilecnt, const uint32_t *n_ptr, uint32_t *total_out);
+hipError_t launch_col_refine(hipStream_t st, int scene, const SceneParams *sp, uint32_t x0, uint32_t x1, uint32_t z0, uint32_t z1, int J,
+                             uint8_t *g_list1, uint8_t *g_mask2, uint8_t *g_mask3, uint4 *colinfo, uint32_t *zero, uint32_t nzero,
+                             void *ff, size_t ff_bytes);
+hipError_t launch_col_emit(hipStream_t st, uint32_t x0, uint32_t x1, uint32_t z0, uint32_t z1, int J, const uint8_t *g_list1,
+                           const uint8_t *g_mask2, const uint8_t *g_mask3, const uint4 *colinfo, Point *out, uint32_t cap,
+                           uint32_t *level_ctr, uint32_t *status);
 hipError_t launch_refine2_mask(hipStream_t st, int grid, int scene, const SceneParams *sp, const Point *vox, const uint32_t *n_ptr,
                                Point cs1, uint8_t *mask1, uint64_t *mask2, uint32_t *tilecnt, uint32_t *n_mid);
 hipError_t launch_refine2_emit(hipStream_t st, int grid, const Point *vox, const uint32_t *n_ptr, Point cs1, const uint8_t *mask1,
@@ -44,18 +52,21 @@ hipError_t launch_tile_dedupe(hipStream_t st, int grid, const Point *vox, const 
 hipError_t launch_tile_prefix(hipStream_t st, const uint4 *tdesc, const uint32_t *ntiles_ptr, uint32_t *tpre, uint32_t *nu_out,
                               uint32_t *coarse);
 hipError_t launch_project(hipStream_t st, int grid, int scene, const SceneParams *sp, Vertex *uverts, const uint4 *tdesc,
-                          const uint32_t *tpre, const uint32_t *coarse, const uint32_t *ntiles_ptr, uint32_t *status, int lanes = 4);
+                          const uint32_t *tpre, const uint32_t *coarse, const uint32_t *ntiles_ptr, uint32_t *status, int lanes = 4,
+                          uint32_t *prof = nullptr, uint64_t *diag = nullptr);
 hipError_t launch_render(hipStream_t st, int scene, const SceneParams *sp, const float *cam13, float fov_fac, float screen_x,
                          float screen_y, float gtex_x, float gtex_y, uint32_t width, uint32_t height, void *rgba);
 hipError_t launch_flip_claim(hipStream_t st, int flip_grid, int claim_grid, int scene, const SceneParams *sp, const Vertex *uverts,
                             const uint32_t *tri_e, const uint32_t *ntri_ptr, uint8_t *flip, int lanes, const uint4 *tdesc,
-                            const uint32_t *ntiles_ptr, uint64_t *wkeys, uint32_t wsize, uint32_t *vslot, uint32_t *status);
+                            const uint32_t *ntiles_ptr, uint64_t *wkeys, uint32_t wsize, uint32_t *vslot, uint32_t *status, bool wide);
 hipError_t launch_flip(hipStream_t st, int grid, int scene, const SceneParams *sp, const Vertex *uverts, const uint32_t *tri_e,
                        const uint32_t *ntri_ptr, uint8_t *flip, int lanes = 4);
 hipError_t launch_raw_desc(hipStream_t st, int grid, const uint32_t *ntri_ptr, uint4 *tdesc, uint8_t *flip, uint32_t *ntiles_out,
                            uint32_t *nu_out);
 hipError_t launch_tile_claim(hipStream_t st, int grid, const Vertex *uverts, const uint4 *tdesc, const uint32_t *ntiles_ptr,
-                             uint64_t *wkeys, uint32_t wsize, uint32_t *vslot, uint32_t *status);
+                             uint64_t *wkeys, uint32_t wsize, uint32_t *vslot, uint32_t *status, bool wide);
+hipError_t launch_merge_by_column(hipStream_t st, const Triangle *const *d_lists, const uint32_t *d_counts, int nranks, uint32_t *d_plan,
+                                  Triangle *d_out, uint32_t cap, uint32_t *total_out, uint32_t *status);
 hipError_t launch_weld(hipStream_t st, int grid, const Vertex *uverts, const uint4 *tdesc, const uint32_t *ntiles_ptr,
                        uint32_t *tri_e, const uint8_t *flip, uint32_t *first_ord, uint2 *wfm,
                        const uint32_t *vslot, uint32_t *wv, uint32_t *torder, uint32_t *tfirst, uint32_t *tfpre,

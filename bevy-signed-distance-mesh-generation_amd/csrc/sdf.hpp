@@ -109,46 +109,59 @@ SDM_HD float along_sq(float p, float lo, float len) {
 
 SDM_HD float sq(float v) { return v * v; }
 
+// Minimum over bar groups without forming every bar (value-preserving, exact):
+// round-to-nearest addition is monotone non-decreasing in each operand, so for non-negative finite terms
+//     min_{i,j} fl(fl(a_i + b) + c_j)  ==  fl(fl(min_i a_i + b) + min_j c_j)
+// (the minimum is attained at the smallest operands; ties give equal values).  A group of four parallel bars that
+// differ in two perpendicular offsets therefore costs 2 min + 2 add instead of 6 add + 3 min.  Moreover, for offsets
+// +-c on one axis, min(sq(p - c), sq(p + c)) == sq(|p| - c) bit for bit: |p| - c is exactly (p - c) or -(p + c),
+// whichever has the smaller magnitude (monotonicity again), and squaring discards the sign.
+SDM_HD float fmin3(float a, float b, float c) { return fmin1(fmin1(a, b), c); }
+
 // sd_box_skeleton(p, 0, (3, 1, 0.5), 0.1) with the reference's indexing bug:
 //   x-bars: y in {-0.5, +0.5},  z in {-0.25, +0.25}, x from -1.5, len 3
 //   y-bars: z in {-0.25, +2.75}, x in {-1.5, +1.5},  y from -0.5, len 1    (z offset uses bs[0]=3)
 //   z-bars: x in {-1.5, -0.5},  y in {-0.5, +0.5},   z from -0.25, len 0.5 (x offset uses bs[1]=1)
-SDM_HD float skeleton_min_d2(float px, float py, float pz) {
-    const float ax = along_sq(px, -1.5f, 3.0f);
-    const float ay = along_sq(py, -0.5f, 1.0f);
-    const float az = along_sq(pz, -0.25f, 0.5f);
-    const float xm15 = sq(px - (-1.5f)), xp15 = sq(px - 1.5f), xm05 = sq(px - (-0.5f));
-    const float ym05 = sq(py - (-0.5f)), yp05 = sq(py - 0.5f);
-    const float zm025 = sq(pz - (-0.25f)), zp025 = sq(pz - 0.25f), zp275 = sq(pz - 2.75f);
-
-    // each d2 is (ex^2 + ey^2) + ez^2 in x, y, z order, as glm::dot evaluates it
-    const float x0 = ax + ym05, x1 = ax + yp05;
-    float m = fmin1(x0 + zm025, x0 + zp025);
-    m = fmin1(m, fmin1(x1 + zm025, x1 + zp025));
-    const float y0 = xm15 + ay, y1 = xp15 + ay;
-    m = fmin1(m, fmin1(y0 + zm025, y0 + zp275));
-    m = fmin1(m, fmin1(y1 + zm025, y1 + zp275));
-    m = fmin1(m, fmin1((xm15 + ym05) + az, (xm15 + yp05) + az));
-    m = fmin1(m, fmin1((xm05 + ym05) + az, (xm05 + yp05) + az));
-    return m;
+// each d2 is (ex^2 + ey^2) + ez^2 in x, y, z order, as glm::dot evaluates it
+struct SkelX { float ax, sx15, mx; };      // along-x residual, min over x in {+-1.5}, min over x in {-1.5, -0.5}
+struct SkelY { float ay, sy; };            // along-y residual, min over y in {+-0.5}
+struct SkelZ { float az, sz, mz; };        // along-z residual, min over z in {+-0.25}, min over z in {-0.25, +2.75}
+SDM_HD SkelX skel_x(float px) {
+    SkelX r;
+    r.ax = along_sq(px, -1.5f, 3.0f);
+    r.sx15 = sq(fabsf(px) - 1.5f);
+    r.mx = fmin1(sq(px - (-1.5f)), sq(px - (-0.5f)));
+    return r;
 }
+SDM_HD SkelY skel_y(float py) {
+    SkelY r;
+    r.ay = along_sq(py, -0.5f, 1.0f);
+    r.sy = sq(fabsf(py) - 0.5f);
+    return r;
+}
+SDM_HD SkelZ skel_z(float pz) {
+    SkelZ r;
+    r.az = along_sq(pz, -0.25f, 0.5f);
+    r.sz = sq(fabsf(pz) - 0.25f);
+    r.mz = fmin1(sq(pz - (-0.25f)), sq(pz - 2.75f));
+    return r;
+}
+SDM_HD float skel_combine(const SkelX &x, const SkelY &y, const SkelZ &z) {
+    const float bx = (x.ax + y.sy) + z.sz;          // the four x-bars
+    const float by = (x.sx15 + y.ay) + z.mz;        // the four y-bars
+    const float bz = (x.mx + y.sy) + z.az;          // the four z-bars
+    return fmin3(bx, by, bz);
+}
+SDM_HD float skeleton_min_d2(float px, float py, float pz) { return skel_combine(skel_x(px), skel_y(py), skel_z(pz)); }
 
 // sd_box_skeleton(p, 0, (5, 5, 5), lw): the bounding-cube wire frame of the preview (compute_render.cu:8-16).  All
 // twelve bars are axis-aligned with ends at +-2.5 (with equal sides the `% 2` of signed_distance.cu:101 changes nothing),
-// so the same rewrite as skeleton_min_d2 applies: unit directions make sd_ray's dot / scale exact, the residual along
-// a bar is along_sq, across it a plain difference, and min_i(sqrt(d2_i) - lw) = sqrt(min_i d2_i) - lw.
+// so the same rewrites apply: unit directions make sd_ray's dot / scale exact, the residual along a bar is along_sq,
+// across it sq(|p| - 2.5) is the smaller of the two offsets, and min_i(sqrt(d2_i) - lw) = sqrt(min_i d2_i) - lw.
 SDM_HD float skeleton_cube5_min_d2(float px, float py, float pz) {
     const float ax = along_sq(px, -2.5f, 5.0f), ay = along_sq(py, -2.5f, 5.0f), az = along_sq(pz, -2.5f, 5.0f);
-    const float xm = sq(px - (-2.5f)), xp = sq(px - 2.5f);
-    const float ym = sq(py - (-2.5f)), yp = sq(py - 2.5f);
-    const float zm = sq(pz - (-2.5f)), zp = sq(pz - 2.5f);
-    // each d2 is (ex^2 + ey^2) + ez^2 in x, y, z order, as glm::dot evaluates it
-    const float x0 = ax + ym, x1 = ax + yp;
-    float m = fmin1(fmin1(x0 + zm, x0 + zp), fmin1(x1 + zm, x1 + zp));
-    const float y0 = xm + ay, y1 = xp + ay;
-    m = fmin1(m, fmin1(fmin1(y0 + zm, y0 + zp), fmin1(y1 + zm, y1 + zp)));
-    m = fmin1(m, fmin1(fmin1((xm + ym) + az, (xm + yp) + az), fmin1((xp + ym) + az, (xp + yp) + az)));
-    return m;
+    const float sx = sq(fabsf(px) - 2.5f), sy = sq(fabsf(py) - 2.5f), sz = sq(fabsf(pz) - 2.5f);
+    return fmin3((ax + sy) + sz, (sx + ay) + sz, (sx + sy) + az);
 }
 
 SDM_HD float sd_box(f3 p, f3 bp, f3 bs) {
@@ -280,33 +293,25 @@ SDM_HD float sdf(float px, float py, float pz, const SceneParams &sp) {
 template <int SCENE>
 struct RowCtx {
     float px, py;
-    float a[8];
+    float a[4];
     SDM_HDM void init(float x, float y, const SceneParams &sp) {
         px = x; py = y;
         if (SCENE == SCENE_SPHERE) {
             a[0] = px * px + py * py;
         } else if (SCENE == SCENE_SDOBJ || SCENE == SCENE_ANIM) {
-            const float ax = along_sq(px, -1.5f, 3.0f), ay = along_sq(py, -0.5f, 1.0f);
-            const float xm15 = sq(px - (-1.5f)), xp15 = sq(px - 1.5f), xm05 = sq(px - (-0.5f));
-            const float ym05 = sq(py - (-0.5f)), yp05 = sq(py - 0.5f);
-            a[0] = ax + ym05; a[1] = ax + yp05;          // x-bars, before + z^2
-            a[2] = xm15 + ay; a[3] = xp15 + ay;          // y-bars, before + z^2
-            a[4] = xm15 + ym05; a[5] = xm15 + yp05;      // z-bars, before + az
-            a[6] = xm05 + ym05; a[7] = xm05 + yp05;
+            const SkelX sx = skel_x(px);
+            const SkelY sy = skel_y(py);
+            a[0] = sx.ax + sy.sy;            // x-bars, before + sz
+            a[1] = sx.sx15 + sy.ay;          // y-bars, before + mz
+            a[2] = sx.mx + sy.sy;            // z-bars, before + az
         }
     }
     SDM_HDM float eval(float pz, const SceneParams &sp) const {
         if (SCENE == SCENE_SPHERE) {
             return sqrt_rn_normal(a[0] + pz * pz) - 1.0f;
         } else if (SCENE == SCENE_SDOBJ || SCENE == SCENE_ANIM) {
-            const float az = along_sq(pz, -0.25f, 0.5f);
-            const float zm025 = sq(pz - (-0.25f)), zp025 = sq(pz - 0.25f), zp275 = sq(pz - 2.75f);
-            float m = fmin1(a[0] + zm025, a[0] + zp025);
-            m = fmin1(m, fmin1(a[1] + zm025, a[1] + zp025));
-            m = fmin1(m, fmin1(a[2] + zm025, a[2] + zp275));
-            m = fmin1(m, fmin1(a[3] + zm025, a[3] + zp275));
-            m = fmin1(m, fmin1(a[4] + az, a[5] + az));
-            m = fmin1(m, fmin1(a[6] + az, a[7] + az));
+            const SkelZ z = skel_z(pz);
+            const float m = fmin3(a[0] + z.sz, a[1] + z.mz, a[2] + z.az);
             const float a1 = sqrt_rn_normal(m) - 0.1f;
             float sy = py;
             if (SCENE == SCENE_ANIM) sy = py - sp.p[0];

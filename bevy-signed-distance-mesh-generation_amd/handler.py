@@ -146,7 +146,12 @@ class CudaHandler:
         self.set_scene("anim", [np.float32(0.5) * np.float32(math.sin(t))])
 
     def set_stream(self, hip_stream):
-        self._chk(self._lib.sdmesh_set_stream(self._h, ctypes.c_void_p(hip_stream or 0)))
+        """Run on a caller-owned hipStream_t handle (an int).  0 is the legacy default stream -- which is what
+        torch.cuda.current_stream().cuda_stream is for torch's default stream; None returns to the handle's own stream."""
+        if hip_stream is None:
+            self._chk(self._lib.sdmesh_use_own_stream(self._h))
+        else:
+            self._chk(self._lib.sdmesh_set_stream(self._h, ctypes.c_void_p(int(hip_stream))))
 
     def set_option(self, name, value):
         self._chk(self._lib.sdmesh_set_option(self._h, name.encode(), int(value)))
@@ -296,11 +301,74 @@ class CudaHandler:
     def column_triangle_counts_into(self, dev_ptr):
         self._chk(self._lib.sdmesh_column_triangle_counts(self._h, ctypes.c_void_p(dev_ptr)))
 
+    # -- one mesh over several GPUs -----------------------------------------------
+    def merge_by_column(self, list_ptrs, counts_ptr, out_ptr, cap):
+        """Order-restoring merge (HIP kernel): list_ptrs = device pointers of the ranks' compact triangle lists, counts_ptr
+        = device pointer of the [R, 1024] uint32 per-column counts; returns the merged triangle count."""
+        arr = (ctypes.c_void_p * len(list_ptrs))(*[int(p) for p in list_ptrs])
+        n = ctypes.c_size_t(0)
+        self._chk(self._lib.sdmesh_merge_by_column(self._h, arr, ctypes.c_void_p(counts_ptr), len(list_ptrs),
+                                                    ctypes.c_void_p(out_ptr), int(cap), ctypes.byref(n)))
+        return n.value
+
+    @staticmethod
+    def comm_unique_id():
+        """128 bytes (an ncclUniqueId) made on rank 0 and handed to every rank's comm_init."""
+        buf = ctypes.create_string_buffer(128)
+        rc = _abi.load().sdmesh_comm_unique_id(buf)
+        if rc != 0:
+            raise SdMeshError(rc, "sdmesh_comm_unique_id (is librccl.so.1 loadable?)")
+        return buf.raw
+
+    def comm_init(self, unique_id, nranks, rank):
+        buf = ctypes.create_string_buffer(bytes(unique_id), 128)
+        self._chk(self._lib.sdmesh_comm_init(self._h, buf, int(nranks), int(rank)))
+
+    def comm_destroy(self):
+        self._chk(self._lib.sdmesh_comm_destroy(self._h))
+
+    def comm_ranks(self):
+        n = ctypes.c_int(0)
+        self._chk(self._lib.sdmesh_comm_ranks(self._h, ctypes.byref(n)))
+        return n.value
+
+    def sharded_regen(self, levels, root=0):
+        """ONE mesh over all ranks of the handle's RCCL communicator (z-slabs, gather to root, merge, weld) in one call."""
+        info = RegenInfo()
+        self._chk(self._lib.sdmesh_sharded_regen(self._h, int(levels), int(root), ctypes.byref(info)))
+        return info
+
     def weld_device_triangles(self, dev_ptr, nslots):
         info = RegenInfo()
         self._chk(self._lib.sdmesh_weld_device_triangles(self._h, ctypes.c_void_p(dev_ptr), int(nslots),
                                                           ctypes.byref(info)))
         return info
+
+    def profile_stages(self):
+        """[(stage name, device ms)] of the last planned regen run with option "profile" = 1."""
+        n = ctypes.c_int(0)
+        self._chk(self._lib.sdmesh_profile_stages(self._h, None, 0, None, 0, ctypes.byref(n)))
+        if n.value == 0:
+            return []
+        names = ctypes.create_string_buffer(64 * n.value)
+        ms = (ctypes.c_float * n.value)()
+        self._chk(self._lib.sdmesh_profile_stages(self._h, names, len(names), ms, n.value, ctypes.byref(n)))
+        return list(zip(names.value.decode().split(","), [float(x) for x in ms]))
+
+    def projection_rounds(self):
+        """Newton rounds (vertex x round, 13 SDF evaluations each) of the projection kernel in the last profiled regen."""
+        n = ctypes.c_uint64(0)
+        self._chk(self._lib.sdmesh_profile_rounds(self._h, ctypes.byref(n)))
+        return int(n.value)
+
+    def project_diag(self):
+        """uint64 [waves, 4]: {start, end, rounds, hw id} per wave of the projection kernel (option "project_diag")."""
+        n = ctypes.c_size_t(0)
+        self._chk(self._lib.sdmesh_project_diag(self._h, None, 0, ctypes.byref(n)))
+        out = np.zeros((n.value, 4), np.uint64)
+        if n.value:
+            self._chk(self._lib.sdmesh_project_diag(self._h, out.ctypes.data, n.value, ctypes.byref(n)))
+        return out
 
     def sample_dense(self, N, dev_ptr):
         ms = ctypes.c_float(0)

@@ -11,7 +11,8 @@ cuda/modules/compute_mesh_generation.cu:51) and the first-seen weld (src/cuda/mo
     column in increasing order, rank 0's triangles of that column, then rank 1's, ...;
   * welding the merged list with the first-seen rule gives the single-GPU vertices and indices, bit for bit.
 
-Pure index arithmetic on torch tensors (CPU or GPU): PyTorch is the plumbing for buffers and collectives.
+The data path is behind the C ABI (`sdmesh_sharded_regen`: RCCL + HIP kernels); this module is its thin Python caller,
+the gloo-staged transport for rehearsals, and a CPU restatement of the merge for the no-GPU tests.
 """
 import torch
 
@@ -25,7 +26,9 @@ def slab_bounds(part, nparts):
 
 
 def merge_destinations(counts):
-    """counts: int64 [R, 1024] triangles per (rank, column).  Returns a list of R int64 tensors: for rank r the
+    """CPU restatement of the merge plan (k_merge_plan / k_merge_copy in csrc/kernels.hip), for the tests that run without a
+    GPU and as the kernel's checker -- the product path calls `sdmesh_merge_by_column`, never this.
+    counts: int64 [R, 1024] triangles per (rank, column).  Returns a list of R int64 tensors: for rank r the
     position in the merged list of each of its triangles (rank lists are column-sorted already)."""
     counts = counts.to(torch.int64)
     R = counts.shape[0]
@@ -44,7 +47,8 @@ def merge_destinations(counts):
 
 
 def merge_triangles(tri_lists, counts):
-    """tri_lists: R tensors [T_r, 18] float32 (compact Triangle structs) on one device; counts [R, 1024].
+    """CPU restatement of `sdmesh_merge_by_column` (see merge_destinations).
+    tri_lists: R tensors [T_r, 18] float32 (compact Triangle structs) on one device; counts [R, 1024].
     Returns the merged [sum T_r, 18] tensor in single-GPU emission order."""
     dests = merge_destinations(counts.to(tri_lists[0].device))
     total = int(sum(t.shape[0] for t in tri_lists))
@@ -56,74 +60,90 @@ def merge_triangles(tri_lists, counts):
 
 
 class ShardedMesher:
-    """ONE mesh across all ranks (strong scaling): rank r meshes level-0 z-slab r with the weld
-    skipped, the 1024 per-column triangle counts are all-gathered (4 KB), the compact per-slab triangle lists go
-    straight to the root with point-to-point send/recv (RCCL: each peer on its own xGMI link), the root restores the
-    single-GPU order and welds.  The handler must run on torch's current stream (`set_stream`).
+    """ONE mesh across all ranks (strong scaling) -- a thin caller of the C ABI.
 
-    The transport is whatever process group is current: with "nccl" (= RCCL) the device buffers are exchanged
-    directly; with "gloo" (tests, CPU rehearsals) they are staged through host memory -- same code otherwise."""
+    With RCCL available to the job (process group backend "nccl", or a single rank) the whole step is ONE library call,
+    `sdmesh_sharded_regen`: z-slab regen per rank (weld skipped), ncclAllGather of the 1024 per-column triangle counts,
+    grouped ncclSend / ncclRecv of the compact per-slab lists to the root (each peer on its own xGMI link), the
+    order-restoring merge kernel and the first-seen weld on the root.  The communicator is the library's own
+    (`sdmesh_comm_init`); torch.distributed only carries the 128-byte unique id to the ranks.
 
-    def __init__(self, pkg, handler, levels, rank, world, device):
+    Under "gloo" (the rehearsals that put several ranks on one GPU, where RCCL refuses duplicate devices) only the
+    TRANSPORT differs: counts and triangle lists are staged through host memory by torch.distributed, everything else
+    -- slab regen, column counts, `sdmesh_merge_by_column`, `sdmesh_weld_device_triangles` -- is the same C ABI."""
+
+    def __init__(self, pkg, handler, levels, rank, world, device, transport=None):
         import torch.distributed as dist
         self.pkg, self.h, self.levels, self.rank, self.world, self.dev = pkg, handler, levels, rank, world, device
         self.dist = dist
-        self.staged = world > 1 and dist.get_backend() == "gloo"
-        handler.set_option("skip_weld", 1)
-        info = handler.regen(levels, pkg.PART_ZSLAB, rank, world)        # capacity discovery
-        handler.set_option("skip_weld", 0)
-        self.cap = int(info.triangles * 1.25) + 1024
-        self.mine = torch.empty((self.cap, 18), dtype=torch.float32, device=device)
-        self.cc = torch.zeros(NCOLS, dtype=torch.int32, device=device)
-        self.allc = torch.zeros((world, NCOLS), dtype=torch.int32, device=device)
-
-    def _all_gather_counts(self):
-        if self.world == 1:
-            self.allc.copy_(self.cc.unsqueeze(0))
-        elif self.staged:
-            mine = self.cc.cpu()
-            parts = [torch.zeros_like(mine) for _ in range(self.world)]
-            self.dist.all_gather(parts, mine)
-            self.allc.copy_(torch.stack(parts))
+        if transport is None:
+            transport = "staged" if (world > 1 and dist.get_backend() == "gloo") else "rccl"
+        self.transport = transport
+        if transport == "rccl":
+            uid = [pkg.CudaHandler.comm_unique_id() if rank == 0 else None]
+            if world > 1:
+                dist.broadcast_object_list(uid, src=0)
+            handler.comm_init(uid[0], world, rank)
+            self.ranks_seen = handler.comm_ranks()
+            if self.ranks_seen != world:
+                raise RuntimeError(f"RCCL communicator saw {self.ranks_seen} ranks, expected {world}")
         else:
-            self.dist.all_gather_into_tensor(self.allc, self.cc)
+            self.ranks_seen = world
+            self.cap = 0
+            self.mine = None
+            self.cc = torch.zeros(NCOLS, dtype=torch.int32, device=device)
+            self.allc = torch.zeros((world, NCOLS), dtype=torch.int32, device=device)
+            self.merged = None
+
+    def close(self):
+        if self.transport == "rccl":
+            self.h.comm_destroy()
 
     def step(self):
         """One sharded regen.  Returns the root's sdmesh_regen_info of the welded mesh (None on the other ranks)."""
+        if self.transport == "rccl":
+            info = self.h.sharded_regen(self.levels, 0)
+            return info if self.rank == 0 else None
+        return self._step_staged()
+
+    # -- gloo rehearsal: same kernels, host-staged transport ---------------------------------------------------------
+    def _step_staged(self):
         h, dist = self.h, self.dist
         h.set_option("skip_weld", 1)
         try:
-            h.regen(self.levels, self.pkg.PART_ZSLAB, self.rank, self.world)
+            info = h.regen(self.levels, self.pkg.PART_ZSLAB, self.rank, self.world)
+            if self.mine is None or info.triangles > self.cap:           # grow before any collective is entered
+                self.cap = int(info.triangles * 1.25) + 1024
+                self.mine = torch.empty((self.cap, 18), dtype=torch.float32, device=self.dev)
             n = h.device_triangles_into(self.mine.data_ptr(), self.cap)
             h.column_triangle_counts_into(self.cc.data_ptr())
         finally:
             h.set_option("skip_weld", 0)
-        self._all_gather_counts()
-        if self.rank == 0:
-            sizes = self.allc.sum(1).cpu().tolist()
-            bufs, ops = [], []
-            for r in range(1, self.world):
-                b = torch.empty((int(sizes[r]), 18), dtype=torch.float32, device="cpu" if self.staged else self.dev)
-                bufs.append(b)
-                if b.numel():
-                    if self.staged:
-                        dist.recv(b, src=r)
-                    else:
-                        ops.append(dist.P2POp(dist.irecv, b, r))
-            if ops:
-                for w in dist.batch_isend_irecv(ops):
-                    w.wait()
-            lists = [self.mine[:n]] + [b.to(self.dev) for b in bufs]
-            merged = merge_triangles(lists, self.allc.to(torch.int64))
-            torch.cuda.current_stream().synchronize()
-            return h.weld_device_triangles(merged.data_ptr(), merged.shape[0])
-        if n:
-            if self.staged:
+        if self.world == 1:
+            self.allc.copy_(self.cc.unsqueeze(0))
+        else:
+            mine = self.cc.cpu()
+            parts = [torch.zeros_like(mine) for _ in range(self.world)]
+            dist.all_gather(parts, mine)
+            self.allc.copy_(torch.stack(parts))
+        if self.rank != 0:
+            if n:
                 dist.send(self.mine[:n].cpu(), dst=0)
-            else:
-                for w in dist.batch_isend_irecv([dist.P2POp(dist.isend, self.mine[:n], 0)]):
-                    w.wait()
-        return None
+            return None
+        sizes = self.allc.sum(1).cpu().tolist()
+        lists = [self.mine]
+        for r in range(1, self.world):
+            b = torch.empty((int(sizes[r]), 18), dtype=torch.float32)
+            if b.numel():
+                dist.recv(b, src=r)
+            lists.append(b.to(self.dev) if b.numel() else torch.empty((1, 18), dtype=torch.float32, device=self.dev))
+        total = int(sum(sizes))
+        if self.merged is None or self.merged.shape[0] < max(total, 1):
+            self.merged = torch.empty((int(total * 1.25) + 1024, 18), dtype=torch.float32, device=self.dev)
+        torch.cuda.current_stream().synchronize()                         # the staged copies above ran on torch's stream
+        got = h.merge_by_column([t.data_ptr() for t in lists], self.allc.data_ptr(), self.merged.data_ptr(), self.merged.shape[0])
+        assert got == total
+        return h.weld_device_triangles(self.merged.data_ptr(), total)
 
 
 def weld_keys(pos):

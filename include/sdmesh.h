@@ -31,8 +31,10 @@ enum {
     SDMESH_ERR_HIP = 2,          /* a HIP runtime call failed (sdmesh_last_error has the text) */
     SDMESH_ERR_NO_DEVICE = 3,    /* no usable gfx950 device */
     SDMESH_ERR_CAPACITY = 4,     /* caller-provided output buffer too small */
-    SDMESH_ERR_WELD_RANGE = 5,   /* a vertex outside +-10.48 units: not representable in the weld key */
-    SDMESH_ERR_INTERNAL = 6      /* invariant violated on the device (bug) */
+    SDMESH_ERR_WELD_RANGE = 5,   /* kept for ABI stability; no longer returned: vertices outside the packed +-10.48 unit key
+                                    are welded with the wide key form, like the reference's [i64; 3] (src/cuda/mod.rs:268-273) */
+    SDMESH_ERR_INTERNAL = 6,     /* invariant violated on the device (bug) */
+    SDMESH_ERR_RCCL = 7          /* librccl missing or a collective failed (sdmesh_last_error has the text) */
 };
 
 /* Scenes.  The reference hard-codes one SDF, sd_obj (cuda/modules/common.cu:222-226) = SDOBJ.
@@ -98,8 +100,12 @@ typedef struct sdmesh_instr {
 } sdmesh_instr;
 int sdmesh_set_program(sdmesh_handle *h, const sdmesh_instr *instrs, int n);
 
-/* Run on a caller-owned hipStream_t (e.g. torch's current stream); NULL = the handle's own. */
+/* Run on a caller-owned hipStream_t, taken exactly as HIP reads it: NULL is the legacy default stream (which is what
+ * torch.cuda.current_stream().cuda_stream is for torch's default stream).  hipGraph replay needs a capturable stream, so
+ * on the NULL stream the "graph" option falls back to eager launches.  sdmesh_use_own_stream returns to the handle's own
+ * (non-blocking) stream, the state after sdmesh_create. */
 int sdmesh_set_stream(sdmesh_handle *h, void *hip_stream);
+int sdmesh_use_own_stream(sdmesh_handle *h);
 /* Options (all have measured defaults; the others exist for A/B runs and are covered by the parity tests):
  *   "direct" = 1        force the per-corner projection path (no edge sharing)
  *   "skip_weld" = 1     sdmesh_regen* stops after the orientation test (a multi-GPU rank exports
@@ -111,9 +117,14 @@ int sdmesh_set_stream(sdmesh_handle *h, void *hip_stream);
  *   "emit_ci" = 0       run k_classify instead of taking the MC cases from the last refine level
  *   "fork" = 0|1|2      weld claim after / on a second stream beside / in one dispatch with the orientation test
  *   "ff_fork" = 0|1|2   weld-table clear inside k_create_field / on a second stream / as a memset node
+ *   "col_refine" = 0    refine level by level from the level-0 field (default 1: levels 0 .. min(levels - 1, 3) are fused
+ *                       per level-0 column, two launches in all)
  *   "refine2" = 1, "mask_chunk" = 8|16|32   refine variants
  *   "dense_grid", "dense_nt", "dense_rows", "dense_contig"   launch shape of the dense sample pass (P1)
- *   "forget_plan" = 1   drop the capacity plan (the next regen discovers sizes again) */
+ *   "forget_plan" = 1   drop the capacity plan (the next regen discovers sizes again)
+ *   "profile" = 1       time every stage of the planned chain with HIP events (sdmesh_profile_stages)
+ *   "weld_wide" = 1     always weld with the unbounded key form (default 0: packed 3 x 21-bit keys, and the wide form
+ *                       automatically from the first vertex that does not fit them) */
 int sdmesh_set_option(sdmesh_handle *h, const char *name, int value);
 
 /* ---- host-buffer API (B2) ----------------------------------------------------------------- */
@@ -185,6 +196,33 @@ int sdmesh_column_triangle_counts(sdmesh_handle *h, uint32_t *d_counts);
 int sdmesh_download_mesh(sdmesh_handle *h, struct Vertex *verts, struct IndexTriangle *tris);
 int sdmesh_download_voxels(sdmesh_handle *h, struct Point *voxels);
 
+/* ---- one mesh over several GPUs (the reference is single-device, src/cuda/mod.rs:52) ------------- */
+
+/* Order-restoring merge of `nranks` per-slab compact triangle lists (each from sdmesh_device_triangles of a
+ * SDMESH_PART_ZSLAB regen) into the single-GPU emission order: d_lists = HOST array of nranks DEVICE pointers, d_counts =
+ * DEVICE array of nranks x 1024 per-column counts (sdmesh_column_triangle_counts of every rank, rank-major).  A HIP
+ * kernel; the merged list (device, cap triangles) is what sdmesh_weld_device_triangles then welds. */
+int sdmesh_merge_by_column(sdmesh_handle *h, const struct Triangle *const *d_lists, const uint32_t *d_counts, int nranks,
+                           struct Triangle *d_out, size_t cap, size_t *n_out);
+
+/* RCCL communicator of the handle (one process per GPU).  Rank 0 makes the id, the host distributes the 128 bytes
+ * (any side channel: the launcher's store, MPI, torch.distributed), every rank calls sdmesh_comm_init.  librccl.so.1 is
+ * bound at run time, so hosts that never call these need no RCCL. */
+typedef struct sdmesh_unique_id { char bytes[128]; } sdmesh_unique_id;      /* = ncclUniqueId */
+int sdmesh_comm_unique_id(sdmesh_unique_id *out);
+int sdmesh_comm_init(sdmesh_handle *h, const sdmesh_unique_id *id, int nranks, int rank);
+int sdmesh_comm_destroy(sdmesh_handle *h);
+/* ncclAllReduce(sum) of 1 over the communicator: how many ranks really took part */
+int sdmesh_comm_ranks(sdmesh_handle *h, int *ranks_seen);
+
+/* ONE regen of ONE mesh over all ranks of the communicator, entirely behind this call: rank r meshes level-0 z-slab r
+ * (no weld), ncclAllGather of the 1024 per-column triangle counts (4 KB), grouped ncclSend / ncclRecv of the compact
+ * per-slab triangle lists straight to `root` (each peer on its own xGMI link), order-restoring merge kernel and first-seen
+ * weld on the root.  On the root *info describes the welded mesh (identical to a single-GPU sdmesh_regen, fetch it with
+ * sdmesh_device_mesh / sdmesh_download_mesh); on the other ranks it describes their slab.  Collective: every rank of
+ * the communicator must call it with the same levels and root. */
+int sdmesh_sharded_regen(sdmesh_handle *h, int levels, int root, sdmesh_regen_info *info);
+
 /* Dense mode: the same regen through the dense (N+1)^3 lattice -- P1 sample, P2a sign bits, P2b
  * LDS-tiled classify with the hierarchical ancestor criterion (A2'), then the usual mesh stage.  O(N^3) work; it
  * exists as the cross-check that "dense == hierarchical" and to measure the two HBM passes, not as the fast path. */
@@ -198,6 +236,17 @@ int sdmesh_sample_dense(sdmesh_handle *h, uint32_t N, float *d_out, float *kerne
  * (bench.py's live roofline measurement).  which: 0 = P1 sample_dense(N) into d_buf; 1 = P2a sign bits of d_buf;
  * 2 = write ceiling (P1's store stream over the same 4 (N+1)^3 bytes with no arithmetic). */
 int sdmesh_time_kernel(sdmesh_handle *h, int which, uint32_t N, float *d_buf, int iters, float *avg_ms);
+
+/* Per-stage device times of the last planned regen, when option "profile" = 1 was set before it (HIP events between the
+ * stages of the chain on the handle's stream; eager launches, never a graph): comma-separated stage names and one time
+ * in ms per stage -- create_field, refine_mask / refine_emit per level, tile_dedupe, tile_prefix, project1|project4,
+ * flip_claim1|flip_claim4, weld.  bench.py's live cross-check of the rocprofv3 kernel trace under profiles/. */
+int sdmesh_profile_stages(sdmesh_handle *h, char *names, size_t names_cap, float *ms, int cap, int *n_out);
+/* Newton rounds (vertex x round; each is 13 SDF evaluations) the projection kernel of that regen performed. */
+int sdmesh_profile_rounds(sdmesh_handle *h, uint64_t *vertex_rounds);
+/* Diagnostic (option "project_diag" = 1): per wave of the projection kernel four u64 {s_memtime at start, at end, vertex
+ * rounds, HW_ID | XCC_ID << 32}; waves without work stay zero.  tools/project_timeline.py turns it into the lifetime histogram. */
+int sdmesh_project_diag(sdmesh_handle *h, uint64_t *out, size_t cap_waves, size_t *n_waves);
 
 /* ---- ray-march preview ------------------------------------------------ */
 

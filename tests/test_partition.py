@@ -43,6 +43,22 @@ def test_merge_restores_column_major_interleave(R):
     assert [P.slab_bounds(p, R) for p in range(R)][0][0] == 0 and P.slab_bounds(R - 1, R)[1] == 32
 
 
+def _join_all(procs, timeout):
+    """Join the workers; none of them outlives the test (a stuck rank would keep the rendezvous port)."""
+    try:
+        for p in procs:
+            p.join(timeout)
+        codes = [p.exitcode for p in procs]
+    finally:
+        for p in procs:
+            if p.exitcode is None:
+                p.terminate()
+                p.join(10)
+                if p.exitcode is None:
+                    p.kill()
+    assert codes == [0] * len(procs), codes
+
+
 def _worker(rank, world, port, levels, q):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     dist.init_process_group("gloo", rank=rank, world_size=world)
@@ -85,9 +101,7 @@ def test_gloo_slab_gather_merge_weld_equals_single(world, levels):
     procs = [ctx.Process(target=_worker, args=(r, world, port, levels, q)) for r in range(world)]
     for p in procs:
         p.start()
-    for p in procs:
-        p.join(300)
-        assert p.exitcode == 0
+    _join_all(procs, 300)
     ok, nt, nref = q.get()
     assert ok and nt == nref
 
@@ -139,8 +153,6 @@ def test_gloo_distributed_weld_equals_single(world, levels):
     procs = [ctx.Process(target=_dist_worker, args=(r, world, port, levels, q)) for r in range(world)]
     for p in procs:
         p.start()
-    for p in procs:
-        p.join(300)
-        assert p.exitcode == 0
+    _join_all(procs, 300)
     ok, nt, nref, nv, nvref = q.get()
     assert ok and (nt, nv) == (nref, nvref)

@@ -1,0 +1,47 @@
+#!/usr/bin/env python3
+"""Per-wave timeline of the projection kernel (option "project_diag"): lifetime histogram, tail, per-SIMD load.
+usage: project_timeline.py [scene] [levels] [out.json]"""
+import json
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import sdmesh_pkg  # noqa: E402
+
+scene = sys.argv[1] if len(sys.argv) > 1 else "sdobj"
+k = int(sys.argv[2]) if len(sys.argv) > 2 else 4
+pkg = sdmesh_pkg.load()
+h = pkg.CudaHandler(0, scene)
+h.regen(k)
+for _ in range(5):
+    h.regen(k)
+h.set_option("project_diag", 1)
+res = []
+for rep in range(3):
+    h.regen(k)
+    d = h.project_diag()
+    d = d[d[:, 1] != 0]
+    t0 = d[:, 0].min()
+    start, end, rounds = (d[:, 0] - t0).astype(np.float64), (d[:, 1] - t0).astype(np.float64), d[:, 2].astype(np.int64)
+    hw = d[:, 3]
+    simd = ((hw >> 4) & 3).astype(np.int64); cu = ((hw >> 8) & 15).astype(np.int64); sh = ((hw >> 12) & 1).astype(np.int64)
+    se = ((hw >> 13) & 7).astype(np.int64); xcc = ((hw >> 32) & 15).astype(np.int64)
+    unit = (((xcc * 8 + se) * 2 + sh) * 16 + cu) * 4 + simd
+    life = end - start
+    span = end.max()
+    per_unit = np.bincount(np.unique(unit, return_inverse=True)[1], weights=rounds)
+    q = lambda a, p: float(np.percentile(a, p))   # noqa: E731
+    res.append({"working_waves": int(len(d)), "kernel_span_ticks": span, "ticks_are": "s_memtime (100 MHz constant clock on gfx9: 10 ns)",
+                "start_p50": q(start, 50), "start_max": float(start.max()),
+                "end_p10": q(end, 10), "end_p50": q(end, 50), "end_p90": q(end, 90), "end_p99": q(end, 99), "end_max": float(end.max()),
+                "life_mean": float(life.mean()), "life_p50": q(life, 50), "life_p99": q(life, 99), "life_max": float(life.max()),
+                "rounds_per_wave_mean": float(rounds.mean()) / 64.0, "rounds_per_wave_hist(ceil(vertex_rounds/64))": np.bincount(((rounds + 63) // 64).astype(np.int64)).tolist(),
+                "waves_alive_frac": float(life.sum() / (len(d) * span)),
+                "simd_units_used": int(len(per_unit)), "vertex_rounds_per_simd_mean": float(per_unit.mean()), "vertex_rounds_per_simd_max": float(per_unit.max()),
+                "end_hist_10_bins": np.histogram(end, bins=10, range=(0, span))[0].tolist()})
+print(json.dumps(res[-1], indent=1))
+if len(sys.argv) > 3:
+    json.dump(res, open(sys.argv[3], "w"), indent=1)
