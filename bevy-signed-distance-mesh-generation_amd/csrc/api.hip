@@ -101,6 +101,8 @@ struct sdmesh_handle {
     DevBuf col_list1, col_mask2, col_mask3, colinfo;
     int skip_weld = 0;         // regen stops after the orientation test (multi-GPU ranks: the root welds)
     int weld_wide = 0;         // option: 1 = always weld with the unbounded [i64; 3] key form
+    int weld_shift = 0;        // option: coarse-cell shift of locality-preserving home slots (0 = uniform hashing, the default:
+                               // locality makes the claim's atomics collide; -1 = shift from the voxel size)
     bool wide_active = false;  // the wide form is in use (forced, or a vertex did not fit the packed 3 x 21-bit key)
     bool welded = false;       // tri_e holds the final corner order
     int dense_grid = 16384;    // workgroups for k_sample_dense
@@ -132,13 +134,13 @@ struct sdmesh_handle {
     uint32_t *d_status = nullptr;  // ST_WORDS
     uint32_t *h_pinned = nullptr;  // CTR_WORDS + ST_WORDS, pinned
     // mesh stage
-    DevBuf cubeidx, trioff, ff_arena, first_ord_buf, uverts, tri_e, vslot, tdesc, tfirst, tfpre, tpre, flip, wvidx, torder;
+    DevBuf cubeidx, trioff, ff_arena, first_ord_buf, uverts, tri_e, vslot, tdesc, tfirst, tfpre, tpre, flip, wvidx, torder, wrep_buf, wfm_buf;
     DevBuf vertices, indices, raw, compact, staging, dense_samples, dense_bits, cellcnt;
     // capacities the device chain was laid out for
     uint32_t cap_vox = 0, ucap = 0, tcap = 0, wsize = 0;
     uint64_t *wkeys = nullptr;
     uint32_t *first_ord = nullptr;
-    uint2 *wfm = nullptr;          // inside ff_arena: per slot {winner's first-seen ordinal, minimum loser ordinal} (one gather)
+    uint2 *wfm = nullptr;          // per representative vertex {its first-seen ordinal, minimum ordinal of the key's other vertices}
 
     // last results (host view)
     uint32_t n_vox = 0, n_tris = 0, n_verts = 0, n_unique = 0;
@@ -170,6 +172,8 @@ struct sdmesh_handle {
     int plan_scene = -1, plan_levels = -1, plan_mode = 0, plan_part = 0, plan_nparts = 1;
     uint32_t plan_counts[SDMESH_MAX_LEVELS + 1] = {0};
     uint32_t plan_uniq = 0;
+    uint32_t plan_tris = 0;
+    uint32_t tri_hint = 0;     // planned triangle count of the chain being enqueued (0 = unknown)
 };
 
 namespace {
@@ -265,22 +269,37 @@ int layout_mesh(sdmesh_handle *h, uint32_t n_cap, uint32_t u_cap_hint) {
     SDCHK(ensure(h, h->tfpre, 4ull * (tiles(n_cap) + tiles(tcap) + 16)));
     SDCHK(ensure(h, h->torder, 4ull * ucap));
     SDCHK(ensure(h, h->flip, (size_t) tcap + 64));
-    SDCHK(ensure(h, h->wvidx, 4ull * wsize));
+    SDCHK(ensure(h, h->wvidx, 4ull * ucap));               // welded index per representative vertex (vertex-slot space)
+    SDCHK(ensure(h, h->wrep_buf, 4ull * wsize));           // representative vertex per table slot (written by the claim's winner)
+    SDCHK(ensure(h, h->wfm_buf, 8ull * ucap));             // records per representative vertex, initialised by the claim's winner
     SDCHK(ensure(h, h->vertices, sizeof(Vertex) * (size_t) uexp));
     SDCHK(ensure(h, h->indices, 12ull * tcap));
-    // one arena for everything that must start as 0xFF (weld keys + loser minima): one memset per regen
-    const size_t o_wkeys = 0, o_wfm = align256(o_wkeys + 8ull * wsize), total = align256(o_wfm + 8ull * wsize);
-    SDCHK(ensure(h, h->ff_arena, total));
-    char *base = (char *) h->ff_arena.p;
-    h->wkeys = (uint64_t *) (base + o_wkeys);
-    h->wfm = (uint2 *) (base + o_wfm);
+    // what must start as 0xFF per regen: the weld keys only (the per-key records are initialised by the claim's winners)
+    SDCHK(ensure(h, h->ff_arena, align256(8ull * wsize)));
+    h->wkeys = (uint64_t *) h->ff_arena.p;
+    h->wfm = (uint2 *) h->wfm_buf.p;
     h->first_ord = (uint32_t *) h->first_ord_buf.p;
     h->wsize = wsize; h->ucap = ucap; h->tcap = tcap; h->cap_vox = n_cap;
     return SDMESH_OK;
 }
 
 size_t ff_bytes(const sdmesh_handle *h) {
-    return (size_t) ((char *) h->wfm - (char *) h->ff_arena.p) + 8ull * h->wsize;
+    return 8ull * h->wsize;
+}
+
+// wide flag | coarse-cell shift << 8 for the weld claim: the coarse cell of the locality-preserving home slot spans about
+// `weld_cell` voxels (default 8) in units of the 1e-5 weld quantum (option "weld_shift" overrides; 0 = uniform hashing)
+uint32_t weld_mode(const sdmesh_handle *h, Point vs) {
+    uint32_t shift;
+    if (h->weld_shift >= 0) {
+        shift = (uint32_t) h->weld_shift;
+    } else {
+        const float span = 8.0f * std::max(vs.x, std::max(vs.y, vs.z)) * 100000.0f;
+        shift = 13;
+        if (span > 1.0f && span < 1.0e6f) { shift = 0; while ((1u << (shift + 1)) <= (uint32_t) span) shift++; }
+    }
+    if (shift > 20) shift = 20;
+    return (h->wide_active ? 1u : 0u) | (shift << 8);
 }
 
 // classify -> tile dedupe -> project -> flip for the voxel list d_vox (count at *n_ptr, at most cap_vox):
@@ -321,14 +340,22 @@ int mesh_front(sdmesh_handle *h, const Point *d_vox, const uint32_t *n_ptr, Poin
     }
     HIPCHK(launch_project(st, h->grid * h->project_mult, h->scene, h->d_sp, (Vertex *) h->uverts.p, (const uint4 *) h->tdesc.p,
                           (const uint32_t *) h->tpre.p, coarse, h->d_ctr + CTR_NTILES, h->d_status, p_lanes, d_prof, d_diag));
-    SDCHK(prof_mark(h, p_lanes == 1 ? "project1" : "project4"));
+    SDCHK(prof_mark(h, p_lanes == 1 ? "project1" : (p_lanes == 2 ? "project2" : "project4")));
     // fork: the weld claim (scattered CAS, latency-bound) runs beside the orientation test (VALU-bound)
-    const int f_grid = h->grid * (f_lanes == 1 ? 1 : h->flip_mult);
+    int f_grid = h->grid * (f_lanes == 1 ? 1 : h->flip_mult);
+    if (h->tri_hint) {
+        // Every lane (1-lane layout) or 4-lane group takes whole passes over the triangle list: with T = 530 536 on 1 024
+        // workgroups 98 of the 4 096 waves ran a third pass and the kernel took three pass times instead of two.  Size the
+        // grid so that the planned count divides into equal passes (the grid-stride loop still covers any actual count).
+        const uint32_t per_wg = f_lanes == 1 ? 256u : 64u;
+        const uint32_t passes = std::max<uint32_t>(1u, (h->tri_hint + per_wg * (uint32_t) f_grid / 2u) / (per_wg * (uint32_t) f_grid));
+        f_grid = (int) std::min<uint32_t>(65535u, (h->tri_hint + passes * per_wg - 1u) / (passes * per_wg) + 1u);
+    }
     if (h->fork == 2) {
         // one dispatch: claim workgroups first (latency-bound, resident early), orientation-test workgroups behind them
         HIPCHK(launch_flip_claim(st, f_grid, h->tgrid, h->scene, h->d_sp, (const Vertex *) h->uverts.p, (const uint32_t *) h->tri_e.p,
                                  h->d_ctr + CTR_NTRI, (uint8_t *) h->flip.p, f_lanes, (const uint4 *) h->tdesc.p, h->d_ctr + CTR_NTILES,
-                                 h->wkeys, h->wsize, (uint32_t *) h->vslot.p, h->d_status, h->wide_active));
+                                 h->wkeys, h->wsize, (uint32_t *) h->vslot.p, h->d_status, weld_mode(h, vs), (uint32_t *) h->wrep_buf.p, h->wfm));
         SDCHK(prof_mark(h, f_lanes == 1 ? "flip_claim1" : "flip_claim4"));
         return SDMESH_OK;
     }
@@ -338,7 +365,7 @@ int mesh_front(sdmesh_handle *h, const Point *d_vox, const uint32_t *n_ptr, Poin
         HIPCHK(hipStreamWaitEvent(h->side, h->ev_fork, 0));
     }
     HIPCHK(launch_tile_claim(cst, h->tgrid, (const Vertex *) h->uverts.p, (const uint4 *) h->tdesc.p, h->d_ctr + CTR_NTILES,
-                             h->wkeys, h->wsize, (uint32_t *) h->vslot.p, h->d_status, h->wide_active));
+                             h->wkeys, h->wsize, (uint32_t *) h->vslot.p, h->d_status, weld_mode(h, vs), (uint32_t *) h->wrep_buf.p, h->wfm));
     if (h->fork) HIPCHK(hipEventRecord(h->ev_join, h->side));
     HIPCHK(launch_flip(st, f_grid, h->scene, h->d_sp, (const Vertex *) h->uverts.p, (const uint32_t *) h->tri_e.p,
                        h->d_ctr + CTR_NTRI, (uint8_t *) h->flip.p, f_lanes));
@@ -350,7 +377,7 @@ int mesh_front(sdmesh_handle *h, const Point *d_vox, const uint32_t *n_ptr, Poin
 int mesh_weld(sdmesh_handle *h, const Vertex *uverts) {
     hipStream_t st = h->stream;
     HIPCHK(launch_weld(st, h->tgrid, uverts, (const uint4 *) h->tdesc.p, h->d_ctr + CTR_NTILES, (uint32_t *) h->tri_e.p,
-                       (const uint8_t *) h->flip.p, h->first_ord, h->wfm, (const uint32_t *) h->vslot.p,
+                       (const uint8_t *) h->flip.p, h->first_ord, h->wfm, (const uint32_t *) h->wrep_buf.p, (uint32_t *) h->vslot.p,
                        (uint32_t *) h->wvidx.p, (uint32_t *) h->torder.p, (uint32_t *) h->tfirst.p, (uint32_t *) h->tfpre.p,
                        (Vertex *) h->vertices.p, (uint32_t) (h->vertices.cap / sizeof(Vertex)), h->d_ctr + CTR_NVERT,
                        (uint32_t *) h->indices.p, h->d_status));
@@ -437,7 +464,7 @@ int weld_raw_device(sdmesh_handle *h, const Triangle *d_raw, uint32_t nslots) {
     HIPCHK(launch_raw_desc(st, h->grid, h->d_ctr + CTR_NTRI, (uint4 *) h->tdesc.p, (uint8_t *) h->flip.p, h->d_ctr + CTR_NTILES,
                            h->d_ctr + CTR_NUNIQ));
     HIPCHK(launch_tile_claim(st, h->tgrid, (const Vertex *) h->compact.p, (const uint4 *) h->tdesc.p, h->d_ctr + CTR_NTILES,
-                             h->wkeys, h->wsize, (uint32_t *) h->vslot.p, h->d_status, h->wide_active));
+                             h->wkeys, h->wsize, (uint32_t *) h->vslot.p, h->d_status, weld_mode(h, h->voxel_size), (uint32_t *) h->wrep_buf.p, h->wfm));
     SDCHK(mesh_weld(h, (const Vertex *) h->compact.p));
     return SDMESH_OK;
 }
@@ -579,8 +606,10 @@ int enqueue_planned_chain(sdmesh_handle *h, int levels, const uint32_t *box, uin
         L++;
     }
     h->lane_hint = h->plan_uniq;
+    h->tri_hint = h->plan_tris;
     const int rc_front = mesh_front(h, (const Point *) h->vox[h->cur].p, h->d_ctr + CTR_LEVEL0 + levels, vs, false, true, mesh_tc != nullptr, mesh_tc);
     h->lane_hint = 0;
+    h->tri_hint = 0;
     SDCHK(rc_front);
     if (!h->skip_weld) SDCHK(mesh_weld(h, (const Vertex *) h->uverts.p));
     *vs_out = vs;
@@ -680,6 +709,7 @@ int regen_impl(sdmesh_handle *h, int levels, int mode, int part, int nparts, sdm
                                    (uint64_t) h->skip_weld | ((uint64_t) h->wide_active << 1) | ((uint64_t) h->col_refine << 2), (uint64_t) (uintptr_t) st, (uint64_t) h->grid | ((uint64_t) h->tgrid << 20) | ((uint64_t) h->project_mult << 40) | ((uint64_t) h->flip_mult << 48) | ((uint64_t) h->refine2 << 56) | ((uint64_t) h->emit_ci << 57) | ((uint64_t) h->project_lanes << 58) | ((uint64_t) h->flip_lanes << 61), 0};
                 for (int i = 0; i <= levels; i++) key[7] = key[7] * 1000003ull + h->plan_counts[i];
                 key[7] = key[7] * 1000003ull + h->plan_uniq;
+                key[7] = key[7] * 1000003ull + h->plan_tris;
                 if (!h->graph_exec || memcmp(key, h->graph_key, sizeof key) != 0) {
                     drop_graph(h);
                     HIPCHK(hipStreamSynchronize(st));
@@ -820,6 +850,7 @@ int regen_impl(sdmesh_handle *h, int levels, int mode, int part, int nparts, sdm
             h->plan_scene = h->scene; h->plan_levels = levels; h->plan_mode = mode; h->plan_part = part; h->plan_nparts = nparts;
             for (int i = 0; i <= levels; i++) h->plan_counts[i] = std::max(h->plan_counts[i] * (async ? 1u : 0u), c[CTR_LEVEL0 + i]);
             h->plan_uniq = std::max(async ? h->plan_uniq : 0u, c[CTR_NUNIQ]);
+            h->plan_tris = std::max(async ? h->plan_tris : 0u, c[CTR_NTRI]);
         }
         fill_info(h, info, levels, direct, ms);
         return SDMESH_OK;
@@ -920,7 +951,7 @@ void sdmesh_destroy(sdmesh_handle *h) {
     if (h->stream) (void) hipStreamSynchronize(h->stream);
     drop_graph(h);
     DevBuf *bufs[] = {&h->render_tex, &h->vox[0], &h->vox[1], &h->mask, &h->mask2x, &h->signs, &h->tilecnt, &h->ctl, &h->cubeidx, &h->trioff, &h->ff_arena,
-                      &h->first_ord_buf, &h->uverts, &h->tri_e, &h->vslot, &h->tdesc, &h->tfirst, &h->tfpre, &h->tpre, &h->flip, &h->wvidx, &h->torder,
+                      &h->first_ord_buf, &h->uverts, &h->tri_e, &h->vslot, &h->tdesc, &h->tfirst, &h->tfpre, &h->tpre, &h->flip, &h->wvidx, &h->torder, &h->wrep_buf, &h->wfm_buf,
                       &h->vertices, &h->indices, &h->raw, &h->compact, &h->staging, &h->dense_samples, &h->dense_bits,
                       &h->cellcnt, &h->col_list1, &h->col_mask2, &h->col_mask3, &h->colinfo, &h->prof_rounds, &h->proj_diag, &h->shard_mine, &h->shard_counts, &h->shard_recv, &h->shard_lists, &h->shard_plan, &h->shard_merged};
     (void) sdmesh_comm_destroy(h);
@@ -992,7 +1023,7 @@ int sdmesh_set_option(sdmesh_handle *h, const char *name, int value) {
     if (!h || !name) return SDMESH_ERR_INVALID;
     if (!strcmp(name, "direct")) { h->force_direct = value ? 1 : 0; h->plan_valid = false; return SDMESH_OK; }
     if (!strcmp(name, "project_mult")) { if (value < 1 || value > 16) return fail(h, SDMESH_ERR_INVALID, "project_mult 1..16"); h->project_mult = value; drop_graph(h); return SDMESH_OK; }
-    if (!strcmp(name, "project_lanes")) { if (value != 0 && value != 1 && value != 4) return fail(h, SDMESH_ERR_INVALID, "project_lanes 0|1|4"); h->project_lanes = value; drop_graph(h); return SDMESH_OK; }
+    if (!strcmp(name, "project_lanes")) { if (value != 0 && value != 1 && value != 2 && value != 4) return fail(h, SDMESH_ERR_INVALID, "project_lanes 0|1|2|4"); h->project_lanes = value; drop_graph(h); return SDMESH_OK; }
     if (!strcmp(name, "flip_lanes")) { if (value != 0 && value != 1 && value != 4) return fail(h, SDMESH_ERR_INVALID, "flip_lanes 0|1|4"); h->flip_lanes = value; drop_graph(h); return SDMESH_OK; }
     if (!strcmp(name, "ff_fork")) { if (value < 0 || value > 2) return fail(h, SDMESH_ERR_INVALID, "ff_fork 0|1|2"); h->ff_fork = value; drop_graph(h); return SDMESH_OK; }
     if (!strcmp(name, "mask_lanes")) { if (value != 0 && value != 1 && value != 32) return fail(h, SDMESH_ERR_INVALID, "mask_lanes 0|1|32"); h->mask_lanes = value; drop_graph(h); return SDMESH_OK; }
@@ -1003,6 +1034,7 @@ int sdmesh_set_option(sdmesh_handle *h, const char *name, int value) {
     if (!strcmp(name, "col_refine")) { h->col_refine = value ? 1 : 0; h->plan_valid = false; drop_graph(h); return SDMESH_OK; }
     if (!strcmp(name, "emit_ci")) { h->emit_ci = value ? 1 : 0; drop_graph(h); return SDMESH_OK; }
     if (!strcmp(name, "skip_weld")) { h->skip_weld = value ? 1 : 0; return SDMESH_OK; }
+    if (!strcmp(name, "weld_shift")) { if (value < -1 || value > 20) return fail(h, SDMESH_ERR_INVALID, "weld_shift -1..20"); h->weld_shift = value; drop_graph(h); return SDMESH_OK; }
     if (!strcmp(name, "profile")) { h->profile = value ? 1 : 0; h->prof_n = 0; h->prof_ms.clear(); return SDMESH_OK; }
     if (!strcmp(name, "project_diag")) { h->project_diag = value ? 1 : 0; return SDMESH_OK; }
     if (!strcmp(name, "weld_wide")) { h->weld_wide = value ? 1 : 0; h->wide_active = value != 0; drop_graph(h); return SDMESH_OK; }

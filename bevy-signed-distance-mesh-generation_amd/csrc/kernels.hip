@@ -528,11 +528,6 @@ __global__ __launch_bounds__(256) void k_col_refine(uint32_t x0, uint32_t z0, ui
     __shared__ uint32_t s_scan[17];
     __shared__ uint32_t s_n3;
     const uint32_t tid = threadIdx.x;
-    // the regen's clears (control block, weld table), spread over the grid
-    for (uint32_t i = blockIdx.x * 256u + tid; i < nzero; i += gridDim.x * 256u) zero[i] = 0u;
-    const uint4 ones = make_uint4(0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu);
-    for (uint32_t i = blockIdx.x * 256u + tid; i < nff16; i += gridDim.x * 256u) ff[i] = ones;
-
     const uint32_t F = MESH_GENERATION_INIT_FACTOR;
     const float h0 = MESH_GENERATION_BB_SIZE / (float) MESH_GENERATION_INIT_FACTOR;
     const float h1 = h0 / 2.0f, h2 = h1 / 2.0f, h3 = h2 / 2.0f;                 // src/cuda/mod.rs:126-130, exact halvings
@@ -577,18 +572,47 @@ __global__ __launch_bounds__(256) void k_col_refine(uint32_t x0, uint32_t z0, ui
             for (uint32_t c = 0; c < 8; c++)
                 if (m2 & (1u << c)) { if (o2 < COL_L2) s_list2[o2] = (uint16_t) (tid * 8u + c); o2++; }
             __syncthreads();
-            // D. level-3: 27 samples per kept level-2 cell, 8 cells per pass
+            // D. level-3: 27 samples per kept level-2 cell.  Few cells: 32 lanes per cell, 8 cells per pass (short dependent
+            // chain).  Many cells (the heaviest columns set the kernel's duration): one lane per cell, its 27 samples z
+            // innermost so the (x, y) terms are shared -- a flat ~1 700 instructions for up to 256 cells instead of 140 per 8.
             uint32_t local3 = 0;
-            for (uint32_t b0 = 0; b0 < n2; b0 += 8u) {
-                const uint32_t b = b0 + grp;
-                uint32_t lx = 0, ly = 0, lz = 0;
-                if (b < n2) {
-                    const uint32_t e = s_list2[b], c2 = e & 7u;
-                    col_l1_index(s_list1[e >> 3], X0, Y0, Z0, lx, ly, lz);
-                    lx = 2u * lx + (c2 >> 2); ly = 2u * ly + ((c2 >> 1) & 1u); lz = 2u * lz + (c2 & 1u);
+            if (n2 > 96u) {
+                for (uint32_t b0 = 0; b0 < n2; b0 += 256u) {
+                    const uint32_t b = b0 + tid;
+                    if (b < n2) {
+                        const uint32_t e = s_list2[b], c2 = e & 7u;
+                        uint32_t lx, ly, lz;
+                        col_l1_index(s_list1[e >> 3], X0, Y0, Z0, lx, ly, lz);
+                        lx = 2u * lx + (c2 >> 2); ly = 2u * ly + ((c2 >> 1) & 1u); lz = 2u * lz + (c2 & 1u);
+                        uint32_t bits = 0;
+#pragma unroll 1
+                        for (uint32_t ix = 0; ix < 3; ix++) {
+                            const float x = lat((int) (2u * lx + ix), h3);
+#pragma unroll 1
+                            for (uint32_t iy = 0; iy < 3; iy++) {
+                                const float y = lat((int) (2u * ly + iy), h3);
+#pragma unroll
+                                for (uint32_t iz = 0; iz < 3; iz++)
+                                    if (sdf<SCENE>(x, y, lat((int) (2u * lz + iz), h3), sp) <= 0.0f) bits |= 1u << (ix * 9u + iy * 3u + iz);
+                            }
+                        }
+                        const uint32_t m = child_mask_from_bits(bits);
+                        g_mask3[(size_t) col * COL_L2 + b] = (uint8_t) m;
+                        local3 += __popc(m);
+                    }
                 }
-                const uint32_t m = col_cell_mask<SCENE>(b < n2, lx, ly, lz, h3, s, sp);
-                if (s == 0 && b < n2) { g_mask3[(size_t) col * COL_L2 + b] = (uint8_t) m; local3 += __popc(m); }
+            } else {
+                for (uint32_t b0 = 0; b0 < n2; b0 += 8u) {
+                    const uint32_t b = b0 + grp;
+                    uint32_t lx = 0, ly = 0, lz = 0;
+                    if (b < n2) {
+                        const uint32_t e = s_list2[b], c2 = e & 7u;
+                        col_l1_index(s_list1[e >> 3], X0, Y0, Z0, lx, ly, lz);
+                        lx = 2u * lx + (c2 >> 2); ly = 2u * ly + ((c2 >> 1) & 1u); lz = 2u * lz + (c2 & 1u);
+                    }
+                    const uint32_t m = col_cell_mask<SCENE>(b < n2, lx, ly, lz, h3, s, sp);
+                    if (s == 0 && b < n2) { g_mask3[(size_t) col * COL_L2 + b] = (uint8_t) m; local3 += __popc(m); }
+                }
             }
             if (local3) atomicAdd(&s_n3, local3);
             __syncthreads();
@@ -600,6 +624,11 @@ __global__ __launch_bounds__(256) void k_col_refine(uint32_t x0, uint32_t z0, ui
         if (J >= 2) g_mask2[(size_t) col * COL_L1 + tid] = s_mask2[tid];
     }
     if (tid == 0) colinfo[col] = make_uint4(n1, n2, n3, 0u);
+    // the regen's clears (control block, weld table), spread over the grid -- behind the column's own work, so the few
+    // heavy columns that set the kernel's duration start at once and the many light ones do most of the clearing
+    for (uint32_t i = blockIdx.x * 256u + tid; i < nzero; i += gridDim.x * 256u) zero[i] = 0u;
+    const uint4 ones = make_uint4(0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu);
+    for (uint32_t i = blockIdx.x * 256u + tid; i < nff16; i += gridDim.x * 256u) ff[i] = ones;
 }
 
 // Ordered emission of the level-J voxel list from the per-column lists (J = 1..3).  Every workgroup sums the counts of
@@ -812,6 +841,40 @@ __device__ __forceinline__ f3 stencil_quad(const f3 g, uint32_t sub, const Scene
     return d;
 }
 
+// value held by the other lane of the caller's 2-lane group (DPP quad_perm [1, 0, 3, 2])
+__device__ __forceinline__ float pair_swap(float v) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, v), 0xB1, 0xf, 0xf, true));
+}
+
+// The same stencil over a 2-lane group: lane 0 owns the offsets (+2e, +e), lane 1 owns (-e, -2e), both evaluate their two
+// samples along x, then y, then z, plus the centre.  The two samples of an axis and the centre share the terms of the
+// other two coordinates (like the one-lane layout), so the instruction count per vertex stays close to the one-lane
+// kernel's while the dependent work per Newton round -- what the slowest wave's lifetime is made of -- is about half.
+template <int SCENE>
+__device__ __forceinline__ f3 stencil_pair(const f3 g, uint32_t sub, const SceneParams &sp, float &centre) {
+    const float e1 = SDM_NORMAL_EPS, e2 = 2.0f * SDM_NORMAL_EPS;
+    const float oa = sub == 0 ? e2 : -e1, ob = sub == 0 ? e1 : -e2;
+    centre = sdf<SCENE>(g.x, g.y, g.z, sp);
+    const float xa = sdf<SCENE>(g.x + oa, g.y, g.z, sp), xb = sdf<SCENE>(g.x + ob, g.y, g.z, sp);
+    const float ya = sdf<SCENE>(g.x, g.y + oa, g.z, sp), yb = sdf<SCENE>(g.x, g.y + ob, g.z, sp);
+    const float za = sdf<SCENE>(g.x, g.y, g.z + oa, sp), zb = sdf<SCENE>(g.x, g.y, g.z + ob, sp);
+    const bool lo = sub == 0;
+    f3 d;
+    {
+        const float pa = pair_swap(xa), pb = pair_swap(xb);
+        d.x = (-(lo ? xa : pa) + 8.0f * (lo ? xb : pb) - 8.0f * (lo ? pa : xa) + (lo ? pb : xb));
+    }
+    {
+        const float pa = pair_swap(ya), pb = pair_swap(yb);
+        d.y = (-(lo ? ya : pa) + 8.0f * (lo ? yb : pb) - 8.0f * (lo ? pa : ya) + (lo ? pb : yb));
+    }
+    {
+        const float pa = pair_swap(za), pb = pair_swap(zb);
+        d.z = (-(lo ? za : pa) + 8.0f * (lo ? zb : pb) - 8.0f * (lo ? pa : za) + (lo ? pb : zb));
+    }
+    return d;
+}
+
 // tile descriptor: x = first vertex id, y = vertex count, z = first triangle, w = triangle count
 __global__ __launch_bounds__(256) void k_tile_dedupe(const Point *__restrict__ vox, const uint32_t *__restrict__ n_ptr, Point vs,
                                                       const uint8_t *__restrict__ cubeidx, const uint32_t *__restrict__ tilecnt,
@@ -933,15 +996,32 @@ __global__ __launch_bounds__(256) void k_tile_dedupe(const Point *__restrict__ v
 static constexpr uint32_t VS_WINNER = 0x80000000u;
 static constexpr uint32_t VS_SLOT = 0x7fffffffu;
 
+// Locality-preserving home slot of a weld key (option "weld_shift" > 0; measured and NOT the default): the table is cut
+// into blocks of WELD_BLOCK slots, the BLOCK is chosen by hashing the key's coarse cell (the low `shift` bits of each
+// quantised coordinate dropped), the slot inside the block by hashing the whole key, so the vertices of a 256-voxel tile
+// share a few KB of table.  Any block / shift gives the same weld.  It loses badly: the claim's compare-and-swaps then
+// hammer a few cache lines at a time and atomics to one line serialise (512^3: claim 25 -> 157 us at 8-voxel cells;
+// milliseconds once a cell holds more keys than a block).  What the locality was wanted for -- the per-slot gathers of
+// the later weld kernels -- is obtained instead by indexing those arrays with the key's representative VERTEX (below).
+static constexpr uint32_t WELD_BLOCK = 256;
+
+__device__ __forceinline__ uint32_t weld_home(uint64_t key, uint64_t coarse, uint32_t wsize) {
+    const uint32_t nblocks = wsize / WELD_BLOCK;
+    if (nblocks == 0) return hash_home(key, wsize);
+    const uint32_t block = (uint32_t) (((mix64(coarse) >> 32) * (uint64_t) nblocks) >> 32);
+    return block * WELD_BLOCK + (uint32_t) (mix64(key) >> 40) % WELD_BLOCK;
+}
+
 __device__ __forceinline__ uint32_t weld_claim(const Point p, uint64_t *__restrict__ wkeys, uint32_t wsize,
-                                               uint32_t *__restrict__ status) {
+                                               uint32_t *__restrict__ status, uint32_t shift) {
     const long long qx = weld_quant(p.x) + 1048576LL, qy = weld_quant(p.y) + 1048576LL, qz = weld_quant(p.z) + 1048576LL;
     if (((unsigned long long) qx | (unsigned long long) qy | (unsigned long long) qz) >> 21) {
         atomicOr(&status[ST_WELD_RANGE], 1u);
         return U32_NONE;
     }
     const uint64_t key = (uint64_t) qx | ((uint64_t) qy << 21) | ((uint64_t) qz << 42);
-    uint32_t s = hash_home(key, wsize);
+    const uint64_t low = (1ull << shift) - 1ull;
+    uint32_t s = shift ? weld_home(key, key & ~(low | (low << 21) | (low << 42)), wsize) : hash_home(key, wsize);
     for (uint32_t probe = 0; probe < wsize; probe++) {
         const uint64_t prev = atomicCAS((unsigned long long *) &wkeys[s], (unsigned long long) KEY_EMPTY, (unsigned long long) key);
         if (prev == KEY_EMPTY) return s | VS_WINNER;
@@ -957,11 +1037,12 @@ __device__ __forceinline__ uint32_t weld_claim(const Point p, uint64_t *__restri
 // two keys are equal iff the quantised triples of the two POSITIONS are (every position was written by an earlier
 // kernel).  Same first-seen semantics, any coordinate the i64 cast can express (NaN -> 0, +-inf saturate, as `as i64`).
 __device__ __forceinline__ uint32_t weld_claim_wide(const Vertex *__restrict__ uverts, uint32_t id, uint64_t *__restrict__ wkeys,
-                                                    uint32_t wsize, uint32_t *__restrict__ status) {
+                                                    uint32_t wsize, uint32_t *__restrict__ status, uint32_t shift) {
     const Point p = uverts[id].position;
     const long long qx = weld_quant(p.x), qy = weld_quant(p.y), qz = weld_quant(p.z);
     const uint64_t hsh = mix64((uint64_t) qx * 0x9E3779B97F4A7C15ull ^ mix64((uint64_t) qy) ^ (mix64((uint64_t) qz) << 1));
-    uint32_t s = (uint32_t) (((hsh >> 32) * (uint64_t) wsize) >> 32);
+    const uint64_t chs = mix64((uint64_t) (qx >> shift) * 0x9E3779B97F4A7C15ull ^ mix64((uint64_t) (qy >> shift)) ^ (mix64((uint64_t) (qz >> shift)) << 1));
+    uint32_t s = shift ? weld_home(hsh, chs, wsize) : (uint32_t) (((hsh >> 32) * (uint64_t) wsize) >> 32);
     for (uint32_t probe = 0; probe < wsize; probe++) {
         const uint64_t prev = atomicCAS((unsigned long long *) &wkeys[s], (unsigned long long) KEY_EMPTY, (unsigned long long) id);
         if (prev == KEY_EMPTY) return s | VS_WINNER;
@@ -1015,7 +1096,7 @@ __device__ __forceinline__ void project_epilogue(uint32_t wave, uint32_t rounds,
 // back to uverts[].position.  16 items in flight per wave (4 lanes each); finished groups refill from
 // the wave's round-robin share of the U work items; item i is mapped to its vertex slot with a binary
 // search in the tile prefix.
-template <int SCENE>
+template <int SCENE, int LANES /* 4: lane = stencil offset; 2: lane = offset pair */>
 __global__ __launch_bounds__(256) void k_project(Vertex *__restrict__ uverts, const uint4 *__restrict__ tdesc,
                                                   const uint32_t *__restrict__ tpre, const uint32_t *__restrict__ coarse, const uint32_t *__restrict__ ntiles_ptr,
                                                   const SceneParams *__restrict__ spp, uint32_t *__restrict__ status,
@@ -1024,21 +1105,22 @@ __global__ __launch_bounds__(256) void k_project(Vertex *__restrict__ uverts, co
     const SceneParams &sp = *spp;  // scene uniform in device memory (a captured graph replays with new values)
     const uint32_t ntiles = *ntiles_ptr;
     const uint32_t U = ntiles ? tpre[ntiles] : 0u;
-    const uint32_t lane = lane_id(), sub = lane & 3u, gbase = lane & ~3u;
+    constexpr uint32_t PER = 64u / LANES, SH = LANES == 4 ? 4u : 5u;      // vertices per wave-batch, log2 of it
+    const uint32_t lane = lane_id(), sub = lane & (LANES - 1u), gbase = lane & ~(LANES - 1u);
     const uint32_t nwaves = gridDim.x * (blockDim.x >> 6);
     const uint32_t wave = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
-    // Work items are dealt to the waves in batches of 16 (one per 4-lane group), round robin: iteration
+    // Work items are dealt to the waves in batches of PER (one per lane group), round robin: iteration
     // counts are spatially correlated (slow convergence near the smooth-min blends), so a contiguous run
     // per wave leaves half the waves idle behind the slow ones (measured: waves alive 46 % of the kernel).
-    // The wave's j-th item is item ((j / 16) * nwaves + wave) * 16 + j % 16.
-    const uint32_t nbatch = (U + 15u) >> 4;
+    // The wave's j-th item is item ((j / PER) * nwaves + wave) * PER + j % PER.
+    const uint32_t nbatch = (U + PER - 1u) >> SH;
     if (wave >= nbatch) return;
     const uint64_t t_start = diag ? __builtin_amdgcn_s_memtime() : 0ull;
     uint32_t rounds = 0;                                              // vertex-rounds this wave evaluated (scalar bookkeeping)
     const uint32_t myb = (nbatch - wave - 1u) / nwaves + 1u;          // batches owned by this wave
     uint32_t qhead = 0;                                               // items handed out so far
-    const uint32_t qend = myb * 16u;
-    const uint64_t lt_leaders = 0x1111111111111111ull & ((1ull << gbase) - 1ull);   // leader lanes below this group
+    const uint32_t qend = myb * PER;
+    const uint64_t lt_leaders = (LANES == 4 ? 0x1111111111111111ull : 0x5555555555555555ull) & ((1ull << gbase) - 1ull);   // leader lanes below this group
     bool have = false, finalize = false;
     uint32_t slot = 0;
     int it = 0;
@@ -1049,7 +1131,7 @@ __global__ __launch_bounds__(256) void k_project(Vertex *__restrict__ uverts, co
         if (need != 0ull && avail != 0u) {
             const uint32_t rank = __popcll(need & lt_leaders);
             const uint32_t j = qhead + rank;
-            const uint32_t item = ((j >> 4) * nwaves + wave) * 16u + (j & 15u);
+            const uint32_t item = ((j >> SH) * nwaves + wave) * PER + (j & (PER - 1u));
             if (!have && rank < avail && item < U) {
                 uint32_t lo = coarse[item >> 6];                       // tile of item 64 * (item / 64): at or before ours
                 while (tpre[lo + 1u] <= item) lo++;                    // (tpre[ntiles] = U > item ends the walk)
@@ -1066,7 +1148,7 @@ __global__ __launch_bounds__(256) void k_project(Vertex *__restrict__ uverts, co
         rounds += __popcll(act);
         if (have) {
             float sd;
-            const f3 nn = normalize3(stencil_quad<SCENE, true>(g, sub, sp, sd));
+            const f3 nn = normalize3(LANES == 4 ? stencil_quad<SCENE, true>(g, sub, sp, sd) : stencil_pair<SCENE>(g, sub, sp, sd));
             if (!finalize) {
                 g = sub3(g, scale3(nn, sd));
                 it++;
@@ -1271,21 +1353,28 @@ __global__ __launch_bounds__(256) void k_raw_desc(const uint32_t *__restrict__ n
 // the orientation test, so the host runs it on a side stream concurrently with the VALU-bound k_flip.
 __device__ __forceinline__ void claim_body(uint32_t bid, uint32_t nblocks, const Vertex *__restrict__ uverts,
                                            const uint4 *__restrict__ tdesc, uint32_t ntiles, uint64_t *__restrict__ wkeys,
-                                           uint32_t wsize, uint32_t *__restrict__ vslot, uint32_t *__restrict__ status, uint32_t wide) {
+                                           uint32_t wsize, uint32_t *__restrict__ vslot, uint32_t *__restrict__ status, uint32_t wmode,
+                                           uint32_t *__restrict__ wrep, uint2 *__restrict__ wfm) {
+    const uint32_t wide = wmode & 1u, shift = wmode >> 8;      // wmode = wide flag | coarse-cell shift << 8
     for (uint32_t tile = bid; tile < ntiles; tile += nblocks) {
         const uint4 d = tdesc[tile];
-        if (wide) {
-            for (uint32_t i = threadIdx.x; i < d.y; i += 256) vslot[d.x + i] = weld_claim_wide(uverts, d.x + i, wkeys, wsize, status);
-        } else {
-            for (uint32_t i = threadIdx.x; i < d.y; i += 256) vslot[d.x + i] = weld_claim(uverts[d.x + i].position, wkeys, wsize, status);
+        for (uint32_t i = threadIdx.x; i < d.y; i += 256) {
+            const uint32_t e = d.x + i;
+            const uint32_t vs = wide ? weld_claim_wide(uverts, e, wkeys, wsize, status, shift) : weld_claim(uverts[e].position, wkeys, wsize, status, shift);
+            vslot[e] = vs;
+            if (vs != U32_NONE && (vs & VS_WINNER)) {
+                wrep[vs & VS_SLOT] = e;                          // the key's representative vertex: this one
+                wfm[e] = make_uint2(U32_NONE, U32_NONE);         // its record {winner's ordinal, minimum loser ordinal}
+            }
         }
     }
 }
 
 __global__ __launch_bounds__(256) void k_tile_claim(const Vertex *__restrict__ uverts, const uint4 *__restrict__ tdesc,
                                                      const uint32_t *__restrict__ ntiles_ptr, uint64_t *__restrict__ wkeys,
-                                                     uint32_t wsize, uint32_t *__restrict__ vslot, uint32_t *__restrict__ status, uint32_t wide) {
-    claim_body(blockIdx.x, gridDim.x, uverts, tdesc, *ntiles_ptr, wkeys, wsize, vslot, status, wide);
+                                                     uint32_t wsize, uint32_t *__restrict__ vslot, uint32_t *__restrict__ status, uint32_t wmode,
+                                                     uint32_t *__restrict__ wrep, uint2 *__restrict__ wfm) {
+    claim_body(blockIdx.x, gridDim.x, uverts, tdesc, *ntiles_ptr, wkeys, wsize, vslot, status, wmode, wrep, wfm);
 }
 
 // Orientation test and weld claim in ONE dispatch: the LAST `claim_blocks` workgroups claim weld-table slots for the
@@ -1299,10 +1388,11 @@ __global__ __launch_bounds__(256) void k_flip_claim(const Vertex *__restrict__ u
                                                      const uint32_t *__restrict__ ntri_ptr, const SceneParams *__restrict__ spp,
                                                      uint8_t *__restrict__ flip, uint32_t claim_blocks, const uint4 *__restrict__ tdesc,
                                                      const uint32_t *__restrict__ ntiles_ptr, uint64_t *__restrict__ wkeys, uint32_t wsize,
-                                                     uint32_t *__restrict__ vslot, uint32_t *__restrict__ status, uint32_t wide) {
+                                                     uint32_t *__restrict__ vslot, uint32_t *__restrict__ status, uint32_t wmode,
+                                                     uint32_t *__restrict__ wrep, uint2 *__restrict__ wfm) {
     const uint32_t flip_blocks = gridDim.x - claim_blocks;
     if (blockIdx.x >= flip_blocks) {
-        claim_body(blockIdx.x - flip_blocks, claim_blocks, uverts, tdesc, *ntiles_ptr, wkeys, wsize, vslot, status, wide);
+        claim_body(blockIdx.x - flip_blocks, claim_blocks, uverts, tdesc, *ntiles_ptr, wkeys, wsize, vslot, status, wmode, wrep, wfm);
     } else if (LANES == 1) {
         flip_body1<SCENE>(blockIdx.x, flip_blocks, uverts, tri_e, *ntri_ptr, *spp, flip);
     } else {
@@ -1317,8 +1407,9 @@ static constexpr uint32_t T_VMAX = 3072;
 // atomics, publish it (winner: plain store, loser: atomicMin)
 __global__ __launch_bounds__(256) void k_tile_first(const uint4 *__restrict__ tdesc, const uint32_t *__restrict__ ntiles_ptr,
                                                      uint32_t *__restrict__ tri_e, const uint8_t *__restrict__ flip,
-                                                     const uint32_t *__restrict__ vslot, uint32_t *__restrict__ first_ord,
-                                                     uint2 *__restrict__ wfm /* per slot: {winner's ordinal, minimum loser ordinal} */) {
+                                                     uint32_t *__restrict__ vslot /* in: claim result; out: representative vertex | winner bit */,
+                                                     uint32_t *__restrict__ first_ord, const uint32_t *__restrict__ wrep,
+                                                     uint2 *__restrict__ wfm /* per REPRESENTATIVE vertex: {its own ordinal, minimum ordinal of the key's other vertices} */) {
     __shared__ uint32_t s_first[T_VMAX];
     const uint32_t ntiles = *ntiles_ptr, tid = threadIdx.x;
     for (uint32_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
@@ -1342,10 +1433,19 @@ __global__ __launch_bounds__(256) void k_tile_first(const uint4 *__restrict__ td
             const uint32_t e = vbase + i, lf = s_first[i];
             const uint32_t fo = lf == U32_NONE ? U32_NONE : 3u * tbase + lf;
             first_ord[e] = fo;
+            // From here on a key is named by its representative vertex (the claim's winner), not by its hash slot: the
+            // per-key records then live in the tile's own contiguous vertex range for every vertex that is not shared with
+            // another tile, and the gathers of the next two kernels hit lines the tile has just touched.
             const uint32_t vs = vslot[e];
             if (vs != U32_NONE) {
-                if (vs & VS_WINNER) wfm[vs & VS_SLOT].x = fo;
-                else if (fo != U32_NONE) atomicMin(&wfm[vs & VS_SLOT].y, fo);
+                if (vs & VS_WINNER) {
+                    vslot[e] = e | VS_WINNER;
+                    wfm[e].x = fo;                                                   // (4-byte store: .y belongs to the losers)
+                } else {
+                    const uint32_t rep = wrep[vs & VS_SLOT];
+                    vslot[e] = rep;
+                    if (fo != U32_NONE) atomicMin(&wfm[rep].y, fo);
+                }
             }
         }
         __syncthreads();
@@ -1353,7 +1453,8 @@ __global__ __launch_bounds__(256) void k_tile_first(const uint4 *__restrict__ td
 }
 
 // per tile: which vertices are first-seen, their rank by ordinal inside the tile, the tile's count.
-// wv[slot] = tile * 4096 + rank for the key's first-seen vertex; torder[3 * tbase + rank] = that vertex.
+// wv[rep] = tile * 4096 + rank for the key's first-seen vertex (rep = the key's representative vertex, vslot & VS_SLOT
+// after k_tile_first); torder[3 * tbase + rank] = that vertex.
 __global__ __launch_bounds__(256) void k_tile_rank(const uint4 *__restrict__ tdesc, const uint32_t *__restrict__ ntiles_ptr,
                                                     const uint32_t *__restrict__ first_ord, const uint2 *__restrict__ wfm,
                                                     const uint32_t *__restrict__ vslot,
@@ -2039,7 +2140,8 @@ hipError_t launch_project(hipStream_t st, int grid, int scene, const SceneParams
                           const uint32_t *tpre, const uint32_t *coarse, const uint32_t *ntiles_ptr, uint32_t *status, int lanes,
                           uint32_t *prof, uint64_t *diag) {
     if (lanes == 1) { SDM_DISPATCH(scene, hipLaunchKernelGGL(k_project1<S>, dim3(grid), dim3(256), 0, st, uverts, tdesc, tpre, coarse, ntiles_ptr, sp, status, prof, diag)); }
-    else { SDM_DISPATCH(scene, hipLaunchKernelGGL(k_project<S>, dim3(grid), dim3(256), 0, st, uverts, tdesc, tpre, coarse, ntiles_ptr, sp, status, prof, diag)); }
+    else if (lanes == 2) { SDM_DISPATCH(scene, hipLaunchKernelGGL((k_project<S, 2>), dim3(grid), dim3(256), 0, st, uverts, tdesc, tpre, coarse, ntiles_ptr, sp, status, prof, diag)); }
+    else { SDM_DISPATCH(scene, hipLaunchKernelGGL((k_project<S, 4>), dim3(grid), dim3(256), 0, st, uverts, tdesc, tpre, coarse, ntiles_ptr, sp, status, prof, diag)); }
     return hipGetLastError();
 }
 
@@ -2052,11 +2154,12 @@ hipError_t launch_flip(hipStream_t st, int grid, int scene, const SceneParams *s
 
 hipError_t launch_flip_claim(hipStream_t st, int flip_grid, int claim_grid, int scene, const SceneParams *sp, const Vertex *uverts,
                             const uint32_t *tri_e, const uint32_t *ntri_ptr, uint8_t *flip, int lanes, const uint4 *tdesc,
-                            const uint32_t *ntiles_ptr, uint64_t *wkeys, uint32_t wsize, uint32_t *vslot, uint32_t *status, bool wide) {
+                            const uint32_t *ntiles_ptr, uint64_t *wkeys, uint32_t wsize, uint32_t *vslot, uint32_t *status, uint32_t wmode,
+                            uint32_t *wrep, uint2 *wfm) {
     const dim3 grid(flip_grid + claim_grid);
-    const uint32_t w = wide ? 1u : 0u;
-    if (lanes == 1) { SDM_DISPATCH(scene, hipLaunchKernelGGL((k_flip_claim<S, 1>), grid, dim3(256), 0, st, uverts, tri_e, ntri_ptr, sp, flip, (uint32_t) claim_grid, tdesc, ntiles_ptr, wkeys, wsize, vslot, status, w)); }
-    else { SDM_DISPATCH(scene, hipLaunchKernelGGL((k_flip_claim<S, 4>), grid, dim3(256), 0, st, uverts, tri_e, ntri_ptr, sp, flip, (uint32_t) claim_grid, tdesc, ntiles_ptr, wkeys, wsize, vslot, status, w)); }
+    const uint32_t w = wmode;
+    if (lanes == 1) { SDM_DISPATCH(scene, hipLaunchKernelGGL((k_flip_claim<S, 1>), grid, dim3(256), 0, st, uverts, tri_e, ntri_ptr, sp, flip, (uint32_t) claim_grid, tdesc, ntiles_ptr, wkeys, wsize, vslot, status, w, wrep, wfm)); }
+    else { SDM_DISPATCH(scene, hipLaunchKernelGGL((k_flip_claim<S, 4>), grid, dim3(256), 0, st, uverts, tri_e, ntri_ptr, sp, flip, (uint32_t) claim_grid, tdesc, ntiles_ptr, wkeys, wsize, vslot, status, w, wrep, wfm)); }
     return hipGetLastError();
 }
 
@@ -2088,17 +2191,17 @@ hipError_t launch_raw_desc(hipStream_t st, int grid, const uint32_t *ntri_ptr, u
 }
 
 hipError_t launch_tile_claim(hipStream_t st, int grid, const Vertex *uverts, const uint4 *tdesc, const uint32_t *ntiles_ptr,
-                             uint64_t *wkeys, uint32_t wsize, uint32_t *vslot, uint32_t *status, bool wide) {
-    hipLaunchKernelGGL(k_tile_claim, dim3(grid), dim3(256), 0, st, uverts, tdesc, ntiles_ptr, wkeys, wsize, vslot, status, wide ? 1u : 0u);
+                             uint64_t *wkeys, uint32_t wsize, uint32_t *vslot, uint32_t *status, uint32_t wmode, uint32_t *wrep, uint2 *wfm) {
+    hipLaunchKernelGGL(k_tile_claim, dim3(grid), dim3(256), 0, st, uverts, tdesc, ntiles_ptr, wkeys, wsize, vslot, status, wmode, wrep, wfm);
     return hipGetLastError();
 }
 
 // first -> rank -> scan -> finish (the claim has already happened: in k_project or k_weld_claim)
 hipError_t launch_weld(hipStream_t st, int grid, const Vertex *uverts, const uint4 *tdesc, const uint32_t *ntiles_ptr,
-                       uint32_t *tri_e, const uint8_t *flip, uint32_t *first_ord, uint2 *wfm,
-                       const uint32_t *vslot, uint32_t *wv, uint32_t *torder, uint32_t *tfirst, uint32_t *tfpre,
+                       uint32_t *tri_e, const uint8_t *flip, uint32_t *first_ord, uint2 *wfm, const uint32_t *wrep,
+                       uint32_t *vslot, uint32_t *wv, uint32_t *torder, uint32_t *tfirst, uint32_t *tfpre,
                        Vertex *vertices, uint32_t vcap, uint32_t *nverts_out, uint32_t *indices, uint32_t *status) {
-    hipLaunchKernelGGL(k_tile_first, dim3(grid), dim3(256), 0, st, tdesc, ntiles_ptr, tri_e, flip, vslot, first_ord, wfm);
+    hipLaunchKernelGGL(k_tile_first, dim3(grid), dim3(256), 0, st, tdesc, ntiles_ptr, tri_e, flip, vslot, first_ord, wrep, wfm);
     hipLaunchKernelGGL(k_tile_rank, dim3(grid), dim3(256), 0, st, tdesc, ntiles_ptr, first_ord, wfm, vslot, wv, torder,
                        tfirst);
     hipLaunchKernelGGL(k_scan_u32, dim3(1), dim3(1024), 0, st, tfirst, ntiles_ptr, tfpre, nverts_out);

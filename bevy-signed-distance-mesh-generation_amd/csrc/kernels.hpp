@@ -58,18 +58,19 @@ hipError_t launch_render(hipStream_t st, int scene, const SceneParams *sp, const
                          float screen_y, float gtex_x, float gtex_y, uint32_t width, uint32_t height, void *rgba);
 hipError_t launch_flip_claim(hipStream_t st, int flip_grid, int claim_grid, int scene, const SceneParams *sp, const Vertex *uverts,
                             const uint32_t *tri_e, const uint32_t *ntri_ptr, uint8_t *flip, int lanes, const uint4 *tdesc,
-                            const uint32_t *ntiles_ptr, uint64_t *wkeys, uint32_t wsize, uint32_t *vslot, uint32_t *status, bool wide);
+                            const uint32_t *ntiles_ptr, uint64_t *wkeys, uint32_t wsize, uint32_t *vslot, uint32_t *status, uint32_t wmode,
+                            uint32_t *wrep, uint2 *wfm);
 hipError_t launch_flip(hipStream_t st, int grid, int scene, const SceneParams *sp, const Vertex *uverts, const uint32_t *tri_e,
                        const uint32_t *ntri_ptr, uint8_t *flip, int lanes = 4);
 hipError_t launch_raw_desc(hipStream_t st, int grid, const uint32_t *ntri_ptr, uint4 *tdesc, uint8_t *flip, uint32_t *ntiles_out,
                            uint32_t *nu_out);
 hipError_t launch_tile_claim(hipStream_t st, int grid, const Vertex *uverts, const uint4 *tdesc, const uint32_t *ntiles_ptr,
-                             uint64_t *wkeys, uint32_t wsize, uint32_t *vslot, uint32_t *status, bool wide);
+                             uint64_t *wkeys, uint32_t wsize, uint32_t *vslot, uint32_t *status, uint32_t wmode, uint32_t *wrep, uint2 *wfm);
 hipError_t launch_merge_by_column(hipStream_t st, const Triangle *const *d_lists, const uint32_t *d_counts, int nranks, uint32_t *d_plan,
                                   Triangle *d_out, uint32_t cap, uint32_t *total_out, uint32_t *status);
 hipError_t launch_weld(hipStream_t st, int grid, const Vertex *uverts, const uint4 *tdesc, const uint32_t *ntiles_ptr,
-                       uint32_t *tri_e, const uint8_t *flip, uint32_t *first_ord, uint2 *wfm,
-                       const uint32_t *vslot, uint32_t *wv, uint32_t *torder, uint32_t *tfirst, uint32_t *tfpre,
+                       uint32_t *tri_e, const uint8_t *flip, uint32_t *first_ord, uint2 *wfm, const uint32_t *wrep,
+                       uint32_t *vslot, uint32_t *wv, uint32_t *torder, uint32_t *tfirst, uint32_t *tfpre,
                        Vertex *vertices, uint32_t vcap, uint32_t *nverts_out, uint32_t *indices, uint32_t *status);
 hipError_t launch_expand_compact(hipStream_t st, int grid, const Vertex *uverts, const uint32_t *tri_e, const uint8_t *flip,
                                  const uint32_t *ntri_ptr, Triangle *out, uint32_t cap);
