@@ -8,6 +8,7 @@ import numpy as np
 _HERE = os.path.dirname(os.path.abspath(__file__))
 # SDMESH_LIB: development override (A/B timing of two builds of this same library on one box, tools/ab_perf.py)
 LIB_PATH = os.environ.get("SDMESH_LIB") or os.path.join(_HERE, "libsdmesh.so")
+FAST_LIB_PATH = os.path.join(_HERE, "libsdmesh_fast.so")     # the opt-in fast numeric build (csrc/Makefile FASTFLAGS)
 HSACO_PATH = os.path.join(_HERE, "compute_mesh_generation.hsaco")
 RENDER_HSACO_PATH = os.path.join(_HERE, "compute_render.hsaco")
 
@@ -125,12 +126,25 @@ SYMBOLS = {
 }
 
 _LIB = None
+_FAST_LIB = None
 
 
-def load():
-    """Load libsdmesh.so and bind every declared symbol.  Raises if the library or a symbol is
-    missing -- the product has no fallback path."""
-    global _LIB
+def load(fast_math=False):
+    """Load libsdmesh.so (or, with fast_math, libsdmesh_fast.so) and bind every declared symbol.  Raises if the
+    library or a symbol is missing -- the product has no fallback path."""
+    global _LIB, _FAST_LIB
+    if fast_math:
+        if _FAST_LIB is None:
+            if not os.path.exists(FAST_LIB_PATH):
+                raise RuntimeError(f"{FAST_LIB_PATH} is missing: build it with __graft_entry__.build()")
+            load()                                        # (torch / HIP runtime first, as below)
+            lib = ctypes.CDLL(FAST_LIB_PATH)
+            for name, (res, args) in SYMBOLS.items():
+                fn = getattr(lib, name)
+                fn.restype = res
+                fn.argtypes = args
+            _FAST_LIB = lib
+        return _FAST_LIB
     if _LIB is None:
         # One HIP runtime per process: PyTorch-ROCm wheels bundle their own libamdhip64 with the same
         # SONAME (libamdhip64.so.7) as the system ROCm one libsdmesh.so is linked against.  Importing

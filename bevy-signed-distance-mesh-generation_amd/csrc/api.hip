@@ -101,6 +101,8 @@ struct sdmesh_handle {
     DevBuf col_list1, col_mask2, col_mask3, colinfo;
     int skip_weld = 0;         // regen stops after the orientation test (multi-GPU ranks: the root welds)
     int weld_wide = 0;         // option: 1 = always weld with the unbounded [i64; 3] key form
+    int claim_in_project = 1;  // the weld claims run in the projection kernel's epilogue (under its tail) instead of beside the
+                               // orientation test; packed-key form and fork = 2 only
     int weld_shift = 0;        // option: coarse-cell shift of locality-preserving home slots (0 = uniform hashing, the default:
                                // locality makes the claim's atomics collide; -1 = shift from the voxel size)
     bool wide_active = false;  // the wide form is in use (forced, or a vertex did not fit the packed 3 x 21-bit key)
@@ -325,6 +327,13 @@ int mesh_front(sdmesh_handle *h, const Point *d_vox, const uint32_t *n_ptr, Poin
     const int plan_lanes = h->lane_hint >= 160000u ? 1 : 4;
     const int p_lanes = h->project_lanes ? h->project_lanes : plan_lanes;
     const int f_lanes = h->flip_lanes ? h->flip_lanes : plan_lanes;
+    // the table must have been cleared before the projection starts if its epilogue claims (always true on the planned
+    // chain and whenever the memset above ran on this stream)
+    // ... and only while a projection wave owns about one batch of vertices: with many batches per wave every claim would
+    // wait for the wave's last batch and pile up at the end of the kernel (2048^3: projection 340 -> 498 us)
+    const uint32_t proj_waves = (uint32_t) (h->grid * h->project_mult) * 4u;
+    const bool early_claim = h->claim_in_project && h->fork == 2 && !h->wide_active && h->lane_hint != 0 &&
+                             h->lane_hint <= 2u * (64u / (uint32_t) p_lanes) * proj_waves;
     uint32_t *d_prof = nullptr;
     uint64_t *d_diag = nullptr;
     if (h->profile) {                       // (profile / diag runs are eager and may allocate: never on the captured path)
@@ -339,7 +348,8 @@ int mesh_front(sdmesh_handle *h, const Point *d_vox, const uint32_t *n_ptr, Poin
         d_diag = (uint64_t *) h->proj_diag.p;
     }
     HIPCHK(launch_project(st, h->grid * h->project_mult, h->scene, h->d_sp, (Vertex *) h->uverts.p, (const uint4 *) h->tdesc.p,
-                          (const uint32_t *) h->tpre.p, coarse, h->d_ctr + CTR_NTILES, h->d_status, p_lanes, d_prof, d_diag));
+                          (const uint32_t *) h->tpre.p, coarse, h->d_ctr + CTR_NTILES, h->d_status, p_lanes, d_prof, d_diag,
+                          h->wkeys, h->wsize, (uint32_t *) h->vslot.p, (uint32_t *) h->wrep_buf.p, h->wfm, weld_mode(h, vs) | (early_claim ? 2u : 0u)));
     SDCHK(prof_mark(h, p_lanes == 1 ? "project1" : (p_lanes == 2 ? "project2" : "project4")));
     // fork: the weld claim (scattered CAS, latency-bound) runs beside the orientation test (VALU-bound)
     int f_grid = h->grid * (f_lanes == 1 ? 1 : h->flip_mult);
@@ -353,7 +363,7 @@ int mesh_front(sdmesh_handle *h, const Point *d_vox, const uint32_t *n_ptr, Poin
     }
     if (h->fork == 2) {
         // one dispatch: claim workgroups first (latency-bound, resident early), orientation-test workgroups behind them
-        HIPCHK(launch_flip_claim(st, f_grid, h->tgrid, h->scene, h->d_sp, (const Vertex *) h->uverts.p, (const uint32_t *) h->tri_e.p,
+        HIPCHK(launch_flip_claim(st, f_grid, early_claim ? 0 : h->tgrid, h->scene, h->d_sp, (const Vertex *) h->uverts.p, (const uint32_t *) h->tri_e.p,
                                  h->d_ctr + CTR_NTRI, (uint8_t *) h->flip.p, f_lanes, (const uint4 *) h->tdesc.p, h->d_ctr + CTR_NTILES,
                                  h->wkeys, h->wsize, (uint32_t *) h->vslot.p, h->d_status, weld_mode(h, vs), (uint32_t *) h->wrep_buf.p, h->wfm));
         SDCHK(prof_mark(h, f_lanes == 1 ? "flip_claim1" : "flip_claim4"));
@@ -706,7 +716,7 @@ int regen_impl(sdmesh_handle *h, int levels, int mode, int part, int nparts, sdm
             n_cap = padded(h->plan_counts[levels]);
             if (h->use_graph && st != nullptr && !h->profile && !h->project_diag) {   // (the legacy null stream cannot be captured: eager launches there)
                 uint64_t key[8] = {h->buf_gen, (uint64_t) h->scene, (uint64_t) levels, ((uint64_t) mode << 40) | ((uint64_t) part << 20) | (uint64_t) nparts,
-                                   (uint64_t) h->skip_weld | ((uint64_t) h->wide_active << 1) | ((uint64_t) h->col_refine << 2), (uint64_t) (uintptr_t) st, (uint64_t) h->grid | ((uint64_t) h->tgrid << 20) | ((uint64_t) h->project_mult << 40) | ((uint64_t) h->flip_mult << 48) | ((uint64_t) h->refine2 << 56) | ((uint64_t) h->emit_ci << 57) | ((uint64_t) h->project_lanes << 58) | ((uint64_t) h->flip_lanes << 61), 0};
+                                   (uint64_t) h->skip_weld | ((uint64_t) h->wide_active << 1) | ((uint64_t) h->col_refine << 2) | ((uint64_t) h->claim_in_project << 3), (uint64_t) (uintptr_t) st, (uint64_t) h->grid | ((uint64_t) h->tgrid << 20) | ((uint64_t) h->project_mult << 40) | ((uint64_t) h->flip_mult << 48) | ((uint64_t) h->refine2 << 56) | ((uint64_t) h->emit_ci << 57) | ((uint64_t) h->project_lanes << 58) | ((uint64_t) h->flip_lanes << 61), 0};
                 for (int i = 0; i <= levels; i++) key[7] = key[7] * 1000003ull + h->plan_counts[i];
                 key[7] = key[7] * 1000003ull + h->plan_uniq;
                 key[7] = key[7] * 1000003ull + h->plan_tris;
@@ -1034,6 +1044,20 @@ int sdmesh_set_option(sdmesh_handle *h, const char *name, int value) {
     if (!strcmp(name, "col_refine")) { h->col_refine = value ? 1 : 0; h->plan_valid = false; drop_graph(h); return SDMESH_OK; }
     if (!strcmp(name, "emit_ci")) { h->emit_ci = value ? 1 : 0; drop_graph(h); return SDMESH_OK; }
     if (!strcmp(name, "skip_weld")) { h->skip_weld = value ? 1 : 0; return SDMESH_OK; }
+    if (!strcmp(name, "fast_math")) {
+        // the numeric mode is a property of the BUILD (like the reference's nvcc --use_fast_math): libsdmesh.so is strict IEEE,
+        // libsdmesh_fast.so contracts FMAs and takes approximate divide / sqrt.  The option only confirms which one is loaded.
+#if defined(SDM_FAST_MATH)
+        const int built = 1;
+#else
+        const int built = 0;
+#endif
+        if ((value ? 1 : 0) != built)
+            return fail(h, SDMESH_ERR_INVALID, built ? "this is the fast-math build (libsdmesh_fast.so); load libsdmesh.so for strict IEEE"
+                                                     : "this is the strict IEEE build (libsdmesh.so); load libsdmesh_fast.so for the fast numeric mode");
+        return SDMESH_OK;
+    }
+    if (!strcmp(name, "claim")) { h->claim_in_project = value ? 1 : 0; drop_graph(h); return SDMESH_OK; }
     if (!strcmp(name, "weld_shift")) { if (value < -1 || value > 20) return fail(h, SDMESH_ERR_INVALID, "weld_shift -1..20"); h->weld_shift = value; drop_graph(h); return SDMESH_OK; }
     if (!strcmp(name, "profile")) { h->profile = value ? 1 : 0; h->prof_n = 0; h->prof_ms.clear(); return SDMESH_OK; }
     if (!strcmp(name, "project_diag")) { h->project_diag = value ? 1 : 0; return SDMESH_OK; }

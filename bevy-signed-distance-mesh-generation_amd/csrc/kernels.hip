@@ -27,7 +27,9 @@
 #include "sdf.hpp"
 #include "render_device.hpp"
 
-#pragma clang fp contract(off)
+#if !defined(SDM_FAST_MATH)
+#pragma clang fp contract(off)       // strict build: no FMA contraction (DESIGN.md "Numerics")
+#endif
 
 namespace sdm {
 
@@ -1096,12 +1098,54 @@ __device__ __forceinline__ void project_epilogue(uint32_t wave, uint32_t rounds,
 // back to uverts[].position.  16 items in flight per wave (4 lanes each); finished groups refill from
 // the wave's round-robin share of the U work items; item i is mapped to its vertex slot with a binary
 // search in the tile prefix.
+// Weld claims of a projection wave's own vertices, issued when the wave has finished all of them (option "claim" = 1,
+// packed-key form only).  The claim is bound by the chip's scattered-atomic rate (~20 G/s: 16 us for 323 k vertices at
+// 512^3) and used to run beside the orientation test, which is half as long; here the waves that finish early claim
+// while the slow ones still iterate, i.e. under the projection's tail, when most of the chip is idle.
+// The wave re-derives its items (item -> tile by the coarse index) and re-reads the positions it wrote (agent-scope
+// loads: the stores are this wave's own and were waited for).
+struct ClaimArgs {
+    uint64_t *wkeys;
+    uint32_t *vslot;
+    uint32_t *wrep;
+    uint2 *wfm;
+    uint32_t wsize;
+    uint32_t wmode;      // bit 0: wide (never set here), bits 8..: coarse shift; bit 1: claims enabled
+};
+
+template <uint32_t PER>
+__device__ __forceinline__ void claim_epilogue(uint32_t wave, uint32_t nwaves, uint32_t myb, uint32_t U, const Vertex *__restrict__ uverts,
+                                               const uint4 *__restrict__ tdesc, const uint32_t *__restrict__ tpre,
+                                               const uint32_t *__restrict__ coarse, const ClaimArgs &ca, uint32_t *__restrict__ status) {
+    if (!(ca.wmode & 2u)) return;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");              // this wave's position stores have left the CU
+    const uint32_t shift = ca.wmode >> 8;
+    for (uint32_t j = lane_id(); j < myb * PER; j += 64u) {
+        const uint32_t item = ((j / PER) * nwaves + wave) * PER + (j % PER);
+        if (item >= U) continue;
+        uint32_t lo = coarse[item >> 6];
+        while (tpre[lo + 1u] <= item) lo++;
+        const uint32_t e = tdesc[lo].x + (item - tpre[lo]);
+        const float *pp = &uverts[e].position.x;
+        Point p;
+        p.x = __hip_atomic_load(pp + 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        p.y = __hip_atomic_load(pp + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        p.z = __hip_atomic_load(pp + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const uint32_t vs = weld_claim(p, ca.wkeys, ca.wsize, status, shift);
+        ca.vslot[e] = vs;
+        if (vs != U32_NONE && (vs & VS_WINNER)) {
+            ca.wrep[vs & VS_SLOT] = e;
+            ca.wfm[e] = make_uint2(U32_NONE, U32_NONE);
+        }
+    }
+}
+
 template <int SCENE, int LANES /* 4: lane = stencil offset; 2: lane = offset pair */>
 __global__ __launch_bounds__(256) void k_project(Vertex *__restrict__ uverts, const uint4 *__restrict__ tdesc,
                                                   const uint32_t *__restrict__ tpre, const uint32_t *__restrict__ coarse, const uint32_t *__restrict__ ntiles_ptr,
                                                   const SceneParams *__restrict__ spp, uint32_t *__restrict__ status,
                                                   uint32_t *__restrict__ prof /* optional: 256 counters of Newton rounds, 64 B apart */,
-                                                  uint64_t *__restrict__ diag /* optional: per wave {start, end, rounds, hw id} */) {
+                                                  uint64_t *__restrict__ diag /* optional: per wave {start, end, rounds, hw id} */, ClaimArgs ca) {
     const SceneParams &sp = *spp;  // scene uniform in device memory (a captured graph replays with new values)
     const uint32_t ntiles = *ntiles_ptr;
     const uint32_t U = ntiles ? tpre[ntiles] : 0u;
@@ -1166,6 +1210,7 @@ __global__ __launch_bounds__(256) void k_project(Vertex *__restrict__ uverts, co
             }
         }
     }
+    claim_epilogue<PER>(wave, nwaves, myb, U, uverts, tdesc, tpre, coarse, ca, status);
     project_epilogue(wave, rounds, t_start, prof, diag);
 }
 
@@ -1230,7 +1275,7 @@ template <int SCENE>
 __global__ __launch_bounds__(256) void k_project1(Vertex *__restrict__ uverts, const uint4 *__restrict__ tdesc,
                                                    const uint32_t *__restrict__ tpre, const uint32_t *__restrict__ coarse, const uint32_t *__restrict__ ntiles_ptr,
                                                    const SceneParams *__restrict__ spp, uint32_t *__restrict__ status,
-                                                   uint32_t *__restrict__ prof, uint64_t *__restrict__ diag) {
+                                                   uint32_t *__restrict__ prof, uint64_t *__restrict__ diag, ClaimArgs ca) {
     const SceneParams &sp = *spp;
     const uint32_t ntiles = *ntiles_ptr;
     const uint32_t U = ntiles ? tpre[ntiles] : 0u;
@@ -1270,7 +1315,13 @@ __global__ __launch_bounds__(256) void k_project1(Vertex *__restrict__ uverts, c
         }
         const uint64_t act = __ballot(have);
         if (act == 0ull) break;
-        if (qend == qhead && __popcll(act) <= 16) {
+#if defined(SDM_FAST_MATH)
+        constexpr bool straggler_mode = false;   // fast build: one instruction sequence per vertex, so the copies of a vertex that two
+                                                 // tiles compute stay bit-identical (contracted FMAs differ between the two layouts)
+#else
+        constexpr bool straggler_mode = true;
+#endif
+        if (straggler_mode && qend == qhead && __popcll(act) <= 16) {
             // Straggler mode.  Iteration counts are spatially correlated (slow convergence near the smooth-min blends), so a
             // few waves are left with a handful of live lanes for many more rounds while a full one-lane round costs ~960
             // instructions whatever the number of live lanes -- measured: the longest wave lives 2x the mean and sets the
@@ -1332,6 +1383,7 @@ __global__ __launch_bounds__(256) void k_project1(Vertex *__restrict__ uverts, c
             }
         }
     }
+    claim_epilogue<64u>(wave, nwaves, myb, U, uverts, tdesc, tpre, coarse, ca, status);
     project_epilogue(wave, rounds, t_start, prof, diag);
 }
 
@@ -2138,10 +2190,13 @@ hipError_t launch_tile_prefix(hipStream_t st, const uint4 *tdesc, const uint32_t
 
 hipError_t launch_project(hipStream_t st, int grid, int scene, const SceneParams *sp, Vertex *uverts, const uint4 *tdesc,
                           const uint32_t *tpre, const uint32_t *coarse, const uint32_t *ntiles_ptr, uint32_t *status, int lanes,
-                          uint32_t *prof, uint64_t *diag) {
-    if (lanes == 1) { SDM_DISPATCH(scene, hipLaunchKernelGGL(k_project1<S>, dim3(grid), dim3(256), 0, st, uverts, tdesc, tpre, coarse, ntiles_ptr, sp, status, prof, diag)); }
-    else if (lanes == 2) { SDM_DISPATCH(scene, hipLaunchKernelGGL((k_project<S, 2>), dim3(grid), dim3(256), 0, st, uverts, tdesc, tpre, coarse, ntiles_ptr, sp, status, prof, diag)); }
-    else { SDM_DISPATCH(scene, hipLaunchKernelGGL((k_project<S, 4>), dim3(grid), dim3(256), 0, st, uverts, tdesc, tpre, coarse, ntiles_ptr, sp, status, prof, diag)); }
+                          uint32_t *prof, uint64_t *diag, uint64_t *wkeys, uint32_t wsize, uint32_t *vslot, uint32_t *wrep, uint2 *wfm,
+                          uint32_t wmode) {
+    ClaimArgs ca;
+    ca.wkeys = wkeys; ca.vslot = vslot; ca.wrep = wrep; ca.wfm = wfm; ca.wsize = wsize; ca.wmode = wmode;
+    if (lanes == 1) { SDM_DISPATCH(scene, hipLaunchKernelGGL(k_project1<S>, dim3(grid), dim3(256), 0, st, uverts, tdesc, tpre, coarse, ntiles_ptr, sp, status, prof, diag, ca)); }
+    else if (lanes == 2) { SDM_DISPATCH(scene, hipLaunchKernelGGL((k_project<S, 2>), dim3(grid), dim3(256), 0, st, uverts, tdesc, tpre, coarse, ntiles_ptr, sp, status, prof, diag, ca)); }
+    else { SDM_DISPATCH(scene, hipLaunchKernelGGL((k_project<S, 4>), dim3(grid), dim3(256), 0, st, uverts, tdesc, tpre, coarse, ntiles_ptr, sp, status, prof, diag, ca)); }
     return hipGetLastError();
 }
 

@@ -53,7 +53,8 @@ hipError_t launch_tile_prefix(hipStream_t st, const uint4 *tdesc, const uint32_t
                               uint32_t *coarse);
 hipError_t launch_project(hipStream_t st, int grid, int scene, const SceneParams *sp, Vertex *uverts, const uint4 *tdesc,
                           const uint32_t *tpre, const uint32_t *coarse, const uint32_t *ntiles_ptr, uint32_t *status, int lanes = 4,
-                          uint32_t *prof = nullptr, uint64_t *diag = nullptr);
+                          uint32_t *prof = nullptr, uint64_t *diag = nullptr, uint64_t *wkeys = nullptr, uint32_t wsize = 0,
+                          uint32_t *vslot = nullptr, uint32_t *wrep = nullptr, uint2 *wfm = nullptr, uint32_t wmode = 0 /* bit 1: claim here */);
 hipError_t launch_render(hipStream_t st, int scene, const SceneParams *sp, const float *cam13, float fov_fac, float screen_x,
                          float screen_y, float gtex_x, float gtex_y, uint32_t width, uint32_t height, void *rgba);
 hipError_t launch_flip_claim(hipStream_t st, int flip_grid, int claim_grid, int scene, const SceneParams *sp, const Vertex *uverts,

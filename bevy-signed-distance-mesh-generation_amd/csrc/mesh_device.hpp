@@ -9,7 +9,9 @@
 #include "mc_tables.hpp"
 #include "sdf.hpp"
 
-#pragma clang fp contract(off)
+#if !defined(SDM_FAST_MATH)
+#pragma clang fp contract(off)       // strict build: no FMA contraction (DESIGN.md "Numerics")
+#endif
 
 namespace sdm {
 

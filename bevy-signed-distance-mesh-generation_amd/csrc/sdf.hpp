@@ -34,7 +34,9 @@
 #define SDM_HDM inline
 #endif
 
-#pragma clang fp contract(off)
+#if !defined(SDM_FAST_MATH)
+#pragma clang fp contract(off)       // strict build: no FMA contraction (DESIGN.md "Numerics")
+#endif
 
 namespace sdm {
 
@@ -249,7 +251,9 @@ SDM_HD float sdf_program(f3 p, const SceneParams &sp) {
 // the only callers are expressions of the form  sqrt(x) - c  with |c| >= 0.1: there any root below 2^-30 is
 // absorbed by the subtraction and the two forms agree bit for bit.  (x = +inf returns +inf, NaN returns NaN.)
 SDM_HD float sqrt_rn_normal(float x) {
-#if defined(__HIP_DEVICE_COMPILE__)
+#if defined(__HIP_DEVICE_COMPILE__) && defined(SDM_FAST_MATH)
+    return __builtin_amdgcn_sqrtf(x);          // fast build: the bare v_sqrt_f32 (1 ulp), as nvcc --use_fast_math takes sqrt.approx
+#elif defined(__HIP_DEVICE_COMPILE__)
     const float y = __builtin_amdgcn_sqrtf(x);
     const float ydn = __builtin_bit_cast(float, __builtin_bit_cast(int, y) - 1);
     const float yup = __builtin_bit_cast(float, __builtin_bit_cast(int, y) + 1);

@@ -96,14 +96,18 @@ def _pt(a):
 
 
 class CudaHandler:
-    def __init__(self, device=0, scene="sdobj", params=None):
-        self._lib = _abi.load()
+    def __init__(self, device=0, scene="sdobj", params=None, fast_math=False):
+        """fast_math: use libsdmesh_fast.so, the opt-in build with the reference's own numeric mode (nvcc --use_fast_math):
+        faster, within 1e-5 relative of the strict build, not bit-reproducible."""
+        self._lib = _abi.load(fast_math)
+        self.fast_math = bool(fast_math)
         hp = ctypes.c_void_p()
         rc = self._lib.sdmesh_create(int(device), ctypes.byref(hp))
         if rc != 0:
             raise SdMeshError(rc, "sdmesh_create failed (is a gfx950 GPU visible?)")
         self._h = hp
         self.device = int(device)
+        self.set_option("fast_math", 1 if fast_math else 0)        # the library confirms its numeric mode
         self.set_scene(scene, params)
 
     # -- lifetime ------------------------------------------------------------------------------

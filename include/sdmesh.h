@@ -122,6 +122,12 @@ int sdmesh_use_own_stream(sdmesh_handle *h);
  *   "refine2" = 1, "mask_chunk" = 8|16|32   refine variants
  *   "dense_grid", "dense_nt", "dense_rows", "dense_contig"   launch shape of the dense sample pass (P1)
  *   "forget_plan" = 1   drop the capacity plan (the next regen discovers sizes again)
+ *   "fast_math" = 0|1   confirms the numeric mode of the loaded library: libsdmesh.so is strict IEEE (bit-exact against the
+ *                       CPU oracle), libsdmesh_fast.so is the same code built like the reference's `nvcc --use_fast_math`
+ *                       (FMA contraction, approximate divide / sqrt, denormals flushed): link or load that file to opt in;
+ *                       the call fails if the value does not match the build
+ *   "claim" = 0         weld claims beside the orientation test instead of in the projection kernel's epilogue
+ *   "weld_shift" = n    locality-preserving weld home slots (measured slower; default 0 = uniform)
  *   "profile" = 1       time every stage of the planned chain with HIP events (sdmesh_profile_stages)
  *   "weld_wide" = 1     always weld with the unbounded key form (default 0: packed 3 x 21-bit keys, and the wide form
  *                       automatically from the first vertex that does not fit them) */
