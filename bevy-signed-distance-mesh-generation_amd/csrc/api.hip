@@ -101,6 +101,9 @@ struct sdmesh_handle {
     DevBuf col_list1, col_mask2, col_mask3, colinfo;
     int skip_weld = 0;         // regen stops after the orientation test (multi-GPU ranks: the root welds)
     int weld_wide = 0;         // option: 1 = always weld with the unbounded [i64; 3] key form
+    int fuse_flip = 1;         // with the claims in the projection kernel and the weld following, the orientation test runs inside
+                               // k_tile_first (one launch less)
+    bool flip_pending = false; // mesh_front left the orientation test to mesh_weld
     int claim_in_project = 1;  // the weld claims run in the projection kernel's epilogue (under its tail) instead of beside the
                                // orientation test; packed-key form and fork = 2 only
     int weld_shift = 0;        // option: coarse-cell shift of locality-preserving home slots (0 = uniform hashing, the default:
@@ -307,7 +310,7 @@ uint32_t weld_mode(const sdmesh_handle *h, Point vs) {
 // classify -> tile dedupe -> project -> flip for the voxel list d_vox (count at *n_ptr, at most cap_vox):
 // leaves (uverts, tri_e, flip, trioff, tdesc) and the counters NUNIQ / NTRI / NTILES on the device
 int mesh_front(sdmesh_handle *h, const Point *d_vox, const uint32_t *n_ptr, Point vs, bool zero_counters, bool ff_done = false,
-               bool have_cubeidx = false, uint32_t *have_tilecnt = nullptr) {
+               bool have_cubeidx = false, uint32_t *have_tilecnt = nullptr, bool weld_follows = false) {
     hipStream_t st = h->stream;
     // have_tilecnt: the last refine level already wrote cubeidx and the per-tile triangle counts (k_refine_emit)
     uint32_t *tilecnt = have_tilecnt ? have_tilecnt : (uint32_t *) h->tilecnt.p;
@@ -361,6 +364,11 @@ int mesh_front(sdmesh_handle *h, const Point *d_vox, const uint32_t *n_ptr, Poin
         const uint32_t passes = std::max<uint32_t>(1u, (h->tri_hint + per_wg * (uint32_t) f_grid / 2u) / (per_wg * (uint32_t) f_grid));
         f_grid = (int) std::min<uint32_t>(65535u, (h->tri_hint + passes * per_wg - 1u) / (passes * per_wg) + 1u);
     }
+    h->flip_pending = false;
+    if (early_claim && h->fuse_flip && weld_follows && (f_lanes == 1 || h->tri_hint >= 80000u || h->fuse_flip == 2)) {   // (measured: pays from ~100 k triangles)
+        h->flip_pending = true;             // no dispatch here: k_tile_first tests the orientation of its tile's triangles itself
+        return SDMESH_OK;
+    }
     if (h->fork == 2) {
         // one dispatch: claim workgroups first (latency-bound, resident early), orientation-test workgroups behind them
         HIPCHK(launch_flip_claim(st, f_grid, early_claim ? 0 : h->tgrid, h->scene, h->d_sp, (const Vertex *) h->uverts.p, (const uint32_t *) h->tri_e.p,
@@ -390,7 +398,8 @@ int mesh_weld(sdmesh_handle *h, const Vertex *uverts) {
                        (const uint8_t *) h->flip.p, h->first_ord, h->wfm, (const uint32_t *) h->wrep_buf.p, (uint32_t *) h->vslot.p,
                        (uint32_t *) h->wvidx.p, (uint32_t *) h->torder.p, (uint32_t *) h->tfirst.p, (uint32_t *) h->tfpre.p,
                        (Vertex *) h->vertices.p, (uint32_t) (h->vertices.cap / sizeof(Vertex)), h->d_ctr + CTR_NVERT,
-                       (uint32_t *) h->indices.p, h->d_status));
+                       (uint32_t *) h->indices.p, h->d_status, h->flip_pending ? h->scene : -1, h->d_sp));
+    h->flip_pending = false;
     SDCHK(prof_mark(h, "weld"));
     return SDMESH_OK;
 }
@@ -617,7 +626,8 @@ int enqueue_planned_chain(sdmesh_handle *h, int levels, const uint32_t *box, uin
     }
     h->lane_hint = h->plan_uniq;
     h->tri_hint = h->plan_tris;
-    const int rc_front = mesh_front(h, (const Point *) h->vox[h->cur].p, h->d_ctr + CTR_LEVEL0 + levels, vs, false, true, mesh_tc != nullptr, mesh_tc);
+    const int rc_front = mesh_front(h, (const Point *) h->vox[h->cur].p, h->d_ctr + CTR_LEVEL0 + levels, vs, false, true, mesh_tc != nullptr, mesh_tc,
+                                    !h->skip_weld);
     h->lane_hint = 0;
     h->tri_hint = 0;
     SDCHK(rc_front);
@@ -716,7 +726,7 @@ int regen_impl(sdmesh_handle *h, int levels, int mode, int part, int nparts, sdm
             n_cap = padded(h->plan_counts[levels]);
             if (h->use_graph && st != nullptr && !h->profile && !h->project_diag) {   // (the legacy null stream cannot be captured: eager launches there)
                 uint64_t key[8] = {h->buf_gen, (uint64_t) h->scene, (uint64_t) levels, ((uint64_t) mode << 40) | ((uint64_t) part << 20) | (uint64_t) nparts,
-                                   (uint64_t) h->skip_weld | ((uint64_t) h->wide_active << 1) | ((uint64_t) h->col_refine << 2) | ((uint64_t) h->claim_in_project << 3), (uint64_t) (uintptr_t) st, (uint64_t) h->grid | ((uint64_t) h->tgrid << 20) | ((uint64_t) h->project_mult << 40) | ((uint64_t) h->flip_mult << 48) | ((uint64_t) h->refine2 << 56) | ((uint64_t) h->emit_ci << 57) | ((uint64_t) h->project_lanes << 58) | ((uint64_t) h->flip_lanes << 61), 0};
+                                   (uint64_t) h->skip_weld | ((uint64_t) h->wide_active << 1) | ((uint64_t) h->col_refine << 2) | ((uint64_t) h->claim_in_project << 3) | ((uint64_t) h->fuse_flip << 4), (uint64_t) (uintptr_t) st, (uint64_t) h->grid | ((uint64_t) h->tgrid << 20) | ((uint64_t) h->project_mult << 40) | ((uint64_t) h->flip_mult << 48) | ((uint64_t) h->refine2 << 56) | ((uint64_t) h->emit_ci << 57) | ((uint64_t) h->project_lanes << 58) | ((uint64_t) h->flip_lanes << 61), 0};
                 for (int i = 0; i <= levels; i++) key[7] = key[7] * 1000003ull + h->plan_counts[i];
                 key[7] = key[7] * 1000003ull + h->plan_uniq;
                 key[7] = key[7] * 1000003ull + h->plan_tris;
@@ -1057,6 +1067,7 @@ int sdmesh_set_option(sdmesh_handle *h, const char *name, int value) {
                                                      : "this is the strict IEEE build (libsdmesh.so); load libsdmesh_fast.so for the fast numeric mode");
         return SDMESH_OK;
     }
+    if (!strcmp(name, "fuse_flip")) { h->fuse_flip = value < 0 ? 0 : (value > 2 ? 2 : value); drop_graph(h); return SDMESH_OK; }
     if (!strcmp(name, "claim")) { h->claim_in_project = value ? 1 : 0; drop_graph(h); return SDMESH_OK; }
     if (!strcmp(name, "weld_shift")) { if (value < -1 || value > 20) return fail(h, SDMESH_ERR_INVALID, "weld_shift -1..20"); h->weld_shift = value; drop_graph(h); return SDMESH_OK; }
     if (!strcmp(name, "profile")) { h->profile = value ? 1 : 0; h->prof_n = 0; h->prof_ms.clear(); return SDMESH_OK; }

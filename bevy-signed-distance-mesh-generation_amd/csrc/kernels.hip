@@ -1457,8 +1457,13 @@ static constexpr uint32_t T_VMAX = 3072;
 
 // per tile: apply the orientation flips to tri_e, derive every tile vertex's first-seen ordinal with LDS
 // atomics, publish it (winner: plain store, loser: atomicMin)
+// FLIP_SCENE >= 0: the orientation test (compute_mesh_generation.cu:102-105, one lane per triangle as in k_flip1) runs here
+// instead of in its own launch -- possible once the weld claims have moved into the projection kernel, so that nothing
+// else needs the separate dispatch; a tile's ~512 triangles are two passes of its 256 threads.
+template <int FLIP_SCENE>
 __global__ __launch_bounds__(256) void k_tile_first(const uint4 *__restrict__ tdesc, const uint32_t *__restrict__ ntiles_ptr,
                                                      uint32_t *__restrict__ tri_e, const uint8_t *__restrict__ flip,
+                                                     const Vertex *__restrict__ uverts, const SceneParams *__restrict__ spp,
                                                      uint32_t *__restrict__ vslot /* in: claim result; out: representative vertex | winner bit */,
                                                      uint32_t *__restrict__ first_ord, const uint32_t *__restrict__ wrep,
                                                      uint2 *__restrict__ wfm /* per REPRESENTATIVE vertex: {its own ordinal, minimum ordinal of the key's other vertices} */) {
@@ -1472,7 +1477,14 @@ __global__ __launch_bounds__(256) void k_tile_first(const uint4 *__restrict__ td
         for (uint32_t tl = tid; tl < ttri; tl += 256) {
             const uint32_t t = tbase + tl;
             uint32_t e0 = tri_e[3 * t], e1 = tri_e[3 * t + 1], e2 = tri_e[3 * t + 2];
-            if (flip[t]) {
+            bool fl;
+            if (FLIP_SCENE >= 0) {
+                const Point p0 = uverts[e0].position, p1 = uverts[e1].position, p2 = uverts[e2].position;
+                fl = change_orientation<(FLIP_SCENE >= 0 ? FLIP_SCENE : 0)>(mk(p0.x, p0.y, p0.z), mk(p1.x, p1.y, p1.z), mk(p2.x, p2.y, p2.z), *spp);
+            } else {
+                fl = flip[t] != 0;
+            }
+            if (fl) {
                 const uint32_t x = e0; e0 = e2; e2 = x;
                 tri_e[3 * t] = e0; tri_e[3 * t + 2] = e2;
             }
@@ -2255,8 +2267,20 @@ hipError_t launch_tile_claim(hipStream_t st, int grid, const Vertex *uverts, con
 hipError_t launch_weld(hipStream_t st, int grid, const Vertex *uverts, const uint4 *tdesc, const uint32_t *ntiles_ptr,
                        uint32_t *tri_e, const uint8_t *flip, uint32_t *first_ord, uint2 *wfm, const uint32_t *wrep,
                        uint32_t *vslot, uint32_t *wv, uint32_t *torder, uint32_t *tfirst, uint32_t *tfpre,
-                       Vertex *vertices, uint32_t vcap, uint32_t *nverts_out, uint32_t *indices, uint32_t *status) {
-    hipLaunchKernelGGL(k_tile_first, dim3(grid), dim3(256), 0, st, tdesc, ntiles_ptr, tri_e, flip, vslot, first_ord, wrep, wfm);
+                       Vertex *vertices, uint32_t vcap, uint32_t *nverts_out, uint32_t *indices, uint32_t *status,
+                       int flip_scene, const SceneParams *sp) {
+    if (flip_scene >= 0) {
+        switch (flip_scene) {
+        case SCENE_SDOBJ: hipLaunchKernelGGL(k_tile_first<SCENE_SDOBJ>, dim3(grid), dim3(256), 0, st, tdesc, ntiles_ptr, tri_e, flip, uverts, sp, vslot, first_ord, wrep, wfm); break;
+        case SCENE_SPHERE: hipLaunchKernelGGL(k_tile_first<SCENE_SPHERE>, dim3(grid), dim3(256), 0, st, tdesc, ntiles_ptr, tri_e, flip, uverts, sp, vslot, first_ord, wrep, wfm); break;
+        case SCENE_CSG3: hipLaunchKernelGGL(k_tile_first<SCENE_CSG3>, dim3(grid), dim3(256), 0, st, tdesc, ntiles_ptr, tri_e, flip, uverts, sp, vslot, first_ord, wrep, wfm); break;
+        case SCENE_ANIM: hipLaunchKernelGGL(k_tile_first<SCENE_ANIM>, dim3(grid), dim3(256), 0, st, tdesc, ntiles_ptr, tri_e, flip, uverts, sp, vslot, first_ord, wrep, wfm); break;
+        case SCENE_PROGRAM: hipLaunchKernelGGL(k_tile_first<SCENE_PROGRAM>, dim3(grid), dim3(256), 0, st, tdesc, ntiles_ptr, tri_e, flip, uverts, sp, vslot, first_ord, wrep, wfm); break;
+        default: return hipErrorInvalidValue;
+        }
+    } else {
+        hipLaunchKernelGGL(k_tile_first<-1>, dim3(grid), dim3(256), 0, st, tdesc, ntiles_ptr, tri_e, flip, uverts, sp, vslot, first_ord, wrep, wfm);
+    }
     hipLaunchKernelGGL(k_tile_rank, dim3(grid), dim3(256), 0, st, tdesc, ntiles_ptr, first_ord, wfm, vslot, wv, torder,
                        tfirst);
     hipLaunchKernelGGL(k_scan_u32, dim3(1), dim3(1024), 0, st, tfirst, ntiles_ptr, tfpre, nverts_out);

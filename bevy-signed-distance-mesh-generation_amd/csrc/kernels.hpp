@@ -72,7 +72,8 @@ hipError_t launch_merge_by_column(hipStream_t st, const Triangle *const *d_lists
 hipError_t launch_weld(hipStream_t st, int grid, const Vertex *uverts, const uint4 *tdesc, const uint32_t *ntiles_ptr,
                        uint32_t *tri_e, const uint8_t *flip, uint32_t *first_ord, uint2 *wfm, const uint32_t *wrep,
                        uint32_t *vslot, uint32_t *wv, uint32_t *torder, uint32_t *tfirst, uint32_t *tfpre,
-                       Vertex *vertices, uint32_t vcap, uint32_t *nverts_out, uint32_t *indices, uint32_t *status);
+                       Vertex *vertices, uint32_t vcap, uint32_t *nverts_out, uint32_t *indices, uint32_t *status,
+                       int flip_scene = -1 /* >= 0: the orientation test runs inside k_tile_first */, const SceneParams *sp = nullptr);
 hipError_t launch_expand_compact(hipStream_t st, int grid, const Vertex *uverts, const uint32_t *tri_e, const uint8_t *flip,
                                  const uint32_t *ntri_ptr, Triangle *out, uint32_t cap);
 hipError_t launch_expand_raw(hipStream_t st, int grid, const Vertex *uverts, const uint32_t *tri_e, const uint8_t *flip,
