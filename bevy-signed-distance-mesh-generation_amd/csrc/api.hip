@@ -320,9 +320,16 @@ int mesh_front(sdmesh_handle *h, const Point *d_vox, const uint32_t *n_ptr, Poin
     if (have_tilecnt) { /* nothing to launch */ }
     else if (have_cubeidx) HIPCHK(launch_tile_tricount(st, h->tgrid, (const uint8_t *) h->cubeidx.p, n_ptr, tilecnt));
     else HIPCHK(launch_classify(st, h->tgrid, h->scene, h->d_sp, d_vox, n_ptr, vs, (uint8_t *) h->cubeidx.p, tilecnt));
+    uint64_t *d_tile_dbg = nullptr;
+    if (h->project_diag == 2) {             // diagnostic: phase stamps of k_tile_dedupe instead of the projection timeline
+        h->diag_waves = 2u * (tiles(h->cap_vox) + 16u);          // 8 stamps per tile = 2 "wave" records of 4 u64
+        SDCHK(ensure(h, h->proj_diag, 32ull * h->diag_waves));
+        HIPCHK(hipMemsetAsync(h->proj_diag.p, 0, 32ull * h->diag_waves, st));
+        d_tile_dbg = (uint64_t *) h->proj_diag.p;
+    }
     HIPCHK(launch_tile_dedupe(st, h->tgrid, d_vox, n_ptr, vs, (const uint8_t *) h->cubeidx.p, (const uint32_t *) tilecnt,
                               (uint32_t *) h->trioff.p, (uint32_t *) h->tri_e.p, (Vertex *) h->uverts.p, (uint4 *) h->tdesc.p,
-                              h->ucap, h->tcap, h->d_ctr + CTR_NTRI, h->d_ctr + CTR_NTILES, h->d_status));
+                              h->ucap, h->tcap, h->d_ctr + CTR_NTRI, h->d_ctr + CTR_NTILES, h->d_status, d_tile_dbg));
     SDCHK(prof_mark(h, "tile_dedupe"));
     uint32_t *coarse = (uint32_t *) h->tpre.p + h->tp_cap;
     HIPCHK(launch_tile_prefix(st, (const uint4 *) h->tdesc.p, h->d_ctr + CTR_NTILES, (uint32_t *) h->tpre.p, h->d_ctr + CTR_NUNIQ, coarse));
@@ -344,7 +351,7 @@ int mesh_front(sdmesh_handle *h, const Point *d_vox, const uint32_t *n_ptr, Poin
         HIPCHK(hipMemsetAsync(h->prof_rounds.p, 0, 256 * 64, st));
         d_prof = (uint32_t *) h->prof_rounds.p;
     }
-    if (h->project_diag) {
+    if (h->project_diag == 1) {
         h->diag_waves = (uint32_t) (h->grid * h->project_mult) * 4u;
         SDCHK(ensure(h, h->proj_diag, 32ull * h->diag_waves));
         HIPCHK(hipMemsetAsync(h->proj_diag.p, 0, 32ull * h->diag_waves, st));
@@ -1071,7 +1078,7 @@ int sdmesh_set_option(sdmesh_handle *h, const char *name, int value) {
     if (!strcmp(name, "claim")) { h->claim_in_project = value ? 1 : 0; drop_graph(h); return SDMESH_OK; }
     if (!strcmp(name, "weld_shift")) { if (value < -1 || value > 20) return fail(h, SDMESH_ERR_INVALID, "weld_shift -1..20"); h->weld_shift = value; drop_graph(h); return SDMESH_OK; }
     if (!strcmp(name, "profile")) { h->profile = value ? 1 : 0; h->prof_n = 0; h->prof_ms.clear(); return SDMESH_OK; }
-    if (!strcmp(name, "project_diag")) { h->project_diag = value ? 1 : 0; return SDMESH_OK; }
+    if (!strcmp(name, "project_diag")) { h->project_diag = value; return SDMESH_OK; }
     if (!strcmp(name, "weld_wide")) { h->weld_wide = value ? 1 : 0; h->wide_active = value != 0; drop_graph(h); return SDMESH_OK; }
     if (!strcmp(name, "graph")) { h->use_graph = value ? 1 : 0; if (!value) drop_graph(h); return SDMESH_OK; }
     if (!strcmp(name, "tgrid")) {

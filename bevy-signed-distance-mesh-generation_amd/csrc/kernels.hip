@@ -42,20 +42,26 @@ static constexpr uint32_t U32_NONE = 0xffffffffu;
 // ------------------------------------------------------------------------------------------
 __device__ __forceinline__ uint32_t lane_id() { return threadIdx.x & 63u; }
 
+// Wave-wide inclusive prefix sum with DPP row shifts / row broadcasts (gfx9 data-parallel primitives: ~6 VALU operations)
+// instead of six __shfl_up steps, each of which is a ds_bpermute_b32 round trip through the LDS crossbar.
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ uint32_t dpp_add(uint32_t v) {
+    // lanes whose DPP source is out of range (or whose row is masked off) contribute `old` = 0
+    return v + (uint32_t) __builtin_amdgcn_update_dpp(0, (int) v, CTRL, ROW_MASK, 0xf, false);
+}
+
 __device__ __forceinline__ uint32_t wave_incl_scan(uint32_t v) {
-    const uint32_t lane = lane_id();
-#pragma unroll
-    for (int d = 1; d < 64; d <<= 1) {
-        uint32_t t = __shfl_up(v, d, 64);
-        if (lane >= (uint32_t) d) v += t;
-    }
+    v = dpp_add<0x111, 0xf>(v);      // row_shr:1
+    v = dpp_add<0x112, 0xf>(v);      // row_shr:2
+    v = dpp_add<0x114, 0xf>(v);      // row_shr:4
+    v = dpp_add<0x118, 0xf>(v);      // row_shr:8   -> inclusive sums inside each row of 16 lanes
+    v = dpp_add<0x142, 0xa>(v);      // row_bcast:15 into rows 1 and 3
+    v = dpp_add<0x143, 0xc>(v);      // row_bcast:31 into rows 2 and 3
     return v;
 }
 
 __device__ __forceinline__ uint32_t wave_sum(uint32_t v) {
-#pragma unroll
-    for (int d = 32; d >= 1; d >>= 1) v += __shfl_xor(v, d, 64);
-    return v;
+    return (uint32_t) __builtin_amdgcn_readlane((int) wave_incl_scan(v), 63);
 }
 
 // Exclusive scan over the workgroup (blockDim.x multiple of 64, <= 1024).  `lds` needs 17 words.
@@ -883,12 +889,20 @@ __global__ __launch_bounds__(256) void k_tile_dedupe(const Point *__restrict__ v
                                                       uint32_t *__restrict__ trioff, uint32_t *__restrict__ tri_e,
                                                       Vertex *__restrict__ uverts, uint4 *__restrict__ tdesc, uint32_t ucap,
                                                       uint32_t tcap, uint32_t *__restrict__ ntri_out,
-                                                      uint32_t *__restrict__ ntiles_out, uint32_t *__restrict__ status) {
+                                                      uint32_t *__restrict__ ntiles_out, uint32_t *__restrict__ status,
+                                                      uint64_t *__restrict__ dbg /* optional: 8 s_memtime stamps per tile (tools/tile_phases.py) */) {
+#define SDM_STAMP(k) do { if (dbg && tid == 0) dbg[8ull * tile + (k)] = __builtin_amdgcn_s_memtime(); } while (0)
     __shared__ uint64_t s_keys[T_HASH];
-    __shared__ uint16_t s_lid[T_HASH];
+    __shared__ uint64_t s_aux[2 * TILE];                    // insert phase: per-voxel lattice coordinates + triangle row;
+    uint64_t *const s_vpack = s_aux, *const s_vrow = s_aux + TILE;
+    uint16_t *const s_lid = reinterpret_cast<uint16_t *>(s_aux);      // afterwards: local vertex id per hash slot (T_HASH x u16 = the same 4 KB)
     __shared__ uint16_t s_tri[T_TRI * 3];
+    __shared__ uint16_t s_vlo[TILE];
+    __shared__ uint8_t s_tvox[T_TRI];
     __shared__ uint32_t s_scan[17];
     __shared__ uint32_t s_bad, s_full;
+    static_assert(sizeof(uint64_t) * 2 * TILE == sizeof(uint16_t) * T_HASH, "s_aux is reused for the local ids");
+    static_assert(T_HASH == 2048, "the cheap tile hash keeps 11 bits");
 
     const uint32_t n = *n_ptr;
     const uint32_t ntiles = (n + TILE - 1) / TILE;
@@ -899,6 +913,7 @@ __global__ __launch_bounds__(256) void k_tile_dedupe(const Point *__restrict__ v
     }
     for (uint32_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
         // issue every independent global load before the first barrier so their latencies overlap
+        SDM_STAMP(0);
         const uint32_t v = tile * TILE + tid;
         const uint32_t ci = v < n ? cubeidx[v] : 0u;
         const Point b = vox[v < n ? v : (n - 1)];
@@ -915,8 +930,10 @@ __global__ __launch_bounds__(256) void k_tile_dedupe(const Point *__restrict__ v
             const bool okx = lattice_coord(b.x, vs.x, mx), oky = lattice_coord(b.y, vs.y, my), okz = lattice_coord(b.z, vs.z, mz);
             lat_ok = okx && oky && okz;
         }
+        SDM_STAMP(1);
         uint32_t ttri;
         const uint32_t lo = block_excl_scan(ntri, ttri, s_scan);
+        SDM_STAMP(2);
         if (v < n) trioff[v] = tbase + lo;
         if (tile == ntiles - 1 && tid == 0) {
             uint32_t tot = tbase + ttri;
@@ -927,32 +944,47 @@ __global__ __launch_bounds__(256) void k_tile_dedupe(const Point *__restrict__ v
         if (tid == 0) { s_bad = 0; s_full = 0; }
         __syncthreads();
         if (!lat_ok) { s_bad = 1; atomicOr(&status[ST_NOT_LATTICE], 1u); }
+        SDM_STAMP(3);
 
-        // insert every triangle corner's edge key; remember the slot per corner
-        if (ntri && lat_ok) {
-            uint64_t row = tri_row;
-            for (uint32_t c = 0; c < 3 * ntri; c++) {
-                const uint64_t key = edge_key(mx, my, mz, (int) (row & 0xF));
-                row >>= 4;
-                uint32_t s = hash_home(key, T_HASH);
+        // Insert every triangle corner's edge key; remember the slot per corner.  The corners are dealt evenly to the threads
+        // (corner i of the tile -> thread i % 256): a voxel has 3 to 15 corners, and with one voxel per thread every wave
+        // ran its insert loop 12-15 times at ~40 % lane use -- 10 000 of the tile's 22 000 cycles (tools/tile_phases.py).
+        // The voxel's lattice coordinates and its triangle row go through LDS (the arrays that later hold the local ids).
+        if (ntri) {
+            s_vpack[tid] = (uint64_t) (uint32_t) mx | ((uint64_t) (uint32_t) my << 21) | ((uint64_t) (uint32_t) mz << 42);
+            s_vrow[tid] = tri_row;
+            s_vlo[tid] = (uint16_t) lo;
+            for (uint32_t j = 0; j < ntri; j++) s_tvox[lo + j] = (uint8_t) tid;
+        }
+        __syncthreads();
+        if (s_bad == 0) {
+            for (uint32_t i = tid; i < 3u * ttri; i += 256u) {
+                const uint32_t t = i / 3u, q = i - 3u * t, vv = s_tvox[t];
+                const uint64_t vp = s_vpack[vv];
+                const int e = (int) ((s_vrow[vv] >> (4u * (3u * (t - s_vlo[vv]) + q))) & 0xFull);
+                const uint64_t key = edge_key((int) (vp & 0x1FFFFFull), (int) ((vp >> 21) & 0x1FFFFFull), (int) ((vp >> 42) & 0x1FFFFFull), e);
+                // cheap home slot: the keys of a tile are a few hundred neighbouring lattice edges; three 32-bit multiplies
+                // spread them as well as the 64-bit mixer did (checked by the overflow statistics: none at any size)
+                uint32_t sl = ((uint32_t) key * 0x9E3779B1u ^ (uint32_t) (key >> 21) * 0x85EBCA77u ^ (uint32_t) (key >> 42) * 0xC2B2AE3Du) >> (32 - 11);
                 bool placed = false;
                 for (uint32_t probe = 0; probe < T_HASH && !placed; probe++) {
-                    const uint64_t prev = atomicCAS((unsigned long long *) &s_keys[s], (unsigned long long) KEY_EMPTY,
-                                                    (unsigned long long) key);
+                    const uint64_t prev = atomicCAS((unsigned long long *) &s_keys[sl], (unsigned long long) KEY_EMPTY, (unsigned long long) key);
                     if (prev == KEY_EMPTY || prev == key) placed = true;
-                    else s = hash_next(s, T_HASH);
+                    else sl = hash_next(sl, T_HASH);
                 }
                 if (!placed) s_full = 1;
-                s_tri[3 * lo + c] = (uint16_t) s;
+                s_tri[i] = (uint16_t) sl;
             }
         }
         __syncthreads();
+        SDM_STAMP(4);
         // dense local ids in slot order (deterministic)
         uint32_t occ = 0;
 #pragma unroll
         for (uint32_t k = 0; k < T_HASH / 256; k++) occ += s_keys[tid * (T_HASH / 256) + k] != KEY_EMPTY ? 1u : 0u;
         uint32_t nu;
         uint32_t lid = block_excl_scan(occ, nu, s_scan);
+        SDM_STAMP(5);
         // vertex slots live in corner-ordinal space: tile t owns [3 * tbase, 3 * (tbase + ttri)), of which
         // the first nu <= 3 * ttri are used -- no global allocation, no atomics
         const uint32_t vbase = 3u * tbase;
@@ -980,11 +1012,14 @@ __global__ __launch_bounds__(256) void k_tile_dedupe(const Point *__restrict__ v
             }
         }
         __syncthreads();
+        SDM_STAMP(6);
         if (fits)
             for (uint32_t i = tid; i < 3 * ttri; i += 256)
                 if (tbase + i / 3u < tcap) tri_e[3u * tbase + i] = vbase + s_lid[s_tri[i]];
         __syncthreads();
+        SDM_STAMP(7);
     }
+#undef SDM_STAMP
 }
 
 // ------------------------------------------------------------------------------------------
@@ -2188,9 +2223,9 @@ hipError_t launch_classify(hipStream_t st, int grid, int scene, const SceneParam
 
 hipError_t launch_tile_dedupe(hipStream_t st, int grid, const Point *vox, const uint32_t *n_ptr, Point vs, const uint8_t *cubeidx,
                               const uint32_t *tilecnt, uint32_t *trioff, uint32_t *tri_e, Vertex *uverts, uint4 *tdesc,
-                              uint32_t ucap, uint32_t tcap, uint32_t *ntri_out, uint32_t *ntiles_out, uint32_t *status) {
+                              uint32_t ucap, uint32_t tcap, uint32_t *ntri_out, uint32_t *ntiles_out, uint32_t *status, uint64_t *dbg) {
     hipLaunchKernelGGL(k_tile_dedupe, dim3(grid), dim3(256), 0, st, vox, n_ptr, vs, cubeidx, tilecnt, trioff, tri_e, uverts, tdesc,
-                       ucap, tcap, ntri_out, ntiles_out, status);
+                       ucap, tcap, ntri_out, ntiles_out, status, dbg);
     return hipGetLastError();
 }
 
