@@ -107,6 +107,8 @@ SYMBOLS = {
     "sdmesh_device_triangles": (_i, [_vp, _vp, _sz, _psz]),
     "sdmesh_weld_device_triangles": (_i, [_vp, _vp, _sz, ctypes.POINTER(RegenInfo)]),
     "sdmesh_column_triangle_counts": (_i, [_vp, _vp]),
+    "sdmesh_set_slab_bounds": (_i, [_vp, _i, _i, _vp]),
+    "sdmesh_balance_slabs": (_i, [_vp, _i, _i, _i, _vp]),
     "sdmesh_merge_by_column": (_i, [_vp, _vp, _vp, _i, _vp, _sz, _psz]),
     "sdmesh_comm_unique_id": (_i, [_vp]),
     "sdmesh_comm_init": (_i, [_vp, _vp, _i, _i]),

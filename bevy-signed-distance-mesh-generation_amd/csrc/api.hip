@@ -172,6 +172,10 @@ struct sdmesh_handle {
     size_t h_counts_words = 0;
     void **h_lists = nullptr;          // pinned: nranks device pointers
 
+    // slab boundaries of the partitioned regens (level-0 layers); slab_nparts == 0: uniform
+    int slab_mode = 0, slab_nparts = 0;
+    uint32_t slab_bounds[33] = {0};
+
     // capacity plan learnt from the last synchronous run (async path)
     bool plan_valid = false;
     int plan_scene = -1, plan_levels = -1, plan_mode = 0, plan_part = 0, plan_nparts = 1;
@@ -470,7 +474,7 @@ int zero_ctl(sdmesh_handle *h, size_t lvl_words) {
 
 // Weld a raw / compact slot list on the device: ordered compaction of the valid slots, then the
 // generic weld with every triangle corner as its own "unique vertex".
-int weld_raw_device(sdmesh_handle *h, const Triangle *d_raw, uint32_t nslots) {
+int weld_raw_device(sdmesh_handle *h, const Triangle *d_raw, uint32_t nslots, bool all_valid = false) {
     hipStream_t st = h->stream;
     if (nslots == 0) {
         h->n_tris = h->n_verts = 0;
@@ -480,18 +484,28 @@ int weld_raw_device(sdmesh_handle *h, const Triangle *d_raw, uint32_t nslots) {
     const uint32_t vcap = 3u * nslots;
     SDCHK(layout_mesh(h, (nslots + 4) / 5, vcap + 64));
     if (h->tcap < nslots) return fail(h, SDMESH_ERR_INTERNAL, "weld layout too small");
-    SDCHK(ensure(h, h->compact, sizeof(Triangle) * (size_t) nslots));
     HIPCHK(hipMemsetAsync(h->ff_arena.p, 0xFF, ff_bytes(h), st));
-    HIPCHK(launch_set_u32(st, h->d_ctr + CTR_NSLOTS, nslots));
-    HIPCHK(launch_raw_count(st, h->tgrid, d_raw, h->d_ctr + CTR_NSLOTS, (uint32_t *) h->tilecnt.p));
-    HIPCHK(launch_scan_tiles(st, (uint32_t *) h->tilecnt.p, h->d_ctr + CTR_NSLOTS, 256, h->d_ctr + CTR_NTRI, nslots, h->d_status));
-    HIPCHK(launch_raw_compact(st, h->tgrid, d_raw, h->d_ctr + CTR_NSLOTS, (const uint32_t *) h->tilecnt.p,
-                              (Triangle *) h->compact.p, (uint32_t *) h->tri_e.p, nslots));
-    HIPCHK(launch_raw_desc(st, h->grid, h->d_ctr + CTR_NTRI, (uint4 *) h->tdesc.p, (uint8_t *) h->flip.p, h->d_ctr + CTR_NTILES,
-                           h->d_ctr + CTR_NUNIQ));
-    HIPCHK(launch_tile_claim(st, h->tgrid, (const Vertex *) h->compact.p, (const uint4 *) h->tdesc.p, h->d_ctr + CTR_NTILES,
+    const Vertex *corners;
+    if (all_valid) {
+        // a compact list (the merged slab lists of the multi-GPU root): every slot is a triangle, nothing to count or move
+        HIPCHK(launch_set_u32(st, h->d_ctr + CTR_NTRI, nslots));
+        HIPCHK(launch_raw_desc(st, h->grid, h->d_ctr + CTR_NTRI, (uint4 *) h->tdesc.p, (uint8_t *) h->flip.p, h->d_ctr + CTR_NTILES,
+                               h->d_ctr + CTR_NUNIQ, (uint32_t *) h->tri_e.p));
+        corners = (const Vertex *) d_raw;
+    } else {
+        SDCHK(ensure(h, h->compact, sizeof(Triangle) * (size_t) nslots));
+        HIPCHK(launch_set_u32(st, h->d_ctr + CTR_NSLOTS, nslots));
+        HIPCHK(launch_raw_count(st, h->tgrid, d_raw, h->d_ctr + CTR_NSLOTS, (uint32_t *) h->tilecnt.p));
+        HIPCHK(launch_scan_tiles(st, (uint32_t *) h->tilecnt.p, h->d_ctr + CTR_NSLOTS, 256, h->d_ctr + CTR_NTRI, nslots, h->d_status));
+        HIPCHK(launch_raw_compact(st, h->tgrid, d_raw, h->d_ctr + CTR_NSLOTS, (const uint32_t *) h->tilecnt.p,
+                                  (Triangle *) h->compact.p, (uint32_t *) h->tri_e.p, nslots));
+        HIPCHK(launch_raw_desc(st, h->grid, h->d_ctr + CTR_NTRI, (uint4 *) h->tdesc.p, (uint8_t *) h->flip.p, h->d_ctr + CTR_NTILES,
+                               h->d_ctr + CTR_NUNIQ));
+        corners = (const Vertex *) h->compact.p;
+    }
+    HIPCHK(launch_tile_claim(st, h->tgrid, corners, (const uint4 *) h->tdesc.p, h->d_ctr + CTR_NTILES,
                              h->wkeys, h->wsize, (uint32_t *) h->vslot.p, h->d_status, weld_mode(h, h->voxel_size), (uint32_t *) h->wrep_buf.p, h->wfm));
-    SDCHK(mesh_weld(h, (const Vertex *) h->compact.p));
+    SDCHK(mesh_weld(h, corners));
     return SDMESH_OK;
 }
 
@@ -697,7 +711,8 @@ int regen_impl(sdmesh_handle *h, int levels, int mode, int part, int nparts, sdm
     SDCHK(sync_scene(h));
     hipStream_t st = h->stream;
     const uint32_t F = MESH_GENERATION_INIT_FACTOR;
-    const uint32_t p0 = F * (uint32_t) part / (uint32_t) nparts, p1 = F * (uint32_t) (part + 1) / (uint32_t) nparts;
+    uint32_t p0 = F * (uint32_t) part / (uint32_t) nparts, p1 = F * (uint32_t) (part + 1) / (uint32_t) nparts;
+    if (mode != SDMESH_PART_NONE && h->slab_nparts == nparts && h->slab_mode == mode) { p0 = h->slab_bounds[part]; p1 = h->slab_bounds[part + 1]; }
     // level-0 cell box {x0, x1, z0, z1} of this part: z layers (ZSLAB) or x layers (XSLAB: x is the outermost digit of
     // the reference's order, so a part's voxel / triangle lists are contiguous ranges of the unpartitioned ones)
     const uint32_t box[4] = {mode == SDMESH_PART_XSLAB ? p0 : 0u, mode == SDMESH_PART_XSLAB ? p1 : F,
@@ -1257,7 +1272,13 @@ int sdmesh_weld_triangles(sdmesh_handle *h, const struct Triangle *raw, size_t n
     return SDMESH_OK;
 }
 
+static int weld_device_impl(sdmesh_handle *h, const struct Triangle *d_raw, size_t nslots, sdmesh_regen_info *info, bool all_valid);
+
 int sdmesh_weld_device_triangles(sdmesh_handle *h, const struct Triangle *d_raw, size_t nslots, sdmesh_regen_info *info) {
+    return weld_device_impl(h, d_raw, nslots, info, false);
+}
+
+static int weld_device_impl(sdmesh_handle *h, const struct Triangle *d_raw, size_t nslots, sdmesh_regen_info *info, bool all_valid) {
     if (!h || (nslots && !d_raw)) return SDMESH_ERR_INVALID;
     if (nslots > 0x0FFFFFFFu) return fail(h, SDMESH_ERR_INVALID, "too many slots");
     HIPCHK(hipSetDevice(h->device));
@@ -1268,7 +1289,7 @@ int sdmesh_weld_device_triangles(sdmesh_handle *h, const struct Triangle *d_raw,
         HIPCHK(hipEventRecord(h->ev0, h->stream));
         SDCHK(zero_status(h));
         HIPCHK(hipMemsetAsync(h->d_ctr + CTR_NUNIQ, 0, 4 * sizeof(uint32_t), h->stream));
-        SDCHK(weld_raw_device(h, d_raw, (uint32_t) nslots));
+        SDCHK(weld_raw_device(h, d_raw, (uint32_t) nslots, all_valid));
         HIPCHK(hipEventRecord(h->ev1, h->stream));
         SDCHK(read_back(h));
         if (!h->h_pinned[CTR_WORDS + ST_WELD_RANGE] || h->wide_active) break;
@@ -1533,6 +1554,67 @@ int sdmesh_render(sdmesh_handle *h, const GlobalsBuffer *globals, const CameraBu
 
 }  // extern "C"
 
+extern "C" int sdmesh_set_slab_bounds(sdmesh_handle *h, int mode, int nparts, const uint32_t *bounds) {
+    if (!h) return SDMESH_ERR_INVALID;
+    if (!bounds) { h->slab_nparts = 0; h->plan_valid = false; drop_graph(h); return SDMESH_OK; }
+    if ((mode != SDMESH_PART_ZSLAB && mode != SDMESH_PART_XSLAB) || nparts < 1 || nparts > 32) return fail(h, SDMESH_ERR_INVALID, "bad slab table");
+    if (bounds[0] != 0 || bounds[nparts] != (uint32_t) MESH_GENERATION_INIT_FACTOR) return fail(h, SDMESH_ERR_INVALID, "slab bounds must run from 0 to %d", MESH_GENERATION_INIT_FACTOR);
+    for (int i = 0; i < nparts; i++)
+        if (bounds[i + 1] < bounds[i]) return fail(h, SDMESH_ERR_INVALID, "slab bounds must not decrease");
+    h->slab_mode = mode; h->slab_nparts = nparts;
+    memcpy(h->slab_bounds, bounds, sizeof(uint32_t) * (size_t) (nparts + 1));
+    h->plan_valid = false;
+    drop_graph(h);
+    return SDMESH_OK;
+}
+
+extern "C" int sdmesh_balance_slabs(sdmesh_handle *h, int mode, int nparts, int probe_levels, uint32_t *bounds_out) {
+    if (!h) return SDMESH_ERR_INVALID;
+    if ((mode != SDMESH_PART_ZSLAB && mode != SDMESH_PART_XSLAB) || nparts < 1 || nparts > 32 || probe_levels < 0 || probe_levels > 4)
+        return fail(h, SDMESH_ERR_INVALID, "bad arguments");
+    const int F = MESH_GENERATION_INIT_FACTOR;
+    // the surface content of every level-0 layer along the slab axis, from an unpartitioned coarse regen of the scene
+    const int saved_skip = h->skip_weld;
+    h->skip_weld = 1;
+    sdmesh_regen_info info;
+    const int rc = regen_impl(h, probe_levels, SDMESH_PART_NONE, 0, 1, &info);
+    h->skip_weld = saved_skip;
+    SDCHK(rc);
+    std::vector<Point> vox(std::max<uint32_t>(h->n_vox, 1));
+    SDCHK(sdmesh_download_voxels(h, vox.data()));
+    double w[32] = {0};
+    const float cell = MESH_GENERATION_BB_SIZE / (float) F;
+    for (uint32_t i = 0; i < h->n_vox; i++) {
+        const float c = mode == SDMESH_PART_XSLAB ? vox[i].x : vox[i].z;
+        int l = (int) floorf((c + MESH_GENERATION_BB_SIZE / 2.0f) / cell);
+        l = l < 0 ? 0 : (l >= F ? F - 1 : l);
+        w[l] += 1.0;
+    }
+    double total = 0;
+    for (int l = 0; l < F; l++) total += w[l];
+    for (int l = 0; l < F; l++) w[l] += 0.002 * total / F + 1e-9;          // an empty layer still costs its level-0 cells: never free
+    // contiguous partition of the 32 layers into nparts slabs minimising the heaviest slab (dynamic programme, 32 x 32 x nparts)
+    double pre[33]; pre[0] = 0;
+    for (int l = 0; l < F; l++) pre[l + 1] = pre[l] + w[l];
+    static double best[33][33]; static int cut[33][33];
+    for (int e = 0; e <= F; e++) { best[1][e] = e >= 1 ? pre[e] : 1e300; cut[1][e] = 0; }
+    for (int k = 2; k <= nparts; k++)
+        for (int e = 0; e <= F; e++) {
+            best[k][e] = 1e300; cut[k][e] = k - 1;
+            for (int m = k - 1; m < e; m++) {                         // every slab at least one layer thick
+                const double v = std::max(best[k - 1][m], pre[e] - pre[m]);
+                if (v < best[k][e]) { best[k][e] = v; cut[k][e] = m; }
+            }
+        }
+    uint32_t b[33];
+    b[nparts] = (uint32_t) F;
+    for (int k = nparts, e = F; k >= 1; k--) { e = cut[k][e]; b[k - 1] = (uint32_t) e; }
+    b[0] = 0;
+    SDCHK(sdmesh_set_slab_bounds(h, mode, nparts, b));
+    if (bounds_out) memcpy(bounds_out, b, sizeof(uint32_t) * (size_t) (nparts + 1));
+    return SDMESH_OK;
+}
+
 extern "C" int sdmesh_profile_rounds(sdmesh_handle *h, uint64_t *vertex_rounds) {
     if (!h || !vertex_rounds) return SDMESH_ERR_INVALID;
     if (!h->prof_rounds.p) return fail(h, SDMESH_ERR_INVALID, "no profiled regen yet (option \"profile\")");
@@ -1768,7 +1850,7 @@ int sdmesh_sharded_regen(sdmesh_handle *h, int levels, int root, sdmesh_regen_in
     }
     // 4. order-restoring merge (HIP kernel), then the first-seen weld of the merged list = the single-GPU mesh
     SDCHK(merge_lists(h, d_counts, R, (Triangle *) h->shard_merged.p, (size_t) total));
-    SDCHK(sdmesh_weld_device_triangles(h, (const Triangle *) h->shard_merged.p, (size_t) total, info));
+    SDCHK(weld_device_impl(h, (const Triangle *) h->shard_merged.p, (size_t) total, info, true));      // (all slots valid: no compaction pass)
     if (info) {
         info->levels = (uint32_t) levels;
         info->voxel_size = slab.voxel_size;

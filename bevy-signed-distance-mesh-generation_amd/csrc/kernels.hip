@@ -1426,9 +1426,11 @@ __global__ __launch_bounds__(256) void k_project1(Vertex *__restrict__ uverts, c
 // its own vertex (tri_e = identity), no flips
 __global__ __launch_bounds__(256) void k_raw_desc(const uint32_t *__restrict__ ntri_ptr, uint4 *__restrict__ tdesc,
                                                    uint8_t *__restrict__ flip, uint32_t *__restrict__ ntiles_out,
-                                                   uint32_t *__restrict__ nu_out) {
+                                                   uint32_t *__restrict__ nu_out, uint32_t *__restrict__ tri_e /* optional: identity */) {
     const uint32_t T = *ntri_ptr, ntiles = (T + 255u) / 256u;
     for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < T; i += gridDim.x * blockDim.x) flip[i] = 0;
+    if (tri_e)
+        for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < 3u * T; i += gridDim.x * blockDim.x) tri_e[i] = i;
     for (uint32_t t = blockIdx.x * blockDim.x + threadIdx.x; t < ntiles; t += gridDim.x * blockDim.x) {
         const uint32_t tt = T - 256u * t < 256u ? T - 256u * t : 256u;
         tdesc[t] = make_uint4(768u * t, 3u * tt, 256u * t, tt);
@@ -2287,8 +2289,8 @@ hipError_t launch_render(hipStream_t st, int scene, const SceneParams *sp, const
 }
 
 hipError_t launch_raw_desc(hipStream_t st, int grid, const uint32_t *ntri_ptr, uint4 *tdesc, uint8_t *flip, uint32_t *ntiles_out,
-                           uint32_t *nu_out) {
-    hipLaunchKernelGGL(k_raw_desc, dim3(grid), dim3(256), 0, st, ntri_ptr, tdesc, flip, ntiles_out, nu_out);
+                           uint32_t *nu_out, uint32_t *tri_e) {
+    hipLaunchKernelGGL(k_raw_desc, dim3(grid), dim3(256), 0, st, ntri_ptr, tdesc, flip, ntiles_out, nu_out, tri_e);
     return hipGetLastError();
 }
 

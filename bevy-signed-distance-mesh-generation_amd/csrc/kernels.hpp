@@ -64,7 +64,7 @@ hipError_t launch_flip_claim(hipStream_t st, int flip_grid, int claim_grid, int 
 hipError_t launch_flip(hipStream_t st, int grid, int scene, const SceneParams *sp, const Vertex *uverts, const uint32_t *tri_e,
                        const uint32_t *ntri_ptr, uint8_t *flip, int lanes = 4);
 hipError_t launch_raw_desc(hipStream_t st, int grid, const uint32_t *ntri_ptr, uint4 *tdesc, uint8_t *flip, uint32_t *ntiles_out,
-                           uint32_t *nu_out);
+                           uint32_t *nu_out, uint32_t *tri_e = nullptr);
 hipError_t launch_tile_claim(hipStream_t st, int grid, const Vertex *uverts, const uint4 *tdesc, const uint32_t *ntiles_ptr,
                              uint64_t *wkeys, uint32_t wsize, uint32_t *vslot, uint32_t *status, uint32_t wmode, uint32_t *wrep, uint2 *wfm);
 hipError_t launch_merge_by_column(hipStream_t st, const Triangle *const *d_lists, const uint32_t *d_counts, int nranks, uint32_t *d_plan,

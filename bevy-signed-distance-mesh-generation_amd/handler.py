@@ -306,6 +306,20 @@ class CudaHandler:
         self._chk(self._lib.sdmesh_column_triangle_counts(self._h, ctypes.c_void_p(dev_ptr)))
 
     # -- one mesh over several GPUs -----------------------------------------------
+    def balance_slabs(self, mode, nparts, probe_levels=3):
+        """Install slab boundaries that give every slab about the same share of the surface (sdmesh_balance_slabs);
+        returns the nparts + 1 level-0 layer boundaries."""
+        b = (ctypes.c_uint32 * (int(nparts) + 1))()
+        self._chk(self._lib.sdmesh_balance_slabs(self._h, int(mode), int(nparts), int(probe_levels), b))
+        return [int(x) for x in b]
+
+    def set_slab_bounds(self, mode, nparts, bounds):
+        if bounds is None:
+            self._chk(self._lib.sdmesh_set_slab_bounds(self._h, int(mode), int(nparts), None))
+        else:
+            b = (ctypes.c_uint32 * len(bounds))(*[int(x) for x in bounds])
+            self._chk(self._lib.sdmesh_set_slab_bounds(self._h, int(mode), int(nparts), b))
+
     def merge_by_column(self, list_ptrs, counts_ptr, out_ptr, cap):
         """Order-restoring merge (HIP kernel): list_ptrs = device pointers of the ranks' compact triangle lists, counts_ptr
         = device pointer of the [R, 1024] uint32 per-column counts; returns the merged triangle count."""

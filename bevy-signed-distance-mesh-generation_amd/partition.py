@@ -72,10 +72,12 @@ class ShardedMesher:
     TRANSPORT differs: counts and triangle lists are staged through host memory by torch.distributed, everything else
     -- slab regen, column counts, `sdmesh_merge_by_column`, `sdmesh_weld_device_triangles` -- is the same C ABI."""
 
-    def __init__(self, pkg, handler, levels, rank, world, device, transport=None):
+    def __init__(self, pkg, handler, levels, rank, world, device, transport=None, balance=True):
         import torch.distributed as dist
         self.pkg, self.h, self.levels, self.rank, self.world, self.dev = pkg, handler, levels, rank, world, device
         self.dist = dist
+        # slabs of equal surface content instead of equal thickness (every rank derives the same table from the scene)
+        self.bounds = handler.balance_slabs(pkg.PART_ZSLAB, world, min(levels, 3)) if (balance and world > 1) else None
         if transport is None:
             transport = "staged" if (world > 1 and dist.get_backend() == "gloo") else "rccl"
         self.transport = transport
@@ -170,12 +172,16 @@ class DistributedMesher:
          concatenates the parts on the root -- no root-side weld, nothing proportional to the whole mesh is re-hashed.
     Transport as in ShardedMesher: the current process group ("nccl" direct, "gloo" staged through host memory)."""
 
-    def __init__(self, pkg, handler, levels, rank, world, device):
+    def __init__(self, pkg, handler, levels, rank, world, device, balance=True, bounds=None):
         import torch.distributed as dist
         self.pkg, self.h, self.levels, self.rank, self.world, self.dev, self.dist = pkg, handler, levels, rank, world, device, dist
         self.staged = world > 1 and dist.get_backend() == "gloo"
         size = torch.tensor(5.0, dtype=torch.float32) / torch.tensor(float(INIT_FACTOR << levels), dtype=torch.float32)
-        lo, hi = slab_bounds(rank, world)
+        if bounds is None and balance and handler is not None and world > 1:
+            # slabs of equal surface content instead of equal thickness (every rank derives the same table from the scene)
+            bounds = handler.balance_slabs(pkg.PART_XSLAB, world, min(levels, 3))
+        self.bounds = bounds
+        lo, hi = (bounds[rank], bounds[rank + 1]) if bounds is not None else slab_bounds(rank, world)
         self.band = 2.5 * float(size)      # a projected vertex stays within ~a voxel diagonal of its lattice edge
         self.x_lo = -2.5 + 5.0 * lo / INIT_FACTOR
         self.x_hi = -2.5 + 5.0 * hi / INIT_FACTOR

@@ -204,6 +204,15 @@ int sdmesh_download_voxels(sdmesh_handle *h, struct Point *voxels);
 
 /* ---- one mesh over several GPUs (the reference is single-device, src/cuda/mod.rs:52) ------------- */
 
+/* Slab boundaries of the partitioned regens, in level-0 layers along the slab axis (z for ZSLAB, x for XSLAB).  Default:
+ * uniform, [32 p / n, 32 (p + 1) / n).  The reference scene occupies 14 of the 32 z layers, so uniform slabs leave half of
+ * eight GPUs idle: sdmesh_balance_slabs meshes the scene once, unpartitioned, at `probe_levels` (<= 4), counts the active
+ * voxels per layer and installs the contiguous split that minimises the heaviest slab.  Deterministic (every rank that
+ * calls it with the same scene gets the same table); bounds_out (optional) receives the nparts + 1 boundaries.
+ * sdmesh_set_slab_bounds installs a caller-made table (NULL: back to uniform).  Empty slabs are allowed. */
+int sdmesh_set_slab_bounds(sdmesh_handle *h, int mode, int nparts, const uint32_t *bounds);
+int sdmesh_balance_slabs(sdmesh_handle *h, int mode, int nparts, int probe_levels, uint32_t *bounds_out);
+
 /* Order-restoring merge of `nranks` per-slab compact triangle lists (each from sdmesh_device_triangles of a
  * SDMESH_PART_ZSLAB regen) into the single-GPU emission order: d_lists = HOST array of nranks DEVICE pointers, d_counts =
  * DEVICE array of nranks x 1024 per-column counts (sdmesh_column_triangle_counts of every rank, rank-major).  A HIP
