@@ -312,11 +312,11 @@ def roofline_step_leg(pkg, local_rank, scene, params, levels, consts, info):
     ceiling = consts.get("valu_ubench_wave_instr_per_s")
     out = {"what": "VALU roofline of the step's throughput-bound kernels: wave64 VALU instructions per launch (SQ_INSTS_VALU, "
                    "profiles/constants.json) / live stage time; peak = 157.3 TF / 2 / 64; ceiling_ubench = what a dependent-free "
-                   "f32 VALU stream sustains on this part (tools/ubench/pk_rate.hip)",
+                   "f32 VALU stream sustains on this part (tools/ubench/valu_rate.hip, profiles/constants.json)",
            "peak": VALU_PEAK_WAVE_INSTR_PER_S, "ceiling_ubench": ceiling, "unit": "wave-instr/s",
            "stage_us": stages, "stage_sum_us": round(sum(stages.values()), 2)}
-    evals = {"project": 13 * rounds if rounds else None, "flip_claim": 12 * int(info.triangles)}
-    for key, stage_prefix in (("project", "project"), ("flip_claim", "flip_claim")):
+    evals = {"project": 13 * rounds if rounds else None, "flip": 12 * int(info.triangles)}
+    for key, stage_prefix in (("project", "project"), ("flip", "flip_claim"), ("flip", "tile_first_flip")):
         name = next((s for s in stages if s.startswith(stage_prefix)), None)
         if name is None:
             continue

@@ -405,13 +405,17 @@ int mesh_front(sdmesh_handle *h, const Point *d_vox, const uint32_t *n_ptr, Poin
 // per-tile weld of (uverts, tri_e, flip) described by tdesc[0..*NTILES) -> vertices / indices
 int mesh_weld(sdmesh_handle *h, const Vertex *uverts) {
     hipStream_t st = h->stream;
-    HIPCHK(launch_weld(st, h->tgrid, uverts, (const uint4 *) h->tdesc.p, h->d_ctr + CTR_NTILES, (uint32_t *) h->tri_e.p,
-                       (const uint8_t *) h->flip.p, h->first_ord, h->wfm, (const uint32_t *) h->wrep_buf.p, (uint32_t *) h->vslot.p,
-                       (uint32_t *) h->wvidx.p, (uint32_t *) h->torder.p, (uint32_t *) h->tfirst.p, (uint32_t *) h->tfpre.p,
-                       (Vertex *) h->vertices.p, (uint32_t) (h->vertices.cap / sizeof(Vertex)), h->d_ctr + CTR_NVERT,
-                       (uint32_t *) h->indices.p, h->d_status, h->flip_pending ? h->scene : -1, h->d_sp));
+    const int flip_scene = h->flip_pending ? h->scene : -1;
     h->flip_pending = false;
-    SDCHK(prof_mark(h, "weld"));
+    for (int part = h->profile ? 1 : 0; part <= (h->profile ? 2 : 0); part++) {        // profiling: a stage marker behind k_tile_first
+        HIPCHK(launch_weld(st, h->tgrid, uverts, (const uint4 *) h->tdesc.p, h->d_ctr + CTR_NTILES, (uint32_t *) h->tri_e.p,
+                           (const uint8_t *) h->flip.p, h->first_ord, h->wfm, (const uint32_t *) h->wrep_buf.p, (uint32_t *) h->vslot.p,
+                           (uint32_t *) h->wvidx.p, (uint32_t *) h->torder.p, (uint32_t *) h->tfirst.p, (uint32_t *) h->tfpre.p,
+                           (Vertex *) h->vertices.p, (uint32_t) (h->vertices.cap / sizeof(Vertex)), h->d_ctr + CTR_NVERT,
+                           (uint32_t *) h->indices.p, h->d_status, flip_scene, h->d_sp, part));
+        if (part == 1) SDCHK(prof_mark(h, flip_scene >= 0 ? "tile_first_flip" : "tile_first"));
+    }
+    SDCHK(prof_mark(h, h->profile ? "weld_rank_scan_finish" : "weld"));
     return SDMESH_OK;
 }
 

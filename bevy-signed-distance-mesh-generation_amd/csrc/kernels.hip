@@ -2305,7 +2305,10 @@ hipError_t launch_weld(hipStream_t st, int grid, const Vertex *uverts, const uin
                        uint32_t *tri_e, const uint8_t *flip, uint32_t *first_ord, uint2 *wfm, const uint32_t *wrep,
                        uint32_t *vslot, uint32_t *wv, uint32_t *torder, uint32_t *tfirst, uint32_t *tfpre,
                        Vertex *vertices, uint32_t vcap, uint32_t *nverts_out, uint32_t *indices, uint32_t *status,
-                       int flip_scene, const SceneParams *sp) {
+                       int flip_scene, const SceneParams *sp, int part) {
+    // part: 0 = the whole weld, 1 = k_tile_first only, 2 = everything behind it (so that a stage marker fits between)
+    const bool stop_after_first = part == 1;
+    if (part == 2) goto rest;
     if (flip_scene >= 0) {
         switch (flip_scene) {
         case SCENE_SDOBJ: hipLaunchKernelGGL(k_tile_first<SCENE_SDOBJ>, dim3(grid), dim3(256), 0, st, tdesc, ntiles_ptr, tri_e, flip, uverts, sp, vslot, first_ord, wrep, wfm); break;
@@ -2318,6 +2321,8 @@ hipError_t launch_weld(hipStream_t st, int grid, const Vertex *uverts, const uin
     } else {
         hipLaunchKernelGGL(k_tile_first<-1>, dim3(grid), dim3(256), 0, st, tdesc, ntiles_ptr, tri_e, flip, uverts, sp, vslot, first_ord, wrep, wfm);
     }
+    if (stop_after_first) return hipGetLastError();
+rest:
     hipLaunchKernelGGL(k_tile_rank, dim3(grid), dim3(256), 0, st, tdesc, ntiles_ptr, first_ord, wfm, vslot, wv, torder,
                        tfirst);
     hipLaunchKernelGGL(k_scan_u32, dim3(1), dim3(1024), 0, st, tfirst, ntiles_ptr, tfpre, nverts_out);

@@ -73,7 +73,8 @@ hipError_t launch_weld(hipStream_t st, int grid, const Vertex *uverts, const uin
                        uint32_t *tri_e, const uint8_t *flip, uint32_t *first_ord, uint2 *wfm, const uint32_t *wrep,
                        uint32_t *vslot, uint32_t *wv, uint32_t *torder, uint32_t *tfirst, uint32_t *tfpre,
                        Vertex *vertices, uint32_t vcap, uint32_t *nverts_out, uint32_t *indices, uint32_t *status,
-                       int flip_scene = -1 /* >= 0: the orientation test runs inside k_tile_first */, const SceneParams *sp = nullptr);
+                       int flip_scene = -1 /* >= 0: the orientation test runs inside k_tile_first */, const SceneParams *sp = nullptr,
+                       int part = 0);
 hipError_t launch_expand_compact(hipStream_t st, int grid, const Vertex *uverts, const uint32_t *tri_e, const uint8_t *flip,
                                  const uint32_t *ntri_ptr, Triangle *out, uint32_t cap);
 hipError_t launch_expand_raw(hipStream_t st, int grid, const Vertex *uverts, const uint32_t *tri_e, const uint8_t *flip,

@@ -7,13 +7,19 @@ R=$(pwd); O=$R/gpurun_out/prof; rm -rf $O; mkdir -p $O
 cd /tmp && export TMPDIR=/tmp
 P=python3
 run() { name=$1; shift; echo "== $name"; timeout -k 10 300 rocprofv3 "$@" > $O/$name.stdout 2> $O/$name.stderr; echo "rc=$?"; }
-run regen_trace --kernel-trace --stats --output-format csv -d $O/regen_trace -- $P $R/tools/prof_regen.py sdobj 4 20 || exit 1
-run regen_pmc_sq --kernel-trace --pmc SQ_INSTS_VALU SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_WAIT_INST_ANY GRBM_GUI_ACTIVE --output-format csv -d $O/regen_pmc_sq -- $P $R/tools/prof_regen.py sdobj 4 3 || exit 1
+run regen_trace --kernel-trace --stats --output-format csv -d $O/regen_trace -- $P $R/tools/prof_regen.py sdobj 4 40 || exit 1
+run regen_pmc_sq --kernel-trace --pmc SQ_INSTS_VALU SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_WAIT_INST_ANY GRBM_GUI_ACTIVE --output-format csv -d $O/regen_pmc_sq -- $P $R/tools/prof_regen.py sdobj 4 5 || exit 1
+run regen_fetch --kernel-trace --pmc FETCH_SIZE --output-format csv -d $O/regen_fetch -- $P $R/tools/prof_regen.py sdobj 4 3 || exit 1
+run regen_write --kernel-trace --pmc WRITE_SIZE --output-format csv -d $O/regen_write -- $P $R/tools/prof_regen.py sdobj 4 3 || exit 1
 run dense_write --kernel-trace --pmc WRITE_SIZE --output-format csv -d $O/dense_write -- $P $R/tools/dense_once.py || exit 1
 run dense_fetch --kernel-trace --pmc FETCH_SIZE --output-format csv -d $O/dense_fetch -- $P $R/tools/dense_once.py || exit 1
-run bench_trace --kernel-trace --stats --output-format csv -d $O/bench_trace -- $P $R/bench.py --steps 100 --warmup 10 --no-cpu-baseline --no-sizes --no-pipelined || exit 1
-cd $R && echo "== plain bench" && timeout -k 10 400 $P bench.py > $O/bench_plain.json 2> $O/bench_plain.stderr; echo "rc=$?"
-python3 $R/tools/streaming_window.py $O/bench_trace $O/streaming_window.csv
+run bench_trace --kernel-trace --stats --output-format csv -d $O/bench_trace -- $P $R/bench.py --steps 100 --warmup 10 --no-cpu-baseline --no-sizes --no-pipelined --no-anim || exit 1
+cd $R
+echo "== ubench"; timeout -k 10 60 ./tools/ubench/valu_rate > $O/valu_rate.jsonl 2> $O/valu_rate.stderr; echo "rc=$?"
+echo "== projection timeline"; timeout -k 10 100 $P tools/project_timeline.py sdobj 4 $O/project_timeline.json > $O/project_timeline.stdout 2>&1; echo "rc=$?"
+echo "== dedupe phases"; timeout -k 10 100 $P tools/tile_phases.py sdobj 4 > $O/tile_phases.txt 2>&1; echo "rc=$?"
+echo "== plain bench"; timeout -k 10 500 $P bench.py > $O/bench_plain.json 2> $O/bench_plain.stderr; echo "rc=$?"
+$P $R/tools/streaming_window.py $O/bench_trace $O/streaming_window.csv
 # keep only the small summaries (the raw traces are large)
 find $O -name '*_kernel_trace.csv' -size +4M -delete
 find $O -name '*_counter_collection.csv' -size +8M -delete
