@@ -115,6 +115,8 @@ SYMBOLS = {
     "sdmesh_comm_destroy": (_i, [_vp]),
     "sdmesh_comm_ranks": (_i, [_vp, ctypes.POINTER(_i)]),
     "sdmesh_sharded_regen": (_i, [_vp, _i, _i, ctypes.POINTER(RegenInfo)]),
+    "sdmesh_distributed_regen": (_i, [_vp, _i, ctypes.POINTER(RegenInfo), ctypes.POINTER(_u32)]),
+    "sdmesh_distributed_regen_rehearsal": (_i, [_vp, _i, _i, _vp, _vp]),
     "sdmesh_download_mesh": (_i, [_vp, _vp, _vp]),
     "sdmesh_download_voxels": (_i, [_vp, _vp]),
     "sdmesh_regen_dense": (_i, [_vp, _i, ctypes.POINTER(RegenInfo)]),

@@ -40,6 +40,10 @@ enum {
     CTR_NSLOTS = 19,
     CTR_SCRATCH = 20,
     CTR_NTILES = 21,
+    CTR_DIST_NUP = 22,      // distributed weld: vertices in the upper / lower face band, vertices kept, vertex count
+    CTR_DIST_NLO = 23,
+    CTR_DIST_NKEEP = 24,
+    CTR_DIST_V = 25,
     CTR_WORDS = 32,
     CTL_LVL0 = 64          // control block: [counters 32 | status 8 | pad | per-level tile counters ...]
 };
@@ -171,6 +175,11 @@ struct sdmesh_handle {
     uint32_t *h_counts = nullptr;      // pinned: nranks x 1024 column counts (root)
     size_t h_counts_words = 0;
     void **h_lists = nullptr;          // pinned: nranks device pointers
+
+    // distributed weld (x-slabs): band lists, neighbour messages, match table, numbering
+    DevBuf dist_upids, dist_upkeys, dist_loids, dist_prevkeys, dist_hkeys, dist_hpos, dist_dupof, dist_newidx, dist_tilecnt, dist_counts,
+        dist_upg, dist_prevg, dist_verts, dist_nups;
+    uint32_t dist_V = 0, dist_T = 0, dist_nup = 0, dist_nprev = 0;
 
     // slab boundaries of the partitioned regens (level-0 layers); slab_nparts == 0: uniform
     int slab_mode = 0, slab_nparts = 0;
@@ -999,7 +1008,8 @@ void sdmesh_destroy(sdmesh_handle *h) {
     DevBuf *bufs[] = {&h->render_tex, &h->vox[0], &h->vox[1], &h->mask, &h->mask2x, &h->signs, &h->tilecnt, &h->ctl, &h->cubeidx, &h->trioff, &h->ff_arena,
                       &h->first_ord_buf, &h->uverts, &h->tri_e, &h->vslot, &h->tdesc, &h->tfirst, &h->tfpre, &h->tpre, &h->flip, &h->wvidx, &h->torder, &h->wrep_buf, &h->wfm_buf,
                       &h->vertices, &h->indices, &h->raw, &h->compact, &h->staging, &h->dense_samples, &h->dense_bits,
-                      &h->cellcnt, &h->col_list1, &h->col_mask2, &h->col_mask3, &h->colinfo, &h->prof_rounds, &h->proj_diag, &h->shard_mine, &h->shard_counts, &h->shard_recv, &h->shard_lists, &h->shard_plan, &h->shard_merged};
+                      &h->cellcnt, &h->dist_upids, &h->dist_upkeys, &h->dist_loids, &h->dist_prevkeys, &h->dist_hkeys, &h->dist_hpos, &h->dist_dupof,
+                      &h->dist_newidx, &h->dist_tilecnt, &h->dist_counts, &h->dist_upg, &h->dist_prevg, &h->dist_verts, &h->dist_nups, &h->col_list1, &h->col_mask2, &h->col_mask3, &h->colinfo, &h->prof_rounds, &h->proj_diag, &h->shard_mine, &h->shard_counts, &h->shard_recv, &h->shard_lists, &h->shard_plan, &h->shard_merged};
     (void) sdmesh_comm_destroy(h);
     if (h->h_counts) (void) hipHostFree(h->h_counts);
     if (h->h_lists) (void) hipHostFree(h->h_lists);
@@ -1858,6 +1868,183 @@ int sdmesh_sharded_regen(sdmesh_handle *h, int levels, int root, sdmesh_regen_in
     if (info) {
         info->levels = (uint32_t) levels;
         info->voxel_size = slab.voxel_size;
+    }
+    return SDMESH_OK;
+}
+
+}  // extern "C"
+
+// ================================================================================================
+// Multi-GPU: ONE mesh, x-slabs, DISTRIBUTED weld (the mesh stays distributed)
+// ================================================================================================
+namespace {
+
+// phase 1: this rank's slab, meshed AND welded locally; then the face bands (enqueued, not waited for)
+int dist_phase_local(sdmesh_handle *h, int levels, int R, int me, sdmesh_regen_info *slab) {
+    SDCHK(regen_impl(h, levels, SDMESH_PART_XSLAB, me, R, slab));
+    if (!h->welded || h->last_direct) return fail(h, SDMESH_ERR_INTERNAL, "the distributed weld needs the locally welded lattice path");
+    hipStream_t st = h->stream;
+    const uint32_t V = h->n_verts, T = h->n_tris;
+    h->dist_V = V; h->dist_T = T;
+    const size_t vcap = std::max<uint32_t>(V, 64);
+    SDCHK(ensure_grow(h, h->dist_upids, 4 * vcap));
+    SDCHK(ensure_grow(h, h->dist_upkeys, 8 * vcap));
+    SDCHK(ensure_grow(h, h->dist_loids, 4 * vcap));
+    SDCHK(ensure_grow(h, h->dist_dupof, 4 * vcap));
+    SDCHK(ensure_grow(h, h->dist_newidx, 4 * vcap));
+    SDCHK(ensure_grow(h, h->dist_tilecnt, 4ull * (tiles((uint32_t) vcap) + 16)));
+    SDCHK(ensure_grow(h, h->dist_upg, 4 * vcap));
+    SDCHK(ensure(h, h->dist_verts, std::max<size_t>(h->vertices.cap, sizeof(Vertex) * vcap)));   // swapped with h->vertices below: same capacity
+    SDCHK(ensure(h, h->dist_counts, 4ull * 32));
+    SDCHK(ensure(h, h->dist_nups, 4ull * 32));
+    const uint32_t F = MESH_GENERATION_INIT_FACTOR;
+    uint32_t lo = F * (uint32_t) me / (uint32_t) R, hi = F * (uint32_t) (me + 1) / (uint32_t) R;
+    if (h->slab_nparts == R && h->slab_mode == SDMESH_PART_XSLAB) { lo = h->slab_bounds[me]; hi = h->slab_bounds[me + 1]; }
+    // a projected vertex stays within about a voxel of its lattice edge: 2.5 voxels of the finest level is a safe band
+    const float band = 2.5f * ((MESH_GENERATION_BB_SIZE / (float) F) / (float) (1u << levels));
+    const float x_lo = -MESH_GENERATION_BB_SIZE / 2.0f + MESH_GENERATION_BB_SIZE * (float) lo / (float) F;
+    const float x_hi = -MESH_GENERATION_BB_SIZE / 2.0f + MESH_GENERATION_BB_SIZE * (float) hi / (float) F;
+    HIPCHK(hipMemsetAsync(h->d_ctr + CTR_DIST_NUP, 0, 4 * sizeof(uint32_t), st));
+    SDCHK(zero_status(h));
+    HIPCHK(launch_band_select(st, h->grid, (const Vertex *) h->vertices.p, V, x_hi - band, x_lo + band, me + 1 < R, me > 0,
+                              (uint32_t *) h->dist_upids.p, (uint64_t *) h->dist_upkeys.p, (uint32_t *) h->dist_loids.p,
+                              h->d_ctr + CTR_DIST_NUP, (uint32_t *) h->dist_dupof.p, h->d_status));
+    return SDMESH_OK;
+}
+
+// phase 2: match my lower band against the lower neighbour's upper-band keys (already in dist_prevkeys), number what I keep
+int dist_phase_match(sdmesh_handle *h, uint32_t n_prev) {
+    hipStream_t st = h->stream;
+    if (n_prev) {
+        const uint32_t hsize = 2u * n_prev + 64u;
+        SDCHK(ensure_grow(h, h->dist_hkeys, 8ull * hsize));
+        SDCHK(ensure_grow(h, h->dist_hpos, 4ull * hsize));
+        HIPCHK(hipMemsetAsync(h->dist_hkeys.p, 0xFF, 8ull * hsize, st));
+        HIPCHK(launch_dist_match(st, h->grid, (const uint64_t *) h->dist_prevkeys.p, n_prev, (uint64_t *) h->dist_hkeys.p, (uint32_t *) h->dist_hpos.p,
+                                 hsize, (const Vertex *) h->vertices.p, (const uint32_t *) h->dist_loids.p, h->d_ctr + CTR_DIST_NLO,
+                                 (uint32_t *) h->dist_dupof.p, h->d_status));
+    }
+    HIPCHK(launch_set_u32(st, h->d_ctr + CTR_DIST_V, h->dist_V));
+    HIPCHK(launch_dist_number(st, h->tgrid, (const uint32_t *) h->dist_dupof.p, h->dist_V, h->d_ctr + CTR_DIST_V, (uint32_t *) h->dist_tilecnt.p,
+                              h->d_ctr + CTR_DIST_NKEEP, (uint32_t *) h->dist_newidx.p, h->d_status));
+    return SDMESH_OK;
+}
+
+// phase 3: the global numbers of my upper band (dist_counts holds every rank's kept count)
+int dist_phase_pack(sdmesh_handle *h, int me, uint32_t n_up) {
+    if (n_up)
+        HIPCHK(launch_dist_pack_up(h->stream, h->grid, (const uint32_t *) h->dist_upids.p, n_up, (const uint32_t *) h->dist_newidx.p,
+                                   (const uint32_t *) h->dist_counts.p, (uint32_t) me, (uint32_t *) h->dist_upg.p));
+    return SDMESH_OK;
+}
+
+// phase 4: kept vertices compacted, indices global (dist_prevg holds the lower neighbour's numbers of its upper band)
+int dist_phase_final(sdmesh_handle *h, int me) {
+    HIPCHK(launch_dist_finalize(h->stream, h->grid, (const Vertex *) h->vertices.p, h->dist_V, h->dist_T, (const uint32_t *) h->dist_dupof.p,
+                                (const uint32_t *) h->dist_newidx.p, (const uint32_t *) h->dist_prevg.p, (const uint32_t *) h->dist_counts.p,
+                                (uint32_t) me, (uint32_t *) h->indices.p, (Vertex *) h->dist_verts.p));
+    std::swap(h->vertices, h->dist_verts);                 // the compacted list becomes the handle's vertex buffer
+    h->buf_gen++;
+    return SDMESH_OK;
+}
+
+int dist_finish_host(sdmesh_handle *h, int R, int me, const uint32_t *counts, sdmesh_regen_info *info, const sdmesh_regen_info &slab,
+                     uint32_t *first_vertex) {
+    if (h->h_pinned[CTR_WORDS + ST_WELD_RANGE]) return fail(h, SDMESH_ERR_WELD_RANGE, "the distributed weld needs vertices inside the packed key range");
+    uint32_t off = 0;
+    for (int r = 0; r < me; r++) off += counts[r];
+    h->n_verts = counts[me];
+    h->mesh_valid = true;
+    if (info) { *info = slab; info->vertices = counts[me]; }
+    if (first_vertex) *first_vertex = off;
+    (void) R;
+    return SDMESH_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int sdmesh_distributed_regen(sdmesh_handle *h, int levels, sdmesh_regen_info *info, uint32_t *first_vertex) {
+    if (!h) return SDMESH_ERR_INVALID;
+    if (!h->comm) return fail(h, SDMESH_ERR_INVALID, "no communicator (sdmesh_comm_init)");
+    const int R = h->comm_nranks, me = h->comm_rank;
+    hipStream_t st = h->stream;
+    sdmesh_regen_info slab;
+    SDCHK(dist_phase_local(h, levels, R, me, &slab));
+    uint32_t nups[32] = {0}, counts[32] = {0};
+    if (R == 1) {
+        HIPCHK(hipStreamSynchronize(st));
+        counts[0] = h->dist_V;
+        return dist_finish_host(h, R, me, counts, info, slab, first_vertex);
+    }
+    // band sizes of every rank (the one extra host synchronisation of a distributed step: message lengths must be host values)
+    uint32_t *d_nups = (uint32_t *) h->dist_nups.p, *d_counts = (uint32_t *) h->dist_counts.p;
+    NCCLCHK(g_rccl.AllGather(h->d_ctr + CTR_DIST_NUP, d_nups, 1, ncclUint32, h->comm, st));
+    HIPCHK(hipMemcpyAsync(nups, d_nups, 4ull * (size_t) R, hipMemcpyDeviceToHost, st));
+    HIPCHK(hipStreamSynchronize(st));
+    const uint32_t n_up = me + 1 < R ? nups[me] : 0u, n_prev = me > 0 ? nups[me - 1] : 0u;
+    SDCHK(ensure_grow(h, h->dist_prevkeys, 8ull * std::max<uint32_t>(n_prev, 1)));
+    SDCHK(ensure_grow(h, h->dist_prevg, 4ull * std::max<uint32_t>(n_prev, 1)));
+    NCCLCHK(g_rccl.GroupStart());
+    if (n_up) NCCLCHK(g_rccl.Send(h->dist_upkeys.p, n_up, ncclUint64, me + 1, h->comm, st));
+    if (n_prev) NCCLCHK(g_rccl.Recv(h->dist_prevkeys.p, n_prev, ncclUint64, me - 1, h->comm, st));
+    NCCLCHK(g_rccl.GroupEnd());
+    SDCHK(dist_phase_match(h, n_prev));
+    NCCLCHK(g_rccl.AllGather(h->d_ctr + CTR_DIST_NKEEP, d_counts, 1, ncclUint32, h->comm, st));
+    SDCHK(dist_phase_pack(h, me, n_up));
+    NCCLCHK(g_rccl.GroupStart());
+    if (n_up) NCCLCHK(g_rccl.Send(h->dist_upg.p, n_up, ncclUint32, me + 1, h->comm, st));
+    if (n_prev) NCCLCHK(g_rccl.Recv(h->dist_prevg.p, n_prev, ncclUint32, me - 1, h->comm, st));
+    NCCLCHK(g_rccl.GroupEnd());
+    SDCHK(dist_phase_final(h, me));
+    HIPCHK(hipMemcpyAsync(counts, d_counts, 4ull * (size_t) R, hipMemcpyDeviceToHost, st));
+    SDCHK(read_back(h));
+    return dist_finish_host(h, R, me, counts, info, slab, first_vertex);
+}
+
+// The same step for `nranks` handles of ONE process on one device, device-to-device copies standing in for the two
+// neighbour messages and host arithmetic for the two all-gathers: every kernel and every phase of the distributed weld
+// runs exactly as under RCCL -- the rehearsal the tests use on a one-GPU box (RCCL refuses two ranks on one device).
+int sdmesh_distributed_regen_rehearsal(sdmesh_handle **hs, int nranks, int levels, sdmesh_regen_info *infos, uint32_t *first_vertex) {
+    if (!hs || nranks < 1 || nranks > 32) return SDMESH_ERR_INVALID;
+    for (int r = 0; r < nranks; r++) if (!hs[r]) return SDMESH_ERR_INVALID;
+    const int R = nranks;
+    std::vector<sdmesh_regen_info> slab((size_t) R);
+    uint32_t nups[32] = {0}, counts[32] = {0};
+    for (int r = 0; r < R; r++) {
+        sdmesh_handle *h = hs[r];
+        SDCHK(dist_phase_local(h, levels, R, r, &slab[(size_t) r]));
+        HIPCHK(hipMemcpyAsync(&nups[r], h->d_ctr + CTR_DIST_NUP, 4, hipMemcpyDeviceToHost, h->stream));
+        HIPCHK(hipStreamSynchronize(h->stream));
+    }
+    for (int r = 0; r < R; r++) {
+        sdmesh_handle *h = hs[r];
+        const uint32_t n_prev = r > 0 ? nups[r - 1] : 0u;
+        if (n_prev) {
+            SDCHK(ensure_grow(h, h->dist_prevkeys, 8ull * n_prev));
+            SDCHK(ensure_grow(h, h->dist_prevg, 4ull * n_prev));
+            HIPCHK(hipMemcpyAsync(h->dist_prevkeys.p, hs[r - 1]->dist_upkeys.p, 8ull * n_prev, hipMemcpyDeviceToDevice, h->stream));
+        } else {
+            SDCHK(ensure_grow(h, h->dist_prevg, 4));
+        }
+        SDCHK(dist_phase_match(h, n_prev));
+        HIPCHK(hipMemcpyAsync(&counts[r], h->d_ctr + CTR_DIST_NKEEP, 4, hipMemcpyDeviceToHost, h->stream));
+        HIPCHK(hipStreamSynchronize(h->stream));
+    }
+    for (int r = 0; r < R; r++) {
+        sdmesh_handle *h = hs[r];
+        HIPCHK(hipMemcpyAsync(h->dist_counts.p, counts, 4ull * (size_t) R, hipMemcpyHostToDevice, h->stream));
+        SDCHK(dist_phase_pack(h, r, r + 1 < R ? nups[r] : 0u));
+        HIPCHK(hipStreamSynchronize(h->stream));
+    }
+    for (int r = 0; r < R; r++) {
+        sdmesh_handle *h = hs[r];
+        const uint32_t n_prev = r > 0 ? nups[r - 1] : 0u;
+        if (n_prev) HIPCHK(hipMemcpyAsync(h->dist_prevg.p, hs[r - 1]->dist_upg.p, 4ull * n_prev, hipMemcpyDeviceToDevice, h->stream));
+        SDCHK(dist_phase_final(h, r));
+        SDCHK(read_back(h));
+        SDCHK(dist_finish_host(h, R, r, counts, infos ? &infos[r] : nullptr, slab[(size_t) r], first_vertex ? &first_vertex[r] : nullptr));
     }
     return SDMESH_OK;
 }

@@ -1873,6 +1873,158 @@ __global__ __launch_bounds__(256) void k_merge_copy(const Triangle *const *__res
     }
 }
 
+
+// ------------------------------------------------------------------------------------------
+// Multi-GPU, DISTRIBUTED weld (x-slabs).  x is the outermost digit of the reference's order (src/cuda/mod.rs:105-122), so
+// rank r's voxel and triangle lists are contiguous ranges of the single-GPU lists and the global first-seen vertex order
+// is: rank 0's vertices in its local first-seen order, then rank 1's vertices that rank 0 does not already hold, ...
+// Every rank runs the complete local pipeline (its own weld included); what remains is about the vertices within
+// `band` of a slab face:
+//   k_band_select        vertices near the upper face (keys go to rank r + 1) and near the lower face (candidates for a
+//                        match with rank r - 1's upper band); wave-aggregated append
+//   k_dist_hash_build /  the lower neighbour's band keys into a small hash set; my lower band looks itself up: equal key =
+//   k_dist_hash_lookup   the same welded vertex of the single-GPU mesh = keep the lower rank's copy (dup_of = its position
+//                        in that rank's band)
+//   k_dist_keep_count /  ordered numbering of the vertices this rank keeps (three-kernel tile scan with k_scan_tiles)
+//   k_dist_newidx
+//   k_dist_pack_up       global numbers of my upper band (an upper-band vertex is never itself a duplicate: the two
+//                        faces of a slab are at least one level-0 cell apart) -> rank r + 1
+//   k_dist_finalize      kept vertices compacted, every index rewritten to its global number
+// Nothing proportional to the mesh crosses a link or is hashed again; the mesh stays distributed.
+// ------------------------------------------------------------------------------------------
+__device__ __forceinline__ bool packed_weld_key(const Point p, uint64_t &key) {
+    const long long qx = weld_quant(p.x) + 1048576LL, qy = weld_quant(p.y) + 1048576LL, qz = weld_quant(p.z) + 1048576LL;
+    key = (uint64_t) qx | ((uint64_t) qy << 21) | ((uint64_t) qz << 42);
+    return (((unsigned long long) qx | (unsigned long long) qy | (unsigned long long) qz) >> 21) == 0ull;
+}
+
+__global__ __launch_bounds__(256) void k_band_select(const Vertex *__restrict__ v, uint32_t V, float up_thr, float lo_thr, uint32_t has_up,
+                                                      uint32_t has_lo, uint32_t *__restrict__ up_ids, uint64_t *__restrict__ up_keys,
+                                                      uint32_t *__restrict__ lo_ids, uint32_t *__restrict__ ctr /* [0] n_up, [1] n_lo */,
+                                                      uint32_t *__restrict__ dup_of, uint32_t *__restrict__ status) {
+    const uint32_t lane = lane_id();
+    const uint64_t lt = (1ull << lane) - 1ull;
+    const uint32_t Vr = (V + 63u) & ~63u;                      // whole waves stay together for the ballots
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < Vr; i += gridDim.x * blockDim.x) {
+        bool up = false, lo = false;
+        Point p = {0.0f, 0.0f, 0.0f};
+        if (i < V) {
+            dup_of[i] = U32_NONE;
+            p = v[i].position;
+            up = has_up && p.x >= up_thr;
+            lo = has_lo && p.x <= lo_thr;
+        }
+        const uint64_t bu = __ballot(up), bl = __ballot(lo);
+        if (bu) {
+            const int leader = (int) __builtin_ctzll(bu);
+            uint32_t base = 0;
+            if ((int) lane == leader) base = atomicAdd(&ctr[0], (uint32_t) __popcll(bu));
+            base = (uint32_t) __shfl((int) base, leader, 64);
+            if (up) {
+                const uint32_t pos = base + (uint32_t) __popcll(bu & lt);
+                uint64_t key;
+                if (!packed_weld_key(p, key)) atomicOr(&status[ST_WELD_RANGE], 1u);
+                up_ids[pos] = i;
+                up_keys[pos] = key;
+            }
+        }
+        if (bl) {
+            const int leader = (int) __builtin_ctzll(bl);
+            uint32_t base = 0;
+            if ((int) lane == leader) base = atomicAdd(&ctr[1], (uint32_t) __popcll(bl));
+            base = (uint32_t) __shfl((int) base, leader, 64);
+            if (lo) lo_ids[base + (uint32_t) __popcll(bl & lt)] = i;
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void k_dist_hash_build(const uint64_t *__restrict__ keys, uint32_t n, uint64_t *__restrict__ hkeys,
+                                                          uint32_t *__restrict__ hpos, uint32_t hsize) {
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+        const uint64_t key = keys[i];
+        uint32_t s = hash_home(key, hsize);
+        for (uint32_t probe = 0; probe < hsize; probe++) {
+            const uint64_t prev = atomicCAS((unsigned long long *) &hkeys[s], (unsigned long long) KEY_EMPTY, (unsigned long long) key);
+            if (prev == KEY_EMPTY) { hpos[s] = i; break; }
+            if (prev == key) break;                              // (a rank's welded vertices have distinct keys; harmless anyway)
+            s = hash_next(s, hsize);
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void k_dist_hash_lookup(const Vertex *__restrict__ v, const uint32_t *__restrict__ lo_ids,
+                                                           const uint32_t *__restrict__ n_lo_ptr, const uint64_t *__restrict__ hkeys,
+                                                           const uint32_t *__restrict__ hpos, uint32_t hsize, uint32_t *__restrict__ dup_of,
+                                                           uint32_t *__restrict__ status) {
+    const uint32_t n = *n_lo_ptr;
+    for (uint32_t j = blockIdx.x * blockDim.x + threadIdx.x; j < n; j += gridDim.x * blockDim.x) {
+        const uint32_t i = lo_ids[j];
+        uint64_t key;
+        if (!packed_weld_key(v[i].position, key)) { atomicOr(&status[ST_WELD_RANGE], 1u); continue; }
+        uint32_t s = hash_home(key, hsize);
+        for (uint32_t probe = 0; probe < hsize; probe++) {
+            const uint64_t k = hkeys[s];
+            if (k == key) { dup_of[i] = hpos[s]; break; }
+            if (k == KEY_EMPTY) break;
+            s = hash_next(s, hsize);
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void k_dist_keep_count(const uint32_t *__restrict__ dup_of, uint32_t V, uint32_t *__restrict__ tilecnt) {
+    __shared__ uint32_t s_cnt;
+    const uint32_t ntiles = (V + TILE - 1) / TILE;
+    for (uint32_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        if (threadIdx.x == 0) s_cnt = 0;
+        __syncthreads();
+        const uint32_t i = tile * TILE + threadIdx.x;
+        const uint32_t ws = wave_sum((i < V && dup_of[i] == U32_NONE) ? 1u : 0u);
+        if (lane_id() == 0 && ws) atomicAdd(&s_cnt, ws);
+        __syncthreads();
+        if (threadIdx.x == 0) tilecnt[tile] = s_cnt;
+        __syncthreads();
+    }
+}
+
+__global__ __launch_bounds__(256) void k_dist_newidx(const uint32_t *__restrict__ dup_of, uint32_t V, const uint32_t *__restrict__ tileoff,
+                                                      uint32_t *__restrict__ newidx) {
+    __shared__ uint32_t lds[17];
+    const uint32_t ntiles = (V + TILE - 1) / TILE;
+    for (uint32_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        const uint32_t i = tile * TILE + threadIdx.x;
+        const uint32_t keep = (i < V && dup_of[i] == U32_NONE) ? 1u : 0u;
+        uint32_t total;
+        const uint32_t ex = block_excl_scan(keep, total, lds);
+        if (i < V) newidx[i] = tileoff[tile] + ex;
+    }
+}
+
+__device__ __forceinline__ uint32_t dist_offset(const uint32_t *__restrict__ counts, uint32_t me) {
+    uint32_t off = 0;
+    for (uint32_t r = 0; r < me; r++) off += counts[r];
+    return off;
+}
+
+__global__ __launch_bounds__(256) void k_dist_pack_up(const uint32_t *__restrict__ up_ids, uint32_t n_up, const uint32_t *__restrict__ newidx,
+                                                       const uint32_t *__restrict__ counts, uint32_t me, uint32_t *__restrict__ up_g) {
+    const uint32_t off = dist_offset(counts, me);
+    for (uint32_t j = blockIdx.x * blockDim.x + threadIdx.x; j < n_up; j += gridDim.x * blockDim.x) up_g[j] = off + newidx[up_ids[j]];
+}
+
+__global__ __launch_bounds__(256) void k_dist_finalize(const Vertex *__restrict__ v, uint32_t V, uint32_t T, const uint32_t *__restrict__ dup_of,
+                                                        const uint32_t *__restrict__ newidx, const uint32_t *__restrict__ prev_g,
+                                                        const uint32_t *__restrict__ counts, uint32_t me, uint32_t *__restrict__ indices,
+                                                        Vertex *__restrict__ out_v) {
+    const uint32_t off = dist_offset(counts, me);
+    const uint32_t stride = gridDim.x * blockDim.x, t0 = blockIdx.x * blockDim.x + threadIdx.x;
+    for (uint32_t i = t0; i < V; i += stride)
+        if (dup_of[i] == U32_NONE) out_v[newidx[i]] = v[i];
+    for (uint32_t c = t0; c < 3u * T; c += stride) {
+        const uint32_t vi = indices[c], d = dup_of[vi];
+        indices[c] = d == U32_NONE ? off + newidx[vi] : prev_g[d];
+    }
+}
+
 // ------------------------------------------------------------------------------------------
 // Dense mode: the same voxel list as the hierarchical refine, derived from
 // the dense (N+1)^3 sample lattice.
@@ -2399,6 +2551,41 @@ hipError_t launch_merge_by_column(hipStream_t st, const Triangle *const *d_lists
                                   Triangle *d_out, uint32_t cap, uint32_t *total_out, uint32_t *status) {
     hipLaunchKernelGGL(k_merge_plan, dim3(1), dim3(1024), 0, st, d_counts, (uint32_t) nranks, d_plan, cap, total_out, status);
     hipLaunchKernelGGL(k_merge_copy, dim3(nranks * 1024), dim3(256), 0, st, d_lists, d_counts, d_plan, (uint32_t) nranks, d_out, cap);
+    return hipGetLastError();
+}
+
+
+hipError_t launch_band_select(hipStream_t st, int grid, const Vertex *v, uint32_t V, float up_thr, float lo_thr, bool has_up, bool has_lo,
+                              uint32_t *up_ids, uint64_t *up_keys, uint32_t *lo_ids, uint32_t *ctr, uint32_t *dup_of, uint32_t *status) {
+    hipLaunchKernelGGL(k_band_select, dim3(grid), dim3(256), 0, st, v, V, up_thr, lo_thr, has_up ? 1u : 0u, has_lo ? 1u : 0u, up_ids, up_keys, lo_ids, ctr,
+                       dup_of, status);
+    return hipGetLastError();
+}
+
+hipError_t launch_dist_match(hipStream_t st, int grid, const uint64_t *prev_keys, uint32_t n_prev, uint64_t *hkeys, uint32_t *hpos, uint32_t hsize,
+                             const Vertex *v, const uint32_t *lo_ids, const uint32_t *n_lo_ptr, uint32_t *dup_of, uint32_t *status) {
+    hipLaunchKernelGGL(k_dist_hash_build, dim3(grid), dim3(256), 0, st, prev_keys, n_prev, hkeys, hpos, hsize);
+    hipLaunchKernelGGL(k_dist_hash_lookup, dim3(grid), dim3(256), 0, st, v, lo_ids, n_lo_ptr, hkeys, hpos, hsize, dup_of, status);
+    return hipGetLastError();
+}
+
+hipError_t launch_dist_number(hipStream_t st, int grid, const uint32_t *dup_of, uint32_t V, const uint32_t *v_ptr, uint32_t *tilecnt,
+                              uint32_t *n_keep_out, uint32_t *newidx, uint32_t *status) {
+    hipLaunchKernelGGL(k_dist_keep_count, dim3(grid), dim3(256), 0, st, dup_of, V, tilecnt);
+    hipLaunchKernelGGL(k_scan_tiles, dim3(1), dim3(1024), 0, st, tilecnt, v_ptr, 256u, n_keep_out, 0xFFFFFFFFu, status);
+    hipLaunchKernelGGL(k_dist_newidx, dim3(grid), dim3(256), 0, st, dup_of, V, (const uint32_t *) tilecnt, newidx);
+    return hipGetLastError();
+}
+
+hipError_t launch_dist_pack_up(hipStream_t st, int grid, const uint32_t *up_ids, uint32_t n_up, const uint32_t *newidx, const uint32_t *counts,
+                               uint32_t me, uint32_t *up_g) {
+    hipLaunchKernelGGL(k_dist_pack_up, dim3(grid), dim3(256), 0, st, up_ids, n_up, newidx, counts, me, up_g);
+    return hipGetLastError();
+}
+
+hipError_t launch_dist_finalize(hipStream_t st, int grid, const Vertex *v, uint32_t V, uint32_t T, const uint32_t *dup_of, const uint32_t *newidx,
+                                const uint32_t *prev_g, const uint32_t *counts, uint32_t me, uint32_t *indices, Vertex *out_v) {
+    hipLaunchKernelGGL(k_dist_finalize, dim3(grid), dim3(256), 0, st, v, V, T, dup_of, newidx, prev_g, counts, me, indices, out_v);
     return hipGetLastError();
 }
 

@@ -93,6 +93,17 @@ hipError_t launch_raw_compact(hipStream_t st, int grid, const Triangle *raw, con
 hipError_t launch_column_counts(hipStream_t st, int grid, const Point *vox, const uint32_t *n_ptr, const uint8_t *cubeidx,
                                 uint32_t *colcnt);
 hipError_t launch_tile_tricount(hipStream_t st, int grid, const uint8_t *cubeidx, const uint32_t *n_ptr, uint32_t *tilecnt);
+// multi-GPU distributed weld (x-slabs)
+hipError_t launch_band_select(hipStream_t st, int grid, const Vertex *v, uint32_t V, float up_thr, float lo_thr, bool has_up, bool has_lo,
+                              uint32_t *up_ids, uint64_t *up_keys, uint32_t *lo_ids, uint32_t *ctr, uint32_t *dup_of, uint32_t *status);
+hipError_t launch_dist_match(hipStream_t st, int grid, const uint64_t *prev_keys, uint32_t n_prev, uint64_t *hkeys, uint32_t *hpos, uint32_t hsize,
+                             const Vertex *v, const uint32_t *lo_ids, const uint32_t *n_lo_ptr, uint32_t *dup_of, uint32_t *status);
+hipError_t launch_dist_number(hipStream_t st, int grid, const uint32_t *dup_of, uint32_t V, const uint32_t *v_ptr, uint32_t *tilecnt,
+                              uint32_t *n_keep_out, uint32_t *newidx, uint32_t *status);
+hipError_t launch_dist_pack_up(hipStream_t st, int grid, const uint32_t *up_ids, uint32_t n_up, const uint32_t *newidx, const uint32_t *counts,
+                               uint32_t me, uint32_t *up_g);
+hipError_t launch_dist_finalize(hipStream_t st, int grid, const Vertex *v, uint32_t V, uint32_t T, const uint32_t *dup_of, const uint32_t *newidx,
+                                const uint32_t *prev_g, const uint32_t *counts, uint32_t me, uint32_t *indices, Vertex *out_v);
 hipError_t launch_sign_bits(hipStream_t st, int grid, const float *samples, uint64_t total, uint32_t *bits);
 hipError_t launch_dense_classify(hipStream_t st, int grid, bool emit, const uint32_t *bits, uint32_t k, uint32_t *cellcnt,
                                  Point *vox, uint8_t *cubeidx, uint32_t cap);

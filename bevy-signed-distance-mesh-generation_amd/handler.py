@@ -356,6 +356,27 @@ class CudaHandler:
         self._chk(self._lib.sdmesh_sharded_regen(self._h, int(levels), int(root), ctypes.byref(info)))
         return info
 
+    def distributed_regen(self, levels):
+        """ONE mesh over all ranks of the handle's communicator with the distributed weld (x-slabs): returns (RegenInfo of
+        this rank's part, global index of its first kept vertex); download_mesh() then gives the part with global indices."""
+        info = RegenInfo()
+        first = ctypes.c_uint32(0)
+        self._chk(self._lib.sdmesh_distributed_regen(self._h, int(levels), ctypes.byref(info), ctypes.byref(first)))
+        return info, int(first.value)
+
+    @staticmethod
+    def distributed_regen_rehearsal(handlers, levels):
+        """The distributed weld for several handlers of THIS process on one GPU (copies instead of RCCL messages)."""
+        n = len(handlers)
+        arr = (ctypes.c_void_p * n)(*[h._h for h in handlers])
+        infos = (RegenInfo * n)()
+        first = (ctypes.c_uint32 * n)()
+        rc = handlers[0]._lib.sdmesh_distributed_regen_rehearsal(arr, n, int(levels), infos, first)
+        if rc != 0:
+            msgs = [h._lib.sdmesh_last_error(h._h).decode(errors="replace") for h in handlers]
+            raise SdMeshError(rc, " | ".join(m for m in msgs if m))
+        return [infos[i] for i in range(n)], [int(first[i]) for i in range(n)]
+
     def weld_device_triangles(self, dev_ptr, nslots):
         info = RegenInfo()
         self._chk(self._lib.sdmesh_weld_device_triangles(self._h, ctypes.c_void_p(dev_ptr), int(nslots),

@@ -181,6 +181,8 @@ class DistributedMesher:
             # slabs of equal surface content instead of equal thickness (every rank derives the same table from the scene)
             bounds = handler.balance_slabs(pkg.PART_XSLAB, world, min(levels, 3))
         self.bounds = bounds
+        self.native = handler is not None and (world == 1 or dist.get_backend() != "gloo")
+        self.comm_ready = False
         lo, hi = (bounds[rank], bounds[rank + 1]) if bounds is not None else slab_bounds(rank, world)
         self.band = 2.5 * float(size)      # a projected vertex stays within ~a voxel diagonal of its lattice edge
         self.x_lo = -2.5 + 5.0 * lo / INIT_FACTOR
@@ -204,8 +206,23 @@ class DistributedMesher:
 
     def step(self):
         """One distributed regen.  Returns (vertices [v, 6] float32 kept by this rank, triangles [t, 3] int32 with GLOBAL
-        vertex indices, global offset of this rank's vertices as a 0-d tensor).  Concatenated over the ranks in order they are the
-        single-GPU mesh, bit for bit."""
+        vertex indices, global offset of this rank's vertices).  Concatenated over the ranks in order they are the
+        single-GPU mesh, bit for bit.
+
+        With RCCL available (backend "nccl", or one rank) the whole step is `sdmesh_distributed_regen`: HIP kernels + two
+        neighbour messages + two 4-byte all-gathers behind the C ABI, no torch arithmetic.  Under "gloo" (several ranks
+        rehearsed on one GPU) the same face exchange runs as torch index arithmetic with a host-staged transport
+        (`exchange` below, also what the no-GPU tests drive with the oracle standing in for the kernels)."""
+        if self.native:
+            if not self.comm_ready:
+                uid = [self.pkg.CudaHandler.comm_unique_id() if self.rank == 0 else None]
+                if self.world > 1:
+                    self.dist.broadcast_object_list(uid, src=0)
+                self.h.comm_init(uid[0], self.world, self.rank)
+                self.comm_ready = True
+            _, first = self.h.distributed_regen(self.levels)
+            verts, tris = self.h.device_mesh_tensors(self.dev)
+            return verts, tris, first
         self.h.regen(self.levels, self.pkg.PART_XSLAB, self.rank, self.world)
         verts, tris = self.h.device_mesh_tensors(self.dev)
         return self.exchange(verts, tris)
@@ -257,6 +274,11 @@ class DistributedMesher:
             gidx[dups] = prev_g[dup_pos[dups]].to(torch.int32)
         out_tris = torch.index_select(gidx, 0, tris.reshape(-1).to(torch.int32)).reshape(-1, 3)
         return verts[keep], out_tris, offsets[r]
+
+    def close(self):
+        if self.comm_ready:
+            self.h.comm_destroy()
+            self.comm_ready = False
 
     def gather(self, part):
         """Concatenate the ranks' parts on rank 0: (vertices [V, 6], triangles [T, 3] int64) there, None elsewhere."""

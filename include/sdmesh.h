@@ -274,6 +274,20 @@ int sdmesh_render(sdmesh_handle *h, const struct GlobalsBuffer *globals, const s
 int sdmesh_render_device(sdmesh_handle *h, const struct GlobalsBuffer *globals, const struct CameraBuffer *camera,
                          struct Rgba *d_target, float *kernel_ms);
 
+/* ONE regen of ONE mesh over all ranks of the communicator with a DISTRIBUTED weld (level-0 x-slabs; balance them with
+ * sdmesh_balance_slabs(h, SDMESH_PART_XSLAB, nranks, ...) first).  x is the outermost digit of the reference's order
+ * (src/cuda/mod.rs:105-122), so rank r's triangles are a contiguous range of the single-GPU list and the global first-seen
+ * vertex order is "rank 0's vertices, then rank 1's that rank 0 does not hold, ...".  Every rank meshes AND welds its slab;
+ * the exchange is two neighbour messages about the vertices within 2.5 voxels of a slab face (their weld keys up, then
+ * their global numbers up) and two 4-byte all-gathers; nothing proportional to the mesh crosses a link.  The mesh stays
+ * distributed: afterwards sdmesh_device_mesh / sdmesh_download_mesh give THIS rank's kept vertices and its triangles with
+ * GLOBAL indices, *first_vertex = the global index of its first kept vertex.  The ranks' parts concatenated in rank order
+ * are the single-GPU mesh, bit for bit.  Collective: every rank calls it with the same levels. */
+int sdmesh_distributed_regen(sdmesh_handle *h, int levels, sdmesh_regen_info *info, uint32_t *first_vertex);
+/* The same step for nranks handles of one process on one device (copies instead of messages): the rehearsal used where
+ * only one GPU exists.  infos / first_vertex: arrays of nranks (optional). */
+int sdmesh_distributed_regen_rehearsal(sdmesh_handle **handles, int nranks, int levels, sdmesh_regen_info *infos, uint32_t *first_vertex);
+
 #ifdef __cplusplus
 }
 #endif
