@@ -216,7 +216,6 @@ def one_mesh_legs(pkg, job, local_rank, scene, params, levels_list, base_levels,
     h.close()
     # --- x-slabs, every rank welds its slab, neighbours unify the shared faces, the mesh stays distributed
     h = pkg.CudaHandler(local_rank, scene, params)
-    h.set_stream(torch.cuda.current_stream().cuda_stream)          # torch's stream: kernels, torch ops and collectives in one order
     xslab = {}
     for lv in levels_list:
         dm = P.DistributedMesher(pkg, h, lv, rank, world, dev)
@@ -237,15 +236,15 @@ def one_mesh_legs(pkg, job, local_rank, scene, params, levels_list, base_levels,
                            "triangles": int(cnt[1]), "vertices": int(cnt[0]), "steps": k}
         if lv == base_levels and dt / k < primary[0] / primary[1]:
             primary = (dt, k, int(cnt[1]), int(cnt[0]), "xslab_distributed_weld")
-    h.set_stream(None)
     h.close()
     return primary, {"n_gpus": world, "ranks_seen": ranks_seen, "slab_bounds": {"z": zbounds, "x": xbounds},
                      "zslab_gather_root_weld": {"what": "sdmesh_sharded_regen: level-0 z-slab per rank, ncclAllGather of 1024 column "
                                                         "counts, ncclSend/ncclRecv of compact triangle lists to rank 0, merge kernel + "
                                                         "first-seen weld there; mesh identical to 1 GPU (counts checked here, bits in tests)",
                                                 **zslab},
-                     "xslab_distributed_weld": {"what": "level-0 x-slab per rank, every rank welds its slab, x-neighbours unify the vertices "
-                                                        "of their shared face by weld key, indices become global, the mesh stays distributed",
+                     "xslab_distributed_weld": {"what": "sdmesh_distributed_regen: level-0 x-slab per rank, every rank welds its slab, x-neighbours unify "
+                                                        "the vertices of their shared face by weld key (two ncclSend/ncclRecv of the face band + two 4-byte "
+                                                        "ncclAllGather), indices become global, the mesh stays distributed",
                                                 **xslab}}
 
 

@@ -6,7 +6,7 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-# SDMESH_LIB: development override (A/B timing of two builds of this same library on one box, tools/ab_perf.py)
+# SDMESH_LIB: development override (A/B timing of two builds of this same library on one box)
 LIB_PATH = os.environ.get("SDMESH_LIB") or os.path.join(_HERE, "libsdmesh.so")
 FAST_LIB_PATH = os.path.join(_HERE, "libsdmesh_fast.so")     # the opt-in fast numeric build (csrc/Makefile FASTFLAGS)
 HSACO_PATH = os.path.join(_HERE, "compute_mesh_generation.hsaco")

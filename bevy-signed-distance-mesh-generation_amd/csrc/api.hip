@@ -977,7 +977,7 @@ int sdmesh_create(int device, sdmesh_handle **out) {
     }
     h->grid = 4 * prop.multiProcessorCount;
     h->tgrid = 16 * prop.multiProcessorCount;   // measured: 512^3 (1037 tiles) -7 % vs 4/CU, 1024^3 (4150 tiles) best at 16/CU
-    h->dense_grid = 48 * prop.multiProcessorCount;   // measured best for the write-only P1 stream (tools/dense_sweep.py)
+    h->dense_grid = 48 * prop.multiProcessorCount;   // measured best for the write-only P1 stream (round-1 sweep over 4 .. 64 per CU)
     if ((e = hipStreamCreateWithFlags(&h->own_stream, hipStreamNonBlocking)) != hipSuccess) return bail(e, "hipStreamCreate");
     h->stream = h->own_stream;
     if ((e = hipEventCreate(&h->ev0)) != hipSuccess) return bail(e, "hipEventCreate");
@@ -1412,7 +1412,7 @@ int sdmesh_download_voxels(sdmesh_handle *h, struct Point *voxels) {
 
 static hipError_t launch_p1(sdmesh_handle *h, float *d_out, uint32_t N) {
     const int grid = h->dense_grid > 0 ? h->dense_grid : 8 * h->grid;
-    // measured (tools/dense_sweep.py): the write-bound sphere wants whole 16-B aligned cache lines per store (flat
+    // measured (round-1 sweep): the write-bound sphere wants whole 16-B aligned cache lines per store (flat
     // quads, 5.5 TB/s vs 3.9 with dword-aligned row stores); the VALU-bound scenes want the leaner row kernel
     const bool rows = h->dense_rows == 2 ? (h->scene != SDMESH_SCENE_SPHERE) : (h->dense_rows != 0);
     return rows ? launch_sample_dense_rows(h->stream, grid, h->scene, h->d_sp, d_out, N, h->dense_nt != 0)

@@ -106,6 +106,7 @@ class CudaHandler:
         if rc != 0:
             raise SdMeshError(rc, "sdmesh_create failed (is a gfx950 GPU visible?)")
         self._h = hp
+        self.comm = None
         self.device = int(device)
         self.set_option("fast_math", 1 if fast_math else 0)        # the library confirms its numeric mode
         self.set_scene(scene, params)
@@ -341,9 +342,23 @@ class CudaHandler:
     def comm_init(self, unique_id, nranks, rank):
         buf = ctypes.create_string_buffer(bytes(unique_id), 128)
         self._chk(self._lib.sdmesh_comm_init(self._h, buf, int(nranks), int(rank)))
+        self.comm = (int(nranks), int(rank))
 
     def comm_destroy(self):
         self._chk(self._lib.sdmesh_comm_destroy(self._h))
+        self.comm = None
+
+    def ensure_comm(self, dist, nranks, rank):
+        """The handle's RCCL communicator over the ranks of the current torch.distributed job (made once per handle; the
+        process group only carries the 128-byte unique id)."""
+        if getattr(self, "comm", None) == (int(nranks), int(rank)):
+            return
+        if getattr(self, "comm", None) is not None:
+            self.comm_destroy()
+        uid = [CudaHandler.comm_unique_id() if rank == 0 else None]
+        if nranks > 1:
+            dist.broadcast_object_list(uid, src=0)
+        self.comm_init(uid[0], nranks, rank)
 
     def comm_ranks(self):
         n = ctypes.c_int(0)

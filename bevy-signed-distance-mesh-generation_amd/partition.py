@@ -82,10 +82,7 @@ class ShardedMesher:
             transport = "staged" if (world > 1 and dist.get_backend() == "gloo") else "rccl"
         self.transport = transport
         if transport == "rccl":
-            uid = [pkg.CudaHandler.comm_unique_id() if rank == 0 else None]
-            if world > 1:
-                dist.broadcast_object_list(uid, src=0)
-            handler.comm_init(uid[0], world, rank)
+            handler.ensure_comm(dist, world, rank)
             self.ranks_seen = handler.comm_ranks()
             if self.ranks_seen != world:
                 raise RuntimeError(f"RCCL communicator saw {self.ranks_seen} ranks, expected {world}")
@@ -98,7 +95,7 @@ class ShardedMesher:
             self.merged = None
 
     def close(self):
-        if self.transport == "rccl":
+        if self.transport == "rccl" and self.h.comm is not None:
             self.h.comm_destroy()
 
     def step(self):
@@ -182,7 +179,6 @@ class DistributedMesher:
             bounds = handler.balance_slabs(pkg.PART_XSLAB, world, min(levels, 3))
         self.bounds = bounds
         self.native = handler is not None and (world == 1 or dist.get_backend() != "gloo")
-        self.comm_ready = False
         lo, hi = (bounds[rank], bounds[rank + 1]) if bounds is not None else slab_bounds(rank, world)
         self.band = 2.5 * float(size)      # a projected vertex stays within ~a voxel diagonal of its lattice edge
         self.x_lo = -2.5 + 5.0 * lo / INIT_FACTOR
@@ -214,12 +210,7 @@ class DistributedMesher:
         rehearsed on one GPU) the same face exchange runs as torch index arithmetic with a host-staged transport
         (`exchange` below, also what the no-GPU tests drive with the oracle standing in for the kernels)."""
         if self.native:
-            if not self.comm_ready:
-                uid = [self.pkg.CudaHandler.comm_unique_id() if self.rank == 0 else None]
-                if self.world > 1:
-                    self.dist.broadcast_object_list(uid, src=0)
-                self.h.comm_init(uid[0], self.world, self.rank)
-                self.comm_ready = True
+            self.h.ensure_comm(self.dist, self.world, self.rank)
             _, first = self.h.distributed_regen(self.levels)
             verts, tris = self.h.device_mesh_tensors(self.dev)
             return verts, tris, first
@@ -276,9 +267,8 @@ class DistributedMesher:
         return verts[keep], out_tris, offsets[r]
 
     def close(self):
-        if self.comm_ready:
+        if self.native and self.h.comm is not None:
             self.h.comm_destroy()
-            self.comm_ready = False
 
     def gather(self, part):
         """Concatenate the ranks' parts on rank 0: (vertices [V, 6], triangles [T, 3] int64) there, None elsewhere."""
