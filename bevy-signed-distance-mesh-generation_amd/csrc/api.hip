@@ -262,6 +262,10 @@ int prof_collect(sdmesh_handle *h) {      // after the stream has been synchroni
 }
 
 inline uint32_t tiles(uint32_t n) { return (n + 255u) / 256u; }
+
+// above this many 256-item tiles the ordered kernels get a single-workgroup scan of the tile counts in front instead of
+// re-summing the counts before their tile in every workgroup (quadratic in the tile count; one extra ~5 us launch)
+constexpr uint32_t PRESCAN_TILES = 2048;
 inline size_t align256(size_t v) { return (v + 255) & ~(size_t) 255; }
 
 Point half_size(Point p) { return Point{p.x / 2.0f, p.y / 2.0f, p.z / 2.0f}; }   // src/cuda/mod.rs:126-130
@@ -342,7 +346,8 @@ int mesh_front(sdmesh_handle *h, const Point *d_vox, const uint32_t *n_ptr, Poin
     }
     HIPCHK(launch_tile_dedupe(st, h->tgrid, d_vox, n_ptr, vs, (const uint8_t *) h->cubeidx.p, (const uint32_t *) tilecnt,
                               (uint32_t *) h->trioff.p, (uint32_t *) h->tri_e.p, (Vertex *) h->uverts.p, (uint4 *) h->tdesc.p,
-                              h->ucap, h->tcap, h->d_ctr + CTR_NTRI, h->d_ctr + CTR_NTILES, h->d_status, d_tile_dbg));
+                              h->ucap, h->tcap, h->d_ctr + CTR_NTRI, h->d_ctr + CTR_NTILES, h->d_status, d_tile_dbg,
+                              tiles(h->cap_vox) > PRESCAN_TILES));
     SDCHK(prof_mark(h, "tile_dedupe"));
     uint32_t *coarse = (uint32_t *) h->tpre.p + h->tp_cap;
     HIPCHK(launch_tile_prefix(st, (const uint4 *) h->tdesc.p, h->d_ctr + CTR_NTILES, (uint32_t *) h->tpre.p, h->d_ctr + CTR_NUNIQ, coarse));
@@ -354,9 +359,12 @@ int mesh_front(sdmesh_handle *h, const Point *d_vox, const uint32_t *n_ptr, Poin
     // chain and whenever the memset above ran on this stream)
     // ... and only while a projection wave owns about one batch of vertices: with many batches per wave every claim would
     // wait for the wave's last batch and pile up at the end of the kernel (2048^3: projection 340 -> 498 us)
+    // Larger meshes (1-lane kernel only): asynchronous claims, issued per finished vertex and looked at a round later.
     const uint32_t proj_waves = (uint32_t) (h->grid * h->project_mult) * 4u;
-    const bool early_claim = h->claim_in_project && h->fork == 2 && !h->wide_active && h->lane_hint != 0 &&
-                             h->lane_hint <= 2u * (64u / (uint32_t) p_lanes) * proj_waves;
+    const bool claim_ok = h->claim_in_project && h->fork == 2 && !h->wide_active && h->lane_hint != 0;
+    const bool few_batches = h->lane_hint <= 2u * (64u / (uint32_t) p_lanes) * proj_waves;
+    const bool async_claim = claim_ok && !few_batches && p_lanes == 1 && h->claim_in_project != 2;
+    const bool early_claim = claim_ok && (few_batches || async_claim);
     uint32_t *d_prof = nullptr;
     uint64_t *d_diag = nullptr;
     if (h->profile) {                       // (profile / diag runs are eager and may allocate: never on the captured path)
@@ -372,7 +380,7 @@ int mesh_front(sdmesh_handle *h, const Point *d_vox, const uint32_t *n_ptr, Poin
     }
     HIPCHK(launch_project(st, h->grid * h->project_mult, h->scene, h->d_sp, (Vertex *) h->uverts.p, (const uint4 *) h->tdesc.p,
                           (const uint32_t *) h->tpre.p, coarse, h->d_ctr + CTR_NTILES, h->d_status, p_lanes, d_prof, d_diag,
-                          h->wkeys, h->wsize, (uint32_t *) h->vslot.p, (uint32_t *) h->wrep_buf.p, h->wfm, weld_mode(h, vs) | (early_claim ? 2u : 0u)));
+                          h->wkeys, h->wsize, (uint32_t *) h->vslot.p, (uint32_t *) h->wrep_buf.p, h->wfm, weld_mode(h, vs) | (early_claim && !async_claim ? 2u : 0u) | (async_claim ? 4u : 0u)));
     SDCHK(prof_mark(h, p_lanes == 1 ? "project1" : (p_lanes == 2 ? "project2" : "project4")));
     // fork: the weld claim (scattered CAS, latency-bound) runs beside the orientation test (VALU-bound)
     int f_grid = h->grid * (f_lanes == 1 ? 1 : h->flip_mult);
@@ -568,7 +576,7 @@ int refine_level(sdmesh_handle *h, int L, uint32_t n_cap_in, uint32_t out_cap, P
     SDCHK(ensure(h, h->vox[dst], sizeof(Point) * (size_t) std::max<uint32_t>(cap, 64)));
     HIPCHK(launch_refine_emit(st, h->tgrid, (const Point *) h->vox[src].p, n_in, cs, (const uint8_t *) h->mask.p, cnt_region,
                               (Point *) h->vox[dst].p, cap, n_out, h->d_status, signs, signs ? (uint8_t *) h->cubeidx.p : nullptr,
-                              mesh_tilecnt));
+                              mesh_tilecnt, tiles(n_cap_in) > PRESCAN_TILES));
     SDCHK(prof_mark(h, "refine_emit"));
     h->cur = dst;
     return SDMESH_OK;
@@ -1104,7 +1112,7 @@ int sdmesh_set_option(sdmesh_handle *h, const char *name, int value) {
         return SDMESH_OK;
     }
     if (!strcmp(name, "fuse_flip")) { h->fuse_flip = value < 0 ? 0 : (value > 2 ? 2 : value); drop_graph(h); return SDMESH_OK; }
-    if (!strcmp(name, "claim")) { h->claim_in_project = value ? 1 : 0; drop_graph(h); return SDMESH_OK; }
+    if (!strcmp(name, "claim")) { h->claim_in_project = value < 0 ? 0 : (value > 2 ? 2 : value); drop_graph(h); return SDMESH_OK; }   // 2: never asynchronous
     if (!strcmp(name, "weld_shift")) { if (value < -1 || value > 20) return fail(h, SDMESH_ERR_INVALID, "weld_shift -1..20"); h->weld_shift = value; drop_graph(h); return SDMESH_OK; }
     if (!strcmp(name, "profile")) { h->profile = value ? 1 : 0; h->prof_n = 0; h->prof_ms.clear(); return SDMESH_OK; }
     if (!strcmp(name, "project_diag")) { h->project_diag = value; return SDMESH_OK; }

@@ -287,7 +287,9 @@ __global__ __launch_bounds__(256) void k_refine_emit(const Point *__restrict__ v
                                                       const uint32_t *__restrict__ tilecnt, Point *__restrict__ out,
                                                       uint32_t cap, uint32_t *__restrict__ n_out, uint32_t *__restrict__ status,
                                                       const uint32_t *__restrict__ signs, uint8_t *__restrict__ cubeidx,
-                                                      uint32_t *__restrict__ mtilecnt) {
+                                                      uint32_t *__restrict__ mtilecnt, uint32_t prescanned) {
+    // prescanned: tilecnt already holds the EXCLUSIVE prefix of the tile counts and *n_out the total (k_scan_tiles ran in front:
+    // above a few thousand tiles the per-workgroup re-summing below is quadratic in the tile count -- 2 G loads at 4096^3)
     // signs != nullptr (last level of a device-resident regen): the parent's 27 lattice signs already hold the 8 corner
     // signs of every child (same sample positions on an exact lattice, same `sd <= 0` test as k_classify), so the
     // marching-cubes index of each child and the triangle count of each 256-voxel MESH tile (pre-zeroed mtilecnt) are
@@ -296,18 +298,22 @@ __global__ __launch_bounds__(256) void k_refine_emit(const Point *__restrict__ v
     __shared__ uint32_t s_mt[12];       // <= 2048 children per pass -> at most 9 mesh tiles touched
     const uint32_t n = *n_ptr;
     const uint32_t ntiles = (n + TILE - 1) / TILE;
-    if (n == 0 && blockIdx.x == 0 && threadIdx.x == 0) *n_out = 0;
+    if (n == 0 && blockIdx.x == 0 && threadIdx.x == 0 && !prescanned) *n_out = 0;
     for (uint32_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
-        uint32_t part = 0;
-        for (uint32_t i = threadIdx.x; i < tile; i += 256) part += tilecnt[i];
         uint32_t tbase;
-        (void) block_excl_scan(part, tbase, lds);
+        if (prescanned) {
+            tbase = tilecnt[tile];
+        } else {
+            uint32_t part = 0;
+            for (uint32_t i = threadIdx.x; i < tile; i += 256) part += tilecnt[i];
+            (void) block_excl_scan(part, tbase, lds);
+        }
         if (signs && threadIdx.x < 12) s_mt[threadIdx.x] = 0;      // (block_excl_scan below synchronises)
         const uint32_t p = tile * TILE + threadIdx.x;
         const uint32_t m = p < n ? mask[p] : 0u;
         uint32_t total;
         uint32_t o = tbase + block_excl_scan(__popc(m), total, lds);
-        if (tile == ntiles - 1 && threadIdx.x == 0) {
+        if (tile == ntiles - 1 && threadIdx.x == 0 && !prescanned) {
             uint32_t tot = tbase + total;
             if (tot > cap) { atomicOr(&status[ST_OVERFLOW], 1u); tot = cap; }
             *n_out = tot;
@@ -890,7 +896,8 @@ __global__ __launch_bounds__(256) void k_tile_dedupe(const Point *__restrict__ v
                                                       Vertex *__restrict__ uverts, uint4 *__restrict__ tdesc, uint32_t ucap,
                                                       uint32_t tcap, uint32_t *__restrict__ ntri_out,
                                                       uint32_t *__restrict__ ntiles_out, uint32_t *__restrict__ status,
-                                                      uint64_t *__restrict__ dbg /* optional: 8 s_memtime stamps per tile (tools/tile_phases.py) */) {
+                                                      uint64_t *__restrict__ dbg /* optional: 8 s_memtime stamps per tile (tools/tile_phases.py) */,
+                                                      uint32_t prescanned /* tilecnt = exclusive prefix, *ntri_out = total (k_scan_tiles in front) */) {
 #define SDM_STAMP(k) do { if (dbg && tid == 0) dbg[8ull * tile + (k)] = __builtin_amdgcn_s_memtime(); } while (0)
     __shared__ uint64_t s_keys[T_HASH];
     __shared__ uint64_t s_aux[2 * TILE];                    // insert phase: per-voxel lattice coordinates + triangle row;
@@ -909,7 +916,7 @@ __global__ __launch_bounds__(256) void k_tile_dedupe(const Point *__restrict__ v
     const uint32_t tid = threadIdx.x;
     if (blockIdx.x == 0 && tid == 0) {
         *ntiles_out = ntiles;
-        if (n == 0) *ntri_out = 0;
+        if (n == 0 && !prescanned) *ntri_out = 0;
     }
     for (uint32_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
         // issue every independent global load before the first barrier so their latencies overlap
@@ -918,11 +925,12 @@ __global__ __launch_bounds__(256) void k_tile_dedupe(const Point *__restrict__ v
         const uint32_t ci = v < n ? cubeidx[v] : 0u;
         const Point b = vox[v < n ? v : (n - 1)];
         uint32_t part = 0;
-        for (uint32_t i = tid; i < tile; i += 256) part += tilecnt[i];
+        if (!prescanned) for (uint32_t i = tid; i < tile; i += 256) part += tilecnt[i];
         const uint32_t ntri = v < n ? (uint32_t) MC_TRI_COUNT[ci] : 0u;
         const uint64_t tri_row = MC_TRI_PACKED[ci];
         uint32_t tbase;
-        (void) block_excl_scan(part, tbase, s_scan);
+        if (prescanned) tbase = tilecnt[tile];
+        else (void) block_excl_scan(part, tbase, s_scan);
 
         int mx = 0, my = 0, mz = 0;
         bool lat_ok = true;
@@ -935,7 +943,7 @@ __global__ __launch_bounds__(256) void k_tile_dedupe(const Point *__restrict__ v
         const uint32_t lo = block_excl_scan(ntri, ttri, s_scan);
         SDM_STAMP(2);
         if (v < n) trioff[v] = tbase + lo;
-        if (tile == ntiles - 1 && tid == 0) {
+        if (tile == ntiles - 1 && tid == 0 && !prescanned) {
             uint32_t tot = tbase + ttri;
             if (tot > tcap) { atomicOr(&status[ST_OVERFLOW], 1u); tot = tcap; }
             *ntri_out = tot;
@@ -1040,6 +1048,12 @@ static constexpr uint32_t VS_SLOT = 0x7fffffffu;
 // hammer a few cache lines at a time and atomics to one line serialise (512^3: claim 25 -> 157 us at 8-voxel cells;
 // milliseconds once a cell holds more keys than a block).  What the locality was wanted for -- the per-slot gathers of
 // the later weld kernels -- is obtained instead by indexing those arrays with the key's representative VERTEX (below).
+__device__ __forceinline__ bool packed_weld_key(const Point p, uint64_t &key) {
+    const long long qx = weld_quant(p.x) + 1048576LL, qy = weld_quant(p.y) + 1048576LL, qz = weld_quant(p.z) + 1048576LL;
+    key = (uint64_t) qx | ((uint64_t) qy << 21) | ((uint64_t) qz << 42);
+    return (((unsigned long long) qx | (unsigned long long) qy | (unsigned long long) qz) >> 21) == 0ull;
+}
+
 static constexpr uint32_t WELD_BLOCK = 256;
 
 __device__ __forceinline__ uint32_t weld_home(uint64_t key, uint64_t coarse, uint32_t wsize) {
@@ -1122,10 +1136,13 @@ __device__ __forceinline__ void project_epilogue(uint32_t wave, uint32_t rounds,
     if (lane_id() != 0) return;
     if (prof) atomicAdd(&prof[(wave & 255u) * 16u], rounds);
     if (diag) {
-        diag[4ull * wave + 0] = t_start;
-        diag[4ull * wave + 1] = __builtin_amdgcn_s_memtime();
-        diag[4ull * wave + 2] = rounds;
-        diag[4ull * wave + 3] = (uint64_t) __builtin_amdgcn_s_getreg((31 << 11) | 4) | ((uint64_t) __builtin_amdgcn_s_getreg((31 << 11) | 20) << 32);   // HW_ID | XCC_ID
+        // per wave: {s_memtime at start (shader clock, per XCD), at end, rounds | XCC_ID << 28 | HW_ID << 32,
+        //            s_memrealtime (constant 100 MHz) at start | at end << 32}
+        diag[4ull * wave + 0] = t_start & 0x00FFFFFFFFFFFFFFull;
+        diag[4ull * wave + 1] = __builtin_amdgcn_s_memtime() & 0x00FFFFFFFFFFFFFFull;
+        diag[4ull * wave + 2] = (uint64_t) (rounds & 0x0FFFFFFFu) | ((uint64_t) (__builtin_amdgcn_s_getreg((31 << 11) | 20) & 0xFu) << 28) |
+                                ((uint64_t) __builtin_amdgcn_s_getreg((31 << 11) | 4) << 32);
+        diag[4ull * wave + 3] = (diag[4ull * wave + 3] & 0xFFFFFFFFull) | ((__builtin_amdgcn_s_memrealtime() & 0xFFFFFFFFull) << 32);
     }
 }
 
@@ -1195,6 +1212,7 @@ __global__ __launch_bounds__(256) void k_project(Vertex *__restrict__ uverts, co
     const uint32_t nbatch = (U + PER - 1u) >> SH;
     if (wave >= nbatch) return;
     const uint64_t t_start = diag ? __builtin_amdgcn_s_memtime() : 0ull;
+    if (diag && lane == 0) diag[4ull * wave + 3] = __builtin_amdgcn_s_memrealtime() & 0xFFFFFFFFull;
     uint32_t rounds = 0;                                              // vertex-rounds this wave evaluated (scalar bookkeeping)
     const uint32_t myb = (nbatch - wave - 1u) / nwaves + 1u;          // batches owned by this wave
     uint32_t qhead = 0;                                               // items handed out so far
@@ -1321,6 +1339,7 @@ __global__ __launch_bounds__(256) void k_project1(Vertex *__restrict__ uverts, c
     const uint32_t nbatch = (U + 63u) >> 6;
     if (wave >= nbatch) return;
     const uint64_t t_start = diag ? __builtin_amdgcn_s_memtime() : 0ull;
+    if (diag && lane == 0) diag[4ull * wave + 3] = __builtin_amdgcn_s_memrealtime() & 0xFFFFFFFFull;
     uint32_t rounds = 0;
     const uint32_t myb = (nbatch - wave - 1u) / nwaves + 1u;
     uint32_t qhead = 0;
@@ -1330,7 +1349,27 @@ __global__ __launch_bounds__(256) void k_project1(Vertex *__restrict__ uverts, c
     uint32_t slot = 0;
     int it = 0;
     f3 g = mk(0.0f, 0.0f, 0.0f);
+    // Asynchronous weld claims (wmode bit 2; waves that own many batches): a lane that has written its vertex issues the
+    // compare-and-swap for it and goes on with its next vertex; the returned value is looked at one Newton round later
+    // (the top of the next loop iteration), by when it has long arrived -- the scattered-atomic traffic (the chip does
+    // ~20 G/s: a millisecond for 20 M vertices at 4096^3) overlaps the projection's arithmetic instead of following it.
+    const bool async_claims = (ca.wmode & 4u) != 0u;
+    const uint32_t cshift = ca.wmode >> 8;
+    bool pend = false;
+    uint64_t pkey = 0;
+    unsigned long long pres = 0;
+    uint32_t pslot = 0, pe = 0;
     for (;;) {
+        if (pend) {                                                   // the claim issued a round ago (or its next probe)
+            if (pres == KEY_EMPTY || pres == pkey) {
+                ca.vslot[pe] = pslot | (pres == KEY_EMPTY ? VS_WINNER : 0u);
+                if (pres == KEY_EMPTY) { ca.wrep[pslot] = pe; ca.wfm[pe] = make_uint2(U32_NONE, U32_NONE); }
+                pend = false;
+            } else {
+                pslot = hash_next(pslot, ca.wsize);
+                pres = atomicCAS((unsigned long long *) &ca.wkeys[pslot], (unsigned long long) KEY_EMPTY, (unsigned long long) pkey);
+            }
+        }
         const uint64_t need = __ballot(!have);
         const uint32_t avail = qend - qhead;
         if (need != 0ull && avail != 0u) {
@@ -1356,7 +1395,7 @@ __global__ __launch_bounds__(256) void k_project1(Vertex *__restrict__ uverts, c
 #else
         constexpr bool straggler_mode = true;
 #endif
-        if (straggler_mode && qend == qhead && __popcll(act) <= 16) {
+        if (straggler_mode && !async_claims && qend == qhead && __popcll(act) <= 16) {
             // Straggler mode.  Iteration counts are spatially correlated (slow convergence near the smooth-min blends), so a
             // few waves are left with a handful of live lanes for many more rounds while a full one-lane round costs ~960
             // instructions whatever the number of live lanes -- measured: the longest wave lives 2x the mean and sets the
@@ -1415,6 +1454,41 @@ __global__ __launch_bounds__(256) void k_project1(Vertex *__restrict__ uverts, c
                 uverts[slot] = o;
                 if (!((g.x - g.x) == 0.0f)) atomicOr(&status[ST_NONFINITE], 1u);       // src/cuda/mod.rs:289 needs the direct path
                 have = false;
+                if (async_claims) {
+                    while (pend) {                                    // (rare: the previous claim is still probing -- finish it now)
+                        if (pres == KEY_EMPTY || pres == pkey) {
+                            ca.vslot[pe] = pslot | (pres == KEY_EMPTY ? VS_WINNER : 0u);
+                            if (pres == KEY_EMPTY) { ca.wrep[pslot] = pe; ca.wfm[pe] = make_uint2(U32_NONE, U32_NONE); }
+                            pend = false;
+                        } else {
+                            pslot = hash_next(pslot, ca.wsize);
+                            pres = atomicCAS((unsigned long long *) &ca.wkeys[pslot], (unsigned long long) KEY_EMPTY, (unsigned long long) pkey);
+                        }
+                    }
+                    uint64_t key;
+                    if (packed_weld_key(o.position, key)) {
+                        const uint64_t low = (1ull << cshift) - 1ull;
+                        pkey = key; pe = slot;
+                        pslot = cshift ? weld_home(key, key & ~(low | (low << 21) | (low << 42)), ca.wsize) : hash_home(key, ca.wsize);
+                        pres = atomicCAS((unsigned long long *) &ca.wkeys[pslot], (unsigned long long) KEY_EMPTY, (unsigned long long) key);
+                        pend = true;
+                    } else {
+                        atomicOr(&status[ST_WELD_RANGE], 1u);
+                        ca.vslot[slot] = U32_NONE;
+                    }
+                }
+            }
+        }
+    }
+    while (__ballot(pend) != 0ull) {                                  // drain: the claims of the wave's last vertices
+        if (pend) {
+            if (pres == KEY_EMPTY || pres == pkey) {
+                ca.vslot[pe] = pslot | (pres == KEY_EMPTY ? VS_WINNER : 0u);
+                if (pres == KEY_EMPTY) { ca.wrep[pslot] = pe; ca.wfm[pe] = make_uint2(U32_NONE, U32_NONE); }
+                pend = false;
+            } else {
+                pslot = hash_next(pslot, ca.wsize);
+                pres = atomicCAS((unsigned long long *) &ca.wkeys[pslot], (unsigned long long) KEY_EMPTY, (unsigned long long) pkey);
             }
         }
     }
@@ -1892,11 +1966,6 @@ __global__ __launch_bounds__(256) void k_merge_copy(const Triangle *const *__res
 //   k_dist_finalize      kept vertices compacted, every index rewritten to its global number
 // Nothing proportional to the mesh crosses a link or is hashed again; the mesh stays distributed.
 // ------------------------------------------------------------------------------------------
-__device__ __forceinline__ bool packed_weld_key(const Point p, uint64_t &key) {
-    const long long qx = weld_quant(p.x) + 1048576LL, qy = weld_quant(p.y) + 1048576LL, qz = weld_quant(p.z) + 1048576LL;
-    key = (uint64_t) qx | ((uint64_t) qy << 21) | ((uint64_t) qz << 42);
-    return (((unsigned long long) qx | (unsigned long long) qy | (unsigned long long) qz) >> 21) == 0ull;
-}
 
 __global__ __launch_bounds__(256) void k_band_select(const Vertex *__restrict__ v, uint32_t V, float up_thr, float lo_thr, uint32_t has_up,
                                                       uint32_t has_lo, uint32_t *__restrict__ up_ids, uint64_t *__restrict__ up_keys,
@@ -2320,9 +2389,11 @@ hipError_t launch_scan_tiles(hipStream_t st, uint32_t *cnt, const uint32_t *n_pt
 
 hipError_t launch_refine_emit(hipStream_t st, int grid, const Point *vox, const uint32_t *n_ptr, Point cs,
                               const uint8_t *mask, const uint32_t *tilecnt, Point *out, uint32_t cap, uint32_t *n_out,
-                              uint32_t *status, const uint32_t *signs, uint8_t *cubeidx, uint32_t *mtilecnt) {
+                              uint32_t *status, const uint32_t *signs, uint8_t *cubeidx, uint32_t *mtilecnt, bool prescan) {
+    if (prescan)        // many tiles: one single-workgroup scan in front instead of every workgroup re-summing all counts before it
+        hipLaunchKernelGGL(k_scan_tiles, dim3(1), dim3(1024), 0, st, const_cast<uint32_t *>(tilecnt), n_ptr, 256u, n_out, cap, status);
     hipLaunchKernelGGL(k_refine_emit, dim3(grid), dim3(256), 0, st, vox, n_ptr, cs, mask, tilecnt, out, cap, n_out, status, signs,
-                       cubeidx, mtilecnt);
+                       cubeidx, mtilecnt, prescan ? 1u : 0u);
     return hipGetLastError();
 }
 
@@ -2377,9 +2448,12 @@ hipError_t launch_classify(hipStream_t st, int grid, int scene, const SceneParam
 
 hipError_t launch_tile_dedupe(hipStream_t st, int grid, const Point *vox, const uint32_t *n_ptr, Point vs, const uint8_t *cubeidx,
                               const uint32_t *tilecnt, uint32_t *trioff, uint32_t *tri_e, Vertex *uverts, uint4 *tdesc,
-                              uint32_t ucap, uint32_t tcap, uint32_t *ntri_out, uint32_t *ntiles_out, uint32_t *status, uint64_t *dbg) {
+                              uint32_t ucap, uint32_t tcap, uint32_t *ntri_out, uint32_t *ntiles_out, uint32_t *status, uint64_t *dbg,
+                              bool prescan) {
+    if (prescan)
+        hipLaunchKernelGGL(k_scan_tiles, dim3(1), dim3(1024), 0, st, const_cast<uint32_t *>(tilecnt), n_ptr, 256u, ntri_out, tcap, status);
     hipLaunchKernelGGL(k_tile_dedupe, dim3(grid), dim3(256), 0, st, vox, n_ptr, vs, cubeidx, tilecnt, trioff, tri_e, uverts, tdesc,
-                       ucap, tcap, ntri_out, ntiles_out, status, dbg);
+                       ucap, tcap, ntri_out, ntiles_out, status, dbg, prescan ? 1u : 0u);
     return hipGetLastError();
 }
 

@@ -29,7 +29,7 @@ hipError_t launch_scan_tiles(hipStream_t st, uint32_t *cnt, const uint32_t *n_pt
 hipError_t launch_refine_emit(hipStream_t st, int grid, const Point *vox, const uint32_t *n_ptr, Point cs,
                               const uint8_t *mask, const uint32_t *tilecnt, Point *out, uint32_t cap, uint32_t *n_out,
                               uint32_t *status, const uint32_t *signs = nullptr, uint8_t *cubeidx = nullptr,
-                              uint32_t *mtilecnt = nullptr);
+                              uint32_t *mtilecnt = nullptr, bool prescan = false);
 hipError_t launch_sum_tiles(hipStream_t st, const uint32_t *tilecnt, const uint32_t *n_ptr, uint32_t *total_out);
 hipError_t launch_col_refine(hipStream_t st, int scene, const SceneParams *sp, uint32_t x0, uint32_t x1, uint32_t z0, uint32_t z1, int J,
                              uint8_t *g_list1, uint8_t *g_mask2, uint8_t *g_mask3, uint4 *colinfo, uint32_t *zero, uint32_t nzero,
@@ -48,7 +48,8 @@ hipError_t launch_classify(hipStream_t st, int grid, int scene, const SceneParam
                            const uint32_t *n_ptr, Point vs, uint8_t *cubeidx, uint32_t *tilecnt);
 hipError_t launch_tile_dedupe(hipStream_t st, int grid, const Point *vox, const uint32_t *n_ptr, Point vs, const uint8_t *cubeidx,
                               const uint32_t *tilecnt, uint32_t *trioff, uint32_t *tri_e, Vertex *uverts, uint4 *tdesc,
-                              uint32_t ucap, uint32_t tcap, uint32_t *ntri_out, uint32_t *ntiles_out, uint32_t *status, uint64_t *dbg = nullptr);
+                              uint32_t ucap, uint32_t tcap, uint32_t *ntri_out, uint32_t *ntiles_out, uint32_t *status, uint64_t *dbg = nullptr,
+                              bool prescan = false);
 hipError_t launch_tile_prefix(hipStream_t st, const uint4 *tdesc, const uint32_t *ntiles_ptr, uint32_t *tpre, uint32_t *nu_out,
                               uint32_t *coarse);
 hipError_t launch_project(hipStream_t st, int grid, int scene, const SceneParams *sp, Vertex *uverts, const uint4 *tdesc,

@@ -25,16 +25,18 @@ for rep in range(3):
     d = h.project_diag()
     d = d[d[:, 1] != 0]
     t0 = d[:, 0].min()
-    start, end, rounds = (d[:, 0] - t0).astype(np.float64), (d[:, 1] - t0).astype(np.float64), d[:, 2].astype(np.int64)
-    hw = d[:, 3]
+    start, end, rounds = (d[:, 0] - t0).astype(np.float64), (d[:, 1] - t0).astype(np.float64), (d[:, 2] & 0x0FFFFFFF).astype(np.int64)
+    hw = d[:, 2] >> 32
     simd = ((hw >> 4) & 3).astype(np.int64); cu = ((hw >> 8) & 15).astype(np.int64); sh = ((hw >> 12) & 1).astype(np.int64)
-    se = ((hw >> 13) & 7).astype(np.int64); xcc = ((hw >> 32) & 15).astype(np.int64)
+    se = ((hw >> 13) & 7).astype(np.int64); xcc = ((d[:, 2] >> 28) & 15).astype(np.int64)
+    rt0, rt1 = (d[:, 3] & 0xFFFFFFFF).astype(np.int64), (d[:, 3] >> 32).astype(np.int64)
+    span_us = max(float((rt1[xcc == x].max() - rt0[xcc == x].min()) % (1 << 32)) / 100.0 for x in np.unique(xcc))
     unit = (((xcc * 8 + se) * 2 + sh) * 16 + cu) * 4 + simd
     life = end - start
     span = end.max()
     per_unit = np.bincount(np.unique(unit, return_inverse=True)[1], weights=rounds)
     q = lambda a, p: float(np.percentile(a, p))   # noqa: E731
-    res.append({"working_waves": int(len(d)), "kernel_span_ticks": span, "ticks_are": "s_memtime (100 MHz constant clock on gfx9: 10 ns)",
+    res.append({"working_waves": int(len(d)), "kernel_span_us_by_s_memrealtime": span_us, "kernel_span_ticks": span, "ticks_are": "s_memtime = shader-clock cycles, one counter per XCD (not comparable across XCDs); the wall span is from s_memrealtime",
                 "start_p50": q(start, 50), "start_max": float(start.max()),
                 "end_p10": q(end, 10), "end_p50": q(end, 50), "end_p90": q(end, 90), "end_p99": q(end, 99), "end_max": float(end.max()),
                 "life_mean": float(life.mean()), "life_p50": q(life, 50), "life_p99": q(life, 99), "life_max": float(life.max()),
