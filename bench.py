@@ -452,18 +452,18 @@ def main():
         return
 
     # -------------------------------------------------------------------- N = 1
+    def device_ms(hh, levels, n=60):
+        """Median HIP-event time of the device chain: a separate pass with option "timing" on (the event pair costs ~9 us of
+        wall time per regen, so the timed steps run without it)."""
+        hh.set_option("timing", 1)
+        ms = [hh.regen(levels).device_ms for _ in range(n + 5)][5:]
+        hh.set_option("timing", 0)
+        return round(float(np.median(ms)), 4)
+
     h = pkg.CudaHandler(local_rank, args.scene, params)
     info = h.regen(args.levels)                      # capacity discovery pass (synchronous, untimed)
     h.set_option("graph", 1 if args.graph else 0)
-    dev_ms = []
-
-    def step():
-        i = h.regen(args.levels)
-        dev_ms.append(i.device_ms)
-        return i
-
-    dt, info = job.timed(step, args.steps, args.warmup)
-    dev_ms = dev_ms[-args.steps:]
+    dt, info = job.timed(lambda: h.regen(args.levels), args.steps, args.warmup)
     ms_per_step = dt / args.steps * 1e3
     out = {
         "metric": "Mvoxels/s (512^3 SDF mesh extract: N^3 grid cells per full regen, whole job)",
@@ -476,7 +476,7 @@ def main():
                    "levels": args.levels, "grid": n_grid, "parallelism": "1 GPU"},
         "mtris_per_s": round(info.triangles * args.steps / dt / 1e6, 2),
         "triangles": int(info.triangles), "vertices": int(info.vertices), "active_voxels": int(info.voxel_count[args.levels]),
-        "device_ms_per_step": round(float(np.median(dev_ms)), 4),
+        "device_ms_per_step": device_ms(h, args.levels),
         "work_actually_done": {"active_gvoxels_per_s": round(int(info.voxel_count[args.levels]) / ms_per_step / 1e6, 3),
                                "gtris_per_s": round(info.triangles / ms_per_step / 1e6, 3),
                                "note": "`value` is the N^3-equivalent rate BASELINE defines; the hierarchical path touches O(surface) cells"},
@@ -484,10 +484,9 @@ def main():
 
     # --- the same step driven the other way (graph replay vs eager launches of the identical chain)
     h.set_option("graph", 0 if args.graph else 1)
-    gdev = []
-    gdt, _ = job.timed(lambda: gdev.append(h.regen(args.levels).device_ms), 100, 10)
+    gdt, _ = job.timed(lambda: h.regen(args.levels), 100, 10)
     out["eager_launches" if args.graph else "hipgraph_replay"] = {
-        "ms_per_step": round(gdt / 100 * 1e3, 4), "device_ms_per_step": round(float(np.median(gdev[-100:])), 4),
+        "ms_per_step": round(gdt / 100 * 1e3, 4), "device_ms_per_step": device_ms(h, args.levels),
         "mvoxels_per_s": round(n_grid ** 3 * 100 / gdt / 1e6, 1)}
     h.set_option("graph", 1 if args.graph else 0)
 
@@ -501,17 +500,10 @@ def main():
             hz = pkg.CudaHandler(local_rank, sc, params if sc == args.scene else None)
             hz.regen(lv)
             hz.set_option("graph", 1 if args.graph else 0)
-            zdev = []
-
-            def zstep():
-                zi = hz.regen(lv)
-                zdev.append(zi.device_ms)
-                return zi
-
-            dz, zi = job.timed(zstep, 50, 5)
+            dz, zi = job.timed(lambda: hz.regen(lv), 50, 5)
             dz /= 50
             ng = 32 << lv
-            sizes[label] = {"grid": ng, "ms_per_step": round(dz * 1e3, 4), "device_ms_per_step": round(float(np.median(zdev[-50:])), 4),
+            sizes[label] = {"grid": ng, "ms_per_step": round(dz * 1e3, 4), "device_ms_per_step": device_ms(hz, lv, 30),
                             "mvoxels_per_s": round(ng ** 3 / dz / 1e6, 1), "mtris_per_s": round(zi.triangles / dz / 1e6, 1),
                             "triangles": int(zi.triangles), "vertices": int(zi.vertices)}
             hz.close()
@@ -581,7 +573,7 @@ def main():
     fdt, finfo = job.timed(lambda: hf.regen(args.levels), 100, 10)
     out["fast_math_build"] = {"what": "same step through libsdmesh_fast.so (FMA contraction, approximate divide / sqrt: the reference's nvcc "
                                       "--use_fast_math mode); opt-in, within 1e-5 relative of the strict build, not bit-exact, never the headline",
-                              "ms_per_step": round(fdt / 100 * 1e3, 4), "device_ms_per_step": round(float(finfo.device_ms), 4),
+                              "ms_per_step": round(fdt / 100 * 1e3, 4), "device_ms_per_step": device_ms(hf, args.levels, 30),
                               "mvoxels_per_s": round(n_grid ** 3 * 100 / fdt / 1e6, 1), "triangles": int(finfo.triangles), "vertices": int(finfo.vertices)}
     hf.close()
 

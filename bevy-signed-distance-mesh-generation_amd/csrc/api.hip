@@ -142,6 +142,11 @@ struct sdmesh_handle {
     uint32_t *d_ctr = nullptr;     // CTR_WORDS
     uint32_t *d_status = nullptr;  // ST_WORDS
     uint32_t *h_pinned = nullptr;  // CTR_WORDS + ST_WORDS, pinned
+    bool ctl_published = false;    // the chain just enqueued writes h_pinned itself (k_tile_finish): no read-back copy
+    int publish_ctl = 1;           // option "publish_ctl": 0 = always read back with a copy
+    int local_prefix = 1;          // option "local_prefix": 0 = always launch k_tile_prefix / k_scan_u32
+    int timing = 0;                // option "timing": 1 = an event pair around the planned chain fills info->device_ms; off by default:
+                                   // the two marker packets cost ~9 us of wall time per regen (0.155 -> 0.146 ms at 512^3)
     // mesh stage
     DevBuf cubeidx, trioff, ff_arena, first_ord_buf, uverts, tri_e, vslot, tdesc, tfirst, tfpre, tpre, flip, wvidx, torder, wrep_buf, wfm_buf;
     DevBuf vertices, indices, raw, compact, staging, dense_samples, dense_bits, cellcnt;
@@ -349,9 +354,13 @@ int mesh_front(sdmesh_handle *h, const Point *d_vox, const uint32_t *n_ptr, Poin
                               h->ucap, h->tcap, h->d_ctr + CTR_NTRI, h->d_ctr + CTR_NTILES, h->d_status, d_tile_dbg,
                               tiles(h->cap_vox) > PRESCAN_TILES));
     SDCHK(prof_mark(h, "tile_dedupe"));
+    // few tiles: the projection's workgroups prefix the tile counts themselves (no k_tile_prefix launch)
+    const bool local_pre = h->local_prefix && tiles(h->cap_vox) <= SDM_LOCAL_TILES;
     uint32_t *coarse = (uint32_t *) h->tpre.p + h->tp_cap;
-    HIPCHK(launch_tile_prefix(st, (const uint4 *) h->tdesc.p, h->d_ctr + CTR_NTILES, (uint32_t *) h->tpre.p, h->d_ctr + CTR_NUNIQ, coarse));
-    SDCHK(prof_mark(h, "tile_prefix"));
+    if (!local_pre) {
+        HIPCHK(launch_tile_prefix(st, (const uint4 *) h->tdesc.p, h->d_ctr + CTR_NTILES, (uint32_t *) h->tpre.p, h->d_ctr + CTR_NUNIQ, coarse));
+        SDCHK(prof_mark(h, "tile_prefix"));
+    }
     const int plan_lanes = h->lane_hint >= 160000u ? 1 : 4;
     const int p_lanes = h->project_lanes ? h->project_lanes : plan_lanes;
     const int f_lanes = h->flip_lanes ? h->flip_lanes : plan_lanes;
@@ -360,7 +369,14 @@ int mesh_front(sdmesh_handle *h, const Point *d_vox, const uint32_t *n_ptr, Poin
     // ... and only while a projection wave owns about one batch of vertices: with many batches per wave every claim would
     // wait for the wave's last batch and pile up at the end of the kernel (2048^3: projection 340 -> 498 us)
     // Larger meshes (1-lane kernel only): asynchronous claims, issued per finished vertex and looked at a round later.
-    const uint32_t proj_waves = (uint32_t) (h->grid * h->project_mult) * 4u;
+    // projection grid: no more workgroups than the planned vertex count fills with one batch per wave (+3 %): workgroups
+    // without work still pay the tile-prefix step before they can tell, and start behind the working ones
+    int p_grid = h->grid * h->project_mult;
+    if (h->lane_hint) {
+        const uint32_t per_wg = 4u * (64u / (uint32_t) p_lanes);
+        p_grid = (int) std::min<uint32_t>((uint32_t) p_grid, (h->lane_hint + h->lane_hint / 32u) / per_wg + 2u);
+    }
+    const uint32_t proj_waves = (uint32_t) p_grid * 4u;
     const bool claim_ok = h->claim_in_project && h->fork == 2 && !h->wide_active && h->lane_hint != 0;
     const bool few_batches = h->lane_hint <= 2u * (64u / (uint32_t) p_lanes) * proj_waves;
     const bool async_claim = claim_ok && !few_batches && p_lanes == 1 && h->claim_in_project != 2;
@@ -373,14 +389,15 @@ int mesh_front(sdmesh_handle *h, const Point *d_vox, const uint32_t *n_ptr, Poin
         d_prof = (uint32_t *) h->prof_rounds.p;
     }
     if (h->project_diag == 1) {
-        h->diag_waves = (uint32_t) (h->grid * h->project_mult) * 4u;
+        h->diag_waves = proj_waves;
         SDCHK(ensure(h, h->proj_diag, 32ull * h->diag_waves));
         HIPCHK(hipMemsetAsync(h->proj_diag.p, 0, 32ull * h->diag_waves, st));
         d_diag = (uint64_t *) h->proj_diag.p;
     }
-    HIPCHK(launch_project(st, h->grid * h->project_mult, h->scene, h->d_sp, (Vertex *) h->uverts.p, (const uint4 *) h->tdesc.p,
-                          (const uint32_t *) h->tpre.p, coarse, h->d_ctr + CTR_NTILES, h->d_status, p_lanes, d_prof, d_diag,
-                          h->wkeys, h->wsize, (uint32_t *) h->vslot.p, (uint32_t *) h->wrep_buf.p, h->wfm, weld_mode(h, vs) | (early_claim && !async_claim ? 2u : 0u) | (async_claim ? 4u : 0u)));
+    HIPCHK(launch_project(st, p_grid, h->scene, h->d_sp, (Vertex *) h->uverts.p, (const uint4 *) h->tdesc.p,
+                          local_pre ? nullptr : (const uint32_t *) h->tpre.p, coarse, h->d_ctr + CTR_NTILES, h->d_status, p_lanes, d_prof, d_diag,
+                          h->wkeys, h->wsize, (uint32_t *) h->vslot.p, (uint32_t *) h->wrep_buf.p, h->wfm, weld_mode(h, vs) | (early_claim && !async_claim ? 2u : 0u) | (async_claim ? 4u : 0u),
+                          h->d_ctr + CTR_NUNIQ));
     SDCHK(prof_mark(h, p_lanes == 1 ? "project1" : (p_lanes == 2 ? "project2" : "project4")));
     // fork: the weld claim (scattered CAS, latency-bound) runs beside the orientation test (VALU-bound)
     int f_grid = h->grid * (f_lanes == 1 ? 1 : h->flip_mult);
@@ -420,16 +437,19 @@ int mesh_front(sdmesh_handle *h, const Point *d_vox, const uint32_t *n_ptr, Poin
 }
 
 // per-tile weld of (uverts, tri_e, flip) described by tdesc[0..*NTILES) -> vertices / indices
-int mesh_weld(sdmesh_handle *h, const Vertex *uverts) {
+int mesh_weld(sdmesh_handle *h, const Vertex *uverts, uint32_t max_tiles, bool publish = false) {
     hipStream_t st = h->stream;
+    const bool local_pre = h->local_prefix && max_tiles <= SDM_LOCAL_TILES;       // k_tile_finish prefixes the tile counts itself
+    h->ctl_published = publish;             // the last kernel writes the control block to the pinned host copy itself
     const int flip_scene = h->flip_pending ? h->scene : -1;
     h->flip_pending = false;
     for (int part = h->profile ? 1 : 0; part <= (h->profile ? 2 : 0); part++) {        // profiling: a stage marker behind k_tile_first
         HIPCHK(launch_weld(st, h->tgrid, uverts, (const uint4 *) h->tdesc.p, h->d_ctr + CTR_NTILES, (uint32_t *) h->tri_e.p,
                            (const uint8_t *) h->flip.p, h->first_ord, h->wfm, (const uint32_t *) h->wrep_buf.p, (uint32_t *) h->vslot.p,
-                           (uint32_t *) h->wvidx.p, (uint32_t *) h->torder.p, (uint32_t *) h->tfirst.p, (uint32_t *) h->tfpre.p,
+                           (uint32_t *) h->wvidx.p, (uint32_t *) h->torder.p, (uint32_t *) h->tfirst.p, local_pre ? nullptr : (uint32_t *) h->tfpre.p,
                            (Vertex *) h->vertices.p, (uint32_t) (h->vertices.cap / sizeof(Vertex)), h->d_ctr + CTR_NVERT,
-                           (uint32_t *) h->indices.p, h->d_status, flip_scene, h->d_sp, part));
+                           (uint32_t *) h->indices.p, h->d_status, flip_scene, h->d_sp, part,
+                           publish ? h->d_ctr : nullptr, publish ? h->h_pinned : nullptr, CTR_WORDS + ST_WORDS, CTR_WORDS + ST_OVERFLOW, CTR_NVERT));
         if (part == 1) SDCHK(prof_mark(h, flip_scene >= 0 ? "tile_first_flip" : "tile_first"));
     }
     SDCHK(prof_mark(h, h->profile ? "weld_rank_scan_finish" : "weld"));
@@ -526,7 +546,7 @@ int weld_raw_device(sdmesh_handle *h, const Triangle *d_raw, uint32_t nslots, bo
     }
     HIPCHK(launch_tile_claim(st, h->tgrid, corners, (const uint4 *) h->tdesc.p, h->d_ctr + CTR_NTILES,
                              h->wkeys, h->wsize, (uint32_t *) h->vslot.p, h->d_status, weld_mode(h, h->voxel_size), (uint32_t *) h->wrep_buf.p, h->wfm));
-    SDCHK(mesh_weld(h, corners));
+    SDCHK(mesh_weld(h, corners, (nslots + 255u) / 256u));
     return SDMESH_OK;
 }
 
@@ -673,7 +693,8 @@ int enqueue_planned_chain(sdmesh_handle *h, int levels, const uint32_t *box, uin
     h->lane_hint = 0;
     h->tri_hint = 0;
     SDCHK(rc_front);
-    if (!h->skip_weld) SDCHK(mesh_weld(h, (const Vertex *) h->uverts.p));
+    h->ctl_published = false;
+    if (!h->skip_weld) SDCHK(mesh_weld(h, (const Vertex *) h->uverts.p, tiles(h->cap_vox), h->publish_ctl != 0));
     *vs_out = vs;
     return SDMESH_OK;
 }
@@ -750,11 +771,13 @@ int regen_impl(sdmesh_handle *h, int levels, int mode, int part, int nparts, sdm
         vs.x = vs.y = vs.z = MESH_GENERATION_BB_SIZE / (float) MESH_GENERATION_INIT_FACTOR;
         uint32_t n_cap = n0;
         bool direct = h->force_direct != 0;
+        bool timed = true;                  // ev0 / ev1 bracket the device work of this attempt
         if (resumed) {
             // the planned chain (and its read-back) were enqueued by regen_begin: just wait for them
             vs = h->pend_vs;
             n_cap = h->pend_ncap;
             direct = false;
+            timed = h->timing != 0;
             HIPCHK(hipStreamSynchronize(st));
         } else if (phase == 1 && !(async && !direct)) {
             // no capacity plan yet: nothing can be enqueued blindly; regen_end will run the discovery path
@@ -769,7 +792,7 @@ int regen_impl(sdmesh_handle *h, int levels, int mode, int part, int nparts, sdm
             n_cap = padded(h->plan_counts[levels]);
             if (h->use_graph && st != nullptr && !h->profile && !h->project_diag) {   // (the legacy null stream cannot be captured: eager launches there)
                 uint64_t key[8] = {h->buf_gen, (uint64_t) h->scene, (uint64_t) levels, ((uint64_t) mode << 40) | ((uint64_t) part << 20) | (uint64_t) nparts,
-                                   (uint64_t) h->skip_weld | ((uint64_t) h->wide_active << 1) | ((uint64_t) h->col_refine << 2) | ((uint64_t) h->claim_in_project << 3) | ((uint64_t) h->fuse_flip << 4), (uint64_t) (uintptr_t) st, (uint64_t) h->grid | ((uint64_t) h->tgrid << 20) | ((uint64_t) h->project_mult << 40) | ((uint64_t) h->flip_mult << 48) | ((uint64_t) h->refine2 << 56) | ((uint64_t) h->emit_ci << 57) | ((uint64_t) h->project_lanes << 58) | ((uint64_t) h->flip_lanes << 61), 0};
+                                   (uint64_t) h->skip_weld | ((uint64_t) h->wide_active << 1) | ((uint64_t) h->col_refine << 2) | ((uint64_t) h->claim_in_project << 3) | ((uint64_t) h->fuse_flip << 4) | ((uint64_t) h->publish_ctl << 6) | ((uint64_t) h->local_prefix << 7), (uint64_t) (uintptr_t) st, (uint64_t) h->grid | ((uint64_t) h->tgrid << 20) | ((uint64_t) h->project_mult << 40) | ((uint64_t) h->flip_mult << 48) | ((uint64_t) h->refine2 << 56) | ((uint64_t) h->emit_ci << 57) | ((uint64_t) h->project_lanes << 58) | ((uint64_t) h->flip_lanes << 61), 0};
                 for (int i = 0; i <= levels; i++) key[7] = key[7] * 1000003ull + h->plan_counts[i];
                 key[7] = key[7] * 1000003ull + h->plan_uniq;
                 key[7] = key[7] * 1000003ull + h->plan_tris;
@@ -778,7 +801,7 @@ int regen_impl(sdmesh_handle *h, int levels, int mode, int part, int nparts, sdm
                     HIPCHK(hipStreamSynchronize(st));
                     HIPCHK(hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal));
                     int rc = enqueue_planned_chain(h, levels, box, n0, lvl_words, &vs);
-                    if (rc == SDMESH_OK) rc = read_back_enqueue(h);
+                    if (rc == SDMESH_OK && !h->ctl_published) rc = read_back_enqueue(h);
                     hipGraph_t g = nullptr;
                     hipError_t ce = hipStreamEndCapture(st, &g);
                     if (rc != SDMESH_OK) { if (g) (void) hipGraphDestroy(g); return rc; }
@@ -791,15 +814,16 @@ int regen_impl(sdmesh_handle *h, int levels, int mode, int part, int nparts, sdm
                 }
                 h->cur = h->graph_cur;
                 vs = h->graph_vs;
-                HIPCHK(hipEventRecord(h->ev0, st));
+                if (h->timing) HIPCHK(hipEventRecord(h->ev0, st));
                 HIPCHK(hipGraphLaunch(h->graph_exec, st));
-                HIPCHK(hipEventRecord(h->ev1, st));
+                if (h->timing) HIPCHK(hipEventRecord(h->ev1, st));
             } else {
-                HIPCHK(hipEventRecord(h->ev0, st));
+                if (h->timing) HIPCHK(hipEventRecord(h->ev0, st));
                 SDCHK(enqueue_planned_chain(h, levels, box, n0, lvl_words, &vs));
-                HIPCHK(hipEventRecord(h->ev1, st));
-                SDCHK(read_back_enqueue(h));
+                if (h->timing) HIPCHK(hipEventRecord(h->ev1, st));
+                if (!h->ctl_published) SDCHK(read_back_enqueue(h));
             }
+            timed = h->timing != 0;
             if (phase == 1) {
                 h->pend_active = true; h->pend_async = true;
                 h->pend_levels = levels; h->pend_mode = mode; h->pend_part = part; h->pend_nparts = nparts;
@@ -849,7 +873,7 @@ int regen_impl(sdmesh_handle *h, int levels, int mode, int part, int nparts, sdm
             if (!direct) {
                 SDCHK(layout_mesh(h, n_cap, 0));
                 SDCHK(mesh_front(h, (const Point *) h->vox[h->cur].p, h->d_ctr + CTR_LEVEL0 + levels, vs, false, false));
-                if (!h->skip_weld) SDCHK(mesh_weld(h, (const Vertex *) h->uverts.p));
+                if (!h->skip_weld) SDCHK(mesh_weld(h, (const Vertex *) h->uverts.p, tiles(h->cap_vox)));
             }
             HIPCHK(hipEventRecord(h->ev1, st));
             SDCHK(read_back(h));
@@ -871,7 +895,7 @@ int regen_impl(sdmesh_handle *h, int levels, int mode, int part, int nparts, sdm
             SDCHK(layout_mesh(h, n_cap, c[CTR_NUNIQ] + 1024));
             SDCHK(zero_status(h));
             SDCHK(mesh_front(h, d_vox, n_ptr, vs, true));
-            if (!h->skip_weld) SDCHK(mesh_weld(h, (const Vertex *) h->uverts.p));
+            if (!h->skip_weld) SDCHK(mesh_weld(h, (const Vertex *) h->uverts.p, tiles(h->cap_vox)));
             HIPCHK(hipEventRecord(h->ev1, st));
             SDCHK(read_back(h));
             if (s[ST_OVERFLOW]) return fail(h, SDMESH_ERR_INTERNAL, "capacity overflow persists (status %u)", s[ST_OVERFLOW]);
@@ -899,7 +923,7 @@ int regen_impl(sdmesh_handle *h, int levels, int mode, int part, int nparts, sdm
         }
         SDCHK(status_to_error(h));
         float ms = 0.0f;
-        HIPCHK(hipEventElapsedTime(&ms, h->ev0, h->ev1));
+        if (timed) HIPCHK(hipEventElapsedTime(&ms, h->ev0, h->ev1));
         h->n_vox = n;
         h->n_unique = c[CTR_NUNIQ];
         h->n_tris = c[CTR_NTRI];
@@ -1111,6 +1135,9 @@ int sdmesh_set_option(sdmesh_handle *h, const char *name, int value) {
                                                      : "this is the strict IEEE build (libsdmesh.so); load libsdmesh_fast.so for the fast numeric mode");
         return SDMESH_OK;
     }
+    if (!strcmp(name, "timing")) { h->timing = value != 0; return SDMESH_OK; }
+    if (!strcmp(name, "local_prefix")) { h->local_prefix = value != 0; drop_graph(h); return SDMESH_OK; }
+    if (!strcmp(name, "publish_ctl")) { h->publish_ctl = value != 0; drop_graph(h); return SDMESH_OK; }
     if (!strcmp(name, "fuse_flip")) { h->fuse_flip = value < 0 ? 0 : (value > 2 ? 2 : value); drop_graph(h); return SDMESH_OK; }
     if (!strcmp(name, "claim")) { h->claim_in_project = value < 0 ? 0 : (value > 2 ? 2 : value); drop_graph(h); return SDMESH_OK; }   // 2: never asynchronous
     if (!strcmp(name, "weld_shift")) { if (value < -1 || value > 20) return fail(h, SDMESH_ERR_INVALID, "weld_shift -1..20"); h->weld_shift = value; drop_graph(h); return SDMESH_OK; }
@@ -1250,7 +1277,7 @@ int sdmesh_voxel_field_to_mesh(sdmesh_handle *h, const struct Point *voxels, siz
     for (int pass = 0; pass < 2; pass++) {
         SDCHK(host_mesh_front(h, voxels, (uint32_t) n, voxel_size, direct));
         if (direct) SDCHK(weld_raw_device(h, (const Triangle *) h->raw.p, 5u * (uint32_t) n));
-        else SDCHK(mesh_weld(h, (const Vertex *) h->uverts.p));
+        else SDCHK(mesh_weld(h, (const Vertex *) h->uverts.p, tiles(h->cap_vox)));
         SDCHK(read_back(h));
         if (!h->h_pinned[CTR_WORDS + ST_WELD_RANGE] || h->wide_active) break;
         h->wide_active = true;               // a vertex outside the packed key range: weld again with [i64; 3]-equivalent keys
@@ -1462,7 +1489,7 @@ int sdmesh_regen_dense(sdmesh_handle *h, int levels, sdmesh_regen_info *info) {
     vs.x = vs.y = vs.z = (MESH_GENERATION_BB_SIZE / (float) MESH_GENERATION_INIT_FACTOR) / (float) (1u << levels);
     for (int attempt = 0; attempt < 2; attempt++) {
         SDCHK(mesh_front(h, (const Point *) h->vox[0].p, h->d_ctr + CTR_LEVEL0 + levels, vs, true, false, true));
-        SDCHK(mesh_weld(h, (const Vertex *) h->uverts.p));
+        SDCHK(mesh_weld(h, (const Vertex *) h->uverts.p, tiles(h->cap_vox)));
         HIPCHK(hipEventRecord(h->ev1, st));
         SDCHK(read_back(h));
         if (!h->h_pinned[CTR_WORDS + ST_OVERFLOW]) break;

@@ -83,6 +83,46 @@ __device__ __forceinline__ uint32_t block_excl_scan(uint32_t v, uint32_t &total,
     return lds[wave] + incl - v;
 }
 
+// Tile counts that a 256-thread workgroup prefixes for itself in LDS (api.hip: LOCAL_TILES).  A single-workgroup scan kernel
+// between two per-tile kernels is a whole dependent launch (~4.7 us at 512^3: dispatch, two dependent loads, the scan, the
+// stores) for ~1 000 numbers; every consumer workgroup re-deriving the prefix costs it one 8-load step instead.
+static constexpr uint32_t LOCAL_TILES = SDM_LOCAL_TILES;
+
+// exclusive prefix of n <= LOCAL_TILES counts (count i at base[i * stride]) -> s_pre[0 .. n]; returns the total.
+// blockDim.x == 256, all threads must call; s_scan needs 17 words.
+__device__ __forceinline__ uint32_t local_prefix(const uint32_t *__restrict__ base, uint32_t stride, uint32_t n,
+                                                 uint32_t *__restrict__ s_pre, uint32_t *__restrict__ s_scan) {
+    constexpr uint32_t PER = LOCAL_TILES / 256;
+    uint32_t v[PER], sum = 0;
+#pragma unroll
+    for (uint32_t k = 0; k < PER; k++) {
+        const uint32_t i = threadIdx.x * PER + k;
+        v[k] = i < n ? base[(size_t) i * stride] : 0u;
+        sum += v[k];
+    }
+    uint32_t total;
+    uint32_t ex = block_excl_scan(sum, total, s_scan);
+#pragma unroll
+    for (uint32_t k = 0; k < PER; k++) {
+        const uint32_t i = threadIdx.x * PER + k;
+        if (i < n) s_pre[i] = ex;
+        ex += v[k];
+    }
+    if (threadIdx.x == 0) s_pre[n] = total;
+    __syncthreads();
+    return total;
+}
+
+// the tile lo in [0, n) with s_pre[lo] <= item < s_pre[lo + 1]   (item < s_pre[n])
+__device__ __forceinline__ uint32_t local_find(const uint32_t *__restrict__ s_pre, uint32_t n, uint32_t item) {
+    uint32_t lo = 0, hi = n;
+    while (hi - lo > 1u) {
+        const uint32_t mid = (lo + hi) >> 1;
+        if (s_pre[mid] <= item) lo = mid; else hi = mid;
+    }
+    return lo;
+}
+
 __device__ __forceinline__ uint64_t mix64(uint64_t h) {
     h ^= h >> 33; h *= 0xff51afd7ed558ccdull; h ^= h >> 33; h *= 0xc4ceb9fe1a85ec53ull; h ^= h >> 33;
     return h;
@@ -1156,6 +1196,19 @@ __device__ __forceinline__ void project_epilogue(uint32_t wave, uint32_t rounds,
 // while the slow ones still iterate, i.e. under the projection's tail, when most of the chip is idle.
 // The wave re-derives its items (item -> tile by the coarse index) and re-reads the positions it wrote (agent-scope
 // loads: the stores are this wave's own and were waited for).
+// vertex slot of work item `item` of the projection: its tile by the workgroup's own LDS prefix (tpre == nullptr) or by
+// k_tile_prefix's global prefix and coarse index
+__device__ __forceinline__ uint32_t item_slot(uint32_t item, const uint4 *__restrict__ tdesc, const uint32_t *__restrict__ tpre,
+                                              const uint32_t *__restrict__ coarse, const uint32_t *__restrict__ s_pre, uint32_t ntiles) {
+    if (tpre == nullptr) {
+        const uint32_t lo = local_find(s_pre, ntiles, item);
+        return tdesc[lo].x + (item - s_pre[lo]);
+    }
+    uint32_t lo = coarse[item >> 6];                               // tile of item 64 * (item / 64): at or before ours
+    while (tpre[lo + 1u] <= item) lo++;                            // (tpre[ntiles] = U > item ends the walk)
+    return tdesc[lo].x + (item - tpre[lo]);
+}
+
 struct ClaimArgs {
     uint64_t *wkeys;
     uint32_t *vslot;
@@ -1168,16 +1221,15 @@ struct ClaimArgs {
 template <uint32_t PER>
 __device__ __forceinline__ void claim_epilogue(uint32_t wave, uint32_t nwaves, uint32_t myb, uint32_t U, const Vertex *__restrict__ uverts,
                                                const uint4 *__restrict__ tdesc, const uint32_t *__restrict__ tpre,
-                                               const uint32_t *__restrict__ coarse, const ClaimArgs &ca, uint32_t *__restrict__ status) {
+                                               const uint32_t *__restrict__ coarse, const ClaimArgs &ca, uint32_t *__restrict__ status,
+                                               const uint32_t *__restrict__ s_pre, uint32_t ntiles) {
     if (!(ca.wmode & 2u)) return;
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");              // this wave's position stores have left the CU
     const uint32_t shift = ca.wmode >> 8;
     for (uint32_t j = lane_id(); j < myb * PER; j += 64u) {
         const uint32_t item = ((j / PER) * nwaves + wave) * PER + (j % PER);
         if (item >= U) continue;
-        uint32_t lo = coarse[item >> 6];
-        while (tpre[lo + 1u] <= item) lo++;
-        const uint32_t e = tdesc[lo].x + (item - tpre[lo]);
+        const uint32_t e = item_slot(item, tdesc, tpre, coarse, s_pre, ntiles);
         const float *pp = &uverts[e].position.x;
         Point p;
         p.x = __hip_atomic_load(pp + 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -1197,10 +1249,19 @@ __global__ __launch_bounds__(256) void k_project(Vertex *__restrict__ uverts, co
                                                   const uint32_t *__restrict__ tpre, const uint32_t *__restrict__ coarse, const uint32_t *__restrict__ ntiles_ptr,
                                                   const SceneParams *__restrict__ spp, uint32_t *__restrict__ status,
                                                   uint32_t *__restrict__ prof /* optional: 256 counters of Newton rounds, 64 B apart */,
-                                                  uint64_t *__restrict__ diag /* optional: per wave {start, end, rounds, hw id} */, ClaimArgs ca) {
+                                                  uint64_t *__restrict__ diag /* optional: per wave {start, end, rounds, hw id} */, ClaimArgs ca,
+                                                  uint32_t *__restrict__ nu_out /* tpre == nullptr: the vertex total goes here */) {
+    __shared__ uint32_t s_pre[LOCAL_TILES + 1], s_scan[17];
     const SceneParams &sp = *spp;  // scene uniform in device memory (a captured graph replays with new values)
     const uint32_t ntiles = *ntiles_ptr;
-    const uint32_t U = ntiles ? tpre[ntiles] : 0u;
+    uint32_t U;
+    if (tpre == nullptr) {
+        if (ntiles > LOCAL_TILES) { if (threadIdx.x == 0) atomicOr(&status[ST_INTERNAL], 32u); return; }
+        U = local_prefix(&tdesc[0].y, 4u, ntiles, s_pre, s_scan);
+        if (blockIdx.x == 0 && threadIdx.x == 0) *nu_out = U;
+    } else {
+        U = ntiles ? tpre[ntiles] : 0u;
+    }
     constexpr uint32_t PER = 64u / LANES, SH = LANES == 4 ? 4u : 5u;      // vertices per wave-batch, log2 of it
     const uint32_t lane = lane_id(), sub = lane & (LANES - 1u), gbase = lane & ~(LANES - 1u);
     const uint32_t nwaves = gridDim.x * (blockDim.x >> 6);
@@ -1230,9 +1291,7 @@ __global__ __launch_bounds__(256) void k_project(Vertex *__restrict__ uverts, co
             const uint32_t j = qhead + rank;
             const uint32_t item = ((j >> SH) * nwaves + wave) * PER + (j & (PER - 1u));
             if (!have && rank < avail && item < U) {
-                uint32_t lo = coarse[item >> 6];                       // tile of item 64 * (item / 64): at or before ours
-                while (tpre[lo + 1u] <= item) lo++;                    // (tpre[ntiles] = U > item ends the walk)
-                slot = tdesc[lo].x + (item - tpre[lo]);
+                slot = item_slot(item, tdesc, tpre, coarse, s_pre, ntiles);
                 const Point p = uverts[slot].position;
                 g = mk(p.x, p.y, p.z);
                 have = true; finalize = false; it = 0;
@@ -1263,7 +1322,7 @@ __global__ __launch_bounds__(256) void k_project(Vertex *__restrict__ uverts, co
             }
         }
     }
-    claim_epilogue<PER>(wave, nwaves, myb, U, uverts, tdesc, tpre, coarse, ca, status);
+    claim_epilogue<PER>(wave, nwaves, myb, U, uverts, tdesc, tpre, coarse, ca, status, s_pre, ntiles);
     project_epilogue(wave, rounds, t_start, prof, diag);
 }
 
@@ -1328,10 +1387,19 @@ template <int SCENE>
 __global__ __launch_bounds__(256) void k_project1(Vertex *__restrict__ uverts, const uint4 *__restrict__ tdesc,
                                                    const uint32_t *__restrict__ tpre, const uint32_t *__restrict__ coarse, const uint32_t *__restrict__ ntiles_ptr,
                                                    const SceneParams *__restrict__ spp, uint32_t *__restrict__ status,
-                                                   uint32_t *__restrict__ prof, uint64_t *__restrict__ diag, ClaimArgs ca) {
+                                                   uint32_t *__restrict__ prof, uint64_t *__restrict__ diag, ClaimArgs ca,
+                                                   uint32_t *__restrict__ nu_out) {
+    __shared__ uint32_t s_pre[LOCAL_TILES + 1], s_scan[17];
     const SceneParams &sp = *spp;
     const uint32_t ntiles = *ntiles_ptr;
-    const uint32_t U = ntiles ? tpre[ntiles] : 0u;
+    uint32_t U;
+    if (tpre == nullptr) {                                            // (see k_project)
+        if (ntiles > LOCAL_TILES) { if (threadIdx.x == 0) atomicOr(&status[ST_INTERNAL], 32u); return; }
+        U = local_prefix(&tdesc[0].y, 4u, ntiles, s_pre, s_scan);
+        if (blockIdx.x == 0 && threadIdx.x == 0) *nu_out = U;
+    } else {
+        U = ntiles ? tpre[ntiles] : 0u;
+    }
     const uint32_t lane = lane_id();
     const uint32_t nwaves = gridDim.x * (blockDim.x >> 6);
     const uint32_t wave = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
@@ -1377,9 +1445,7 @@ __global__ __launch_bounds__(256) void k_project1(Vertex *__restrict__ uverts, c
             const uint32_t j = qhead + rank;
             const uint32_t item = ((j >> 6) * nwaves + wave) * 64u + (j & 63u);
             if (!have && rank < avail && item < U) {
-                uint32_t lo = coarse[item >> 6];                       // tile of item 64 * (item / 64): at or before ours
-                while (tpre[lo + 1u] <= item) lo++;                    // (tpre[ntiles] = U > item ends the walk)
-                slot = tdesc[lo].x + (item - tpre[lo]);
+                slot = item_slot(item, tdesc, tpre, coarse, s_pre, ntiles);
                 const Point p = uverts[slot].position;
                 g = mk(p.x, p.y, p.z);
                 have = true; finalize = false; it = 0;
@@ -1492,7 +1558,7 @@ __global__ __launch_bounds__(256) void k_project1(Vertex *__restrict__ uverts, c
             }
         }
     }
-    claim_epilogue<64u>(wave, nwaves, myb, U, uverts, tdesc, tpre, coarse, ca, status);
+    claim_epilogue<64u>(wave, nwaves, myb, U, uverts, tdesc, tpre, coarse, ca, status, s_pre, ntiles);
     project_epilogue(wave, rounds, t_start, prof, diag);
 }
 
@@ -1719,16 +1785,42 @@ __global__ __launch_bounds__(1024) void k_scan_u32(const uint32_t *__restrict__ 
 }
 
 // per tile: welded vertices (dense, first-seen order) and the welded index of every corner
+// tfpre == nullptr (<= LOCAL_TILES tiles): every workgroup prefixes the tiles' first-seen counts for itself in LDS (no
+// k_scan_u32 launch in front) and workgroup 0 publishes the welded total.
 __global__ __launch_bounds__(256) void k_tile_finish(const Vertex *__restrict__ uverts, const uint4 *__restrict__ tdesc,
                                                       const uint32_t *__restrict__ ntiles_ptr, const uint32_t *__restrict__ tfpre,
                                                       const uint32_t *__restrict__ tfirst, const uint32_t *__restrict__ torder,
                                                       const uint32_t *__restrict__ tri_e, const uint32_t *__restrict__ vslot,
                                                       const uint32_t *__restrict__ wv, Vertex *__restrict__ vertices, uint32_t vcap,
-                                                      uint32_t *__restrict__ indices, uint32_t *__restrict__ status) {
+                                                      uint32_t *__restrict__ indices, uint32_t *__restrict__ status,
+                                                      uint32_t *__restrict__ nverts_out,
+                                                      const uint32_t *__restrict__ pub_src, uint32_t *__restrict__ pub_dst, uint32_t pub_words,
+                                                      uint32_t pub_ovf, uint32_t pub_nvert) {
+    __shared__ uint32_t s_pre[LOCAL_TILES + 1], s_scan[17];
     const uint32_t ntiles = *ntiles_ptr, tid = threadIdx.x;
+    const bool local = tfpre == nullptr;
+    if (blockIdx.x >= ntiles && blockIdx.x != 0) return;
+    uint32_t total;
+    if (local) {
+        if (ntiles > LOCAL_TILES) { if (tid == 0) atomicOr(&status[ST_INTERNAL], 64u); return; }
+        total = local_prefix(tfirst, 1u, ntiles, s_pre, s_scan);
+        if (blockIdx.x == 0 && tid == 0) *nverts_out = total;
+    } else {
+        total = tfpre[ntiles];
+    }
+    // The control block (counters + status) goes to the host from here: every word is final before this kernel starts
+    // except the welded total (above) and this kernel's own overflow flag, which is known up front (the total against
+    // the capacity).  A separate device-to-host copy behind the chain costs ~10 us of wall time per regen (barrier
+    // packet + blit kernel).
+    if (pub_dst && blockIdx.x == 0 && tid < pub_words) {
+        uint32_t v = pub_src[tid];
+        if (tid == pub_nvert) v = total;
+        if (tid == pub_ovf && total > vcap) v |= 16u;
+        pub_dst[tid] = v;
+    }
     for (uint32_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
         const uint4 d = tdesc[tile];
-        const uint32_t base = tfpre[tile], nf = tfirst[tile];
+        const uint32_t base = local ? s_pre[tile] : tfpre[tile], nf = tfirst[tile];
         for (uint32_t r = tid; r < nf; r += 256) {
             if (base + r < vcap) vertices[base + r] = uverts[torder[3u * d.z + r]];
             else atomicOr(&status[ST_OVERFLOW], 16u);
@@ -1739,7 +1831,7 @@ __global__ __launch_bounds__(256) void k_tile_finish(const Vertex *__restrict__ 
             uint32_t idx = U32_NONE;
             if (vs != U32_NONE) {
                 const uint32_t w = wv[vs & VS_SLOT];
-                idx = tfpre[w >> 12] + (w & 4095u);
+                idx = (local ? s_pre[w >> 12] : tfpre[w >> 12]) + (w & 4095u);
             }
             indices[o] = idx;
         }
@@ -2466,12 +2558,12 @@ hipError_t launch_tile_prefix(hipStream_t st, const uint4 *tdesc, const uint32_t
 hipError_t launch_project(hipStream_t st, int grid, int scene, const SceneParams *sp, Vertex *uverts, const uint4 *tdesc,
                           const uint32_t *tpre, const uint32_t *coarse, const uint32_t *ntiles_ptr, uint32_t *status, int lanes,
                           uint32_t *prof, uint64_t *diag, uint64_t *wkeys, uint32_t wsize, uint32_t *vslot, uint32_t *wrep, uint2 *wfm,
-                          uint32_t wmode) {
+                          uint32_t wmode, uint32_t *nu_out) {
     ClaimArgs ca;
     ca.wkeys = wkeys; ca.vslot = vslot; ca.wrep = wrep; ca.wfm = wfm; ca.wsize = wsize; ca.wmode = wmode;
-    if (lanes == 1) { SDM_DISPATCH(scene, hipLaunchKernelGGL(k_project1<S>, dim3(grid), dim3(256), 0, st, uverts, tdesc, tpre, coarse, ntiles_ptr, sp, status, prof, diag, ca)); }
-    else if (lanes == 2) { SDM_DISPATCH(scene, hipLaunchKernelGGL((k_project<S, 2>), dim3(grid), dim3(256), 0, st, uverts, tdesc, tpre, coarse, ntiles_ptr, sp, status, prof, diag, ca)); }
-    else { SDM_DISPATCH(scene, hipLaunchKernelGGL((k_project<S, 4>), dim3(grid), dim3(256), 0, st, uverts, tdesc, tpre, coarse, ntiles_ptr, sp, status, prof, diag, ca)); }
+    if (lanes == 1) { SDM_DISPATCH(scene, hipLaunchKernelGGL(k_project1<S>, dim3(grid), dim3(256), 0, st, uverts, tdesc, tpre, coarse, ntiles_ptr, sp, status, prof, diag, ca, nu_out)); }
+    else if (lanes == 2) { SDM_DISPATCH(scene, hipLaunchKernelGGL((k_project<S, 2>), dim3(grid), dim3(256), 0, st, uverts, tdesc, tpre, coarse, ntiles_ptr, sp, status, prof, diag, ca, nu_out)); }
+    else { SDM_DISPATCH(scene, hipLaunchKernelGGL((k_project<S, 4>), dim3(grid), dim3(256), 0, st, uverts, tdesc, tpre, coarse, ntiles_ptr, sp, status, prof, diag, ca, nu_out)); }
     return hipGetLastError();
 }
 
@@ -2531,7 +2623,8 @@ hipError_t launch_weld(hipStream_t st, int grid, const Vertex *uverts, const uin
                        uint32_t *tri_e, const uint8_t *flip, uint32_t *first_ord, uint2 *wfm, const uint32_t *wrep,
                        uint32_t *vslot, uint32_t *wv, uint32_t *torder, uint32_t *tfirst, uint32_t *tfpre,
                        Vertex *vertices, uint32_t vcap, uint32_t *nverts_out, uint32_t *indices, uint32_t *status,
-                       int flip_scene, const SceneParams *sp, int part) {
+                       int flip_scene, const SceneParams *sp, int part, const uint32_t *pub_src, uint32_t *pub_dst, uint32_t pub_words,
+                       uint32_t pub_ovf, uint32_t pub_nvert) {
     // part: 0 = the whole weld, 1 = k_tile_first only, 2 = everything behind it (so that a stage marker fits between)
     const bool stop_after_first = part == 1;
     if (part == 2) goto rest;
@@ -2551,9 +2644,10 @@ hipError_t launch_weld(hipStream_t st, int grid, const Vertex *uverts, const uin
 rest:
     hipLaunchKernelGGL(k_tile_rank, dim3(grid), dim3(256), 0, st, tdesc, ntiles_ptr, first_ord, wfm, vslot, wv, torder,
                        tfirst);
-    hipLaunchKernelGGL(k_scan_u32, dim3(1), dim3(1024), 0, st, tfirst, ntiles_ptr, tfpre, nverts_out);
+    // tfpre == nullptr: few enough tiles for k_tile_finish to prefix the first-seen counts itself
+    if (tfpre) hipLaunchKernelGGL(k_scan_u32, dim3(1), dim3(1024), 0, st, tfirst, ntiles_ptr, tfpre, nverts_out);
     hipLaunchKernelGGL(k_tile_finish, dim3(grid), dim3(256), 0, st, uverts, tdesc, ntiles_ptr, tfpre, tfirst, torder, tri_e, vslot,
-                       wv, vertices, vcap, indices, status);
+                       wv, vertices, vcap, indices, status, nverts_out, pub_src, pub_dst, pub_words, pub_ovf, pub_nvert);
     return hipGetLastError();
 }
 

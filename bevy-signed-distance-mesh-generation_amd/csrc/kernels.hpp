@@ -55,7 +55,9 @@ hipError_t launch_tile_prefix(hipStream_t st, const uint4 *tdesc, const uint32_t
 hipError_t launch_project(hipStream_t st, int grid, int scene, const SceneParams *sp, Vertex *uverts, const uint4 *tdesc,
                           const uint32_t *tpre, const uint32_t *coarse, const uint32_t *ntiles_ptr, uint32_t *status, int lanes = 4,
                           uint32_t *prof = nullptr, uint64_t *diag = nullptr, uint64_t *wkeys = nullptr, uint32_t wsize = 0,
-                          uint32_t *vslot = nullptr, uint32_t *wrep = nullptr, uint2 *wfm = nullptr, uint32_t wmode = 0 /* bit 1: claim here */);
+                          uint32_t *vslot = nullptr, uint32_t *wrep = nullptr, uint2 *wfm = nullptr, uint32_t wmode = 0 /* bit 1: claim here */,
+                          uint32_t *nu_out = nullptr /* tpre == nullptr: workgroups prefix the tile counts themselves; total -> *nu_out */);
+constexpr uint32_t SDM_LOCAL_TILES = 2048;     // = LOCAL_TILES of kernels.hip: tile counts a workgroup prefixes for itself in LDS
 hipError_t launch_render(hipStream_t st, int scene, const SceneParams *sp, const float *cam13, float fov_fac, float screen_x,
                          float screen_y, float gtex_x, float gtex_y, uint32_t width, uint32_t height, void *rgba);
 hipError_t launch_flip_claim(hipStream_t st, int flip_grid, int claim_grid, int scene, const SceneParams *sp, const Vertex *uverts,
@@ -75,7 +77,8 @@ hipError_t launch_weld(hipStream_t st, int grid, const Vertex *uverts, const uin
                        uint32_t *vslot, uint32_t *wv, uint32_t *torder, uint32_t *tfirst, uint32_t *tfpre,
                        Vertex *vertices, uint32_t vcap, uint32_t *nverts_out, uint32_t *indices, uint32_t *status,
                        int flip_scene = -1 /* >= 0: the orientation test runs inside k_tile_first */, const SceneParams *sp = nullptr,
-                       int part = 0);
+                       int part = 0, const uint32_t *pub_src = nullptr /* control block -> host copy by k_tile_finish */, uint32_t *pub_dst = nullptr,
+                       uint32_t pub_words = 0, uint32_t pub_ovf = 0, uint32_t pub_nvert = 0);
 hipError_t launch_expand_compact(hipStream_t st, int grid, const Vertex *uverts, const uint32_t *tri_e, const uint8_t *flip,
                                  const uint32_t *ntri_ptr, Triangle *out, uint32_t cap);
 hipError_t launch_expand_raw(hipStream_t st, int grid, const Vertex *uverts, const uint32_t *tri_e, const uint8_t *flip,

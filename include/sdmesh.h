@@ -66,7 +66,8 @@ typedef struct sdmesh_regen_info {
     struct Point voxel_size;                           /* of the final level */
     uint32_t status[8];                                /* device status block (all 0 = healthy) */
     uint32_t used_direct_path;                         /* 1 if the non-lattice fallback ran */
-    float device_ms;                                   /* HIP-event time of the device chain */
+    float device_ms;                                   /* HIP-event time of the device chain; 0 for a planned (repeat) regen unless
+                                                        * option "timing" = 1 (the event pair costs ~9 us of wall time per regen) */
 } sdmesh_regen_info;
 
 /* ---- lifetime ----------------------------------------------------------------------------- */
@@ -128,6 +129,11 @@ int sdmesh_use_own_stream(sdmesh_handle *h);
  *                       the call fails if the value does not match the build
  *   "claim" = 0         weld claims beside the orientation test instead of in the projection kernel's epilogue
  *   "weld_shift" = n    locality-preserving weld home slots (measured slower; default 0 = uniform)
+ *   "timing" = 1        bracket the planned chain with an event pair: sdmesh_regen_info.device_ms (default 0)
+ *   "local_prefix" = 0  always launch the single-workgroup prefix kernels (default 1: up to 2 048 tiles the consumers'
+ *                       workgroups prefix the ~1 000 tile counts themselves in LDS, two launches fewer)
+ *   "publish_ctl" = 0   read the counters back with a device-to-host copy behind the chain (default 1: the chain's last
+ *                       kernel writes them to the handle's pinned host block itself)
  *   "profile" = 1       time every stage of the planned chain with HIP events (sdmesh_profile_stages)
  *   "weld_wide" = 1     always weld with the unbounded key form (default 0: packed 3 x 21-bit keys, and the wide form
  *                       automatically from the first vertex that does not fit them) */

@@ -7,6 +7,7 @@ sys.path.insert(0, ROOT)
 import sdmesh_pkg
 pkg = sdmesh_pkg.load()
 h = pkg.CudaHandler(0, "sdobj")
+h.set_option("timing", 1)
 for k in (3, 4):
     ts, tm = [], []
     for rep in range(6):

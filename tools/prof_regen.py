@@ -10,6 +10,7 @@ import sdmesh_pkg  # noqa: E402
 scene, k, reps = sys.argv[1], int(sys.argv[2]), int(sys.argv[3])
 pkg = sdmesh_pkg.load()
 h = pkg.CudaHandler(0, scene)
+h.set_option("timing", 1)
 h.regen(k)
 for _ in range(reps):
     info = h.regen(k)
