@@ -21,9 +21,9 @@ N > 1    the step is ONE mesh over all N GPUs (`sdmesh_sharded_rege
          of the run: every rank exits non-zero.
 roofline the north-star HBM pass P1 = dense (N+1)^3 f32 SDF sample, timed live with HIP events on the
          stream the kernel runs on: algorithmic bytes 4*(N+1)^3 per launch / average launch time, vs 8 TB/s.
-roofline_step  the two throughput-bound kernels of the timed step itself (k_project1, k_flip_claim): VALU wave-instructions
-         per launch (SQ_INSTS_VALU from the committed PMC pass, profiles/constants.json) / live stage time (HIP events
-         between the stages, option "profile") vs the VALU issue peak and vs the measured micro-benchmark ceiling.
+roofline_step  the two throughput-bound kernels of the timed step itself (k_project1, k_tile_first with the orientation test): VALU
+         machine instructions per launch (SQ_INSTS_VALU from the committed PMC pass, profiles/constants.json) / live time, vs the
+         spec VALU peak and vs the issue-cost bound of the kernel's own instruction mix (tools/ubench/valu_issue.hip, tools/isa_mix.py).
 cpu_baseline  the CPU oracle (oracle/, a port of the reference algorithm) on the host cores of this box,
          same workload, whole regen, all cores ("port").  Reported, not a target.
 """
@@ -321,12 +321,15 @@ def roofline_step_leg(pkg, local_rank, scene, params, levels, consts, info):
     h.close()
     stages = {k: round(float(np.median(v)) * 1e3, 2) for k, v in acc.items()}                              # us per regen
     pmc = (consts.get("step_kernels") or {}).get(f"{scene}_{32 << levels}", {})
-    ceiling = consts.get("valu_ubench_wave_instr_per_s")
-    out = {"what": "VALU roofline of the step's throughput-bound kernels: wave64 VALU instructions per launch (SQ_INSTS_VALU, "
-                   "profiles/constants.json) / live stage time; peak = 157.3 TF / 2 / 64; ceiling_ubench = what a dependent-free "
-                   "f32 VALU stream sustains on this part (tools/ubench/valu_rate.hip, profiles/constants.json)",
-           "peak": VALU_PEAK_WAVE_INSTR_PER_S, "ceiling_ubench": ceiling, "unit": "wave-instr/s",
-           "stage_us": stages, "stage_sum_us": round(sum(stages.values()), 2)}
+    icost = consts.get("issue_cost") or {}
+    clock = consts.get("shader_clock_ghz_under_valu_load") or 2.2
+    out = {"what": "VALU roofline of the step's throughput-bound kernels: wave64 VALU MACHINE instructions per launch (SQ_INSTS_VALU, "
+                   "profiles/constants.json) / live time.  frac = against the spec peak 157.3 TF / 2 / 64, which only a stream of packed FMAs "
+                   "reaches; frac_of_issue_bound = against the time this kernel's own instruction mix needs if every SIMD issues back to "
+                   "back: instructions x mean issue cost (per-kind costs measured by tools/ubench/valu_issue.hip: add/mul ~3.0, min/max/fma/"
+                   "packed ~4.3, compare/select ~3.7, sqrt/rcp ~8.3 cycles per SIMD at 5 waves) / (1024 SIMDs x measured shader clock)",
+           "peak": VALU_PEAK_WAVE_INSTR_PER_S, "unit": "wave-instr/s", "issue_cost_cycles_per_instr_by_kind": icost.get("cycles_per_instr_by_kind"),
+           "shader_clock_ghz": clock, "stage_us": stages, "stage_sum_us": round(sum(stages.values()), 2)}
     evals = {"project": 13 * rounds if rounds else None, "flip": 12 * int(info.triangles)}
     for key, stage_prefix in (("project", "project"), ("flip", "flip_claim"), ("flip", "tile_first_flip")):
         name = next((s for s in stages if s.startswith(stage_prefix)), None)
@@ -341,8 +344,11 @@ def roofline_step_leg(pkg, local_rank, scene, params, levels, consts, info):
                "vgpr": k.get("vgpr"), "waves_per_simd": k.get("waves_per_simd")}
         if wi:
             ach = wi / (us * 1e-6)
-            row.update({"achieved": round(ach, 1), "frac": round(ach / VALU_PEAK_WAVE_INSTR_PER_S, 4),
-                        "frac_of_ceiling": round(ach / ceiling, 4) if ceiling else None})
+            row.update({"achieved": round(ach, 1), "frac": round(ach / VALU_PEAK_WAVE_INSTR_PER_S, 4)})
+            mc = ((icost.get("kernels") or {}).get(name) or {}).get("mean_cycles_per_instr")
+            if mc:
+                bound_us = wi * mc / (1024.0 * clock * 1e9) * 1e6
+                row.update({"mean_issue_cycles_per_instr": mc, "issue_bound_us": round(bound_us, 2), "frac_of_issue_bound": round(bound_us / us, 4)})
         if evals[key]:
             row.update({"sdf_evals": int(evals[key]), "sdf_evals_per_s": round(evals[key] / (us * 1e-6), 1)})
         out[key] = row

@@ -145,6 +145,11 @@ struct sdmesh_handle {
     bool ctl_published = false;    // the chain just enqueued writes h_pinned itself (k_tile_finish): no read-back copy
     int publish_ctl = 1;           // option "publish_ctl": 0 = always read back with a copy
     int local_prefix = 1;          // option "local_prefix": 0 = always launch k_tile_prefix / k_scan_u32
+    int project_prio = 0;          // option "project_prio" = 1: k_project1's waves lower their issue priority as they advance (s_setprio):
+                                   // the waves of a SIMD then finish together instead of oldest first, at the same total time (measured)
+    int project_grid = 0;          // option "project_grid": workgroups of the projection (0 = grid * project_mult, capped by the plan)
+    int project_batch = 6;         // option "project_batch": log2 of k_project1's dealing unit (64 = one contiguous run per wave; shorter
+                                   // runs even the waves out but every wave then pays the straggler rounds: measured slower, 48.7 -> 57 us)
     int timing = 0;                // option "timing": 1 = an event pair around the planned chain fills info->device_ms; off by default:
                                    // the two marker packets cost ~9 us of wall time per regen (0.155 -> 0.146 ms at 512^3)
     // mesh stage
@@ -371,7 +376,7 @@ int mesh_front(sdmesh_handle *h, const Point *d_vox, const uint32_t *n_ptr, Poin
     // Larger meshes (1-lane kernel only): asynchronous claims, issued per finished vertex and looked at a round later.
     // projection grid: no more workgroups than the planned vertex count fills with one batch per wave (+3 %): workgroups
     // without work still pay the tile-prefix step before they can tell, and start behind the working ones
-    int p_grid = h->grid * h->project_mult;
+    int p_grid = h->project_grid > 0 ? h->project_grid : h->grid * h->project_mult;
     if (h->lane_hint) {
         const uint32_t per_wg = 4u * (64u / (uint32_t) p_lanes);
         p_grid = (int) std::min<uint32_t>((uint32_t) p_grid, (h->lane_hint + h->lane_hint / 32u) / per_wg + 2u);
@@ -396,8 +401,8 @@ int mesh_front(sdmesh_handle *h, const Point *d_vox, const uint32_t *n_ptr, Poin
     }
     HIPCHK(launch_project(st, p_grid, h->scene, h->d_sp, (Vertex *) h->uverts.p, (const uint4 *) h->tdesc.p,
                           local_pre ? nullptr : (const uint32_t *) h->tpre.p, coarse, h->d_ctr + CTR_NTILES, h->d_status, p_lanes, d_prof, d_diag,
-                          h->wkeys, h->wsize, (uint32_t *) h->vslot.p, (uint32_t *) h->wrep_buf.p, h->wfm, weld_mode(h, vs) | (early_claim && !async_claim ? 2u : 0u) | (async_claim ? 4u : 0u),
-                          h->d_ctr + CTR_NUNIQ));
+                          h->wkeys, h->wsize, (uint32_t *) h->vslot.p, (uint32_t *) h->wrep_buf.p, h->wfm, weld_mode(h, vs) | (early_claim && !async_claim ? 2u : 0u) | (async_claim ? 4u : 0u) | (h->project_prio ? 8u : 0u),
+                          h->d_ctr + CTR_NUNIQ, (uint32_t) h->project_batch));
     SDCHK(prof_mark(h, p_lanes == 1 ? "project1" : (p_lanes == 2 ? "project2" : "project4")));
     // fork: the weld claim (scattered CAS, latency-bound) runs beside the orientation test (VALU-bound)
     int f_grid = h->grid * (f_lanes == 1 ? 1 : h->flip_mult);
@@ -792,7 +797,7 @@ int regen_impl(sdmesh_handle *h, int levels, int mode, int part, int nparts, sdm
             n_cap = padded(h->plan_counts[levels]);
             if (h->use_graph && st != nullptr && !h->profile && !h->project_diag) {   // (the legacy null stream cannot be captured: eager launches there)
                 uint64_t key[8] = {h->buf_gen, (uint64_t) h->scene, (uint64_t) levels, ((uint64_t) mode << 40) | ((uint64_t) part << 20) | (uint64_t) nparts,
-                                   (uint64_t) h->skip_weld | ((uint64_t) h->wide_active << 1) | ((uint64_t) h->col_refine << 2) | ((uint64_t) h->claim_in_project << 3) | ((uint64_t) h->fuse_flip << 4) | ((uint64_t) h->publish_ctl << 6) | ((uint64_t) h->local_prefix << 7), (uint64_t) (uintptr_t) st, (uint64_t) h->grid | ((uint64_t) h->tgrid << 20) | ((uint64_t) h->project_mult << 40) | ((uint64_t) h->flip_mult << 48) | ((uint64_t) h->refine2 << 56) | ((uint64_t) h->emit_ci << 57) | ((uint64_t) h->project_lanes << 58) | ((uint64_t) h->flip_lanes << 61), 0};
+                                   (uint64_t) h->skip_weld | ((uint64_t) h->wide_active << 1) | ((uint64_t) h->col_refine << 2) | ((uint64_t) h->claim_in_project << 3) | ((uint64_t) h->fuse_flip << 4) | ((uint64_t) h->publish_ctl << 6) | ((uint64_t) h->local_prefix << 7) | ((uint64_t) h->project_batch << 8) | ((uint64_t) h->project_grid << 12) | ((uint64_t) h->project_prio << 30), (uint64_t) (uintptr_t) st, (uint64_t) h->grid | ((uint64_t) h->tgrid << 20) | ((uint64_t) h->project_mult << 40) | ((uint64_t) h->flip_mult << 48) | ((uint64_t) h->refine2 << 56) | ((uint64_t) h->emit_ci << 57) | ((uint64_t) h->project_lanes << 58) | ((uint64_t) h->flip_lanes << 61), 0};
                 for (int i = 0; i <= levels; i++) key[7] = key[7] * 1000003ull + h->plan_counts[i];
                 key[7] = key[7] * 1000003ull + h->plan_uniq;
                 key[7] = key[7] * 1000003ull + h->plan_tris;
@@ -1135,6 +1140,9 @@ int sdmesh_set_option(sdmesh_handle *h, const char *name, int value) {
                                                      : "this is the strict IEEE build (libsdmesh.so); load libsdmesh_fast.so for the fast numeric mode");
         return SDMESH_OK;
     }
+    if (!strcmp(name, "project_prio")) { h->project_prio = value != 0; drop_graph(h); return SDMESH_OK; }
+    if (!strcmp(name, "project_grid")) { h->project_grid = value < 0 ? 0 : (value > 65535 ? 65535 : value); drop_graph(h); return SDMESH_OK; }
+    if (!strcmp(name, "project_batch")) { h->project_batch = value < 0 ? 0 : (value > 6 ? 6 : value); drop_graph(h); return SDMESH_OK; }
     if (!strcmp(name, "timing")) { h->timing = value != 0; return SDMESH_OK; }
     if (!strcmp(name, "local_prefix")) { h->local_prefix = value != 0; drop_graph(h); return SDMESH_OK; }
     if (!strcmp(name, "publish_ctl")) { h->publish_ctl = value != 0; drop_graph(h); return SDMESH_OK; }

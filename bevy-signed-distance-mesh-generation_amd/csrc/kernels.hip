@@ -1216,18 +1216,18 @@ struct ClaimArgs {
     uint2 *wfm;
     uint32_t wsize;
     uint32_t wmode;      // bit 0: wide (never set here), bits 8..: coarse shift; bit 1: claims enabled
+    uint32_t bsh;        // k_project1: log2 of the dealing unit (runs of 2^bsh consecutive vertices go round robin to the waves)
 };
 
-template <uint32_t PER>
-__device__ __forceinline__ void claim_epilogue(uint32_t wave, uint32_t nwaves, uint32_t myb, uint32_t U, const Vertex *__restrict__ uverts,
+__device__ __forceinline__ void claim_epilogue(uint32_t bsh, uint32_t wave, uint32_t nwaves, uint32_t myb, uint32_t U, const Vertex *__restrict__ uverts,
                                                const uint4 *__restrict__ tdesc, const uint32_t *__restrict__ tpre,
                                                const uint32_t *__restrict__ coarse, const ClaimArgs &ca, uint32_t *__restrict__ status,
                                                const uint32_t *__restrict__ s_pre, uint32_t ntiles) {
     if (!(ca.wmode & 2u)) return;
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");              // this wave's position stores have left the CU
     const uint32_t shift = ca.wmode >> 8;
-    for (uint32_t j = lane_id(); j < myb * PER; j += 64u) {
-        const uint32_t item = ((j / PER) * nwaves + wave) * PER + (j % PER);
+    for (uint32_t j = lane_id(); j < (myb << bsh); j += 64u) {
+        const uint32_t item = (((j >> bsh) * nwaves + wave) << bsh) + (j & ((1u << bsh) - 1u));
         if (item >= U) continue;
         const uint32_t e = item_slot(item, tdesc, tpre, coarse, s_pre, ntiles);
         const float *pp = &uverts[e].position.x;
@@ -1322,7 +1322,7 @@ __global__ __launch_bounds__(256) void k_project(Vertex *__restrict__ uverts, co
             }
         }
     }
-    claim_epilogue<PER>(wave, nwaves, myb, U, uverts, tdesc, tpre, coarse, ca, status, s_pre, ntiles);
+    claim_epilogue(SH, wave, nwaves, myb, U, uverts, tdesc, tpre, coarse, ca, status, s_pre, ntiles);
     project_epilogue(wave, rounds, t_start, prof, diag);
 }
 
@@ -1403,15 +1403,20 @@ __global__ __launch_bounds__(256) void k_project1(Vertex *__restrict__ uverts, c
     const uint32_t lane = lane_id();
     const uint32_t nwaves = gridDim.x * (blockDim.x >> 6);
     const uint32_t wave = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
-    // batches of 64 items dealt round robin to the waves: the wave's j-th item is ((j / 64) * nwaves + wave) * 64 + j % 64
-    const uint32_t nbatch = (U + 63u) >> 6;
+    // Runs of B = 2^bsh consecutive items are dealt round robin to the waves: the wave's j-th item is
+    // ((j / B) * nwaves + wave) * B + j % B.  B = 64 (one contiguous run per wave) is the default.  Iteration counts are
+    // spatially correlated, so with B = 64 some waves are slow in ALL lanes; short runs (B = 8: every wave sees the same
+    // mix) were measured and lose: every wave then carries a few slow vertices through all the straggler rounds
+    // (+16 % instructions, 48.7 -> 57 us at 512^3); fewer, persistent waves with lane refill lose more (2 per SIMD: 75 us).
+    const uint32_t bsh = ca.bsh, bmask = (1u << bsh) - 1u;
+    const uint32_t nbatch = (U + bmask) >> bsh;
     if (wave >= nbatch) return;
     const uint64_t t_start = diag ? __builtin_amdgcn_s_memtime() : 0ull;
     if (diag && lane == 0) diag[4ull * wave + 3] = __builtin_amdgcn_s_memrealtime() & 0xFFFFFFFFull;
-    uint32_t rounds = 0;
+    uint32_t rounds = 0, wround = 0;                                  // vertex-rounds evaluated (bookkeeping); loop iterations of this wave
     const uint32_t myb = (nbatch - wave - 1u) / nwaves + 1u;
     uint32_t qhead = 0;
-    const uint32_t qend = myb * 64u;
+    const uint32_t qend = myb << bsh;
     const uint64_t lt_mask = (1ull << lane) - 1ull;
     bool have = false, finalize = false;
     uint32_t slot = 0;
@@ -1443,7 +1448,7 @@ __global__ __launch_bounds__(256) void k_project1(Vertex *__restrict__ uverts, c
         if (need != 0ull && avail != 0u) {
             const uint32_t rank = __popcll(need & lt_mask);
             const uint32_t j = qhead + rank;
-            const uint32_t item = ((j >> 6) * nwaves + wave) * 64u + (j & 63u);
+            const uint32_t item = (((j >> bsh) * nwaves + wave) << bsh) + (j & bmask);
             if (!have && rank < avail && item < U) {
                 slot = item_slot(item, tdesc, tpre, coarse, s_pre, ntiles);
                 const Point p = uverts[slot].position;
@@ -1505,6 +1510,17 @@ __global__ __launch_bounds__(256) void k_project1(Vertex *__restrict__ uverts, c
             break;
         }
         rounds += __popcll(act);
+        // Option "project_prio": issue priority by progress.  The SIMD's arbiter serves its waves oldest first: the five waves
+        // of a SIMD finish one after the other (13.7 / 18.3 / 21.9 / 27.4 / 33.8 us at 512^3).  With this switch a wave that
+        // has done fewer rounds outranks the ones ahead of it and they finish in order of their work instead (14.8 ... 33.6 us)
+        // -- the last one at the same time: the kernel is bound by the SIMD's VALU issue, not by which wave is served.
+        if (ca.wmode & 8u) {
+            if (wround == 0u) __builtin_amdgcn_s_setprio(3);
+            else if (wround == 1u) __builtin_amdgcn_s_setprio(2);
+            else if (wround == 2u) __builtin_amdgcn_s_setprio(1);
+            else __builtin_amdgcn_s_setprio(0);
+        }
+        wround++;
         if (have) {
             const float sd = sdf<SCENE>(g.x, g.y, g.z, sp);
             const f3 nn = empirical_normal<SCENE>(g, sp);
@@ -1558,7 +1574,7 @@ __global__ __launch_bounds__(256) void k_project1(Vertex *__restrict__ uverts, c
             }
         }
     }
-    claim_epilogue<64u>(wave, nwaves, myb, U, uverts, tdesc, tpre, coarse, ca, status, s_pre, ntiles);
+    claim_epilogue(bsh, wave, nwaves, myb, U, uverts, tdesc, tpre, coarse, ca, status, s_pre, ntiles);
     project_epilogue(wave, rounds, t_start, prof, diag);
 }
 
@@ -2558,9 +2574,10 @@ hipError_t launch_tile_prefix(hipStream_t st, const uint4 *tdesc, const uint32_t
 hipError_t launch_project(hipStream_t st, int grid, int scene, const SceneParams *sp, Vertex *uverts, const uint4 *tdesc,
                           const uint32_t *tpre, const uint32_t *coarse, const uint32_t *ntiles_ptr, uint32_t *status, int lanes,
                           uint32_t *prof, uint64_t *diag, uint64_t *wkeys, uint32_t wsize, uint32_t *vslot, uint32_t *wrep, uint2 *wfm,
-                          uint32_t wmode, uint32_t *nu_out) {
+                          uint32_t wmode, uint32_t *nu_out, uint32_t batch_shift) {
     ClaimArgs ca;
     ca.wkeys = wkeys; ca.vslot = vslot; ca.wrep = wrep; ca.wfm = wfm; ca.wsize = wsize; ca.wmode = wmode;
+    ca.bsh = batch_shift > 6u ? 6u : batch_shift;
     if (lanes == 1) { SDM_DISPATCH(scene, hipLaunchKernelGGL(k_project1<S>, dim3(grid), dim3(256), 0, st, uverts, tdesc, tpre, coarse, ntiles_ptr, sp, status, prof, diag, ca, nu_out)); }
     else if (lanes == 2) { SDM_DISPATCH(scene, hipLaunchKernelGGL((k_project<S, 2>), dim3(grid), dim3(256), 0, st, uverts, tdesc, tpre, coarse, ntiles_ptr, sp, status, prof, diag, ca, nu_out)); }
     else { SDM_DISPATCH(scene, hipLaunchKernelGGL((k_project<S, 4>), dim3(grid), dim3(256), 0, st, uverts, tdesc, tpre, coarse, ntiles_ptr, sp, status, prof, diag, ca, nu_out)); }

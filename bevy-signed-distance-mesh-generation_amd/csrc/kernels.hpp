@@ -56,7 +56,8 @@ hipError_t launch_project(hipStream_t st, int grid, int scene, const SceneParams
                           const uint32_t *tpre, const uint32_t *coarse, const uint32_t *ntiles_ptr, uint32_t *status, int lanes = 4,
                           uint32_t *prof = nullptr, uint64_t *diag = nullptr, uint64_t *wkeys = nullptr, uint32_t wsize = 0,
                           uint32_t *vslot = nullptr, uint32_t *wrep = nullptr, uint2 *wfm = nullptr, uint32_t wmode = 0 /* bit 1: claim here */,
-                          uint32_t *nu_out = nullptr /* tpre == nullptr: workgroups prefix the tile counts themselves; total -> *nu_out */);
+                          uint32_t *nu_out = nullptr /* tpre == nullptr: workgroups prefix the tile counts themselves; total -> *nu_out */,
+                          uint32_t batch_shift = 6 /* k_project1: runs of 2^n consecutive vertices are dealt round robin to the waves */);
 constexpr uint32_t SDM_LOCAL_TILES = 2048;     // = LOCAL_TILES of kernels.hip: tile counts a workgroup prefixes for itself in LDS
 hipError_t launch_render(hipStream_t st, int scene, const SceneParams *sp, const float *cam13, float fov_fac, float screen_x,
                          float screen_y, float gtex_x, float gtex_y, uint32_t width, uint32_t height, void *rgba);

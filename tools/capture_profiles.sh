@@ -16,6 +16,7 @@ run dense_fetch --kernel-trace --pmc FETCH_SIZE --output-format csv -d $O/dense_
 run bench_trace --kernel-trace --stats --output-format csv -d $O/bench_trace -- $P $R/bench.py --steps 100 --warmup 10 --no-cpu-baseline --no-sizes --no-pipelined --no-anim || exit 1
 cd $R
 echo "== ubench"; timeout -k 10 60 ./tools/ubench/valu_rate > $O/valu_rate.jsonl 2> $O/valu_rate.stderr; echo "rc=$?"
+echo "== ubench (machine instructions)"; timeout -k 10 200 ./tools/ubench/valu_issue > $O/valu_issue.jsonl 2> $O/valu_issue.stderr; echo "rc=$?"
 echo "== projection timeline"; timeout -k 10 100 $P tools/project_timeline.py sdobj 4 $O/project_timeline.json > $O/project_timeline.stdout 2>&1; echo "rc=$?"
 echo "== dedupe phases"; timeout -k 10 100 $P tools/tile_phases.py sdobj 4 > $O/tile_phases.txt 2>&1; echo "rc=$?"
 echo "== plain bench"; timeout -k 10 500 $P bench.py > $O/bench_plain.json 2> $O/bench_plain.stderr; echo "rc=$?"

@@ -13,6 +13,7 @@ open(f"profiles/{tag}_bench_under_rocprof.json", "w").write(
     "".join(l for l in open(f"{P}/bench_trace.stdout") if l.startswith("{")))
 shutil.copy(f"{P}/bench_plain.json", f"profiles/{tag}_bench_plain.json")
 for src, dst in (("streaming_window.csv", f"{tag}_bench_streaming_kernels_timed_window.csv"), ("valu_rate.jsonl", f"{tag}_ubench_valu_rate.jsonl"),
+                 ("valu_issue.jsonl", f"{tag}_ubench_valu_issue.jsonl"),
                  ("project_timeline.json", f"{tag}_project1_wave_timeline.json"), ("tile_phases.txt", f"{tag}_tile_dedupe_phases.txt")):
     if os.path.exists(f"{P}/{src}"):
         shutil.copy(f"{P}/{src}", f"profiles/{dst}")
@@ -105,14 +106,31 @@ for k, c in dense.items():
 
 ub = [json.loads(l) for l in open(f"{P}/valu_rate.jsonl") if l.startswith("{")] if os.path.exists(f"{P}/valu_rate.jsonl") else []
 ceiling = max((u["wave_instr_per_s"] for u in ub), default=None)
+tl_path = f"profiles/{tag}_project1_wave_timeline.json"
+clock = None
+if os.path.exists(tl_path):
+    clock = json.load(open(tl_path))[-1].get("shader_clock_ghz")
 const = {"_what": "measured constants for bench.py, written by tools/install_profiles.py from the rocprofv3 passes committed beside this file",
          "round": tag,
          "p1_traffic_bytes": {"512": p1},
          "step_kernels": {"sdobj_512": step},
+         "shader_clock_ghz_under_valu_load": clock or 2.2,
          "valu_ubench_wave_instr_per_s": ceiling,
+         "valu_ubench_note": "valu_rate.hip counts SOURCE operations: hipcc packs its mul/add chains into v_pk_* (two per machine instruction), so this is "
+                             "not a machine-instruction ceiling; see issue_cost (tools/ubench/valu_issue.hip, tools/isa_mix.py)",
          "valu_ubench_rows": ub,
          "regen_hbm_bytes": {"fetch_x2": round(tf), "write": round(tw)}}
 json.dump(const, open("profiles/constants.json", "w"), indent=1)
+# issue-cost bound of the VALU-bound kernels from their instruction mix (needs constants.json; adds to it)
+if os.path.exists(f"profiles/{tag}_ubench_valu_issue.jsonl"):
+    import subprocess
+    subprocess.run([sys.executable, "tools/isa_mix.py", tag], check=True, stdout=subprocess.DEVNULL)
+    ib = json.load(open(f"profiles/{tag}_issue_bound.json"))
+    const["issue_cost"] = {"what": "mean issue cost of one VALU machine instruction of the kernel's hot block, from the per-kind costs of "
+                                   "tools/ubench/valu_issue.hip at 5 waves per SIMD (tools/isa_mix.py)",
+                           "cycles_per_instr_by_kind": ib["cost_cycles_per_instr_per_simd"],
+                           "kernels": {k: {"mean_cycles_per_instr": v["mean_cycles_per_instr"], "by_class": v["by_class"]} for k, v in ib["kernels"].items()}}
+    json.dump(const, open("profiles/constants.json", "w"), indent=1)
 print(json.dumps(const["step_kernels"], indent=1)); print("p1", p1, "ceiling", ceiling, "regen traffic", tf / 1e6, tw / 1e6)
 j = json.loads(open(f"{P}/bench_plain.json").read())
 print("bench_plain", j["value"], j["ms_per_step"], j["device_ms_per_step"], j["roofline"]["frac"], j["cpu_baseline"]["value"])
