@@ -14,7 +14,7 @@ metric   Mvoxels/s = N_grid^3 * steps / wall  (BASELINE.json: "Mvoxels/s + Mtris
 N = 1    the step runs on one GPU.
 N > 1    the step is ONE mesh over all N GPUs (`sdmesh_sharded_regen`): rank r meshes level-0 z-slab r,
          RCCL all-gather of the per-column counts, RCCL send/recv of the per-slab triangle lists to rank 0, merge kernel,
-         weld on rank 0 -> "scaling": "strong".  `one_mesh` repeats that at 512^3 / 1024^3 (BASELINE configs[3]) /
+         weld on rank 0 -> "scaling": "strong".  `one_mesh` repeats that at 256^3 / 512^3 / 1024^3 (BASELINE configs[3]) /
          2048^3 / 4096^3 with the same-size 1-rank time measured in the same invocation, for both one-mesh forms (z-slab
          gather + root weld; x-slab distributed weld), plus `ranks_seen` from an RCCL all-reduce.  N independent regens
          (no exchange at all) are reported as the extra `replicas`.  A failure or hang in any multi-rank leg is a failure
@@ -416,7 +416,8 @@ def main():
 
     if multi:
         # ---------------------------------------------------------------- N > 1: the step is ONE mesh over all ranks
-        levels_list = [lv for lv in range(args.levels, max(args.levels, args.max_levels) + 1)]
+        # 256^3 (one level below the workload) ... 4096^3: the sizes the north star names and the ones where one mesh can scale
+        levels_list = [lv for lv in range(max(0, args.levels - 1), max(args.levels, args.max_levels) + 1)]
         job.arm_watchdog(900, "one-mesh legs (z-slab RCCL gather / x-slab distributed weld)")
         primary, one_mesh = one_mesh_legs(pkg, job, local_rank, args.scene, params, levels_list, args.levels, args.steps, args.warmup, args.graph)
         job.disarm_watchdog()
