@@ -330,6 +330,21 @@ def roofline_step_leg(pkg, local_rank, scene, params, levels, consts, info):
                    "packed ~4.3, compare/select ~3.7, sqrt/rcp ~8.3 cycles per SIMD at 5 waves) / (1024 SIMDs x measured shader clock)",
            "peak": VALU_PEAK_WAVE_INSTR_PER_S, "unit": "wave-instr/s", "issue_cost_cycles_per_instr_by_kind": icost.get("cycles_per_instr_by_kind"),
            "shader_clock_ghz": clock, "stage_us": stages, "stage_sum_us": round(sum(stages.values()), 2)}
+    # SURVEY 8(d)'s other passes: algorithmic bytes (its table) / live stage time -- reported, not claimed: they are latency- or
+    # VALU-bound at this size, and the build never materialises the 72-byte triangle records P4 / P5 count
+    A, T, V = int(info.voxel_count[levels]), int(info.triangles), int(info.vertices)
+    st = lambda *names: sum(v for k, v in stages.items() if any(k.startswith(n) for n in names))   # noqa: E731
+    passes = {}
+    for key, what, nbytes, us in (
+            ("P3_emit_active_list", "hierarchical refine to the level-k voxel list: write 12 B x A_k", 12.0 * A, st("col_", "refine_", "create_field")),
+            ("P4_triangles", "marching cubes + projection + orientation: read 12 B x A_k, write 72 B x T", 12.0 * A + 72.0 * T, st("tile_dedupe", "tile_prefix", "project", "flip_claim", "tile_first")),
+            ("P5_weld", "first-seen weld: read 72 B x T, write 24 B x V + 12 B x T", 72.0 * T + 24.0 * V + 12.0 * T, st("weld", "tile_first"))):
+        if us > 0:
+            gbps = nbytes / (us * 1e-6) / 1e9
+            passes[key] = {"what": what, "bytes": nbytes, "stage_us": round(us, 2), "achieved": round(gbps, 1), "unit": "GB/s", "peak": HBM_PEAK_GBPS,
+                           "frac": round(gbps / HBM_PEAK_GBPS, 4)}
+    out["hbm_passes"] = {"what": "SURVEY 8(d) algorithmic bytes of the hierarchical passes / live stage time (HIP events between the stages; k_tile_first "
+                                 "counts in both P4 and P5: it holds the orientation test and the first-seen pass); reported, not claimed", **passes}
     evals = {"project": 13 * rounds if rounds else None, "flip": 12 * int(info.triangles)}
     for key, stage_prefix in (("project", "project"), ("flip", "flip_claim"), ("flip", "tile_first_flip")):
         name = next((s for s in stages if s.startswith(stage_prefix)), None)

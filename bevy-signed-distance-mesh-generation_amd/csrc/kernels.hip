@@ -2452,10 +2452,16 @@ __global__ __launch_bounds__(256) void k_sample_dense_rows(float *__restrict__ o
         for (uint32_t q = lane; q < nq; q += 64) {
             const uint32_t z = q << 2;
             v4fu v;
+#if defined(SDM_HAVE_PAIRS)
+            const v2f lo = row_eval2<SCENE>(rc, mk2((float) z * h - 2.5f, (float) (z + 1u) * h - 2.5f), sp);
+            const v2f hi = row_eval2<SCENE>(rc, mk2((float) (z + 2u) * h - 2.5f, (float) (z + 3u) * h - 2.5f), sp);
+            v.x = lo.x; v.y = lo.y; v.z = hi.x; v.w = hi.y;
+#else
             v.x = rc.eval((float) z * h - 2.5f, sp);
             v.y = rc.eval((float) (z + 1u) * h - 2.5f, sp);
             v.z = rc.eval((float) (z + 2u) * h - 2.5f, sp);
             v.w = rc.eval((float) (z + 3u) * h - 2.5f, sp);
+#endif
             if (NT) __builtin_nontemporal_store(v, reinterpret_cast<v4fu *>(o + z));
             else *reinterpret_cast<v4fu *>(o + z) = v;
         }

@@ -329,9 +329,112 @@ struct RowCtx {
 
 #define SDM_NORMAL_EPS 0.001f
 
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(SDM_NO_PAIRS)
+// ---------------------------------------------------------------------------------------------
+// Two stencil samples at a time (device only).  The projection and the orientation test are bound by VALU ISSUE
+// (DESIGN.md 6): a packed f32 add / mul / fma (v_pk_*_f32) does two operations for 4.3 issue cycles where two scalar ones
+// cost 2 x 3.0, and the +-e samples of one axis run the identical instruction sequence on two values.  Everything that
+// has a packed form is written on a 2-vector; min / max / med3 / abs / sqrt / compare / select have none and stay per
+// component.  Same operations in the same order on each component as sdf<SCENE>() -> the same bits
+// (tests: every golden hash goes through this path).
+// ---------------------------------------------------------------------------------------------
+typedef float v2f __attribute__((ext_vector_type(2)));
+typedef int v2i __attribute__((ext_vector_type(2)));
+SDM_HD v2f mk2(float a, float b) { v2f r; r.x = a; r.y = b; return r; }
+SDM_HD v2f min2(v2f a, v2f b) { return mk2(fmin1(a.x, b.x), fmin1(a.y, b.y)); }
+SDM_HD v2f max2s(v2f a, float b) { return mk2(fmax1(a.x, b), fmax1(a.y, b)); }
+SDM_HD v2f abs2(v2f a) { return mk2(fabsf(a.x), fabsf(a.y)); }
+SDM_HD v2f clamp2(v2f t, float lo, float hi) { return mk2(clamp1(t.x, lo, hi), clamp1(t.y, lo, hi)); }
+SDM_HD v2f sq2(v2f v) { return v * v; }
+SDM_HD v2f along_sq2(v2f p, float lo, float len) {
+    const v2f t = p - lo;
+    const v2f q = lo + clamp2(t, 0.0f, len);
+    const v2f e = p - q;
+    return e * e;
+}
+SDM_HD v2f sqrt_rn_normal2(v2f x) {
+#if defined(SDM_FAST_MATH)
+    return mk2(__builtin_amdgcn_sqrtf(x.x), __builtin_amdgcn_sqrtf(x.y));
+#else
+    const v2f y = mk2(__builtin_amdgcn_sqrtf(x.x), __builtin_amdgcn_sqrtf(x.y));
+    const v2i yi = __builtin_bit_cast(v2i, y);
+    const v2f ydn = __builtin_bit_cast(v2f, yi - 1), yup = __builtin_bit_cast(v2f, yi + 1);
+    const v2f rdn = __builtin_elementwise_fma(-ydn, y, x);
+    const v2f rup = __builtin_elementwise_fma(-yup, y, x);
+    v2f r;
+    r.x = rdn.x <= 0.0f ? ydn.x : y.x; r.x = rup.x > 0.0f ? yup.x : r.x;
+    r.y = rdn.y <= 0.0f ? ydn.y : y.y; r.y = rup.y > 0.0f ? yup.y : r.y;
+    return r;
+#endif
+}
+SDM_HD v2f smooth_min2(v2f a, v2f b, float k) {
+    const v2f h = max2s(k - abs2(a - b), 0.0f) / k;
+    return min2(a, b) - h * h * h * k * (1.0f / 6.0f);
+}
+// sd_obj at (px.x, py, pz) and (px.y, py, pz) etc.: AXIS = the coordinate the two points differ in; `u` holds its two values
+template <int SCENE, int AXIS>
+SDM_HD v2f sdobj_pair(v2f u, float px, float py, float pz, const SceneParams &sp) {
+    float sy = py;
+    if (SCENE == SCENE_ANIM) sy = py - sp.p[0];
+    v2f m, s;
+    if (AXIS == 0) {
+        const SkelY y = skel_y(py); const SkelZ z = skel_z(pz);
+        const v2f ax = along_sq2(u, -1.5f, 3.0f), sx15 = sq2(abs2(u) - 1.5f), mx = min2(sq2(u - (-1.5f)), sq2(u - (-0.5f)));
+        m = min2(min2((ax + y.sy) + z.sz, (sx15 + y.ay) + z.mz), (mx + y.sy) + z.az);
+        s = (u * u + sy * sy) + pz * pz;
+    } else if (AXIS == 1) {
+        const SkelX x = skel_x(px); const SkelZ z = skel_z(pz);
+        const v2f ay = along_sq2(u, -0.5f, 1.0f), sy2 = sq2(abs2(u) - 0.5f);
+        m = min2(min2((x.ax + sy2) + z.sz, (x.sx15 + ay) + z.mz), (x.mx + sy2) + z.az);
+        v2f sv = u;
+        if (SCENE == SCENE_ANIM) sv = u - sp.p[0];
+        s = (px * px + sv * sv) + pz * pz;
+    } else {
+        const SkelX x = skel_x(px); const SkelY y = skel_y(py);
+        const v2f az = along_sq2(u, -0.25f, 0.5f), sz = sq2(abs2(u) - 0.25f), mz = min2(sq2(u - (-0.25f)), sq2(u - 2.75f));
+        m = min2(min2((x.ax + y.sy) + sz, (x.sx15 + y.ay) + mz), (x.mx + y.sy) + az);
+        s = (px * px + sy * sy) + u * u;
+    }
+    const v2f a1 = sqrt_rn_normal2(m) - 0.1f;
+    const v2f a2 = sqrt_rn_normal2(s) - 1.0f;
+    return smooth_min2(a1, a2, 0.5f);
+}
+template <int SCENE, int AXIS>
+SDM_HD float sdobj_axis_derivative(float c, float px, float py, float pz, const SceneParams &sp) {
+    const float e1 = SDM_NORMAL_EPS, e2 = 2.0f * SDM_NORMAL_EPS;
+    const v2f o = sdobj_pair<SCENE, AXIS>(mk2(c + e2, c + (-e2)), px, py, pz, sp);      // {f(+2e), f(-2e)}
+    const v2f i = sdobj_pair<SCENE, AXIS>(mk2(c + e1, c + (-e1)), px, py, pz, sp);      // {f(+e), f(-e)}
+    return (-o.x + 8.0f * i.x - 8.0f * i.y + o.y);
+}
+// two z samples of one (x, y) row (k_sample_dense_rows): RowCtx::eval() on a 2-vector
+template <int SCENE>
+SDM_HD v2f row_eval2(const RowCtx<SCENE> &rc, v2f pz, const SceneParams &sp) {
+    if (SCENE == SCENE_SPHERE) {
+        return sqrt_rn_normal2(rc.a[0] + pz * pz) - 1.0f;
+    } else if (SCENE == SCENE_SDOBJ || SCENE == SCENE_ANIM) {
+        const v2f az = along_sq2(pz, -0.25f, 0.5f), sz = sq2(abs2(pz) - 0.25f), mz = min2(sq2(pz - (-0.25f)), sq2(pz - 2.75f));
+        const v2f m = min2(min2(rc.a[0] + sz, rc.a[1] + mz), rc.a[2] + az);
+        const v2f a1 = sqrt_rn_normal2(m) - 0.1f;
+        float sy = rc.py;
+        if (SCENE == SCENE_ANIM) sy = rc.py - sp.p[0];
+        const v2f a2 = sqrt_rn_normal2((rc.px * rc.px + sy * sy) + pz * pz) - 1.0f;
+        return smooth_min2(a1, a2, 0.5f);
+    } else {
+        return mk2(rc.eval(pz.x, sp), rc.eval(pz.y, sp));
+    }
+}
+#define SDM_HAVE_PAIRS 1
+#endif
+
 // 4th-order central stencil, un-normalised weights, then normalize (signed_distance.cu:179-202)
 template <int SCENE>
 SDM_HD f3 empirical_normal(f3 p, const SceneParams &sp) {
+#if defined(SDM_HAVE_PAIRS)
+    if (SCENE == SCENE_SDOBJ || SCENE == SCENE_ANIM) {
+        return normalize3(mk(sdobj_axis_derivative<SCENE, 0>(p.x, p.x, p.y, p.z, sp), sdobj_axis_derivative<SCENE, 1>(p.y, p.x, p.y, p.z, sp),
+                             sdobj_axis_derivative<SCENE, 2>(p.z, p.x, p.y, p.z, sp)));
+    }
+#endif
     const float e1 = SDM_NORMAL_EPS, e2 = 2.0f * SDM_NORMAL_EPS;
     float dx = (-sdf<SCENE>(p.x + e2, p.y, p.z, sp) + 8.0f * sdf<SCENE>(p.x + e1, p.y, p.z, sp) -
                 8.0f * sdf<SCENE>(p.x + (-e1), p.y, p.z, sp) + sdf<SCENE>(p.x + (-e2), p.y, p.z, sp));
