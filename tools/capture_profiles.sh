@@ -15,6 +15,9 @@ run dense_write --kernel-trace --pmc WRITE_SIZE --output-format csv -d $O/dense_
 run dense_fetch --kernel-trace --pmc FETCH_SIZE --output-format csv -d $O/dense_fetch -- $P $R/tools/dense_once.py || exit 1
 run bench_trace --kernel-trace --stats --output-format csv -d $O/bench_trace -- $P $R/bench.py --steps 100 --warmup 10 --no-cpu-baseline --no-sizes --no-pipelined --no-anim || exit 1
 cd $R
+for u in valu_rate valu_issue; do      # (built in-tree by the builder; a fresh clone compiles them here)
+  [ -x tools/ubench/$u ] || /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -w $([ $u = valu_rate ] && echo -ffp-contract=off) tools/ubench/$u.hip -o tools/ubench/$u
+done
 echo "== ubench"; timeout -k 10 60 ./tools/ubench/valu_rate > $O/valu_rate.jsonl 2> $O/valu_rate.stderr; echo "rc=$?"
 echo "== ubench (machine instructions)"; timeout -k 10 200 ./tools/ubench/valu_issue > $O/valu_issue.jsonl 2> $O/valu_issue.stderr; echo "rc=$?"
 echo "== projection timeline"; timeout -k 10 100 $P tools/project_timeline.py sdobj 4 $O/project_timeline.json > $O/project_timeline.stdout 2>&1; echo "rc=$?"
