@@ -586,8 +586,35 @@ def main():
                 anim[mode] = {"frames_per_s": round(120 / da, 1), "ms_per_frame": round(da / 120 * 1e3, 4),
                               "mtris_per_s": round(atris / da / 1e6, 1)}
         anim["frames_per_s"] = anim["hipgraph"]["frames_per_s"]
-        out["animated"] = anim
         ha.close()
+        # the same 120 frames with three frames in flight (one handle each, sdmesh_regen_begin / _end): frame f + 1 and f + 2 are
+        # meshed while frame f is waited for -- throughput of a renderer that double-buffers its meshes; an extra, not `frames_per_s`
+        depth = 3
+        hs = [pkg.CudaHandler(local_rank, "anim", [0.5]) for _ in range(depth)]
+        for hh in hs:
+            for cy in (0.5, -0.5, 0.0):
+                hh.set_scene("anim", [cy]); hh.regen(args.levels)
+        best = None
+        for _ in range(2):
+            torch.cuda.synchronize()
+            ta = time.perf_counter()
+            atris = 0
+            for f in range(min(depth, 120)):
+                hs[f % depth].set_animation_time(f / 60.0); hs[f % depth].regen_begin(args.levels)
+            for f in range(120):
+                hh = hs[f % depth]
+                atris += hh.regen_end().triangles
+                if f + depth < 120:
+                    hh.set_animation_time((f + depth) / 60.0); hh.regen_begin(args.levels)
+            torch.cuda.synchronize()
+            da = time.perf_counter() - ta
+            if best is None or da < best[0]:
+                best = (da, atris)
+        anim["frames_in_flight_3"] = {"frames_per_s": round(120 / best[0], 1), "ms_per_frame": round(best[0] / 120 * 1e3, 4),
+                                      "mtris_per_s": round(best[1] / best[0] / 1e6, 1)}
+        for hh in hs:
+            hh.close()
+        out["animated"] = anim
 
     # --- the opt-in fast numeric build (libsdmesh_fast.so = the reference's own --use_fast_math mode): reported, never `value`
     hf = pkg.CudaHandler(local_rank, args.scene, params, fast_math=True)
