@@ -145,6 +145,7 @@ struct sdmesh_handle {
     bool ctl_published = false;    // the chain just enqueued writes h_pinned itself (k_tile_finish): no read-back copy
     int publish_ctl = 1;           // option "publish_ctl": 0 = always read back with a copy
     int local_prefix = 1;          // option "local_prefix": 0 = always launch k_tile_prefix / k_scan_u32
+    int tf_threads = 512;          // option "tf_threads": workgroup size of k_tile_first when it holds the orientation test (128 .. 1024)
     int project_prio = 0;          // option "project_prio" = 1: k_project1's waves lower their issue priority as they advance (s_setprio):
                                    // the waves of a SIMD then finish together instead of oldest first, at the same total time (measured)
     int project_grid = 0;          // option "project_grid": workgroups of the projection (0 = grid * project_mult, capped by the plan)
@@ -454,7 +455,8 @@ int mesh_weld(sdmesh_handle *h, const Vertex *uverts, uint32_t max_tiles, bool p
                            (uint32_t *) h->wvidx.p, (uint32_t *) h->torder.p, (uint32_t *) h->tfirst.p, local_pre ? nullptr : (uint32_t *) h->tfpre.p,
                            (Vertex *) h->vertices.p, (uint32_t) (h->vertices.cap / sizeof(Vertex)), h->d_ctr + CTR_NVERT,
                            (uint32_t *) h->indices.p, h->d_status, flip_scene, h->d_sp, part,
-                           publish ? h->d_ctr : nullptr, publish ? h->h_pinned : nullptr, CTR_WORDS + ST_WORDS, CTR_WORDS + ST_OVERFLOW, CTR_NVERT));
+                           publish ? h->d_ctr : nullptr, publish ? h->h_pinned : nullptr, CTR_WORDS + ST_WORDS, CTR_WORDS + ST_OVERFLOW, CTR_NVERT,
+                           flip_scene >= 0 ? h->tf_threads : 256));
         if (part == 1) SDCHK(prof_mark(h, flip_scene >= 0 ? "tile_first_flip" : "tile_first"));
     }
     SDCHK(prof_mark(h, h->profile ? "weld_rank_scan_finish" : "weld"));
@@ -797,7 +799,7 @@ int regen_impl(sdmesh_handle *h, int levels, int mode, int part, int nparts, sdm
             n_cap = padded(h->plan_counts[levels]);
             if (h->use_graph && st != nullptr && !h->profile && !h->project_diag) {   // (the legacy null stream cannot be captured: eager launches there)
                 uint64_t key[8] = {h->buf_gen, (uint64_t) h->scene, (uint64_t) levels, ((uint64_t) mode << 40) | ((uint64_t) part << 20) | (uint64_t) nparts,
-                                   (uint64_t) h->skip_weld | ((uint64_t) h->wide_active << 1) | ((uint64_t) h->col_refine << 2) | ((uint64_t) h->claim_in_project << 3) | ((uint64_t) h->fuse_flip << 4) | ((uint64_t) h->publish_ctl << 6) | ((uint64_t) h->local_prefix << 7) | ((uint64_t) h->project_batch << 8) | ((uint64_t) h->project_grid << 12) | ((uint64_t) h->project_prio << 30), (uint64_t) (uintptr_t) st, (uint64_t) h->grid | ((uint64_t) h->tgrid << 20) | ((uint64_t) h->project_mult << 40) | ((uint64_t) h->flip_mult << 48) | ((uint64_t) h->refine2 << 56) | ((uint64_t) h->emit_ci << 57) | ((uint64_t) h->project_lanes << 58) | ((uint64_t) h->flip_lanes << 61), 0};
+                                   (uint64_t) h->skip_weld | ((uint64_t) h->wide_active << 1) | ((uint64_t) h->col_refine << 2) | ((uint64_t) h->claim_in_project << 3) | ((uint64_t) h->fuse_flip << 4) | ((uint64_t) h->publish_ctl << 6) | ((uint64_t) h->local_prefix << 7) | ((uint64_t) h->project_batch << 8) | ((uint64_t) h->project_grid << 12) | ((uint64_t) h->project_prio << 30) | ((uint64_t) h->tf_threads << 32), (uint64_t) (uintptr_t) st, (uint64_t) h->grid | ((uint64_t) h->tgrid << 20) | ((uint64_t) h->project_mult << 40) | ((uint64_t) h->flip_mult << 48) | ((uint64_t) h->refine2 << 56) | ((uint64_t) h->emit_ci << 57) | ((uint64_t) h->project_lanes << 58) | ((uint64_t) h->flip_lanes << 61), 0};
                 for (int i = 0; i <= levels; i++) key[7] = key[7] * 1000003ull + h->plan_counts[i];
                 key[7] = key[7] * 1000003ull + h->plan_uniq;
                 key[7] = key[7] * 1000003ull + h->plan_tris;
@@ -1140,6 +1142,7 @@ int sdmesh_set_option(sdmesh_handle *h, const char *name, int value) {
                                                      : "this is the strict IEEE build (libsdmesh.so); load libsdmesh_fast.so for the fast numeric mode");
         return SDMESH_OK;
     }
+    if (!strcmp(name, "tf_threads")) { h->tf_threads = value; drop_graph(h); return SDMESH_OK; }
     if (!strcmp(name, "project_prio")) { h->project_prio = value != 0; drop_graph(h); return SDMESH_OK; }
     if (!strcmp(name, "project_grid")) { h->project_grid = value < 0 ? 0 : (value > 65535 ? 65535 : value); drop_graph(h); return SDMESH_OK; }
     if (!strcmp(name, "project_batch")) { h->project_batch = value < 0 ? 0 : (value > 6 ? 6 : value); drop_graph(h); return SDMESH_OK; }

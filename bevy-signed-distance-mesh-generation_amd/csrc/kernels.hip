@@ -1653,8 +1653,11 @@ static constexpr uint32_t T_VMAX = 3072;
 // FLIP_SCENE >= 0: the orientation test (compute_mesh_generation.cu:102-105, one lane per triangle as in k_flip1) runs here
 // instead of in its own launch -- possible once the weld claims have moved into the projection kernel, so that nothing
 // else needs the separate dispatch; a tile's ~512 triangles are two passes of its 256 threads.
+// Workgroup size: any multiple of 64 up to 1 024 (launch_weld).  512 threads per tile are the default when the orientation test
+// runs here: a tile then takes half as long, so the tiles that do not divide evenly over the CUs (1 037 tiles on 256 CUs at
+// 512^3: thirteen CUs get a fifth one) cost less at the end of the kernel (22.0 -> 21.2 us).
 template <int FLIP_SCENE>
-__global__ __launch_bounds__(256) void k_tile_first(const uint4 *__restrict__ tdesc, const uint32_t *__restrict__ ntiles_ptr,
+__global__ __launch_bounds__(1024) void k_tile_first(const uint4 *__restrict__ tdesc, const uint32_t *__restrict__ ntiles_ptr,
                                                      uint32_t *__restrict__ tri_e, const uint8_t *__restrict__ flip,
                                                      const Vertex *__restrict__ uverts, const SceneParams *__restrict__ spp,
                                                      uint32_t *__restrict__ vslot /* in: claim result; out: representative vertex | winner bit */,
@@ -1665,9 +1668,9 @@ __global__ __launch_bounds__(256) void k_tile_first(const uint4 *__restrict__ td
     for (uint32_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
         const uint4 d = tdesc[tile];
         const uint32_t vbase = d.x, nu = d.y, tbase = d.z, ttri = d.w;
-        for (uint32_t i = tid; i < nu; i += 256) s_first[i] = U32_NONE;
+        for (uint32_t i = tid; i < nu; i += blockDim.x) s_first[i] = U32_NONE;
         __syncthreads();
-        for (uint32_t tl = tid; tl < ttri; tl += 256) {
+        for (uint32_t tl = tid; tl < ttri; tl += blockDim.x) {
             const uint32_t t = tbase + tl;
             uint32_t e0 = tri_e[3 * t], e1 = tri_e[3 * t + 1], e2 = tri_e[3 * t + 2];
             bool fl;
@@ -1686,7 +1689,7 @@ __global__ __launch_bounds__(256) void k_tile_first(const uint4 *__restrict__ td
             atomicMin(&s_first[e2 - vbase], 3 * tl + 2);
         }
         __syncthreads();
-        for (uint32_t i = tid; i < nu; i += 256) {
+        for (uint32_t i = tid; i < nu; i += blockDim.x) {
             const uint32_t e = vbase + i, lf = s_first[i];
             const uint32_t fo = lf == U32_NONE ? U32_NONE : 3u * tbase + lf;
             first_ord[e] = fo;
@@ -2647,21 +2650,22 @@ hipError_t launch_weld(hipStream_t st, int grid, const Vertex *uverts, const uin
                        uint32_t *vslot, uint32_t *wv, uint32_t *torder, uint32_t *tfirst, uint32_t *tfpre,
                        Vertex *vertices, uint32_t vcap, uint32_t *nverts_out, uint32_t *indices, uint32_t *status,
                        int flip_scene, const SceneParams *sp, int part, const uint32_t *pub_src, uint32_t *pub_dst, uint32_t pub_words,
-                       uint32_t pub_ovf, uint32_t pub_nvert) {
+                       uint32_t pub_ovf, uint32_t pub_nvert, int tf_threads) {
+    if (tf_threads != 128 && tf_threads != 256 && tf_threads != 512 && tf_threads != 768 && tf_threads != 1024) tf_threads = 256;
     // part: 0 = the whole weld, 1 = k_tile_first only, 2 = everything behind it (so that a stage marker fits between)
     const bool stop_after_first = part == 1;
     if (part == 2) goto rest;
     if (flip_scene >= 0) {
         switch (flip_scene) {
-        case SCENE_SDOBJ: hipLaunchKernelGGL(k_tile_first<SCENE_SDOBJ>, dim3(grid), dim3(256), 0, st, tdesc, ntiles_ptr, tri_e, flip, uverts, sp, vslot, first_ord, wrep, wfm); break;
-        case SCENE_SPHERE: hipLaunchKernelGGL(k_tile_first<SCENE_SPHERE>, dim3(grid), dim3(256), 0, st, tdesc, ntiles_ptr, tri_e, flip, uverts, sp, vslot, first_ord, wrep, wfm); break;
-        case SCENE_CSG3: hipLaunchKernelGGL(k_tile_first<SCENE_CSG3>, dim3(grid), dim3(256), 0, st, tdesc, ntiles_ptr, tri_e, flip, uverts, sp, vslot, first_ord, wrep, wfm); break;
-        case SCENE_ANIM: hipLaunchKernelGGL(k_tile_first<SCENE_ANIM>, dim3(grid), dim3(256), 0, st, tdesc, ntiles_ptr, tri_e, flip, uverts, sp, vslot, first_ord, wrep, wfm); break;
-        case SCENE_PROGRAM: hipLaunchKernelGGL(k_tile_first<SCENE_PROGRAM>, dim3(grid), dim3(256), 0, st, tdesc, ntiles_ptr, tri_e, flip, uverts, sp, vslot, first_ord, wrep, wfm); break;
+        case SCENE_SDOBJ: hipLaunchKernelGGL(k_tile_first<SCENE_SDOBJ>, dim3(grid), dim3(tf_threads), 0, st, tdesc, ntiles_ptr, tri_e, flip, uverts, sp, vslot, first_ord, wrep, wfm); break;
+        case SCENE_SPHERE: hipLaunchKernelGGL(k_tile_first<SCENE_SPHERE>, dim3(grid), dim3(tf_threads), 0, st, tdesc, ntiles_ptr, tri_e, flip, uverts, sp, vslot, first_ord, wrep, wfm); break;
+        case SCENE_CSG3: hipLaunchKernelGGL(k_tile_first<SCENE_CSG3>, dim3(grid), dim3(tf_threads), 0, st, tdesc, ntiles_ptr, tri_e, flip, uverts, sp, vslot, first_ord, wrep, wfm); break;
+        case SCENE_ANIM: hipLaunchKernelGGL(k_tile_first<SCENE_ANIM>, dim3(grid), dim3(tf_threads), 0, st, tdesc, ntiles_ptr, tri_e, flip, uverts, sp, vslot, first_ord, wrep, wfm); break;
+        case SCENE_PROGRAM: hipLaunchKernelGGL(k_tile_first<SCENE_PROGRAM>, dim3(grid), dim3(tf_threads), 0, st, tdesc, ntiles_ptr, tri_e, flip, uverts, sp, vslot, first_ord, wrep, wfm); break;
         default: return hipErrorInvalidValue;
         }
     } else {
-        hipLaunchKernelGGL(k_tile_first<-1>, dim3(grid), dim3(256), 0, st, tdesc, ntiles_ptr, tri_e, flip, uverts, sp, vslot, first_ord, wrep, wfm);
+        hipLaunchKernelGGL(k_tile_first<-1>, dim3(grid), dim3(tf_threads), 0, st, tdesc, ntiles_ptr, tri_e, flip, uverts, sp, vslot, first_ord, wrep, wfm);
     }
     if (stop_after_first) return hipGetLastError();
 rest:

@@ -79,7 +79,7 @@ hipError_t launch_weld(hipStream_t st, int grid, const Vertex *uverts, const uin
                        Vertex *vertices, uint32_t vcap, uint32_t *nverts_out, uint32_t *indices, uint32_t *status,
                        int flip_scene = -1 /* >= 0: the orientation test runs inside k_tile_first */, const SceneParams *sp = nullptr,
                        int part = 0, const uint32_t *pub_src = nullptr /* control block -> host copy by k_tile_finish */, uint32_t *pub_dst = nullptr,
-                       uint32_t pub_words = 0, uint32_t pub_ovf = 0, uint32_t pub_nvert = 0);
+                       uint32_t pub_words = 0, uint32_t pub_ovf = 0, uint32_t pub_nvert = 0, int tf_threads = 256 /* workgroup size of k_tile_first */);
 hipError_t launch_expand_compact(hipStream_t st, int grid, const Vertex *uverts, const uint32_t *tri_e, const uint8_t *flip,
                                  const uint32_t *ntri_ptr, Triangle *out, uint32_t cap);
 hipError_t launch_expand_raw(hipStream_t st, int grid, const Vertex *uverts, const uint32_t *tri_e, const uint8_t *flip,

@@ -129,6 +129,9 @@ int sdmesh_use_own_stream(sdmesh_handle *h);
  *                       the call fails if the value does not match the build
  *   "claim" = 0         weld claims beside the orientation test instead of in the projection kernel's epilogue
  *   "weld_shift" = n    locality-preserving weld home slots (measured slower; default 0 = uniform)
+ *   "tf_threads" = n    workgroup size of k_tile_first when the orientation test runs inside it (128 / 256 / 512 / 768 / 1024; default 512)
+ *   "project_batch", "project_grid", "project_prio"   A/B knobs of the projection kernel (dealing unit, grid, wave priorities;
+ *                       measured, defaults are the fastest)
  *   "timing" = 1        bracket the planned chain with an event pair: sdmesh_regen_info.device_ms (default 0)
  *   "local_prefix" = 0  always launch the single-workgroup prefix kernels (default 1: up to 2 048 tiles the consumers'
  *                       workgroups prefix the ~1 000 tile counts themselves in LDS, two launches fewer)
