@@ -145,6 +145,8 @@ struct sdmesh_handle {
     bool ctl_published = false;    // the chain just enqueued writes h_pinned itself (k_tile_finish): no read-back copy
     int publish_ctl = 1;           // option "publish_ctl": 0 = always read back with a copy
     int local_prefix = 1;          // option "local_prefix": 0 = always launch k_tile_prefix / k_scan_u32
+    int col_segs = 1;              // option "col_segs": z segments per level-0 column in the column kernels (1 / 2 / 4 / 8); measured: more,
+                                   // smaller units are slower (the kernels are bound by the fixed phase chain of a workgroup, not by the heaviest column)
     int tf_threads = 512;          // option "tf_threads": workgroup size of k_tile_first when it holds the orientation test (128 .. 1024)
     int project_prio = 0;          // option "project_prio" = 1: k_project1's waves lower their issue priority as they advance (s_setprio):
                                    // the waves of a SIMD then finish together instead of oldest first, at the same total time (measured)
@@ -617,6 +619,7 @@ int col_levels(const sdmesh_handle *h, int levels, uint32_t n0) {
 }
 
 int ensure_col_scratch(sdmesh_handle *h, uint32_t ncols) {
+    ncols *= SDM_COL_SEGS_MAX;              // units: a column may be cut into up to this many z segments
     SDCHK(ensure(h, h->col_list1, 256ull * ncols));
     SDCHK(ensure(h, h->col_mask2, 256ull * ncols));
     SDCHK(ensure(h, h->col_mask3, 2048ull * ncols));
@@ -652,12 +655,12 @@ int enqueue_planned_chain(sdmesh_handle *h, int levels, const uint32_t *box, uin
         // levels 0 .. J per level-0 column: two launches, whatever J is (the level-0 .. J-1 lists are never materialised)
         HIPCHK(launch_col_refine(st, h->scene, h->d_sp, x0, x1, z0, z1, J, (uint8_t *) h->col_list1.p, (uint8_t *) h->col_mask2.p,
                                  (uint8_t *) h->col_mask3.p, (uint4 *) h->colinfo.p, (uint32_t *) h->ctl.p, (uint32_t) (CTL_LVL0 + lvl_words),
-                                 ff_in_kernel ? h->ff_arena.p : nullptr, (ff_bytes(h) + 15) & ~(size_t) 15));
+                                 ff_in_kernel ? h->ff_arena.p : nullptr, (ff_bytes(h) + 15) & ~(size_t) 15, h->col_segs));
         SDCHK(prof_mark(h, "col_refine"));
         n_cap = padded(h->plan_counts[J]);
         HIPCHK(launch_col_emit(st, x0, x1, z0, z1, J, (const uint8_t *) h->col_list1.p, (const uint8_t *) h->col_mask2.p,
                                (const uint8_t *) h->col_mask3.p, (const uint4 *) h->colinfo.p, (Point *) h->vox[0].p, n_cap,
-                               h->d_ctr + CTR_LEVEL0, h->d_status));
+                               h->d_ctr + CTR_LEVEL0, h->d_status, h->col_segs));
         SDCHK(prof_mark(h, "col_emit"));
         for (int i = 0; i < J; i++) vs = half_size(vs);
     } else {
@@ -799,7 +802,7 @@ int regen_impl(sdmesh_handle *h, int levels, int mode, int part, int nparts, sdm
             n_cap = padded(h->plan_counts[levels]);
             if (h->use_graph && st != nullptr && !h->profile && !h->project_diag) {   // (the legacy null stream cannot be captured: eager launches there)
                 uint64_t key[8] = {h->buf_gen, (uint64_t) h->scene, (uint64_t) levels, ((uint64_t) mode << 40) | ((uint64_t) part << 20) | (uint64_t) nparts,
-                                   (uint64_t) h->skip_weld | ((uint64_t) h->wide_active << 1) | ((uint64_t) h->col_refine << 2) | ((uint64_t) h->claim_in_project << 3) | ((uint64_t) h->fuse_flip << 4) | ((uint64_t) h->publish_ctl << 6) | ((uint64_t) h->local_prefix << 7) | ((uint64_t) h->project_batch << 8) | ((uint64_t) h->project_grid << 12) | ((uint64_t) h->project_prio << 30) | ((uint64_t) h->tf_threads << 32), (uint64_t) (uintptr_t) st, (uint64_t) h->grid | ((uint64_t) h->tgrid << 20) | ((uint64_t) h->project_mult << 40) | ((uint64_t) h->flip_mult << 48) | ((uint64_t) h->refine2 << 56) | ((uint64_t) h->emit_ci << 57) | ((uint64_t) h->project_lanes << 58) | ((uint64_t) h->flip_lanes << 61), 0};
+                                   (uint64_t) h->skip_weld | ((uint64_t) h->wide_active << 1) | ((uint64_t) h->col_refine << 2) | ((uint64_t) h->claim_in_project << 3) | ((uint64_t) h->fuse_flip << 4) | ((uint64_t) h->publish_ctl << 6) | ((uint64_t) h->local_prefix << 7) | ((uint64_t) h->project_batch << 8) | ((uint64_t) h->project_grid << 12) | ((uint64_t) h->project_prio << 30) | ((uint64_t) h->tf_threads << 32) | ((uint64_t) h->col_segs << 44), (uint64_t) (uintptr_t) st, (uint64_t) h->grid | ((uint64_t) h->tgrid << 20) | ((uint64_t) h->project_mult << 40) | ((uint64_t) h->flip_mult << 48) | ((uint64_t) h->refine2 << 56) | ((uint64_t) h->emit_ci << 57) | ((uint64_t) h->project_lanes << 58) | ((uint64_t) h->flip_lanes << 61), 0};
                 for (int i = 0; i <= levels; i++) key[7] = key[7] * 1000003ull + h->plan_counts[i];
                 key[7] = key[7] * 1000003ull + h->plan_uniq;
                 key[7] = key[7] * 1000003ull + h->plan_tris;
@@ -851,11 +854,11 @@ int regen_impl(sdmesh_handle *h, int levels, int mode, int part, int nparts, sdm
                 // column kernels: lists first, then the totals (count-only emit + one host sync), then the level-J voxel list
                 SDCHK(ensure_col_scratch(h, n0 / (box[3] - box[2])));
                 HIPCHK(launch_col_refine(st, h->scene, h->d_sp, box[0], box[1], box[2], box[3], J, (uint8_t *) h->col_list1.p,
-                                         (uint8_t *) h->col_mask2.p, (uint8_t *) h->col_mask3.p, (uint4 *) h->colinfo.p, nullptr, 0, nullptr, 0));
+                                         (uint8_t *) h->col_mask2.p, (uint8_t *) h->col_mask3.p, (uint4 *) h->colinfo.p, nullptr, 0, nullptr, 0, h->col_segs));
                 for (int pass = 0; pass < 2; pass++) {
                     HIPCHK(launch_col_emit(st, box[0], box[1], box[2], box[3], J, (const uint8_t *) h->col_list1.p, (const uint8_t *) h->col_mask2.p,
                                            (const uint8_t *) h->col_mask3.p, (const uint4 *) h->colinfo.p, pass ? (Point *) h->vox[0].p : nullptr,
-                                           n_cap, h->d_ctr + CTR_LEVEL0, h->d_status));
+                                           n_cap, h->d_ctr + CTR_LEVEL0, h->d_status, h->col_segs));
                     if (pass) break;
                     uint32_t cnt = 0;
                     HIPCHK(hipMemcpyAsync(&cnt, h->d_ctr + CTR_LEVEL0 + J, 4, hipMemcpyDeviceToHost, st));
@@ -1142,6 +1145,7 @@ int sdmesh_set_option(sdmesh_handle *h, const char *name, int value) {
                                                      : "this is the strict IEEE build (libsdmesh.so); load libsdmesh_fast.so for the fast numeric mode");
         return SDMESH_OK;
     }
+    if (!strcmp(name, "col_segs")) { h->col_segs = value < 1 ? 1 : (value > (int) SDM_COL_SEGS_MAX ? (int) SDM_COL_SEGS_MAX : value); drop_graph(h); return SDMESH_OK; }
     if (!strcmp(name, "tf_threads")) { h->tf_threads = value; drop_graph(h); return SDMESH_OK; }
     if (!strcmp(name, "project_prio")) { h->project_prio = value != 0; drop_graph(h); return SDMESH_OK; }
     if (!strcmp(name, "project_grid")) { h->project_grid = value < 0 ? 0 : (value > 65535 ? 65535 : value); drop_graph(h); return SDMESH_OK; }

@@ -573,7 +573,11 @@ template <int SCENE>
 __global__ __launch_bounds__(256) void k_col_refine(uint32_t x0, uint32_t z0, uint32_t zs, uint32_t J, const SceneParams *__restrict__ spp,
                                                      uint8_t *__restrict__ g_list1, uint8_t *__restrict__ g_mask2, uint8_t *__restrict__ g_mask3,
                                                      uint4 *__restrict__ colinfo, uint32_t *__restrict__ zero, uint32_t nzero,
-                                                     uint4 *__restrict__ ff, uint32_t nff16) {
+                                                     uint4 *__restrict__ ff, uint32_t nff16, uint32_t segs) {
+    // segs (option "col_segs", default 1): a column cut into `segs` equal z segments, one workgroup ("unit") each -- a segment is a
+    // contiguous range of the order too (z is the innermost digit).  Measured slower (2 / 4 / 8 segments: col_refine 20.5 -> 22.8 /
+    // 26.6 / 26.9 us, col_emit 8.5 -> 10 / 16 / 37 us): the kernels are bound by the fixed phase chain of a workgroup, not by
+    // the heaviest column.
     const SceneParams &sp = *spp;
     __shared__ uint8_t s_sign[COL_S1];
     __shared__ uint8_t s_list1[COL_L1];
@@ -585,7 +589,9 @@ __global__ __launch_bounds__(256) void k_col_refine(uint32_t x0, uint32_t z0, ui
     const uint32_t F = MESH_GENERATION_INIT_FACTOR;
     const float h0 = MESH_GENERATION_BB_SIZE / (float) MESH_GENERATION_INIT_FACTOR;
     const float h1 = h0 / 2.0f, h2 = h1 / 2.0f, h3 = h2 / 2.0f;                 // src/cuda/mod.rs:126-130, exact halvings
-    const uint32_t col = blockIdx.x, X0 = x0 + col / F, Y0 = col % F, Z0 = z0;
+    const uint32_t unit = blockIdx.x, col = unit / segs;
+    zs /= segs;                                                                 // (from here on: the unit's own z extent)
+    const uint32_t X0 = x0 + col / F, Y0 = col % F, Z0 = z0 + (unit % segs) * zs;
     const uint32_t nz1 = 2u * zs + 1u;                                          // level-1 lattice points along z
     if (tid == 0) s_n3 = 0;
     // A. signs of the column's level-1 lattice: (ix, iy) in 0..2, iz in 0..2 zs
@@ -651,7 +657,7 @@ __global__ __launch_bounds__(256) void k_col_refine(uint32_t x0, uint32_t z0, ui
                             }
                         }
                         const uint32_t m = child_mask_from_bits(bits);
-                        g_mask3[(size_t) col * COL_L2 + b] = (uint8_t) m;
+                        g_mask3[(size_t) unit * COL_L2 + b] = (uint8_t) m;
                         local3 += __popc(m);
                     }
                 }
@@ -665,7 +671,7 @@ __global__ __launch_bounds__(256) void k_col_refine(uint32_t x0, uint32_t z0, ui
                         lx = 2u * lx + (c2 >> 2); ly = 2u * ly + ((c2 >> 1) & 1u); lz = 2u * lz + (c2 & 1u);
                     }
                     const uint32_t m = col_cell_mask<SCENE>(b < n2, lx, ly, lz, h3, s, sp);
-                    if (s == 0 && b < n2) { g_mask3[(size_t) col * COL_L2 + b] = (uint8_t) m; local3 += __popc(m); }
+                    if (s == 0 && b < n2) { g_mask3[(size_t) unit * COL_L2 + b] = (uint8_t) m; local3 += __popc(m); }
                 }
             }
             if (local3) atomicAdd(&s_n3, local3);
@@ -674,10 +680,10 @@ __global__ __launch_bounds__(256) void k_col_refine(uint32_t x0, uint32_t z0, ui
         }
     }
     if (tid < n1) {
-        g_list1[(size_t) col * COL_L1 + tid] = s_list1[tid];
-        if (J >= 2) g_mask2[(size_t) col * COL_L1 + tid] = s_mask2[tid];
+        g_list1[(size_t) unit * COL_L1 + tid] = s_list1[tid];
+        if (J >= 2) g_mask2[(size_t) unit * COL_L1 + tid] = s_mask2[tid];
     }
-    if (tid == 0) colinfo[col] = make_uint4(n1, n2, n3, 0u);
+    if (tid == 0) colinfo[unit] = make_uint4(n1, n2, n3, 0u);
     // the regen's clears (control block, weld table), spread over the grid -- behind the column's own work, so the few
     // heavy columns that set the kernel's duration start at once and the many light ones do most of the clearing
     for (uint32_t i = blockIdx.x * 256u + tid; i < nzero; i += gridDim.x * 256u) zero[i] = 0u;
@@ -691,15 +697,15 @@ __global__ __launch_bounds__(256) void k_col_emit(uint32_t x0, uint32_t z0, uint
                                                    const uint8_t *__restrict__ g_list1, const uint8_t *__restrict__ g_mask2,
                                                    const uint8_t *__restrict__ g_mask3, const uint4 *__restrict__ colinfo,
                                                    Point *__restrict__ out, uint32_t cap, uint32_t *__restrict__ level_ctr /* [0..J] */,
-                                                   uint32_t *__restrict__ status) {
+                                                   uint32_t *__restrict__ status, uint32_t segs /* units per column; ncols = units */) {
     __shared__ uint8_t s_list1[COL_L1];
     __shared__ uint16_t s_list2[COL_L2];
     __shared__ uint32_t s_scan[17];
     const uint32_t F = MESH_GENERATION_INIT_FACTOR, tid = threadIdx.x;
     const float h0 = MESH_GENERATION_BB_SIZE / (float) MESH_GENERATION_INIT_FACTOR;
     const float hJ = J == 1 ? h0 / 2.0f : (J == 2 ? h0 / 4.0f : h0 / 8.0f);
-    const uint32_t col = blockIdx.x, X0 = x0 + col / F, Y0 = col % F, Z0 = z0;
-    // offset of this column in the level-J list; block 0 sums everything for the totals
+    const uint32_t col = blockIdx.x /* = unit */, X0 = x0 + (col / segs) / F, Y0 = (col / segs) % F, Z0 = z0 + (col % segs) * (zs / segs);
+    // offset of this unit in the level-J list; block 0 sums everything for the totals
     uint32_t before = 0, t1 = 0, t2 = 0, t3 = 0;
     for (uint32_t c = tid; c < ncols; c += 256u) {
         const uint4 ci = colinfo[c];
@@ -716,7 +722,7 @@ __global__ __launch_bounds__(256) void k_col_emit(uint32_t x0, uint32_t z0, uint
         if (tid == 0) {
             uint32_t tj = J == 1 ? T1 : (J == 2 ? T2 : T3);
             if (out && tj > cap) { atomicOr(&status[ST_OVERFLOW], 1u); tj = cap; }
-            level_ctr[0] = ncols * zs;
+            level_ctr[0] = (ncols / segs) * zs;
             level_ctr[1] = J == 1 ? tj : T1;
             if (J >= 2) level_ctr[2] = J == 2 ? tj : T2;
             if (J >= 3) level_ctr[3] = tj;
@@ -2514,22 +2520,31 @@ hipError_t launch_refine_emit(hipStream_t st, int grid, const Point *vox, const 
     return hipGetLastError();
 }
 
+// z segments per column (units of the column kernels): the largest power of two <= pref that divides the slab's z extent
+static uint32_t col_segments(uint32_t zs, int pref) {
+    uint32_t q = 1;
+    while (q * 2u <= (uint32_t) (pref < 1 ? 1 : (pref > (int) SDM_COL_SEGS_MAX ? (int) SDM_COL_SEGS_MAX : pref)) && zs % (q * 2u) == 0u) q *= 2u;
+    return q;
+}
+
 hipError_t launch_col_refine(hipStream_t st, int scene, const SceneParams *sp, uint32_t x0, uint32_t x1, uint32_t z0, uint32_t z1, int J,
                              uint8_t *g_list1, uint8_t *g_mask2, uint8_t *g_mask3, uint4 *colinfo, uint32_t *zero, uint32_t nzero,
-                             void *ff, size_t ff_bytes) {
+                             void *ff, size_t ff_bytes, int segs_pref) {
     const uint32_t ncols = (x1 - x0) * MESH_GENERATION_INIT_FACTOR;
     if (ncols == 0 || z1 <= z0) return hipErrorInvalidValue;
-    SDM_DISPATCH(scene, hipLaunchKernelGGL(k_col_refine<S>, dim3(ncols), dim3(256), 0, st, x0, z0, z1 - z0, (uint32_t) J, sp, g_list1, g_mask2, g_mask3,
-                                           colinfo, zero, nzero, (uint4 *) ff, ff ? (uint32_t) (ff_bytes / 16) : 0u));
+    const uint32_t segs = col_segments(z1 - z0, segs_pref);
+    SDM_DISPATCH(scene, hipLaunchKernelGGL(k_col_refine<S>, dim3(ncols * segs), dim3(256), 0, st, x0, z0, z1 - z0, (uint32_t) J, sp, g_list1, g_mask2, g_mask3,
+                                           colinfo, zero, nzero, (uint4 *) ff, ff ? (uint32_t) (ff_bytes / 16) : 0u, segs));
     return hipGetLastError();
 }
 
 hipError_t launch_col_emit(hipStream_t st, uint32_t x0, uint32_t x1, uint32_t z0, uint32_t z1, int J, const uint8_t *g_list1,
                            const uint8_t *g_mask2, const uint8_t *g_mask3, const uint4 *colinfo, Point *out, uint32_t cap,
-                           uint32_t *level_ctr, uint32_t *status) {
+                           uint32_t *level_ctr, uint32_t *status, int segs_pref) {
     const uint32_t ncols = (x1 - x0) * MESH_GENERATION_INIT_FACTOR;
-    hipLaunchKernelGGL(k_col_emit, dim3(ncols), dim3(256), 0, st, x0, z0, z1 - z0, ncols, (uint32_t) J, g_list1, g_mask2, g_mask3, colinfo, out, cap,
-                       level_ctr, status);
+    const uint32_t segs = col_segments(z1 - z0, segs_pref);
+    hipLaunchKernelGGL(k_col_emit, dim3(ncols * segs), dim3(256), 0, st, x0, z0, z1 - z0, ncols * segs, (uint32_t) J, g_list1, g_mask2, g_mask3, colinfo, out, cap,
+                       level_ctr, status, segs);
     return hipGetLastError();
 }
 

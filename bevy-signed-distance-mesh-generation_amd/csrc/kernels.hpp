@@ -33,10 +33,11 @@ hipError_t launch_refine_emit(hipStream_t st, int grid, const Point *vox, const 
 hipError_t launch_sum_tiles(hipStream_t st, const uint32_t *tilecnt, const uint32_t *n_ptr, uint32_t *total_out);
 hipError_t launch_col_refine(hipStream_t st, int scene, const SceneParams *sp, uint32_t x0, uint32_t x1, uint32_t z0, uint32_t z1, int J,
                              uint8_t *g_list1, uint8_t *g_mask2, uint8_t *g_mask3, uint4 *colinfo, uint32_t *zero, uint32_t nzero,
-                             void *ff, size_t ff_bytes);
+                             void *ff, size_t ff_bytes, int segs_pref = 1 /* z segments per column (a power of two that divides z1 - z0 is used) */);
+constexpr uint32_t SDM_COL_SEGS_MAX = 8;      // the per-column scratch arrays hold this many units per column
 hipError_t launch_col_emit(hipStream_t st, uint32_t x0, uint32_t x1, uint32_t z0, uint32_t z1, int J, const uint8_t *g_list1,
                            const uint8_t *g_mask2, const uint8_t *g_mask3, const uint4 *colinfo, Point *out, uint32_t cap,
-                           uint32_t *level_ctr, uint32_t *status);
+                           uint32_t *level_ctr, uint32_t *status, int segs_pref = 1);
 hipError_t launch_refine2_mask(hipStream_t st, int grid, int scene, const SceneParams *sp, const Point *vox, const uint32_t *n_ptr,
                                Point cs1, uint8_t *mask1, uint64_t *mask2, uint32_t *tilecnt, uint32_t *n_mid);
 hipError_t launch_refine2_emit(hipStream_t st, int grid, const Point *vox, const uint32_t *n_ptr, Point cs1, const uint8_t *mask1,

@@ -129,6 +129,7 @@ int sdmesh_use_own_stream(sdmesh_handle *h);
  *                       the call fails if the value does not match the build
  *   "claim" = 0         weld claims beside the orientation test instead of in the projection kernel's epilogue
  *   "weld_shift" = n    locality-preserving weld home slots (measured slower; default 0 = uniform)
+ *   "col_segs" = n      z segments per level-0 column in the column kernels (1 / 2 / 4 / 8; default 1: measured fastest)
  *   "tf_threads" = n    workgroup size of k_tile_first when the orientation test runs inside it (128 / 256 / 512 / 768 / 1024; default 512)
  *   "project_batch", "project_grid", "project_prio"   A/B knobs of the projection kernel (dealing unit, grid, wave priorities;
  *                       measured, defaults are the fastest)
