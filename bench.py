@@ -274,7 +274,9 @@ def roofline_legs(h, out, n_grid, scene, params, consts):
     out["roofline_p2_sign_bits"] = {"bound": "hbm", "kernel": "k_sign_bits", "achieved": round(gb2, 1), "peak": HBM_PEAK_GBPS,
                                     "unit": "GB/s", "frac": round(gb2 / HBM_PEAK_GBPS, 4), "traffic": None,
                                     "bytes_per_launch": alg_bytes + alg_bytes / 32, "avg_launch_ms": round(ms2, 5)}
-    # write ceiling on THIS box: P1's store stream (same bytes, same launch shape) with no arithmetic in front
+    # write ceiling on THIS box: P1's store stream (same bytes, same launch shape: one float4 store per thread, one 4 KiB piece
+    # per workgroup) with no arithmetic in front.  The sphere pass itself stops at its own VALU issue (four correctly rounded
+    # square roots per quad), see DESIGN.md 6.
     ms3 = h.time_kernel(2, n_grid, buf.data_ptr(), 50)
     gb3 = alg_bytes / (ms3 * 1e-3) / 1e9
     h.set_scene(scene, params)

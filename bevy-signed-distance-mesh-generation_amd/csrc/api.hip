@@ -117,6 +117,7 @@ struct sdmesh_handle {
     int dense_grid = 16384;    // workgroups for k_sample_dense
     int dense_nt = 1;          // nontemporal stores in k_sample_dense
     int dense_contig = 1;      // flat P1 kernel: every workgroup writes one contiguous run (measured best)
+    int dense_q1 = 1;          // flat P1 kernel: one quad per thread, one 4 KiB piece per workgroup (the shape the write stream is fastest in)
     int dense_rows = 2;        // P1 kernel: 0 = flat 16-B aligned quads, 1 = one wave per z-row, 2 = auto
     char err[512] = {0};
     uint64_t buf_gen = 0;      // bumped whenever a device buffer is (re)allocated: invalidates a captured graph
@@ -1173,6 +1174,7 @@ int sdmesh_set_option(sdmesh_handle *h, const char *name, int value) {
     if (!strcmp(name, "dense_grid")) { h->dense_grid = value; return SDMESH_OK; }
     if (!strcmp(name, "dense_nt")) { h->dense_nt = value ? 1 : 0; return SDMESH_OK; }
     if (!strcmp(name, "dense_rows")) { h->dense_rows = value; return SDMESH_OK; }
+    if (!strcmp(name, "dense_q1")) { h->dense_q1 = value ? 1 : 0; return SDMESH_OK; }
     if (!strcmp(name, "dense_contig")) { h->dense_contig = value ? 1 : 0; return SDMESH_OK; }
     if (!strcmp(name, "forget_plan")) { h->plan_valid = false; return SDMESH_OK; }
     return fail(h, SDMESH_ERR_INVALID, "unknown option %s", name);
@@ -1465,6 +1467,8 @@ static hipError_t launch_p1(sdmesh_handle *h, float *d_out, uint32_t N) {
     // measured (round-1 sweep): the write-bound sphere wants whole 16-B aligned cache lines per store (flat
     // quads, 5.5 TB/s vs 3.9 with dword-aligned row stores); the VALU-bound scenes want the leaner row kernel
     const bool rows = h->dense_rows == 2 ? (h->scene != SDMESH_SCENE_SPHERE) : (h->dense_rows != 0);
+    const uint64_t total = (uint64_t) (N + 1) * (N + 1) * (N + 1);
+    if (!rows && h->dense_q1 && total < 0xFFFFFFF0ull) return launch_sample_dense_q1(h->stream, h->scene, h->d_sp, d_out, N, h->dense_nt != 0);
     return rows ? launch_sample_dense_rows(h->stream, grid, h->scene, h->d_sp, d_out, N, h->dense_nt != 0)
                          : launch_sample_dense(h->stream, grid, h->scene, h->d_sp, d_out, N, h->dense_nt != 0, h->dense_contig != 0);
 }
@@ -1562,7 +1566,7 @@ int sdmesh_time_kernel(sdmesh_handle *h, int which, uint32_t N, float *d_buf, in
     }
     if (which == 2) {     // write ceiling: P1's store stream without the arithmetic
         const uint64_t total = (uint64_t) (N + 1) * (N + 1) * (N + 1);
-        const int grid = h->dense_grid > 0 ? h->dense_grid : 8 * h->grid;
+        const int grid = h->dense_q1 ? 0 : (h->dense_grid > 0 ? h->dense_grid : 8 * h->grid);       // 0 = one quad per thread
         HIPCHK(launch_stream_fill(h->stream, grid, d_buf, total, 1.0f));
         HIPCHK(hipEventRecord(h->ev0, h->stream));
         for (int i = 0; i < iters; i++) HIPCHK(launch_stream_fill(h->stream, grid, d_buf, total, 1.0f));

@@ -2433,6 +2433,7 @@ __global__ __launch_bounds__(256) void k_sample_dense(float *__restrict__ out, u
 // Write ceiling for P1: the same store stream (contiguous run of float4 per workgroup, nontemporal) with no
 // arithmetic in front of it.  bench.py times it beside P1 to show how much of the achievable write rate P1 reaches.
 __global__ __launch_bounds__(256) void k_stream_fill(float *__restrict__ out, uint64_t total, float value) {
+    // (grid = ceil(quads / 256): every thread issues one store -- the shape the write stream is fastest in, see k_sample_dense_q1)
     typedef float v4f __attribute__((ext_vector_type(4)));
     const uint64_t nquads = total >> 2;
     const uint64_t per = ((nquads + gridDim.x - 1) / gridDim.x + blockDim.x - 1) / blockDim.x * blockDim.x;
@@ -2446,6 +2447,93 @@ __global__ __launch_bounds__(256) void k_stream_fill(float *__restrict__ out, ui
 // P1, row-structured variant: one wave per z-row of S = N + 1 samples.  Lane l evaluates the quads l, l + 64, ...
 // of its row and stores them as dword-aligned float4 (a row starts at byte 4 * S * row, S odd), the S % 4 tail samples
 // go out as scalars.  No div/mod or row-wrap logic in the sample loop; the (x, y) terms are computed once per row.
+// P1, one 16-byte quad per thread, one 4 KiB piece per workgroup, as many workgroups as pieces (no loop).
+//
+// The write stream itself decides the shape: a pure fill of the 540 MB volume sustains 7.1 TB/s when every thread issues
+// exactly ONE float4 store and retires (131 842 workgroups at 512^3), 6.1 TB/s with two stores per thread, 5.3 TB/s in
+// the persistent shapes of k_sample_dense (profiles: r02 bench, write_ceiling / tools sweep) -- a wave that still has
+// stores to issue holds its slot, and the memory pipeline prefers many short waves.  With one quad per thread the index
+// arithmetic cannot be amortised over a loop, so (x, y, z) comes from two exact 32-bit divisions by S = N + 1 done with a
+// host-computed magic number (mulhi + shift + fixup: 6 instructions each), and the sphere's four samples are evaluated
+// as two packed pairs (pz = (float) z * h - 2.5f etc. on v_pk_*; same operations in the same order per component).
+// Volumes of 2^32 samples or more keep the persistent kernel.
+struct DivMagic { uint32_t m, add, sh; };           // q = add ? (((n - hi) >> 1) + hi) >> sh : hi >> sh,  hi = mulhi(n, m)
+__device__ __forceinline__ uint32_t div_magic(uint32_t n, DivMagic d) {
+    const uint32_t hi = __umulhi(n, d.m);
+    return d.add ? (((n - hi) >> 1) + hi) >> d.sh : hi >> d.sh;
+}
+
+template <int SCENE, bool NT>
+__global__ __launch_bounds__(256) void k_sample_dense_q1(float *__restrict__ out, uint32_t N, uint32_t total, const SceneParams *__restrict__ spp,
+                                                          DivMagic dS, float h /* = 5.0f / (float) N, computed on the host: the same IEEE quotient */) {
+    typedef float v4f __attribute__((ext_vector_type(4)));
+    const SceneParams &sp = *spp;
+    const uint32_t S = N + 1u;
+    const uint32_t i0 = (blockIdx.x * 256u + threadIdx.x) << 2;
+    if (i0 >= total) return;
+    // (x, y, z) of the workgroup's first sample on the scalar unit (two magic divisions of a uniform value), then at most two
+    // row steps per thread: a piece is 1 024 consecutive samples and a row has S >= 2 of them
+    const uint32_t iw = blockIdx.x << 10;
+    const uint32_t r0 = div_magic(iw, dS), x0 = div_magic(r0, dS);
+    uint32_t z = (iw - r0 * S) + (threadIdx.x << 2), y = r0 - x0 * S, x = x0;
+    if (S >= 512u) {                                         // (the usual case: no loop)
+        if (z >= S) { z -= S; y++; }
+        if (z >= S) { z -= S; y++; }
+        if (z >= S) { z -= S; y++; }
+        if (y >= S) { y -= S; x++; }
+    } else {
+        const uint32_t rr = div_magic(i0, dS);
+        z = i0 - rr * S; x = div_magic(rr, dS); y = rr - x * S;
+    }
+    float v[4];
+    if (SCENE == SCENE_SPHERE) {
+        // |p|^2 is 0 or a normal float on the lattice, hence the lean sqrt
+        const float px = (float) x * h - 2.5f, py = (float) y * h - 2.5f;
+        const float a_cur = px * px + py * py;
+#if defined(SDM_HAVE_PAIRS)
+        if (z + 3u < S) {                                    // the whole quad lies in one row (125 of 128 quads of a row)
+            const float zf = (float) z;
+            const v2f p0 = mk2(zf, zf + 1.0f) * h - 2.5f, p1 = mk2(zf + 2.0f, zf + 3.0f) * h - 2.5f;     // (float) (z + k) exactly
+            const v2f r0 = sqrt_rn_normal2(a_cur + p0 * p0) - 1.0f, r1 = sqrt_rn_normal2(a_cur + p1 * p1) - 1.0f;
+            v[0] = r0.x; v[1] = r0.y; v[2] = r1.x; v[3] = r1.y;
+        } else
+#endif
+        {
+            // the quad crosses a row end: samples k >= rem belong to the next row
+            const uint32_t rem = S - z;
+            const bool ywrap = (y + 1u == S);
+            const float nx = (float) (ywrap ? x + 1u : x) * h - 2.5f, ny = (float) (ywrap ? 0u : y + 1u) * h - 2.5f;
+            const float a_nxt = nx * nx + ny * ny;
+#pragma unroll
+            for (uint32_t k = 0; k < 4; k++) {
+                const bool nxt = k >= rem;
+                const float pz = (float) (nxt ? k - rem : z + k) * h - 2.5f;
+                v[k] = sqrt_rn_normal((nxt ? a_nxt : a_cur) + pz * pz) - 1.0f;
+            }
+        }
+    } else {
+        uint32_t cx = x, cy = y, cz = z;
+        RowCtx<SCENE> row;
+        row.init((float) cx * h - 2.5f, (float) cy * h - 2.5f, sp);
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            v[k] = row.eval((float) cz * h - 2.5f, sp);
+            if (++cz == S) {
+                cz = 0;
+                if (++cy == S) { cy = 0; ++cx; }
+                row.init((float) cx * h - 2.5f, (float) cy * h - 2.5f, sp);
+            }
+        }
+    }
+    if (i0 + 3u < total) {
+        const v4f q = {v[0], v[1], v[2], v[3]};
+        if (NT) __builtin_nontemporal_store(q, reinterpret_cast<v4f *>(out + i0));
+        else *reinterpret_cast<v4f *>(out + i0) = q;
+    } else {
+        for (uint32_t k = 0; k < 4u && i0 + k < total; k++) out[i0 + k] = v[k];
+    }
+}
+
 template <int SCENE, bool NT>
 __global__ __launch_bounds__(256) void k_sample_dense_rows(float *__restrict__ out, uint32_t N, const SceneParams *__restrict__ spp) {
     typedef float v4fu __attribute__((ext_vector_type(4), aligned(4)));
@@ -2729,7 +2817,28 @@ hipError_t launch_sample_dense(hipStream_t st, int grid, int scene, const SceneP
 }
 
 hipError_t launch_stream_fill(hipStream_t st, int grid, float *out, uint64_t total, float value) {
+    if (grid <= 0) grid = (int) std::min<uint64_t>(((total >> 2) + 255ull) / 256ull, 0x7FFFFFFFull);      // one quad per thread
     hipLaunchKernelGGL(k_stream_fill, dim3(grid), dim3(256), 0, st, out, total, value);
+    return hipGetLastError();
+}
+
+// exact unsigned division of any 32-bit n by d (2 <= d < 2^31) as mulhi + shift (+ fixup): Granlund & Montgomery / libdivide
+static DivMagic make_div_magic(uint32_t d) {
+    DivMagic r;
+    uint32_t l = 0;
+    while ((1ull << l) < d) l++;                                    // ceil(log2 d)
+    const uint64_t m = ((1ull << 32) * ((1ull << l) - d)) / d + 1ull;   // low 32 bits of the 33-bit multiplier
+    r.m = (uint32_t) m; r.add = 1u; r.sh = l - 1u;                    // q = (((n - hi) >> 1) + hi) >> (l - 1)
+    return r;
+}
+
+hipError_t launch_sample_dense_q1(hipStream_t st, int scene, const SceneParams *sp, float *out, uint32_t N, bool nt) {
+    const uint64_t total = (uint64_t) (N + 1) * (N + 1) * (N + 1);
+    if (total >= 0xFFFFFFF0ull || N < 1u) return hipErrorInvalidValue;
+    const DivMagic dS = make_div_magic(N + 1u);
+    const uint32_t grid = (uint32_t) (((total + 3ull) / 4ull + 255ull) / 256ull);
+    if (nt) { SDM_DISPATCH(scene, hipLaunchKernelGGL((k_sample_dense_q1<S, true>), dim3(grid), dim3(256), 0, st, out, N, (uint32_t) total, sp, dS, 5.0f / (float) N)); }
+    else { SDM_DISPATCH(scene, hipLaunchKernelGGL((k_sample_dense_q1<S, false>), dim3(grid), dim3(256), 0, st, out, N, (uint32_t) total, sp, dS, 5.0f / (float) N)); }
     return hipGetLastError();
 }
 

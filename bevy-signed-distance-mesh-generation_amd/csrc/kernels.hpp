@@ -87,6 +87,7 @@ hipError_t launch_expand_raw(hipStream_t st, int grid, const Vertex *uverts, con
                              const uint8_t *cubeidx, const uint32_t *trioff, uint32_t n, Triangle *out);
 hipError_t launch_triangles_direct(hipStream_t st, int scene, const SceneParams *sp, const Point *vox, uint32_t n, Point vs,
                                    Triangle *out);
+hipError_t launch_sample_dense_q1(hipStream_t st, int scene, const SceneParams *sp, float *out, uint32_t N, bool nt);   // one quad per thread (< 2^32 samples)
 hipError_t launch_stream_fill(hipStream_t st, int grid, float *out, uint64_t total, float value);
 hipError_t launch_sample_dense_rows(hipStream_t st, int grid, int scene, const SceneParams *sp, float *out, uint32_t N, bool nt);
 hipError_t launch_sample_dense(hipStream_t st, int grid, int scene, const SceneParams *sp, float *out, uint32_t N, bool nt,

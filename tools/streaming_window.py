@@ -7,7 +7,7 @@ f = max(glob.glob(sys.argv[1] + '/**/*_kernel_trace.csv', recursive=True), key=o
 rows = sorted(csv.DictReader(open(f)), key=lambda r: int(r['Start_Timestamp']))
 w = csv.writer(open(sys.argv[2], 'w', newline=''))
 w.writerow(["kernel", "launches", "avg_us_all_launches", "avg_us_first_20", "avg_us_last_50_(the_window_bench.py_times)"])
-for key in ("k_sample_dense<1, true>", "k_stream_fill", "k_sign_bits"):
+for key in ("k_sample_dense_q1<1, true>", "k_sample_dense<1, true>", "k_stream_fill", "k_sign_bits"):
     d = [(int(r['End_Timestamp']) - int(r['Start_Timestamp'])) / 1e3 for r in rows if key in r['Kernel_Name']]
     if len(d) >= 50:
         w.writerow([key, len(d), "%.2f" % (sum(d) / len(d)), "%.2f" % (sum(d[:20]) / 20), "%.2f" % (sum(d[-50:]) / 50)])
