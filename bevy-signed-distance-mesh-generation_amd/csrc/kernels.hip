@@ -2487,19 +2487,27 @@ __global__ __launch_bounds__(256) void k_sample_dense_q1(float *__restrict__ out
     }
     float v[4];
     if (SCENE == SCENE_SPHERE) {
-        // |p|^2 is 0 or a normal float on the lattice, hence the lean sqrt
+        // |p|^2 is 0 or a normal float on the lattice, hence the lean sqrt.  A quad may cross a row end (S is odd: 37 % of
+        // the waves hold such a quad): samples k with z + k >= S belong to the next row.  That is folded into the one code
+        // path with selects (the row's x^2 + y^2 term and z - S per sample: ~17 instructions) instead of a divergent second
+        // path the whole wave would walk (~74).  All the integers involved are < 2^24, so the float adds are exact.
         const float px = (float) x * h - 2.5f, py = (float) y * h - 2.5f;
-        const float a_cur = px * px + py * py;
+        const float px2 = px * px, a_cur = px2 + py * py;
 #if defined(SDM_HAVE_PAIRS)
-        if (z + 3u < S) {                                    // the whole quad lies in one row (125 of 128 quads of a row)
-            const float zf = (float) z;
-            const v2f p0 = mk2(zf, zf + 1.0f) * h - 2.5f, p1 = mk2(zf + 2.0f, zf + 3.0f) * h - 2.5f;     // (float) (z + k) exactly
-            const v2f r0 = sqrt_rn_normal2(a_cur + p0 * p0) - 1.0f, r1 = sqrt_rn_normal2(a_cur + p1 * p1) - 1.0f;
-            v[0] = r0.x; v[1] = r0.y; v[2] = r1.x; v[3] = r1.y;
-        } else
-#endif
+        float ny = (float) (y + 1u) * h - 2.5f, a_nxt = px2 + ny * ny;
+        if (z + 3u >= S && y + 1u == S) {                   // ... and the next row is the first of the next x plane (rare)
+            const float nx = (float) (x + 1u) * h - 2.5f;
+            a_nxt = nx * nx + 6.25f;                        // ny = 0 * h - 2.5f = -2.5f exactly; (-2.5f)^2 = 6.25f exactly
+        }
+        const float zf = (float) z, Sf = (float) S;
+        const bool w1 = z + 1u >= S, w2 = z + 2u >= S, w3 = z + 3u >= S;
+        const v2f q0 = mk2(zf, zf + 1.0f) - mk2(0.0f, w1 ? Sf : 0.0f), q1 = mk2(zf + 2.0f, zf + 3.0f) - mk2(w2 ? Sf : 0.0f, w3 ? Sf : 0.0f);
+        const v2f p0 = q0 * h - 2.5f, p1 = q1 * h - 2.5f;
+        const v2f r0 = sqrt_rn_normal2(mk2(a_cur, w1 ? a_nxt : a_cur) + p0 * p0) - 1.0f;
+        const v2f r1 = sqrt_rn_normal2(mk2(w2 ? a_nxt : a_cur, w3 ? a_nxt : a_cur) + p1 * p1) - 1.0f;
+        v[0] = r0.x; v[1] = r0.y; v[2] = r1.x; v[3] = r1.y;
+#else
         {
-            // the quad crosses a row end: samples k >= rem belong to the next row
             const uint32_t rem = S - z;
             const bool ywrap = (y + 1u == S);
             const float nx = (float) (ywrap ? x + 1u : x) * h - 2.5f, ny = (float) (ywrap ? 0u : y + 1u) * h - 2.5f;
@@ -2511,6 +2519,7 @@ __global__ __launch_bounds__(256) void k_sample_dense_q1(float *__restrict__ out
                 v[k] = sqrt_rn_normal((nxt ? a_nxt : a_cur) + pz * pz) - 1.0f;
             }
         }
+#endif
     } else {
         uint32_t cx = x, cy = y, cz = z;
         RowCtx<SCENE> row;
