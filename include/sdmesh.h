@@ -121,6 +121,8 @@ int sdmesh_use_own_stream(sdmesh_handle *h);
  *   "col_refine" = 0    refine level by level from the level-0 field (default 1: levels 0 .. min(levels - 1, 3) are fused
  *                       per level-0 column, two launches in all)
  *   "refine2" = 1, "mask_chunk" = 8|16|32   refine variants
+ *   "dense_q1" = 0      dense sample pass (P1) of the flat kernels in the persistent shape (default 1: one float4 store per thread,
+ *                       one 4 KiB piece per workgroup -- the shape the HBM write stream is fastest in; volumes of < 2^32 samples)
  *   "dense_grid", "dense_nt", "dense_rows", "dense_contig"   launch shape of the dense sample pass (P1)
  *   "forget_plan" = 1   drop the capacity plan (the next regen discovers sizes again)
  *   "fast_math" = 0|1   confirms the numeric mode of the loaded library: libsdmesh.so is strict IEEE (bit-exact against the
