@@ -387,6 +387,8 @@ class StdoutGuard:
 
 
 def main():
+    # (before anything initialises the GPU runtime: the host driver only supports dmabuf IPC, RCCL needs this for multi-process work)
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     guard = StdoutGuard()
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
