@@ -1,0 +1,58 @@
+"""The driver's contract for bench.py, checked on the GPU box: ONE JSON line on stdout with the required keys, for the N = 1 run
+and for the degenerate one-rank form of the N > 1 run (`--one-mesh-selftest`: the same code path torch.distributed.run drives)."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+REQUIRED = ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype",
+            "data", "config")
+
+
+def _run(*flags):
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), *flags], cwd=ROOT, capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0, p.stderr[-2000:]
+    lines = [l for l in p.stdout.splitlines() if l.strip()]
+    assert len(lines) == 1, lines                                    # exactly one line on stdout (RCCL's banner etc. go to stderr)
+    return json.loads(lines[0])
+
+
+@pytest.mark.gpu
+def test_single_gpu_line_keeps_the_contract():
+    j = _run("--steps", "20", "--warmup", "3", "--no-sizes", "--no-anim", "--no-pipelined")
+    for k in REQUIRED:
+        assert k in j, k
+    assert j["n_gpus"] == 1 and j["steps"] == 20 and j["warmup"] == 3 and j["higher_is_better"] is True
+    assert j["unit"] == "Mvoxels/s" and j["dtype"] == "f32" and j["data"] == "synthetic" and j["vs_baseline"] is None
+    assert "workload" in j["config"] and "model" not in j["config"]
+    assert abs(j["value"] - 512 ** 3 / (j["ms_per_step"] * 1e-3) / 1e6) / j["value"] < 1e-3
+    assert (j["triangles"], j["vertices"]) == (530536, 265262)      # SURVEY 8(c), sd_obj k = 4
+    r = j["roofline"]
+    assert r["bound"] == "hbm" and r["unit"] == "GB/s" and r["peak"] == 8000.0
+    assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-3 and 0.3 < r["frac"] < 1.0
+    assert abs(r["achieved"] - 4 * 513 ** 3 / (r["avg_launch_ms"] * 1e-3) / 1e9) / r["achieved"] < 1e-3
+    assert r["traffic"] is None or abs(r["traffic"] - 4 * 513 ** 3) / (4 * 513 ** 3) < 0.05
+    assert r["write_ceiling"]["achieved"] > r["achieved"]            # the bare store stream is faster than the pass that computes
+    c = j["cpu_baseline"]
+    assert c["kind"] == "port" and c["cores"] >= 1 and c["value"] > 0 and "sample" in c
+    s = j["roofline_step"]
+    assert s["project"]["wave_instr"] > 0 and 0.0 < s["project"]["frac"] < 1.0
+    assert s["project"].get("frac_of_issue_bound") is None or 0.0 < s["project"]["frac_of_issue_bound"] <= 1.0
+    assert set(s["hbm_passes"]) >= {"P3_emit_active_list", "P4_triangles", "P5_weld"}
+
+
+@pytest.mark.gpu
+def test_one_mesh_line_keeps_the_contract_on_one_rank():
+    j = _run("--one-mesh-selftest", "--steps", "8", "--warmup", "2", "--max-levels", "5", "--no-replicas")
+    for k in REQUIRED:
+        assert k in j, k
+    assert j["n_gpus"] == 1 and j["scaling"] == "strong" and j["ranks_seen"] == 1
+    assert j["config"]["one_mesh_form"] in ("zslab_gather_root_weld", "xslab_distributed_weld")
+    for form in ("zslab_gather_root_weld", "xslab_distributed_weld"):
+        for size in ("256^3", "512^3", "1024^3"):
+            row = j["one_mesh"][form][size]
+            assert row["t_1rank_ms"] > 0 and row["ms_per_regen"] > 0 and row["triangles"] > 0
+    assert (j["one_mesh"]["xslab_distributed_weld"]["512^3"]["triangles"], j["one_mesh"]["xslab_distributed_weld"]["512^3"]["vertices"]) == (530536, 265262)
