@@ -132,6 +132,7 @@ struct sdmesh_handle {
     int pend_levels = 0, pend_mode = 0, pend_part = 0, pend_nparts = 1;
     Point pend_vs{0, 0, 0};
     uint32_t pend_ncap = 0;
+    bool pend_timed = false;
 
     // voxel lists (ping-pong), refine scratch
     DevBuf vox[2];
@@ -154,6 +155,8 @@ struct sdmesh_handle {
     int project_grid = 0;          // option "project_grid": workgroups of the projection (0 = grid * project_mult, capped by the plan)
     int project_batch = 6;         // option "project_batch": log2 of k_project1's dealing unit (64 = one contiguous run per wave; shorter
                                    // runs even the waves out but every wave then pays the straggler rounds: measured slower, 48.7 -> 57 us)
+    int inject_fail = 0;           // option "inject_fail" (tests of the multi-GPU agreement): 1 = this rank's local phase of the next one-mesh
+                                   // call fails, 2 = its buffer growth after the first agreement fails; cleared by the call
     int timing = 0;                // option "timing": 1 = an event pair around the planned chain fills info->device_ms; off by default:
                                    // the two marker packets cost ~9 us of wall time per regen (0.155 -> 0.146 ms at 512^3)
     // mesh stage
@@ -186,7 +189,7 @@ struct sdmesh_handle {
     ncclComm_t comm = nullptr;
     int comm_rank = 0, comm_nranks = 1;
     DevBuf shard_mine, shard_counts, shard_recv, shard_lists, shard_plan, shard_merged;
-    uint32_t *h_counts = nullptr;      // pinned: nranks x 1024 column counts (root)
+    uint32_t *h_counts = nullptr;      // pinned: nranks x SHARD_ROW words (column counts + status record of every rank)
     size_t h_counts_words = 0;
     void **h_lists = nullptr;          // pinned: nranks device pointers
 
@@ -475,6 +478,17 @@ int read_back_enqueue(sdmesh_handle *h) {
 int read_back(sdmesh_handle *h) {
     SDCHK(read_back_enqueue(h));
     HIPCHK(hipStreamSynchronize(h->stream));
+    return SDMESH_OK;
+}
+
+// The planned chain's last kernel writes the host copy of the control block itself (no read-back copy).  Should that kernel
+// ever leave without publishing, the host must not mistake the previous regen's numbers for this one's: the last status
+// word (never set on the device, so it arrives as 0 by either route) is poisoned before the chain is enqueued, and a chain
+// that comes back with the poison still there is read back the ordinary way.
+constexpr uint32_t PIN_SENTINEL = CTR_WORDS + ST_WORDS - 1;
+void poison_pinned(sdmesh_handle *h) { h->h_pinned[PIN_SENTINEL] = 0xFFFFFFFFu; }
+int unpoison_pinned(sdmesh_handle *h) {
+    if (h->h_pinned[PIN_SENTINEL] == 0xFFFFFFFFu) SDCHK(read_back(h));
     return SDMESH_OK;
 }
 
@@ -788,8 +802,9 @@ int regen_impl(sdmesh_handle *h, int levels, int mode, int part, int nparts, sdm
             vs = h->pend_vs;
             n_cap = h->pend_ncap;
             direct = false;
-            timed = h->timing != 0;
+            timed = h->pend_timed;              // (latched by regen_begin: the events exist only if "timing" was on THEN)
             HIPCHK(hipStreamSynchronize(st));
+            SDCHK(unpoison_pinned(h));
         } else if (phase == 1 && !(async && !direct)) {
             // no capacity plan yet: nothing can be enqueued blindly; regen_end will run the discovery path
             h->pend_active = true; h->pend_async = false;
@@ -801,6 +816,7 @@ int regen_impl(sdmesh_handle *h, int levels, int mode, int part, int nparts, sdm
             uint32_t lvl_words = 0;
             SDCHK(presize_planned_chain(h, levels, n0, box[3] - box[2], &lvl_words));
             n_cap = padded(h->plan_counts[levels]);
+            poison_pinned(h);
             if (h->use_graph && st != nullptr && !h->profile && !h->project_diag) {   // (the legacy null stream cannot be captured: eager launches there)
                 uint64_t key[8] = {h->buf_gen, (uint64_t) h->scene, (uint64_t) levels, ((uint64_t) mode << 40) | ((uint64_t) part << 20) | (uint64_t) nparts,
                                    (uint64_t) h->skip_weld | ((uint64_t) h->wide_active << 1) | ((uint64_t) h->col_refine << 2) | ((uint64_t) h->claim_in_project << 3) | ((uint64_t) h->fuse_flip << 4) | ((uint64_t) h->publish_ctl << 6) | ((uint64_t) h->local_prefix << 7) | ((uint64_t) h->project_batch << 8) | ((uint64_t) h->project_grid << 12) | ((uint64_t) h->project_prio << 30) | ((uint64_t) h->tf_threads << 32) | ((uint64_t) h->col_segs << 44), (uint64_t) (uintptr_t) st, (uint64_t) h->grid | ((uint64_t) h->tgrid << 20) | ((uint64_t) h->project_mult << 40) | ((uint64_t) h->flip_mult << 48) | ((uint64_t) h->refine2 << 56) | ((uint64_t) h->emit_ci << 57) | ((uint64_t) h->project_lanes << 58) | ((uint64_t) h->flip_lanes << 61), 0};
@@ -838,10 +854,11 @@ int regen_impl(sdmesh_handle *h, int levels, int mode, int part, int nparts, sdm
             if (phase == 1) {
                 h->pend_active = true; h->pend_async = true;
                 h->pend_levels = levels; h->pend_mode = mode; h->pend_part = part; h->pend_nparts = nparts;
-                h->pend_vs = vs; h->pend_ncap = n_cap;
+                h->pend_vs = vs; h->pend_ncap = n_cap; h->pend_timed = timed;
                 return SDMESH_OK;
             }
             HIPCHK(hipStreamSynchronize(st));
+            SDCHK(unpoison_pinned(h));
             if (h->profile) SDCHK(prof_collect(h));
         } else {
             // ---- discovery path: sizes become known level by level (one host sync per level)
@@ -1147,7 +1164,11 @@ int sdmesh_set_option(sdmesh_handle *h, const char *name, int value) {
         return SDMESH_OK;
     }
     if (!strcmp(name, "col_segs")) { h->col_segs = value < 1 ? 1 : (value > (int) SDM_COL_SEGS_MAX ? (int) SDM_COL_SEGS_MAX : value); drop_graph(h); return SDMESH_OK; }
-    if (!strcmp(name, "tf_threads")) { h->tf_threads = value; drop_graph(h); return SDMESH_OK; }
+    if (!strcmp(name, "tf_threads")) {
+        if (value != 128 && value != 256 && value != 512 && value != 768 && value != 1024) return fail(h, SDMESH_ERR_INVALID, "tf_threads: 128, 256, 512, 768 or 1024");
+        h->tf_threads = value; drop_graph(h); return SDMESH_OK;
+    }
+    if (!strcmp(name, "inject_fail")) { h->inject_fail = value; return SDMESH_OK; }
     if (!strcmp(name, "project_prio")) { h->project_prio = value != 0; drop_graph(h); return SDMESH_OK; }
     if (!strcmp(name, "project_grid")) { h->project_grid = value < 0 ? 0 : (value > 65535 ? 65535 : value); drop_graph(h); return SDMESH_OK; }
     if (!strcmp(name, "project_batch")) { h->project_batch = value < 0 ? 0 : (value > 6 ? 6 : value); drop_graph(h); return SDMESH_OK; }
@@ -1627,8 +1648,12 @@ extern "C" int sdmesh_set_slab_bounds(sdmesh_handle *h, int mode, int nparts, co
     if (!bounds) { h->slab_nparts = 0; h->plan_valid = false; drop_graph(h); return SDMESH_OK; }
     if ((mode != SDMESH_PART_ZSLAB && mode != SDMESH_PART_XSLAB) || nparts < 1 || nparts > 32) return fail(h, SDMESH_ERR_INVALID, "bad slab table");
     if (bounds[0] != 0 || bounds[nparts] != (uint32_t) MESH_GENERATION_INIT_FACTOR) return fail(h, SDMESH_ERR_INVALID, "slab bounds must run from 0 to %d", MESH_GENERATION_INIT_FACTOR);
-    for (int i = 0; i < nparts; i++)
+    for (int i = 0; i < nparts; i++) {
         if (bounds[i + 1] < bounds[i]) return fail(h, SDMESH_ERR_INVALID, "slab bounds must not decrease");
+        // the distributed weld unifies a rank's lower face with rank r - 1's upper face only: an empty x-slab would leave the
+        // duplicates between its two neighbours un-unified (wrong vertex count and indices, silently)
+        if (mode == SDMESH_PART_XSLAB && bounds[i + 1] == bounds[i]) return fail(h, SDMESH_ERR_INVALID, "x-slab %d is empty: every x-slab needs at least one level-0 layer", i);
+    }
     h->slab_mode = mode; h->slab_nparts = nparts;
     memcpy(h->slab_bounds, bounds, sizeof(uint32_t) * (size_t) (nparts + 1));
     h->plan_valid = false;
@@ -1664,7 +1689,7 @@ extern "C" int sdmesh_balance_slabs(sdmesh_handle *h, int mode, int nparts, int 
     // contiguous partition of the 32 layers into nparts slabs minimising the heaviest slab (dynamic programme, 32 x 32 x nparts)
     double pre[33]; pre[0] = 0;
     for (int l = 0; l < F; l++) pre[l + 1] = pre[l] + w[l];
-    static double best[33][33]; static int cut[33][33];
+    double best[33][33]; int cut[33][33];                 // (locals: two handles may balance from two threads)
     for (int e = 0; e <= F; e++) { best[1][e] = e >= 1 ? pre[e] : 1e300; cut[1][e] = 0; }
     for (int k = 2; k <= nparts; k++)
         for (int e = 0; e <= F; e++) {
@@ -1766,7 +1791,7 @@ int ensure_grow(sdmesh_handle *h, DevBuf &b, size_t bytes) {      // like ensure
 }
 
 int ensure_shard_host(sdmesh_handle *h, int nranks) {
-    const size_t words = (size_t) nranks * 1024;
+    const size_t words = (size_t) nranks * SHARD_ROW;
     if (h->h_counts_words >= words) return SDMESH_OK;
     if (h->h_counts) (void) hipHostFree(h->h_counts);
     if (h->h_lists) (void) hipHostFree(h->h_lists);
@@ -1777,12 +1802,13 @@ int ensure_shard_host(sdmesh_handle *h, int nranks) {
     return SDMESH_OK;
 }
 
-// merged list of `nranks` device lists (pointers in h->h_lists, pinned) by the nranks x 1024 counts at d_counts
-int merge_lists(sdmesh_handle *h, const uint32_t *d_counts, int nranks, Triangle *d_out, size_t cap) {
+// merged list of `nranks` device lists (pointers in h->h_lists, pinned) by the per-rank column counts at d_counts (`cstride`
+// words per rank)
+int merge_lists(sdmesh_handle *h, const uint32_t *d_counts, uint32_t cstride, int nranks, Triangle *d_out, size_t cap) {
     SDCHK(ensure(h, h->shard_lists, sizeof(void *) * (size_t) nranks));
     SDCHK(ensure(h, h->shard_plan, 8ull * (size_t) nranks * 1024));
     HIPCHK(hipMemcpyAsync(h->shard_lists.p, h->h_lists, sizeof(void *) * (size_t) nranks, hipMemcpyHostToDevice, h->stream));
-    HIPCHK(launch_merge_by_column(h->stream, (const Triangle *const *) h->shard_lists.p, d_counts, nranks, (uint32_t *) h->shard_plan.p,
+    HIPCHK(launch_merge_by_column(h->stream, (const Triangle *const *) h->shard_lists.p, d_counts, cstride, nranks, (uint32_t *) h->shard_plan.p,
                                   d_out, (uint32_t) std::min<size_t>(cap, 0xFFFFFFFFu), h->d_ctr + CTR_SCRATCH, h->d_status));
     return SDMESH_OK;
 }
@@ -1846,64 +1872,135 @@ int sdmesh_merge_by_column(sdmesh_handle *h, const struct Triangle *const *d_lis
     SDCHK(ensure_shard_host(h, nranks));
     for (int r = 0; r < nranks; r++) h->h_lists[r] = (void *) d_lists[r];
     SDCHK(zero_status(h));
-    SDCHK(merge_lists(h, d_counts, nranks, d_out, cap));
+    SDCHK(merge_lists(h, d_counts, 1024u, nranks, d_out, cap));
     SDCHK(read_back(h));
     *n_out = h->h_pinned[CTR_SCRATCH];
     if (h->h_pinned[CTR_WORDS + ST_OVERFLOW]) return fail(h, SDMESH_ERR_CAPACITY, "merged list needs room for %u triangles", h->h_pinned[CTR_SCRATCH]);
     return SDMESH_OK;
 }
 
+}  // extern "C"
+
+namespace {
+
+// Agreement before payload (both one-mesh entry points).  A rank that fails locally -- its slab regen, an allocation, a
+// device-side invariant -- must not simply return: the others would wait for it in the next collective forever.  So every
+// rank ALWAYS enters the all-gather that carries the sizes, with a status word in its record; after it every rank holds
+// every rank's status and sizes, evaluates the same checks on the same numbers, and all of them leave the call at the same
+// point: the failing rank with its own error, the others with SDMESH_ERR_PEER.  Buffers whose size is only known after
+// that exchange are grown behind a second, one-word agreement, which runs only when some rank's published capacity is too
+// small (every rank can tell from the records) -- never in steady state.  After an agreed failure the communicator is
+// still usable; after an SDMESH_ERR_RCCL (a collective itself failed) it is not.
+int peer_failure(sdmesh_handle *h, int R, int me, const uint32_t *rec, uint32_t stride, uint32_t status_word, int local_rc) {
+    if (local_rc != SDMESH_OK) return local_rc;                              // (h->err already says why)
+    for (int r = 0; r < R; r++)
+        if (r != me && rec[(size_t) r * stride + status_word])
+            return fail(h, SDMESH_ERR_PEER, "rank %d failed in this collective call (status 0x%x); every rank returns an error", r,
+                        rec[(size_t) r * stride + status_word]);
+    return SDMESH_OK;
+}
+
+// one-word agreement: max over the ranks of `flag` (0 = go)
+int agree_flag(sdmesh_handle *h, uint32_t flag, uint32_t *out) {
+    hipStream_t st = h->stream;
+    HIPCHK(launch_set_u32(st, h->d_ctr + CTR_SCRATCH, flag));
+    NCCLCHK(g_rccl.AllReduce(h->d_ctr + CTR_SCRATCH, h->d_ctr + CTR_SCRATCH, 1, ncclUint32, ncclMax, h->comm, st));
+    HIPCHK(hipMemcpyAsync(h->h_pinned + CTR_SCRATCH, h->d_ctr + CTR_SCRATCH, 4, hipMemcpyDeviceToHost, st));
+    HIPCHK(hipStreamSynchronize(st));
+    *out = h->h_pinned[CTR_SCRATCH];
+    return SDMESH_OK;
+}
+
+uint32_t cap_items(const DevBuf &b, size_t item) { return (uint32_t) std::min<size_t>(b.p ? b.cap / item : 0, 0xFFFFFFFFu); }
+
+}  // namespace
+
+extern "C" {
+
 int sdmesh_sharded_regen(sdmesh_handle *h, int levels, int root, sdmesh_regen_info *info) {
     if (!h) return SDMESH_ERR_INVALID;
+    // (argument errors are found before any communication: they must be the same on every rank, like the arguments)
     if (!h->comm) return fail(h, SDMESH_ERR_INVALID, "no communicator (sdmesh_comm_init)");
     const int R = h->comm_nranks, me = h->comm_rank;
     if (root < 0 || root >= R) return fail(h, SDMESH_ERR_INVALID, "root %d outside the communicator", root);
     hipStream_t st = h->stream;
-    // 1. this rank's level-0 z-slab: refine^levels, marching cubes, projection, orientation; no weld
-    const int saved_skip = h->skip_weld;
-    h->skip_weld = 1;
+    const int inject = h->inject_fail;
+    h->inject_fail = 0;
+    // 0. the fixed-size scratch of the exchange itself.  (A rank that cannot even get these few KB cannot tell anybody.)
+    SDCHK(ensure(h, h->shard_counts, 4ull * (size_t) R * SHARD_ROW));
+    SDCHK(ensure(h, h->shard_lists, sizeof(void *) * (size_t) R));
+    SDCHK(ensure(h, h->shard_plan, 8ull * (size_t) R * 1024));
+    SDCHK(ensure_shard_host(h, R));
+    uint32_t *d_counts = (uint32_t *) h->shard_counts.p, *d_row = d_counts + (size_t) me * SHARD_ROW;
+    // 1. this rank's level-0 z-slab: refine^levels, marching cubes, projection, orientation; no weld; then its compact
+    //    triangle list and its per-column counts.  Any failure in here becomes this rank's status word.
     sdmesh_regen_info slab;
-    const int rc = regen_impl(h, levels, SDMESH_PART_ZSLAB, me, R, &slab);
-    h->skip_weld = saved_skip;
-    SDCHK(rc);
-    if (h->last_direct) return fail(h, SDMESH_ERR_INTERNAL, "a slab took the direct path: no column counts");
-    const uint32_t n_mine = h->n_tris;
-    // 2. compact triangle list of the slab + its per-column counts, then the 4 KB all-gather of the counts
-    SDCHK(ensure_grow(h, h->shard_mine, sizeof(Triangle) * (size_t) std::max<uint32_t>(n_mine, 1)));
-    SDCHK(ensure(h, h->shard_counts, 4ull * (size_t) R * 1024));
-    uint32_t *d_counts = (uint32_t *) h->shard_counts.p;
-    if (n_mine)
-        HIPCHK(launch_expand_compact(st, h->grid, (const Vertex *) h->uverts.p, (const uint32_t *) h->tri_e.p, (const uint8_t *) h->flip.p,
-                                     h->d_ctr + CTR_NTRI, (Triangle *) h->shard_mine.p, n_mine));
-    HIPCHK(hipMemsetAsync(d_counts + (size_t) me * 1024, 0, 4096, st));
-    if (h->n_vox) {
-        HIPCHK(launch_set_u32(st, h->d_ctr + CTR_SCRATCH, h->n_vox));
-        HIPCHK(launch_column_counts(st, std::min(h->grid, (int) tiles(h->n_vox)), (const Point *) h->vox[h->cur].p,
-                                    h->d_ctr + CTR_SCRATCH, (const uint8_t *) h->cubeidx.p, d_counts + (size_t) me * 1024));
+    memset(&slab, 0, sizeof slab);
+    uint32_t n_mine = 0;
+    auto local_phase = [&]() -> int {
+        const int saved_skip = h->skip_weld;
+        h->skip_weld = 1;
+        const int rc = inject == 1 ? fail(h, SDMESH_ERR_INTERNAL, "injected failure (option inject_fail)") : regen_impl(h, levels, SDMESH_PART_ZSLAB, me, R, &slab);
+        h->skip_weld = saved_skip;
+        SDCHK(rc);
+        if (h->last_direct) return fail(h, SDMESH_ERR_INTERNAL, "a slab took the direct path: no column counts");
+        n_mine = h->n_tris;
+        SDCHK(ensure_grow(h, h->shard_mine, sizeof(Triangle) * (size_t) std::max<uint32_t>(n_mine, 1)));
+        if (n_mine)
+            HIPCHK(launch_expand_compact(st, h->grid, (const Vertex *) h->uverts.p, (const uint32_t *) h->tri_e.p, (const uint8_t *) h->flip.p,
+                                         h->d_ctr + CTR_NTRI, (Triangle *) h->shard_mine.p, n_mine));
+        HIPCHK(hipMemsetAsync(d_row, 0, 4096, st));
+        if (h->n_vox) {
+            HIPCHK(launch_set_u32(st, h->d_ctr + CTR_SCRATCH, h->n_vox));
+            HIPCHK(launch_column_counts(st, std::min(h->grid, (int) tiles(h->n_vox)), (const Point *) h->vox[h->cur].p,
+                                        h->d_ctr + CTR_SCRATCH, (const uint8_t *) h->cubeidx.p, d_row));
+        }
+        return SDMESH_OK;
+    };
+    const int lrc = local_phase();
+    if (lrc != SDMESH_OK) { n_mine = 0; HIPCHK(hipMemsetAsync(d_row, 0, 4096, st)); }
+    // 2. the all-gather of the counts -- ALWAYS entered; record = {status, triangles, what this rank could receive / merge}
+    HIPCHK(launch_pack_record(st, d_row + 1024, nullptr, nullptr, (uint32_t) lrc, n_mine, cap_items(h->shard_recv, sizeof(Triangle)),
+                              cap_items(h->shard_merged, sizeof(Triangle))));
+    // (k_pack_record writes {v0, v1 | status, v2, v3}: word 0 = status, word 1 = triangles here)
+    NCCLCHK(g_rccl.AllGather(d_row, d_counts, SHARD_ROW, ncclUint32, h->comm, st));                     // in place
+    HIPCHK(hipMemcpyAsync(h->h_counts, d_counts, 4ull * (size_t) R * SHARD_ROW, hipMemcpyDeviceToHost, st));
+    HIPCHK(hipStreamSynchronize(st));
+    // 3. every rank, on the same numbers: did anybody fail, do the counts add up, does the mesh fit one weld
+    SDCHK(peer_failure(h, R, me, h->h_counts, SHARD_ROW, 1024, lrc));
+    std::vector<uint64_t> tr((size_t) R, 0);
+    uint64_t total = 0, foreign = 0;
+    for (int r = 0; r < R; r++) {
+        const uint32_t *row = h->h_counts + (size_t) r * SHARD_ROW;
+        for (int c = 0; c < 1024; c++) tr[r] += row[c];
+        if (tr[r] != row[1025])
+            return fail(h, SDMESH_ERR_INTERNAL, "rank %d: column counts (%llu) disagree with the slab's triangle count (%u)", r, (unsigned long long) tr[r], row[1025]);
+        total += tr[r];
+        if (r != root) foreign += tr[r];
     }
-    NCCLCHK(g_rccl.AllGather(d_counts + (size_t) me * 1024, d_counts, 1024, ncclUint32, h->comm, st));   // in place
+    if (total > 0x0FFFFFFFull) return fail(h, SDMESH_ERR_INVALID, "too many triangles for one weld");
+    // 4. the root's receive / merge buffers; grown behind a second agreement only if its published capacity is too small
+    const uint32_t *root_row = h->h_counts + (size_t) root * SHARD_ROW;
+    if (foreign > root_row[1026] || total > root_row[1027] || inject == 2) {
+        int grc = SDMESH_OK;
+        if (me == root) {
+            grc = inject == 2 ? fail(h, SDMESH_ERR_HIP, "injected allocation failure (option inject_fail)")
+                                      : ensure_grow(h, h->shard_recv, sizeof(Triangle) * (size_t) std::max<uint64_t>(foreign, 1));
+            if (grc == SDMESH_OK) grc = ensure_grow(h, h->shard_merged, sizeof(Triangle) * (size_t) std::max<uint64_t>(total, 1));
+        }
+        uint32_t worst = 0;
+        SDCHK(agree_flag(h, grc == SDMESH_OK ? 0u : 1u, &worst));
+        if (grc != SDMESH_OK) return grc;
+        if (worst) return fail(h, SDMESH_ERR_PEER, "the root (rank %d) could not grow its receive buffers; every rank returns an error", root);
+    }
     if (me != root) {
-        // 3a. peers: the slab's triangles go straight to the root (each peer on its own xGMI link)
+        // 5a. peers: the slab's triangles go straight to the root (each peer on its own xGMI link)
         if (n_mine) NCCLCHK(g_rccl.Send(h->shard_mine.p, (size_t) n_mine * 18, ncclFloat32, root, h->comm, st));
         HIPCHK(hipStreamSynchronize(st));
         if (info) *info = slab;
         return SDMESH_OK;
     }
-    // 3b. root: sizes from the gathered counts (the one extra host synchronisation of a sharded step), grouped receives
-    SDCHK(ensure_shard_host(h, R));
-    HIPCHK(hipMemcpyAsync(h->h_counts, d_counts, 4ull * (size_t) R * 1024, hipMemcpyDeviceToHost, st));
-    HIPCHK(hipStreamSynchronize(st));
-    std::vector<uint64_t> tr((size_t) R, 0);
-    uint64_t total = 0, foreign = 0;
-    for (int r = 0; r < R; r++) {
-        for (int c = 0; c < 1024; c++) tr[r] += h->h_counts[(size_t) r * 1024 + c];
-        total += tr[r];
-        if (r != root) foreign += tr[r];
-    }
-    if (tr[root] != n_mine) return fail(h, SDMESH_ERR_INTERNAL, "column counts (%llu) disagree with the slab's triangle count (%u)", (unsigned long long) tr[root], n_mine);
-    if (total > 0x0FFFFFFFull) return fail(h, SDMESH_ERR_INVALID, "too many triangles for one weld");
-    SDCHK(ensure_grow(h, h->shard_recv, sizeof(Triangle) * (size_t) std::max<uint64_t>(foreign, 1)));
-    SDCHK(ensure_grow(h, h->shard_merged, sizeof(Triangle) * (size_t) std::max<uint64_t>(total, 1)));
+    // 5b. root: grouped receives
     uint64_t off = 0;
     for (int r = 0; r < R; r++) {
         if (r == root) { h->h_lists[r] = h->shard_mine.p; continue; }
@@ -1916,8 +2013,9 @@ int sdmesh_sharded_regen(sdmesh_handle *h, int levels, int root, sdmesh_regen_in
             if (r != root && tr[r]) NCCLCHK(g_rccl.Recv(h->h_lists[r], (size_t) tr[r] * 18, ncclFloat32, r, h->comm, st));
         NCCLCHK(g_rccl.GroupEnd());
     }
-    // 4. order-restoring merge (HIP kernel), then the first-seen weld of the merged list = the single-GPU mesh
-    SDCHK(merge_lists(h, d_counts, R, (Triangle *) h->shard_merged.p, (size_t) total));
+    // 6. order-restoring merge (HIP kernel), then the first-seen weld of the merged list = the single-GPU mesh.  (From here
+    //    on nobody waits for the root any more: a failure is the root's alone.)
+    SDCHK(merge_lists(h, d_counts, SHARD_ROW, R, (Triangle *) h->shard_merged.p, (size_t) total));
     SDCHK(weld_device_impl(h, (const Triangle *) h->shard_merged.p, (size_t) total, info, true));      // (all slots valid: no compaction pass)
     if (info) {
         info->levels = (uint32_t) levels;
@@ -1934,7 +2032,14 @@ int sdmesh_sharded_regen(sdmesh_handle *h, int levels, int root, sdmesh_regen_in
 namespace {
 
 // phase 1: this rank's slab, meshed AND welded locally; then the face bands (enqueued, not waited for)
+int dist_scratch(sdmesh_handle *h) {                       // the records of the two exchanges: DIST_REC words per rank, <= 32 ranks
+    SDCHK(ensure(h, h->dist_counts, 4ull * 32 * DIST_REC));
+    SDCHK(ensure(h, h->dist_nups, 4ull * 32 * DIST_REC));
+    return SDMESH_OK;
+}
+
 int dist_phase_local(sdmesh_handle *h, int levels, int R, int me, sdmesh_regen_info *slab) {
+    if (h->inject_fail == 1) { h->inject_fail = 0; return fail(h, SDMESH_ERR_INTERNAL, "injected failure (option inject_fail)"); }
     SDCHK(regen_impl(h, levels, SDMESH_PART_XSLAB, me, R, slab));
     if (!h->welded || h->last_direct) return fail(h, SDMESH_ERR_INTERNAL, "the distributed weld needs the locally welded lattice path");
     hipStream_t st = h->stream;
@@ -1949,8 +2054,6 @@ int dist_phase_local(sdmesh_handle *h, int levels, int R, int me, sdmesh_regen_i
     SDCHK(ensure_grow(h, h->dist_tilecnt, 4ull * (tiles((uint32_t) vcap) + 16)));
     SDCHK(ensure_grow(h, h->dist_upg, 4 * vcap));
     SDCHK(ensure(h, h->dist_verts, std::max<size_t>(h->vertices.cap, sizeof(Vertex) * vcap)));   // swapped with h->vertices below: same capacity
-    SDCHK(ensure(h, h->dist_counts, 4ull * 32));
-    SDCHK(ensure(h, h->dist_nups, 4ull * 32));
     const uint32_t F = MESH_GENERATION_INIT_FACTOR;
     uint32_t lo = F * (uint32_t) me / (uint32_t) R, hi = F * (uint32_t) (me + 1) / (uint32_t) R;
     if (h->slab_nparts == R && h->slab_mode == SDMESH_PART_XSLAB) { lo = h->slab_bounds[me]; hi = h->slab_bounds[me + 1]; }
@@ -1966,13 +2069,29 @@ int dist_phase_local(sdmesh_handle *h, int levels, int R, int me, sdmesh_regen_i
     return SDMESH_OK;
 }
 
+// what this rank can take from its lower neighbour without growing anything: band vertices
+uint32_t dist_prev_capacity(const sdmesh_handle *h) {
+    if (!h->dist_prevkeys.p || !h->dist_prevg.p || !h->dist_hkeys.p || !h->dist_hpos.p) return 0;
+    const size_t a = h->dist_prevkeys.cap / 8, b = h->dist_prevg.cap / 4;
+    const size_t c = h->dist_hkeys.cap / 8 > 64 ? (h->dist_hkeys.cap / 8 - 64) / 2 : 0, d = h->dist_hpos.cap / 4 > 64 ? (h->dist_hpos.cap / 4 - 64) / 2 : 0;
+    return (uint32_t) std::min<size_t>(std::min(std::min(a, b), std::min(c, d)), 0xFFFFFFFFu);
+}
+
+int dist_grow_prev(sdmesh_handle *h, uint32_t n_prev) {
+    if (h->inject_fail == 2) { h->inject_fail = 0; return fail(h, SDMESH_ERR_HIP, "injected allocation failure (option inject_fail)"); }
+    const uint32_t n = std::max<uint32_t>(n_prev, 1);
+    SDCHK(ensure_grow(h, h->dist_prevkeys, 8ull * n));
+    SDCHK(ensure_grow(h, h->dist_prevg, 4ull * n));
+    SDCHK(ensure_grow(h, h->dist_hkeys, 8ull * (2ull * n + 64)));
+    SDCHK(ensure_grow(h, h->dist_hpos, 4ull * (2ull * n + 64)));
+    return SDMESH_OK;
+}
+
 // phase 2: match my lower band against the lower neighbour's upper-band keys (already in dist_prevkeys), number what I keep
 int dist_phase_match(sdmesh_handle *h, uint32_t n_prev) {
     hipStream_t st = h->stream;
     if (n_prev) {
-        const uint32_t hsize = 2u * n_prev + 64u;
-        SDCHK(ensure_grow(h, h->dist_hkeys, 8ull * hsize));
-        SDCHK(ensure_grow(h, h->dist_hpos, 4ull * hsize));
+        const uint32_t hsize = 2u * n_prev + 64u;                // (dist_grow_prev made room)
         HIPCHK(hipMemsetAsync(h->dist_hkeys.p, 0xFF, 8ull * hsize, st));
         HIPCHK(launch_dist_match(st, h->grid, (const uint64_t *) h->dist_prevkeys.p, n_prev, (uint64_t *) h->dist_hkeys.p, (uint32_t *) h->dist_hpos.p,
                                  hsize, (const Vertex *) h->vertices.p, (const uint32_t *) h->dist_loids.p, h->d_ctr + CTR_DIST_NLO,
@@ -2002,9 +2121,8 @@ int dist_phase_final(sdmesh_handle *h, int me) {
     return SDMESH_OK;
 }
 
-int dist_finish_host(sdmesh_handle *h, int R, int me, const uint32_t *counts, sdmesh_regen_info *info, const sdmesh_regen_info &slab,
-                     uint32_t *first_vertex) {
-    if (h->h_pinned[CTR_WORDS + ST_WELD_RANGE]) return fail(h, SDMESH_ERR_WELD_RANGE, "the distributed weld needs vertices inside the packed key range");
+int dist_finish_host(sdmesh_handle *h, int R, int me, const uint32_t *counts /* kept vertices per rank */, sdmesh_regen_info *info,
+                     const sdmesh_regen_info &slab, uint32_t *first_vertex) {
     uint32_t off = 0;
     for (int r = 0; r < me; r++) off += counts[r];
     h->n_verts = counts[me];
@@ -2024,36 +2142,68 @@ int sdmesh_distributed_regen(sdmesh_handle *h, int levels, sdmesh_regen_info *in
     if (!h->comm) return fail(h, SDMESH_ERR_INVALID, "no communicator (sdmesh_comm_init)");
     const int R = h->comm_nranks, me = h->comm_rank;
     hipStream_t st = h->stream;
+    SDCHK(dist_scratch(h));                                    // (before anything can fail on one rank only, see peer_failure)
+    SDCHK(ensure_shard_host(h, R));                            // pinned landing zone of the records (>= 32 x DIST_REC words)
     sdmesh_regen_info slab;
-    SDCHK(dist_phase_local(h, levels, R, me, &slab));
-    uint32_t nups[32] = {0}, counts[32] = {0};
+    memset(&slab, 0, sizeof slab);
+    const int lrc = dist_phase_local(h, levels, R, me, &slab);
+    uint32_t counts[32] = {0};
     if (R == 1) {
-        HIPCHK(hipStreamSynchronize(st));
+        SDCHK(lrc);
+        SDCHK(read_back(h));
+        if (h->h_pinned[CTR_WORDS + ST_WELD_RANGE]) return fail(h, SDMESH_ERR_WELD_RANGE, "the distributed weld needs vertices inside the packed key range");
         counts[0] = h->dist_V;
         return dist_finish_host(h, R, me, counts, info, slab, first_vertex);
     }
-    // band sizes of every rank (the one extra host synchronisation of a distributed step: message lengths must be host values)
+    // 1. band sizes of every rank (the one extra host synchronisation of a distributed step: message lengths must be host
+    //    values), each with the rank's status and what it can take from its lower neighbour without growing -- ALWAYS entered
     uint32_t *d_nups = (uint32_t *) h->dist_nups.p, *d_counts = (uint32_t *) h->dist_counts.p;
-    NCCLCHK(g_rccl.AllGather(h->d_ctr + CTR_DIST_NUP, d_nups, 1, ncclUint32, h->comm, st));
-    HIPCHK(hipMemcpyAsync(nups, d_nups, 4ull * (size_t) R, hipMemcpyDeviceToHost, st));
+    HIPCHK(launch_pack_record(st, d_nups + (size_t) me * DIST_REC, lrc == SDMESH_OK ? h->d_ctr + CTR_DIST_NUP : nullptr, nullptr, 0u, (uint32_t) lrc,
+                              dist_prev_capacity(h), 0u));
+    NCCLCHK(g_rccl.AllGather(d_nups + (size_t) me * DIST_REC, d_nups, DIST_REC, ncclUint32, h->comm, st));        // in place
+    uint32_t *rec = h->h_counts;
+    HIPCHK(hipMemcpyAsync(rec, d_nups, 4ull * (size_t) R * DIST_REC, hipMemcpyDeviceToHost, st));
     HIPCHK(hipStreamSynchronize(st));
+    SDCHK(peer_failure(h, R, me, rec, DIST_REC, 1, lrc));
+    uint32_t nups[32];
+    for (int r = 0; r < R; r++) nups[r] = rec[(size_t) r * DIST_REC];
     const uint32_t n_up = me + 1 < R ? nups[me] : 0u, n_prev = me > 0 ? nups[me - 1] : 0u;
-    SDCHK(ensure_grow(h, h->dist_prevkeys, 8ull * std::max<uint32_t>(n_prev, 1)));
-    SDCHK(ensure_grow(h, h->dist_prevg, 4ull * std::max<uint32_t>(n_prev, 1)));
+    // 2. room for the neighbour's band; grown behind a one-word agreement only if some rank's published capacity is too small
+    bool any_grow = false;
+    for (int r = 1; r < R; r++) any_grow = any_grow || nups[r - 1] > rec[(size_t) r * DIST_REC + 2];
+    for (int r = 0; r < R; r++) any_grow = any_grow || rec[(size_t) r * DIST_REC + 2] == 0u;          // (a first call: nothing allocated yet)
+    if (any_grow || h->inject_fail == 2) {
+        const int grc = dist_grow_prev(h, n_prev);
+        uint32_t worst = 0;
+        SDCHK(agree_flag(h, grc == SDMESH_OK ? 0u : 1u, &worst));
+        if (grc != SDMESH_OK) return grc;
+        if (worst) return fail(h, SDMESH_ERR_PEER, "a rank could not grow its band buffers; every rank returns an error");
+    }
     NCCLCHK(g_rccl.GroupStart());
     if (n_up) NCCLCHK(g_rccl.Send(h->dist_upkeys.p, n_up, ncclUint64, me + 1, h->comm, st));
     if (n_prev) NCCLCHK(g_rccl.Recv(h->dist_prevkeys.p, n_prev, ncclUint64, me - 1, h->comm, st));
     NCCLCHK(g_rccl.GroupEnd());
+    // (nothing below allocates: a failure from here on is a HIP / RCCL error, after which the communicator is gone anyway)
     SDCHK(dist_phase_match(h, n_prev));
-    NCCLCHK(g_rccl.AllGather(h->d_ctr + CTR_DIST_NKEEP, d_counts, 1, ncclUint32, h->comm, st));
+    // 3. kept counts of every rank (stay on the device for the kernels) + each rank's device status: a vertex outside the
+    //    packed key range on ONE rank fails the call on ALL of them
+    HIPCHK(launch_pack_record(st, d_counts + (size_t) me * DIST_REC, h->d_ctr + CTR_DIST_NKEEP, h->d_status, 0u, 0u, 0u, 0u));
+    NCCLCHK(g_rccl.AllGather(d_counts + (size_t) me * DIST_REC, d_counts, DIST_REC, ncclUint32, h->comm, st));
     SDCHK(dist_phase_pack(h, me, n_up));
     NCCLCHK(g_rccl.GroupStart());
     if (n_up) NCCLCHK(g_rccl.Send(h->dist_upg.p, n_up, ncclUint32, me + 1, h->comm, st));
     if (n_prev) NCCLCHK(g_rccl.Recv(h->dist_prevg.p, n_prev, ncclUint32, me - 1, h->comm, st));
     NCCLCHK(g_rccl.GroupEnd());
     SDCHK(dist_phase_final(h, me));
-    HIPCHK(hipMemcpyAsync(counts, d_counts, 4ull * (size_t) R, hipMemcpyDeviceToHost, st));
+    HIPCHK(hipMemcpyAsync(rec, d_counts, 4ull * (size_t) R * DIST_REC, hipMemcpyDeviceToHost, st));
     SDCHK(read_back(h));
+    for (int r = 0; r < R; r++) {
+        counts[r] = rec[(size_t) r * DIST_REC];
+        if (rec[(size_t) r * DIST_REC + 1] & 0x100u)
+            return fail(h, r == me ? SDMESH_ERR_WELD_RANGE : SDMESH_ERR_PEER, "rank %d: the distributed weld needs vertices inside the packed key range", r);
+        if (rec[(size_t) r * DIST_REC + 1])
+            return fail(h, r == me ? SDMESH_ERR_INTERNAL : SDMESH_ERR_PEER, "rank %d: device status 0x%x in the distributed weld", r, rec[(size_t) r * DIST_REC + 1]);
+    }
     return dist_finish_host(h, R, me, counts, info, slab, first_vertex);
 }
 
@@ -2066,29 +2216,36 @@ int sdmesh_distributed_regen_rehearsal(sdmesh_handle **hs, int nranks, int level
     const int R = nranks;
     std::vector<sdmesh_regen_info> slab((size_t) R);
     uint32_t nups[32] = {0}, counts[32] = {0};
+    // (the agreement of the RCCL form, with the host standing in for the all-gather: every handle runs its local phase whatever
+    //  the others did, then all of them fail together if one did)
+    int worst = SDMESH_OK, worst_rank = -1;
     for (int r = 0; r < R; r++) {
         sdmesh_handle *h = hs[r];
-        SDCHK(dist_phase_local(h, levels, R, r, &slab[(size_t) r]));
+        SDCHK(dist_scratch(h));
+        const int lrc = dist_phase_local(h, levels, R, r, &slab[(size_t) r]);
+        if (lrc != SDMESH_OK) { if (worst == SDMESH_OK) { worst = lrc; worst_rank = r; } continue; }
         HIPCHK(hipMemcpyAsync(&nups[r], h->d_ctr + CTR_DIST_NUP, 4, hipMemcpyDeviceToHost, h->stream));
         HIPCHK(hipStreamSynchronize(h->stream));
+    }
+    if (worst != SDMESH_OK) {
+        for (int r = 0; r < R; r++)
+            if (r != worst_rank) (void) fail(hs[r], SDMESH_ERR_PEER, "rank %d failed in this collective call (status 0x%x); every rank returns an error", worst_rank, worst);
+        return worst;
     }
     for (int r = 0; r < R; r++) {
         sdmesh_handle *h = hs[r];
         const uint32_t n_prev = r > 0 ? nups[r - 1] : 0u;
-        if (n_prev) {
-            SDCHK(ensure_grow(h, h->dist_prevkeys, 8ull * n_prev));
-            SDCHK(ensure_grow(h, h->dist_prevg, 4ull * n_prev));
-            HIPCHK(hipMemcpyAsync(h->dist_prevkeys.p, hs[r - 1]->dist_upkeys.p, 8ull * n_prev, hipMemcpyDeviceToDevice, h->stream));
-        } else {
-            SDCHK(ensure_grow(h, h->dist_prevg, 4));
-        }
+        if (n_prev > dist_prev_capacity(h) || dist_prev_capacity(h) == 0u) SDCHK(dist_grow_prev(h, n_prev));
+        if (n_prev) HIPCHK(hipMemcpyAsync(h->dist_prevkeys.p, hs[r - 1]->dist_upkeys.p, 8ull * n_prev, hipMemcpyDeviceToDevice, h->stream));
         SDCHK(dist_phase_match(h, n_prev));
         HIPCHK(hipMemcpyAsync(&counts[r], h->d_ctr + CTR_DIST_NKEEP, 4, hipMemcpyDeviceToHost, h->stream));
         HIPCHK(hipStreamSynchronize(h->stream));
     }
+    uint32_t recs[32 * DIST_REC] = {0};
+    for (int r = 0; r < R; r++) recs[(size_t) r * DIST_REC] = counts[r];
     for (int r = 0; r < R; r++) {
         sdmesh_handle *h = hs[r];
-        HIPCHK(hipMemcpyAsync(h->dist_counts.p, counts, 4ull * (size_t) R, hipMemcpyHostToDevice, h->stream));
+        HIPCHK(hipMemcpyAsync(h->dist_counts.p, recs, 4ull * (size_t) R * DIST_REC, hipMemcpyHostToDevice, h->stream));
         SDCHK(dist_phase_pack(h, r, r + 1 < R ? nups[r] : 0u));
         HIPCHK(hipStreamSynchronize(h->stream));
     }
@@ -2098,6 +2255,7 @@ int sdmesh_distributed_regen_rehearsal(sdmesh_handle **hs, int nranks, int level
         if (n_prev) HIPCHK(hipMemcpyAsync(h->dist_prevg.p, hs[r - 1]->dist_upg.p, 4ull * n_prev, hipMemcpyDeviceToDevice, h->stream));
         SDCHK(dist_phase_final(h, r));
         SDCHK(read_back(h));
+        if (h->h_pinned[CTR_WORDS + ST_WELD_RANGE]) return fail(h, SDMESH_ERR_WELD_RANGE, "the distributed weld needs vertices inside the packed key range");
         SDCHK(dist_finish_host(h, R, r, counts, infos ? &infos[r] : nullptr, slab[(size_t) r], first_vertex ? &first_vertex[r] : nullptr));
     }
     return SDMESH_OK;

@@ -1349,7 +1349,7 @@ __device__ __forceinline__ void flip_body4(uint32_t bid, uint32_t nblocks, const
             const Point p0 = uverts[tri_e[3 * t]].position, p1 = uverts[tri_e[3 * t + 1]].position, p2 = uverts[tri_e[3 * t + 2]].position;
             v0 = mk(p0.x, p0.y, p0.z); v1 = mk(p1.x, p1.y, p1.z); v2 = mk(p2.x, p2.y, p2.z);
             const f3 s = add3(add3(v0, v1), v2);
-            c = mk(s.x / 3.0f, s.y / 3.0f, s.z / 3.0f);
+            c = mk(third_rn(s.x), third_rn(s.y), third_rn(s.z));
         }
         float unused;
         const f3 d = stencil_quad<SCENE, false>(c, sub, sp, unused);     // whole quads are active or idle together
@@ -1827,7 +1827,13 @@ __global__ __launch_bounds__(256) void k_tile_finish(const Vertex *__restrict__ 
     if (blockIdx.x >= ntiles && blockIdx.x != 0) return;
     uint32_t total;
     if (local) {
-        if (ntiles > LOCAL_TILES) { if (tid == 0) atomicOr(&status[ST_INTERNAL], 64u); return; }
+        if (ntiles > LOCAL_TILES) {
+            // (never reached: the host launches the prefix kernels above LOCAL_TILES.)  The host still has to SEE the flag: this
+            // kernel is the only writer of its copy of the control block, so publish before leaving.
+            if (tid == 0) atomicOr(&status[ST_INTERNAL], 64u);
+            if (pub_dst && blockIdx.x == 0 && tid < pub_words) pub_dst[tid] = pub_src[tid] | (tid == pub_ovf + (ST_INTERNAL - ST_OVERFLOW) ? 64u : 0u);
+            return;
+        }
         total = local_prefix(tfirst, 1u, ntiles, s_pre, s_scan);
         if (blockIdx.x == 0 && tid == 0) *nverts_out = total;
     } else {
@@ -2026,17 +2032,17 @@ __global__ __launch_bounds__(256) void k_column_counts(const Point *__restrict__
 // ------------------------------------------------------------------------------------------
 static constexpr uint32_t NCOL = MESH_GENERATION_INIT_FACTOR * MESH_GENERATION_INIT_FACTOR;     // 1024 columns = one per thread
 
-__global__ __launch_bounds__(1024) void k_merge_plan(const uint32_t *__restrict__ counts, uint32_t nranks, uint32_t *__restrict__ plan,
-                                                      uint32_t cap, uint32_t *__restrict__ total_out, uint32_t *__restrict__ status) {
+__global__ __launch_bounds__(1024) void k_merge_plan(const uint32_t *__restrict__ counts, uint32_t cstride /* words per rank, >= NCOL */, uint32_t nranks,
+                                                      uint32_t *__restrict__ plan, uint32_t cap, uint32_t *__restrict__ total_out, uint32_t *__restrict__ status) {
     __shared__ uint32_t lds[17];
     const uint32_t c = threadIdx.x;
     uint32_t col_total = 0;
-    for (uint32_t r = 0; r < nranks; r++) col_total += counts[r * NCOL + c];
+    for (uint32_t r = 0; r < nranks; r++) col_total += counts[r * cstride + c];
     uint32_t total;
     const uint32_t col_base = block_excl_scan(col_total, total, lds);
     uint32_t within = 0;
     for (uint32_t r = 0; r < nranks; r++) {
-        const uint32_t n = counts[r * NCOL + c];
+        const uint32_t n = counts[r * cstride + c];
         uint32_t rank_total;
         const uint32_t src = block_excl_scan(n, rank_total, lds);
         plan[(r * NCOL + c) * 2u] = src;
@@ -2049,11 +2055,11 @@ __global__ __launch_bounds__(1024) void k_merge_plan(const uint32_t *__restrict_
     }
 }
 
-__global__ __launch_bounds__(256) void k_merge_copy(const Triangle *const *__restrict__ lists, const uint32_t *__restrict__ counts,
+__global__ __launch_bounds__(256) void k_merge_copy(const Triangle *const *__restrict__ lists, const uint32_t *__restrict__ counts, uint32_t cstride,
                                                      const uint32_t *__restrict__ plan, uint32_t nranks, Triangle *__restrict__ out, uint32_t cap) {
     const uint32_t nseg = nranks * NCOL;
     for (uint32_t seg = blockIdx.x; seg < nseg; seg += gridDim.x) {
-        const uint32_t n = counts[seg];
+        const uint32_t n = counts[(seg / NCOL) * cstride + seg % NCOL];
         if (n == 0) continue;
         const uint32_t src = plan[2u * seg], dst = plan[2u * seg + 1u];
         if (dst + n > cap) continue;                                  // flagged by k_merge_plan
@@ -2185,10 +2191,23 @@ __global__ __launch_bounds__(256) void k_dist_newidx(const uint32_t *__restrict_
     }
 }
 
+// (counts = the all-gathered per-rank records of the kept-count exchange: DIST_REC words each, word 0 = vertices kept)
 __device__ __forceinline__ uint32_t dist_offset(const uint32_t *__restrict__ counts, uint32_t me) {
     uint32_t off = 0;
-    for (uint32_t r = 0; r < me; r++) off += counts[r];
+    for (uint32_t r = 0; r < me; r++) off += counts[r * DIST_REC];
     return off;
+}
+
+// One record of a status-carrying all-gather (the multi-GPU entry points agree on success before any payload moves):
+// dst[0] = *count (a device-side count) or v0, dst[1] = v1 | the device status words that make the step fail, dst[2..3] = v2, v3.
+__global__ void k_pack_record(uint32_t *__restrict__ dst, const uint32_t *__restrict__ count, const uint32_t *__restrict__ status,
+                              uint32_t v0, uint32_t v1, uint32_t v2, uint32_t v3) {
+    uint32_t st = v1;
+    if (status) st |= (status[ST_WELD_RANGE] ? 0x100u : 0u) | (status[ST_INTERNAL] ? 0x200u : 0u) | (status[ST_OVERFLOW] ? 0x400u : 0u);
+    dst[0] = count ? *count : v0;
+    dst[1] = st;
+    dst[2] = v2;
+    dst[3] = v3;
 }
 
 __global__ __launch_bounds__(256) void k_dist_pack_up(const uint32_t *__restrict__ up_ids, uint32_t n_up, const uint32_t *__restrict__ newidx,
@@ -2875,10 +2894,10 @@ hipError_t launch_column_counts(hipStream_t st, int grid, const Point *vox, cons
     return hipGetLastError();
 }
 
-hipError_t launch_merge_by_column(hipStream_t st, const Triangle *const *d_lists, const uint32_t *d_counts, int nranks, uint32_t *d_plan,
+hipError_t launch_merge_by_column(hipStream_t st, const Triangle *const *d_lists, const uint32_t *d_counts, uint32_t cstride, int nranks, uint32_t *d_plan,
                                   Triangle *d_out, uint32_t cap, uint32_t *total_out, uint32_t *status) {
-    hipLaunchKernelGGL(k_merge_plan, dim3(1), dim3(1024), 0, st, d_counts, (uint32_t) nranks, d_plan, cap, total_out, status);
-    hipLaunchKernelGGL(k_merge_copy, dim3(nranks * 1024), dim3(256), 0, st, d_lists, d_counts, d_plan, (uint32_t) nranks, d_out, cap);
+    hipLaunchKernelGGL(k_merge_plan, dim3(1), dim3(1024), 0, st, d_counts, cstride, (uint32_t) nranks, d_plan, cap, total_out, status);
+    hipLaunchKernelGGL(k_merge_copy, dim3(nranks * 1024), dim3(256), 0, st, d_lists, d_counts, cstride, d_plan, (uint32_t) nranks, d_out, cap);
     return hipGetLastError();
 }
 
@@ -2931,6 +2950,12 @@ hipError_t launch_dense_classify(hipStream_t st, int grid, bool emit, const uint
                                  Point *vox, uint8_t *cubeidx, uint32_t cap) {
     if (emit) hipLaunchKernelGGL(k_dense_classify<true>, dim3(grid), dim3(256), 0, st, bits, k, cellcnt, vox, cubeidx, cap);
     else hipLaunchKernelGGL(k_dense_classify<false>, dim3(grid), dim3(256), 0, st, bits, k, cellcnt, vox, cubeidx, cap);
+    return hipGetLastError();
+}
+
+hipError_t launch_pack_record(hipStream_t st, uint32_t *dst, const uint32_t *count, const uint32_t *status, uint32_t v0, uint32_t v1, uint32_t v2,
+                              uint32_t v3) {
+    hipLaunchKernelGGL(k_pack_record, dim3(1), dim3(1), 0, st, dst, count, status, v0, v1, v2, v3);
     return hipGetLastError();
 }
 

@@ -22,6 +22,12 @@ enum StatusWord : int {
     ST_WORDS = 8
 };
 
+// Multi-GPU agreement records (every rank learns every rank's status in the all-gather that moves the sizes anyway):
+//   z-slab gather   SHARD_ROW words per rank: 1024 column counts, then {status, triangles, receive capacity, merged capacity}
+//   x-slab weld     DIST_REC words per rank: {band size or kept count, status, capacity for the neighbour's band, 0}
+static constexpr uint32_t SHARD_ROW = 1024 + 4;
+static constexpr uint32_t DIST_REC = 4;
+
 hipError_t launch_refine_mask(hipStream_t st, int grid, int scene, const SceneParams *sp, const Point *vox,
                               const uint32_t *n_ptr, Point cs, uint8_t *mask, uint32_t *tilecnt, int chunk = 32, uint32_t *signs = nullptr);
 hipError_t launch_scan_tiles(hipStream_t st, uint32_t *cnt, const uint32_t *n_ptr, uint32_t items_per_tile,
@@ -72,7 +78,7 @@ hipError_t launch_raw_desc(hipStream_t st, int grid, const uint32_t *ntri_ptr, u
                            uint32_t *nu_out, uint32_t *tri_e = nullptr);
 hipError_t launch_tile_claim(hipStream_t st, int grid, const Vertex *uverts, const uint4 *tdesc, const uint32_t *ntiles_ptr,
                              uint64_t *wkeys, uint32_t wsize, uint32_t *vslot, uint32_t *status, uint32_t wmode, uint32_t *wrep, uint2 *wfm);
-hipError_t launch_merge_by_column(hipStream_t st, const Triangle *const *d_lists, const uint32_t *d_counts, int nranks, uint32_t *d_plan,
+hipError_t launch_merge_by_column(hipStream_t st, const Triangle *const *d_lists, const uint32_t *d_counts, uint32_t cstride, int nranks, uint32_t *d_plan,
                                   Triangle *d_out, uint32_t cap, uint32_t *total_out, uint32_t *status);
 hipError_t launch_weld(hipStream_t st, int grid, const Vertex *uverts, const uint4 *tdesc, const uint32_t *ntiles_ptr,
                        uint32_t *tri_e, const uint8_t *flip, uint32_t *first_ord, uint2 *wfm, const uint32_t *wrep,
@@ -115,5 +121,8 @@ hipError_t launch_sign_bits(hipStream_t st, int grid, const float *samples, uint
 hipError_t launch_dense_classify(hipStream_t st, int grid, bool emit, const uint32_t *bits, uint32_t k, uint32_t *cellcnt,
                                  Point *vox, uint8_t *cubeidx, uint32_t cap);
 hipError_t launch_set_u32(hipStream_t st, uint32_t *p, uint32_t v);
+// one 4-word record of a status-carrying all-gather: {*count or v0, v1 | device status flags (0x100 weld range, 0x200 internal, 0x400 overflow), v2, v3}
+hipError_t launch_pack_record(hipStream_t st, uint32_t *dst, const uint32_t *count, const uint32_t *status, uint32_t v0, uint32_t v1, uint32_t v2,
+                              uint32_t v3);
 
 }  // namespace sdm

@@ -18,7 +18,7 @@ template <int SCENE>
 __device__ __forceinline__ float sd_scene(f3 p, const SceneParams &sp) {          // compute_render.cu:3-19
     float sd = 3.40282347E+38f;
     sd = gmin(sd, sdf<SCENE>(p.x, p.y, p.z, sp));
-    sd = gmin(sd, sqrtf(skeleton_cube5_min_d2(p.x, p.y, p.z)) - 0.05f);     // = sd_box_skeleton(p, 0, (5, 5, 5), 0.05), see sdf.hpp
+    sd = gmin(sd, sqrt_rn_normal(skeleton_cube5_min_d2(p.x, p.y, p.z)) - 0.05f);     // = sd_box_skeleton(p, 0, (5, 5, 5), 0.05), see sdf.hpp
     return sd;
 }
 
@@ -50,7 +50,7 @@ __device__ __forceinline__ uchar4 render_pixel(uint32_t x, uint32_t y, const Ren
     const f3 b0 = pixel_dir((float) x - SQI, (float) y - SQI, r), b1 = pixel_dir((float) x - SQI, (float) y + SQI, r);
     const f3 b2 = pixel_dir((float) x + SQI, (float) y - SQI, r), b3 = pixel_dir((float) x + SQI, (float) y + SQI, r);
     const f3 d0 = sub3(dir, b0), d1 = sub3(dir, b1), d2 = sub3(dir, b2), d3 = sub3(dir, b3);
-    const float cone = gmax(gmax(sqrtf(dot3(d0, d0)), sqrtf(dot3(d1, d1))), gmax(sqrtf(dot3(d2, d2)), sqrtf(dot3(d3, d3))));
+    const float cone = gmax(gmax(sqrt_rn(dot3(d0, d0)), sqrt_rn(dot3(d1, d1))), gmax(sqrt_rn(dot3(d2, d2)), sqrt_rn(dot3(d3, d3))));
     f3 pos = mk(r.pos[0], r.pos[1], r.pos[2]);
     float depth = 0.0f;
     int outcome = 1;                                                                  // StepLimit

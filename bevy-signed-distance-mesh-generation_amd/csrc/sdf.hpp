@@ -85,10 +85,84 @@ SDM_HD float dot3(f3 a, f3 b) { return (a.x * b.x + a.y * b.y) + a.z * b.z; }
 SDM_HD f3 sub3(f3 a, f3 b) { return mk(a.x - b.x, a.y - b.y, a.z - b.z); }
 SDM_HD f3 add3(f3 a, f3 b) { return mk(a.x + b.x, a.y + b.y, a.z + b.z); }
 SDM_HD f3 scale3(f3 a, float s) { return mk(a.x * s, a.y * s, a.z * s); }
-SDM_HD f3 normalize3(f3 a) { return scale3(a, 1.0f / sqrtf(dot3(a, a))); }
 SDM_HD f3 cross3(f3 x, f3 y) {
     return mk(x.y * y.z - y.y * x.z, x.z * y.x - y.z * x.x, x.x * y.y - y.x * x.y);
 }
+
+// Correctly rounded square root / reciprocal / third on gfx950 WITHOUT the two-sided residual tests and the scaling hipcc
+// expands sqrtf and `/` into.  One Markstein step on the hardware's 1-ulp estimate,
+//     y = v_rsq_f32(x); g = x * y; h = y / 2; e = fma(-g, g, x); r = fma(e, h, g)
+// is not correctly rounded for an arbitrary 1-ulp estimate, but it IS for this chip's v_rsq_f32: tools/ubench/exact_sqrt.hip
+// and tests/test_parity_gpu.py::test_lean_exact_arithmetic_is_exact_for_every_input compare it with hipcc's sqrtf for EVERY float
+// in [2^-100, FLT_MAX] (2^31 inputs, a second on the GPU): zero mismatches (profiles/r03_exact_sqrt.jsonl).  Likewise
+// fma(fma(-b, y, 1), y, y) with y = v_rcp_f32(b) equals 1.0f / b for every normal b whose reciprocal is normal, and
+// fma(fma(-3, q, a), c, q) with c = RN(1/3), q = a * c equals a / 3.0f for every a with a normal quotient.
+// Cost per wave and SIMD (same micro-benchmark): 11 ns against 21 ns for round 2's v_sqrt_f32 + two-sided test.
+//
+// sqrt_rn_normal(x): x == 0, or x >= 2^-95, finite.  The input is nudged by 2^-120 (x + 2^-120 == x for every x >= 2^-95: the
+// addend is far below half an ulp) so that x == 0 gives 2^-60 instead of 0 * inf = NaN; for 0 < x < 2^-95 the result is some
+// value in [0, 2^-47].  The only callers are expressions  sqrt(x) - c  with |c| >= 0.1: there any root below 2^-30 is absorbed by
+// the subtraction and the value equals the reference's bit for bit.  (NaN returns NaN; x = +inf, which no bounded point
+// produces, would return NaN instead of +inf.)
+#define SDM_SQRT_NUDGE 7.52316384526264e-37f       /* 2^-120 */
+SDM_HD float sqrt_rn_normal(float x) {
+#if defined(__HIP_DEVICE_COMPILE__) && defined(SDM_FAST_MATH)
+    return __builtin_amdgcn_sqrtf(x);          // fast build: the bare v_sqrt_f32 (1 ulp), as nvcc --use_fast_math takes sqrt.approx
+#elif defined(__HIP_DEVICE_COMPILE__)
+    const float xc = x + SDM_SQRT_NUDGE;
+    const float y = __builtin_amdgcn_rsqf(xc);
+    const float g = xc * y, h = 0.5f * y;
+    const float e = __builtin_fmaf(-g, g, xc);
+    return __builtin_fmaf(e, h, g);
+#else
+    return sqrtf(x);
+#endif
+}
+
+// sqrtf(x) for ANY x: the lean form inside [2^-90, 2^90] (no nudge needed there), hipcc's expansion outside (zero, denormal,
+// huge, negative, NaN) behind a branch.  For the callers that may meet an exact zero whose root matters (sd_box: a point on
+// the box's face has u = 0 and the sign of 0 + idst decides) and for runtime programs, whose constants are not known here.
+SDM_HD float sqrt_rn(float x) {
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(SDM_FAST_MATH)
+    if (__builtin_expect(x >= 8.0779356694631609e-28f && x <= 1.2379400392853803e+27f, 1)) {
+        const float y = __builtin_amdgcn_rsqf(x);
+        const float g = x * y, h = 0.5f * y;
+        return __builtin_fmaf(__builtin_fmaf(-g, g, x), h, g);
+    }
+#endif
+    return sqrtf(x);
+}
+
+// 1 / sqrt(d) rounded twice, as glm::normalize takes it (sqrt, then the division), for ANY d: inside [2^-90, 2^90] by the two
+// lean exact forms, outside (zero: a degenerate triangle or a vanishing gradient must give inf / NaN exactly as the reference
+// does; denormal, huge, NaN) by hipcc's own expansions behind a branch no wave of a sane scene takes.
+SDM_HD float inv_length_rn(float d) {
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(SDM_FAST_MATH)
+    if (__builtin_expect(d >= 8.0779356694631609e-28f && d <= 1.2379400392853803e+27f, 1)) {
+        const float y = __builtin_amdgcn_rsqf(d);
+        const float g = d * y, h = 0.5f * y;
+        const float r = __builtin_fmaf(__builtin_fmaf(-g, g, d), h, g);          // = sqrtf(d), in [2^-45, 2^45]
+        const float q = __builtin_amdgcn_rcpf(r);
+        return __builtin_fmaf(__builtin_fmaf(-r, q, 1.0f), q, q);                // = 1.0f / r
+    }
+#endif
+    return 1.0f / sqrtf(d);
+}
+
+// a / 3 (the centroid of the orientation test, compute_mesh_generation.cu:104).  Exact for every a whose quotient is normal; a
+// zero keeps its magnitude (the sign of a zero centroid coordinate is lost: it only ever enters c + eps), and a quotient below
+// 2^-126 may differ in its last denormal bit -- both are absorbed by the + -eps of the stencil it feeds.
+SDM_HD float third_rn(float a) {
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(SDM_FAST_MATH)
+    const float c = 0.333333343267440796f;
+    const float q = a * c;
+    return __builtin_fmaf(__builtin_fmaf(-3.0f, q, a), c, q);
+#else
+    return a / 3.0f;
+#endif
+}
+
+SDM_HD f3 normalize3(f3 a) { return scale3(a, inv_length_rn(dot3(a, a))); }
 
 SDM_HD float smooth_min(float a, float b, float k) {
     // (fmax1/fmin1: k - |a-b| and a, b are finite; if a == b both forms return the same value, and a zero h has
@@ -171,7 +245,7 @@ SDM_HD float sd_box(f3 p, f3 bp, f3 bs) {
     f3 hs = mk(bs.x / 2.0f, bs.y / 2.0f, bs.z / 2.0f);
     f3 q = mk(fabsf(d.x) - hs.x, fabsf(d.y) - hs.y, fabsf(d.z) - hs.z);
     f3 u = mk(gmax(q.x, 0.0f), gmax(q.y, 0.0f), gmax(q.z, 0.0f));
-    float udst = sqrtf(dot3(u, u));
+    float udst = sqrt_rn(dot3(u, u));
     f3 m = mk(gmin(q.x, 0.0f), gmin(q.y, 0.0f), gmin(q.z, 0.0f));
     float idst = gmax(gmax(m.x, m.y), m.z);
     return udst + idst;
@@ -185,12 +259,12 @@ SDM_HD float sd_ray_g(f3 p, f3 bl, f3 bd, float len) {              // signed_di
     else if (d > len) q = add3(bl, scale3(bd, len));
     else q = add3(bl, scale3(bd, d));
     f3 e = sub3(p, q);
-    return sqrtf(dot3(e, e));
+    return sqrt_rn(dot3(e, e));
 }
 
 SDM_HD float sd_line_g(f3 p, f3 b0, f3 b1) {                        // signed_distance.cu:77-80
     f3 d = sub3(b1, b0);
-    float len = sqrtf(dot3(d, d));
+    float len = sqrt_rn(dot3(d, d));
     return sd_ray_g(p, b0, mk(d.x / len, d.y / len, d.z / len), len);
 }
 
@@ -221,14 +295,14 @@ SDM_HD float sdf_program(f3 p, const SceneParams &sp) {
         const f3 c = mk(in.a[0], in.a[1], in.a[2]);
         float d;
         switch (in.op) {
-        case OP_SPHERE: { f3 e = sub3(p, c); d = sqrtf(dot3(e, e)) - in.a[3]; } break;
+        case OP_SPHERE: { f3 e = sub3(p, c); d = sqrt_rn(dot3(e, e)) - in.a[3]; } break;
         case OP_BOX: d = sd_box(p, c, mk(in.a[3], in.a[4], in.a[5])); break;
         case OP_BOX_SKELETON: d = sd_box_skeleton_g(p, c, mk(in.a[3], in.a[4], in.a[5]), in.a[6]); break;
         case OP_CAPSULE: d = sd_line_g(p, c, mk(in.a[3], in.a[4], in.a[5])) - in.a[6]; break;
         case OP_TORUS_Y: {
             f3 e = sub3(p, c);
-            float qx = sqrtf(e.x * e.x + e.z * e.z) - in.a[3];
-            d = sqrtf(qx * qx + e.y * e.y) - in.a[4];
+            float qx = sqrt_rn(e.x * e.x + e.z * e.z) - in.a[3];
+            d = sqrt_rn(qx * qx + e.y * e.y) - in.a[4];
         } break;
         default: d = 3.40282347E+38f; break;
         }
@@ -244,28 +318,6 @@ SDM_HD float sdf_program(f3 p, const SceneParams &sp) {
     return acc;
 }
 
-// Correctly rounded sqrt for x == 0 or x a NORMAL positive float: the same v_sqrt_f32 + two-sided fma residual
-// correction hipcc emits for sqrtf, minus the denormal pre-scaling and the class test (9 instructions instead of
-// 16).  x == 0 falls through correctly (both residual tests fail).  For a DENORMAL x the result is some value in
-// [0, 2^-63] (v_sqrt_f32 sees zero or a tiny number; at most one ulp step is added), as is the exact root, so
-// the only callers are expressions of the form  sqrt(x) - c  with |c| >= 0.1: there any root below 2^-30 is
-// absorbed by the subtraction and the two forms agree bit for bit.  (x = +inf returns +inf, NaN returns NaN.)
-SDM_HD float sqrt_rn_normal(float x) {
-#if defined(__HIP_DEVICE_COMPILE__) && defined(SDM_FAST_MATH)
-    return __builtin_amdgcn_sqrtf(x);          // fast build: the bare v_sqrt_f32 (1 ulp), as nvcc --use_fast_math takes sqrt.approx
-#elif defined(__HIP_DEVICE_COMPILE__)
-    const float y = __builtin_amdgcn_sqrtf(x);
-    const float ydn = __builtin_bit_cast(float, __builtin_bit_cast(int, y) - 1);
-    const float yup = __builtin_bit_cast(float, __builtin_bit_cast(int, y) + 1);
-    const float rdn = __builtin_fmaf(-ydn, y, x);
-    const float rup = __builtin_fmaf(-yup, y, x);
-    float r = rdn <= 0.0f ? ydn : y;
-    r = rup > 0.0f ? yup : r;
-    return r;
-#else
-    return sqrtf(x);
-#endif
-}
 
 template <int SCENE>
 SDM_HD float sdf(float px, float py, float pz, const SceneParams &sp) {
@@ -275,10 +327,10 @@ SDM_HD float sdf(float px, float py, float pz, const SceneParams &sp) {
         return sqrt_rn_normal((px * px + py * py) + pz * pz) - 1.0f;
     } else if (SCENE == SCENE_CSG3) {
         // build-defined scene; mirrors oracle sdf_eval SCENE_CSG3
-        float a = sqrtf((px * px + py * py) + pz * pz) - 1.0f;
+        float a = sqrt_rn_normal((px * px + py * py) + pz * pz) - 1.0f;
         float b = sd_box(mk(px, py, pz), mk(1.2f, 0.0f, 0.0f), mk(1.2f, 1.2f, 1.2f));
-        float qx = sqrtf(px * px + pz * pz) - 1.5f;
-        float c = sqrtf(qx * qx + py * py) - 0.25f;
+        float qx = sqrt_rn_normal(px * px + pz * pz) - 1.5f;
+        float c = sqrt_rn_normal(qx * qx + py * py) - 0.25f;
         return smooth_min(smooth_min(a, b, 0.3f), c, 0.3f);
     } else {
         const float a1 = sqrt_rn_normal(skeleton_min_d2(px, py, pz)) - 0.1f;
@@ -356,15 +408,11 @@ SDM_HD v2f sqrt_rn_normal2(v2f x) {
 #if defined(SDM_FAST_MATH)
     return mk2(__builtin_amdgcn_sqrtf(x.x), __builtin_amdgcn_sqrtf(x.y));
 #else
-    const v2f y = mk2(__builtin_amdgcn_sqrtf(x.x), __builtin_amdgcn_sqrtf(x.y));
-    const v2i yi = __builtin_bit_cast(v2i, y);
-    const v2f ydn = __builtin_bit_cast(v2f, yi - 1), yup = __builtin_bit_cast(v2f, yi + 1);
-    const v2f rdn = __builtin_elementwise_fma(-ydn, y, x);
-    const v2f rup = __builtin_elementwise_fma(-yup, y, x);
-    v2f r;
-    r.x = rdn.x <= 0.0f ? ydn.x : y.x; r.x = rup.x > 0.0f ? yup.x : r.x;
-    r.y = rdn.y <= 0.0f ? ydn.y : y.y; r.y = rup.y > 0.0f ? yup.y : r.y;
-    return r;
+    const v2f xc = x + SDM_SQRT_NUDGE;                                   // sqrt_rn_normal() on both components
+    const v2f y = mk2(__builtin_amdgcn_rsqf(xc.x), __builtin_amdgcn_rsqf(xc.y));
+    const v2f g = xc * y, h = 0.5f * y;
+    const v2f e = __builtin_elementwise_fma(-g, g, xc);
+    return __builtin_elementwise_fma(e, h, g);
 #endif
 }
 SDM_HD v2f smooth_min2(v2f a, v2f b, float k) {
@@ -470,7 +518,7 @@ template <int SCENE>
 SDM_HD bool change_orientation(f3 v0, f3 v1, f3 v2, const SceneParams &sp) {
     f3 tn = normalize3(cross3(sub3(v1, v0), sub3(v2, v0)));
     f3 s = add3(add3(v0, v1), v2);
-    f3 c = mk(s.x / 3.0f, s.y / 3.0f, s.z / 3.0f);
+    f3 c = mk(third_rn(s.x), third_rn(s.y), third_rn(s.z));
     f3 an = empirical_normal<SCENE>(c, sp);
     return dot3(tn, an) <= 0.0f;
 }

@@ -34,7 +34,11 @@ enum {
     SDMESH_ERR_WELD_RANGE = 5,   /* kept for ABI stability; no longer returned: vertices outside the packed +-10.48 unit key
                                     are welded with the wide key form, like the reference's [i64; 3] (src/cuda/mod.rs:268-273) */
     SDMESH_ERR_INTERNAL = 6,     /* invariant violated on the device (bug) */
-    SDMESH_ERR_RCCL = 7          /* librccl missing or a collective failed (sdmesh_last_error has the text) */
+    SDMESH_ERR_RCCL = 7,         /* librccl missing or a collective failed (sdmesh_last_error has the text); the communicator is
+                                    unusable afterwards */
+    SDMESH_ERR_PEER = 8          /* a collective call failed on ANOTHER rank (which returns its own error code): every rank of the
+                                    communicator returns an error from the same call, nobody is left waiting; the communicator
+                                    stays usable */
 };
 
 /* Scenes.  The reference hard-codes one SDF, sd_obj (cuda/modules/common.cu:222-226) = SDOBJ.
@@ -247,7 +251,12 @@ int sdmesh_comm_ranks(sdmesh_handle *h, int *ranks_seen);
  * per-slab triangle lists straight to `root` (each peer on its own xGMI link), order-restoring merge kernel and first-seen
  * weld on the root.  On the root *info describes the welded mesh (identical to a single-GPU sdmesh_regen, fetch it with
  * sdmesh_device_mesh / sdmesh_download_mesh); on the other ranks it describes their slab.  Collective: every rank of
- * the communicator must call it with the same levels and root. */
+ * the communicator must call it with the same levels and root.
+ * Failure is collective too: the all-gather carries a status word per rank and is entered even by a rank whose slab
+ * failed, so when any rank fails (its regen, an allocation, a count mismatch) every rank returns from this call with an
+ * error -- the failing one with its own code, the others with SDMESH_ERR_PEER -- and none is left waiting in a collective.
+ * The root's receive buffers grow behind a second one-word agreement, entered only when its published capacity is too
+ * small (never in steady state).  Only an SDMESH_ERR_RCCL / SDMESH_ERR_HIP from a collective itself is not agreed upon. */
 int sdmesh_sharded_regen(sdmesh_handle *h, int levels, int root, sdmesh_regen_info *info);
 
 /* Dense mode: the same regen through the dense (N+1)^3 lattice -- P1 sample, P2a sign bits, P2b
@@ -294,7 +303,9 @@ int sdmesh_render_device(sdmesh_handle *h, const struct GlobalsBuffer *globals, 
  * their global numbers up) and two 4-byte all-gathers; nothing proportional to the mesh crosses a link.  The mesh stays
  * distributed: afterwards sdmesh_device_mesh / sdmesh_download_mesh give THIS rank's kept vertices and its triangles with
  * GLOBAL indices, *first_vertex = the global index of its first kept vertex.  The ranks' parts concatenated in rank order
- * are the single-GPU mesh, bit for bit.  Collective: every rank calls it with the same levels. */
+ * are the single-GPU mesh, bit for bit.  Collective: every rank calls it with the same levels; failure is collective as in
+ * sdmesh_sharded_regen (status words ride in the two all-gathers; a vertex outside the packed weld-key range on one rank
+ * fails the call on all).  x-slabs must not be empty (sdmesh_set_slab_bounds rejects such a table). */
 int sdmesh_distributed_regen(sdmesh_handle *h, int levels, sdmesh_regen_info *info, uint32_t *first_vertex);
 /* The same step for nranks handles of one process on one device (copies instead of messages): the rehearsal used where
  * only one GPU exists.  infos / first_vertex: arrays of nranks (optional). */
