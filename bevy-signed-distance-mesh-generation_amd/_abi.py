@@ -45,7 +45,8 @@ def pack_program(program):
 PART_NONE, PART_ZSLAB, PART_XSLAB = 0, 1, 2
 
 ERRORS = {1: "invalid argument", 2: "HIP runtime error", 3: "no gfx950 device", 4: "output buffer too small",
-          5: "vertex outside the weld key range", 6: "internal device error", 7: "RCCL error"}
+          5: "vertex outside the weld key range", 6: "internal device error", 7: "RCCL error",
+          8: "another rank of the communicator failed in this collective call"}
 
 
 class Point(ctypes.Structure):
@@ -124,6 +125,7 @@ SYMBOLS = {
     "sdmesh_time_kernel": (_i, [_vp, _i, _u32, _vp, _i, ctypes.POINTER(ctypes.c_float)]),
     "sdmesh_profile_stages": (_i, [_vp, _vp, _sz, _vp, _i, ctypes.POINTER(_i)]),
     "sdmesh_profile_rounds": (_i, [_vp, ctypes.POINTER(ctypes.c_uint64)]),
+    "sdmesh_selfcheck_arithmetic": (_i, [_vp, ctypes.POINTER(ctypes.c_uint64), _i]),
     "sdmesh_project_diag": (_i, [_vp, _vp, _sz, _psz]),
     "sdmesh_render": (_i, [_vp, _vp, _vp, _vp]),
     "sdmesh_render_device": (_i, [_vp, _vp, _vp, _vp, ctypes.POINTER(ctypes.c_float)]),

@@ -1708,6 +1708,19 @@ extern "C" int sdmesh_balance_slabs(sdmesh_handle *h, int mode, int nparts, int 
     return SDMESH_OK;
 }
 
+extern "C" int sdmesh_selfcheck_arithmetic(sdmesh_handle *h, uint64_t *mismatches, int n) {
+    if (!h || !mismatches || n < 1) return SDMESH_ERR_INVALID;
+    HIPCHK(hipSetDevice(h->device));
+    SDCHK(ensure(h, h->staging, 8ull * SDMESH_SELFCHECKS));
+    HIPCHK(hipMemsetAsync(h->staging.p, 0, 8ull * SDMESH_SELFCHECKS, h->stream));
+    for (int w = 0; w < SDMESH_SELFCHECKS && w < n; w++) HIPCHK(launch_selfcheck(h->stream, w, (unsigned long long *) h->staging.p + w));
+    uint64_t host[SDMESH_SELFCHECKS] = {0};
+    HIPCHK(hipMemcpyAsync(host, h->staging.p, sizeof host, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    for (int w = 0; w < n; w++) mismatches[w] = w < SDMESH_SELFCHECKS ? host[w] : 0;
+    return SDMESH_OK;
+}
+
 extern "C" int sdmesh_profile_rounds(sdmesh_handle *h, uint64_t *vertex_rounds) {
     if (!h || !vertex_rounds) return SDMESH_ERR_INVALID;
     if (!h->prof_rounds.p) return fail(h, SDMESH_ERR_INVALID, "no profiled regen yet (option \"profile\")");
@@ -2148,13 +2161,7 @@ int sdmesh_distributed_regen(sdmesh_handle *h, int levels, sdmesh_regen_info *in
     memset(&slab, 0, sizeof slab);
     const int lrc = dist_phase_local(h, levels, R, me, &slab);
     uint32_t counts[32] = {0};
-    if (R == 1) {
-        SDCHK(lrc);
-        SDCHK(read_back(h));
-        if (h->h_pinned[CTR_WORDS + ST_WELD_RANGE]) return fail(h, SDMESH_ERR_WELD_RANGE, "the distributed weld needs vertices inside the packed key range");
-        counts[0] = h->dist_V;
-        return dist_finish_host(h, R, me, counts, info, slab, first_vertex);
-    }
+    // (a one-rank communicator takes the same route: its collectives are degenerate, every phase still runs)
     // 1. band sizes of every rank (the one extra host synchronisation of a distributed step: message lengths must be host
     //    values), each with the rank's status and what it can take from its lower neighbour without growing -- ALWAYS entered
     uint32_t *d_nups = (uint32_t *) h->dist_nups.p, *d_counts = (uint32_t *) h->dist_counts.p;
@@ -2179,10 +2186,12 @@ int sdmesh_distributed_regen(sdmesh_handle *h, int levels, sdmesh_regen_info *in
         if (grc != SDMESH_OK) return grc;
         if (worst) return fail(h, SDMESH_ERR_PEER, "a rank could not grow its band buffers; every rank returns an error");
     }
-    NCCLCHK(g_rccl.GroupStart());
-    if (n_up) NCCLCHK(g_rccl.Send(h->dist_upkeys.p, n_up, ncclUint64, me + 1, h->comm, st));
-    if (n_prev) NCCLCHK(g_rccl.Recv(h->dist_prevkeys.p, n_prev, ncclUint64, me - 1, h->comm, st));
-    NCCLCHK(g_rccl.GroupEnd());
+    if (n_up || n_prev) {
+        NCCLCHK(g_rccl.GroupStart());
+        if (n_up) NCCLCHK(g_rccl.Send(h->dist_upkeys.p, n_up, ncclUint64, me + 1, h->comm, st));
+        if (n_prev) NCCLCHK(g_rccl.Recv(h->dist_prevkeys.p, n_prev, ncclUint64, me - 1, h->comm, st));
+        NCCLCHK(g_rccl.GroupEnd());
+    }
     // (nothing below allocates: a failure from here on is a HIP / RCCL error, after which the communicator is gone anyway)
     SDCHK(dist_phase_match(h, n_prev));
     // 3. kept counts of every rank (stay on the device for the kernels) + each rank's device status: a vertex outside the
@@ -2190,10 +2199,12 @@ int sdmesh_distributed_regen(sdmesh_handle *h, int levels, sdmesh_regen_info *in
     HIPCHK(launch_pack_record(st, d_counts + (size_t) me * DIST_REC, h->d_ctr + CTR_DIST_NKEEP, h->d_status, 0u, 0u, 0u, 0u));
     NCCLCHK(g_rccl.AllGather(d_counts + (size_t) me * DIST_REC, d_counts, DIST_REC, ncclUint32, h->comm, st));
     SDCHK(dist_phase_pack(h, me, n_up));
-    NCCLCHK(g_rccl.GroupStart());
-    if (n_up) NCCLCHK(g_rccl.Send(h->dist_upg.p, n_up, ncclUint32, me + 1, h->comm, st));
-    if (n_prev) NCCLCHK(g_rccl.Recv(h->dist_prevg.p, n_prev, ncclUint32, me - 1, h->comm, st));
-    NCCLCHK(g_rccl.GroupEnd());
+    if (n_up || n_prev) {
+        NCCLCHK(g_rccl.GroupStart());
+        if (n_up) NCCLCHK(g_rccl.Send(h->dist_upg.p, n_up, ncclUint32, me + 1, h->comm, st));
+        if (n_prev) NCCLCHK(g_rccl.Recv(h->dist_prevg.p, n_prev, ncclUint32, me - 1, h->comm, st));
+        NCCLCHK(g_rccl.GroupEnd());
+    }
     SDCHK(dist_phase_final(h, me));
     HIPCHK(hipMemcpyAsync(rec, d_counts, 4ull * (size_t) R * DIST_REC, hipMemcpyDeviceToHost, st));
     SDCHK(read_back(h));

@@ -2953,6 +2953,65 @@ hipError_t launch_dense_classify(hipStream_t st, int grid, bool emit, const uint
     return hipGetLastError();
 }
 
+// ------------------------------------------------------------------------------------------
+// Self-check of the lean exact arithmetic (sdf.hpp: sqrt_rn_normal / sqrt_rn / inv_length_rn / third_rn) against
+// hipcc's own correctly rounded expansions, for EVERY input of each function's domain: 2^32 bit patterns per check,
+// about a second in all.  The strict build's bit-exactness rests on "one Markstein step on this chip's v_rsq_f32 /
+// v_rcp_f32 rounds correctly"; that is a property of the silicon, so the library can prove it on the device it runs on.
+//   0  sqrt_rn_normal(x) == sqrtf(x) for x in [2^-95, FLT_MAX]; for 0 <= x < 2^-95 the result is finite and <= 2^-40
+//   1  sqrt_rn(x) == sqrtf(x) for every bit pattern (NaNs compare as NaN)
+//   2  inv_length_rn(d) == 1.0f / sqrtf(d) for every bit pattern
+//   3  third_rn(a) == a / 3.0f for every finite a with a normal quotient, and for +-0 by value (+-inf gives NaN: the centroid of
+//      a non-finite triangle, whose orientation test is "no flip" either way)
+//   4  sqrt_rn_normal2({x, y}) == {sqrt_rn_normal(x), sqrt_rn_normal(y)} (y = a second walk through the same range)
+// ------------------------------------------------------------------------------------------
+__device__ __forceinline__ bool same_f32(float a, float b) {
+    return __builtin_bit_cast(uint32_t, a) == __builtin_bit_cast(uint32_t, b) || (a != a && b != b);
+}
+template <int WHICH>
+__global__ __launch_bounds__(256) void k_selfcheck(unsigned long long *__restrict__ bad) {
+    const uint64_t stride = (uint64_t) gridDim.x * blockDim.x;
+    unsigned long long mine = 0;
+    for (uint64_t b = (uint64_t) blockIdx.x * blockDim.x + threadIdx.x; b < (1ull << 32); b += stride) {
+        const float x = __builtin_bit_cast(float, (uint32_t) b);
+        if (WHICH == 0) {
+            if ((uint32_t) b >= 0x7f800000u) continue;                       // negative, inf, NaN: outside the domain
+            const float r = sqrt_rn_normal(x);
+            if ((uint32_t) b >= 0x10000000u) { if (!same_f32(r, sqrtf(x))) mine++; }
+            else if (!(r >= 0.0f && r <= 9.094947017729282e-13f)) mine++;
+        } else if (WHICH == 1) {
+            if (!same_f32(sqrt_rn(x), sqrtf(x))) mine++;
+        } else if (WHICH == 2) {
+            if (!same_f32(inv_length_rn(x), 1.0f / sqrtf(x))) mine++;
+        } else if (WHICH == 3) {
+            const float q = x / 3.0f, t = third_rn(x);
+            if (x == 0.0f) { if (t != 0.0f) mine++; }
+            else if (fabsf(x) >= 4.70197740328915e-38f && fabsf(x) < __builtin_inff()) { if (!same_f32(t, q)) mine++; }   // 2^-124 <= |a| < inf
+            else if (x != x && t == t) mine++;                                                                       // NaN stays NaN
+        } else {
+#if defined(SDM_HAVE_PAIRS)
+            if ((uint32_t) b >= 0x7f800000u) continue;
+            const float y = __builtin_bit_cast(float, (uint32_t) ((b * 2654435761ull) % 0x7f800000ull));
+            const v2f r = sqrt_rn_normal2(mk2(x, y));
+            if (!same_f32(r.x, sqrt_rn_normal(x)) || !same_f32(r.y, sqrt_rn_normal(y))) mine++;
+#endif
+        }
+    }
+    if (mine) atomicAdd(bad, mine);
+}
+
+hipError_t launch_selfcheck(hipStream_t st, int which, unsigned long long *bad) {
+    const dim3 g(256 * 8), b(256);
+    switch (which) {
+    case 0: hipLaunchKernelGGL(k_selfcheck<0>, g, b, 0, st, bad); break;
+    case 1: hipLaunchKernelGGL(k_selfcheck<1>, g, b, 0, st, bad); break;
+    case 2: hipLaunchKernelGGL(k_selfcheck<2>, g, b, 0, st, bad); break;
+    case 3: hipLaunchKernelGGL(k_selfcheck<3>, g, b, 0, st, bad); break;
+    default: hipLaunchKernelGGL(k_selfcheck<4>, g, b, 0, st, bad); break;
+    }
+    return hipGetLastError();
+}
+
 hipError_t launch_pack_record(hipStream_t st, uint32_t *dst, const uint32_t *count, const uint32_t *status, uint32_t v0, uint32_t v1, uint32_t v2,
                               uint32_t v3) {
     hipLaunchKernelGGL(k_pack_record, dim3(1), dim3(1), 0, st, dst, count, status, v0, v1, v2, v3);

@@ -121,6 +121,8 @@ hipError_t launch_sign_bits(hipStream_t st, int grid, const float *samples, uint
 hipError_t launch_dense_classify(hipStream_t st, int grid, bool emit, const uint32_t *bits, uint32_t k, uint32_t *cellcnt,
                                  Point *vox, uint8_t *cubeidx, uint32_t cap);
 hipError_t launch_set_u32(hipStream_t st, uint32_t *p, uint32_t v);
+// exhaustive self-check of the lean exact arithmetic of sdf.hpp (which = 0..4, see kernels.hip); *bad += mismatches
+hipError_t launch_selfcheck(hipStream_t st, int which, unsigned long long *bad);
 // one 4-word record of a status-carrying all-gather: {*count or v0, v1 | device status flags (0x100 weld range, 0x200 internal, 0x400 overflow), v2, v3}
 hipError_t launch_pack_record(hipStream_t st, uint32_t *dst, const uint32_t *count, const uint32_t *status, uint32_t v0, uint32_t v1, uint32_t v2,
                               uint32_t v3);

@@ -151,7 +151,8 @@ SDM_HD float inv_length_rn(float d) {
 
 // a / 3 (the centroid of the orientation test, compute_mesh_generation.cu:104).  Exact for every a whose quotient is normal; a
 // zero keeps its magnitude (the sign of a zero centroid coordinate is lost: it only ever enters c + eps), and a quotient below
-// 2^-126 may differ in its last denormal bit -- both are absorbed by the + -eps of the stencil it feeds.
+// 2^-126 may differ in its last denormal bit -- both are absorbed by the + -eps of the stencil it feeds.  (+-inf gives NaN where
+// the division gives inf: the stencil around either is NaN, and the orientation test then keeps the triangle as it is.)
 SDM_HD float third_rn(float a) {
 #if defined(__HIP_DEVICE_COMPILE__) && !defined(SDM_FAST_MATH)
     const float c = 0.333333343267440796f;

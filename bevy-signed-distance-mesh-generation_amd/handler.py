@@ -415,6 +415,13 @@ class CudaHandler:
         self._chk(self._lib.sdmesh_profile_rounds(self._h, ctypes.byref(n)))
         return int(n.value)
 
+    def selfcheck_arithmetic(self):
+        """Mismatch counts of the library's lean exact arithmetic (sqrt_rn_normal, sqrt_rn, inv_length_rn, third_rn, packed sqrt)
+        against hipcc's correctly rounded expansions over all 2^32 inputs each, on this device (about a second)."""
+        out = (ctypes.c_uint64 * 5)()
+        self._chk(self._lib.sdmesh_selfcheck_arithmetic(self._h, out, 5))
+        return [int(v) for v in out]
+
     def project_diag(self):
         """uint64 [waves, 4]: {start, end, rounds, hw id} per wave of the projection kernel (option "project_diag")."""
         n = ctypes.c_size_t(0)

@@ -284,6 +284,14 @@ int sdmesh_profile_rounds(sdmesh_handle *h, uint64_t *vertex_rounds);
  * rounds, HW_ID | XCC_ID << 32}; waves without work stay zero.  tools/project_timeline.py turns it into the lifetime histogram. */
 int sdmesh_project_diag(sdmesh_handle *h, uint64_t *out, size_t cap_waves, size_t *n_waves);
 
+/* Exhaustive self-check of the strict build's lean exact arithmetic on THIS device (csrc/sdf.hpp: correctly rounded sqrt,
+ * 1/sqrt and x/3 from one Markstein step on the hardware's 1-ulp v_rsq_f32 / v_rcp_f32 estimates): every one of the 2^32
+ * inputs of each function against hipcc's own correctly rounded expansion, about a second in all.  mismatches[i] for
+ * i < min(n, SDMESH_SELFCHECKS): 0 sqrt_rn_normal, 1 sqrt_rn, 2 inv_length_rn, 3 third_rn, 4 the packed-pair sqrt.  All
+ * zero = the build's results are the IEEE-754 results on this chip (the fast build returns its approximations' counts). */
+#define SDMESH_SELFCHECKS 5
+int sdmesh_selfcheck_arithmetic(sdmesh_handle *h, uint64_t *mismatches, int n);
+
 /* ---- ray-march preview ------------------------------------------------ */
 
 /* CudaHandler::render (src/cuda/mod.rs:348-420): sphere-traces the current scene (plus the bounding-cube wire frame of
