@@ -2490,43 +2490,56 @@ __global__ __launch_bounds__(256) void k_sample_dense_q1(float *__restrict__ out
     const uint32_t S = N + 1u;
     const uint32_t i0 = (blockIdx.x * 256u + threadIdx.x) << 2;
     if (i0 >= total) return;
-    // (x, y, z) of the workgroup's first sample on the scalar unit (two magic divisions of a uniform value), then at most two
-    // row steps per thread: a piece is 1 024 consecutive samples and a row has S >= 2 of them
+    // (x, y, z) of the WAVE's first sample on the scalar unit: two magic divisions of the workgroup's first index, then the wave's
+    // offset and at most two row steps (a piece is 1 024 consecutive samples, a row has S >= 512 of them), all on uniform values.
+    // A wave's 256 samples touch at most two rows, so a lane needs one compare and three selects.
     const uint32_t iw = blockIdx.x << 10;
     const uint32_t r0 = div_magic(iw, dS), x0 = div_magic(r0, dS);
-    uint32_t z = (iw - r0 * S) + (threadIdx.x << 2), y = r0 - x0 * S, x = x0;
+    uint32_t x, y, z;
     if (S >= 512u) {                                         // (the usual case: no loop)
-        if (z >= S) { z -= S; y++; }
-        if (z >= S) { z -= S; y++; }
-        if (z >= S) { z -= S; y++; }
-        if (y >= S) { y -= S; x++; }
+        const uint32_t wv = __builtin_amdgcn_readfirstlane(threadIdx.x) & ~63u;
+        uint32_t zw = (iw - r0 * S) + (wv << 2), yw = r0 - x0 * S, xw = x0;
+        if (zw >= S) { zw -= S; yw++; }
+        if (zw >= S) { zw -= S; yw++; }
+        if (yw >= S) { yw -= S; xw++; }
+        uint32_t ya = yw + 1u, xa = xw;                      // the wave's second row
+        if (ya == S) { ya = 0u; xa++; }
+        z = zw + ((threadIdx.x & 63u) << 2);
+        const bool c = z >= S;
+        z = c ? z - S : z; y = c ? ya : yw; x = c ? xa : xw;
     } else {
         const uint32_t rr = div_magic(i0, dS);
         z = i0 - rr * S; x = div_magic(rr, dS); y = rr - x * S;
     }
     float v[4];
     if (SCENE == SCENE_SPHERE) {
-        // |p|^2 is 0 or a normal float on the lattice, hence the lean sqrt.  A quad may cross a row end (S is odd: 37 % of
-        // the waves hold such a quad): samples k with z + k >= S belong to the next row.  That is folded into the one code
-        // path with selects (the row's x^2 + y^2 term and z - S per sample: ~17 instructions) instead of a divergent second
-        // path the whole wave would walk (~74).  All the integers involved are < 2^24, so the float adds are exact.
+        // |p|^2 is 0 or a normal float on the lattice, hence the lean sqrt; its 2^-120 nudge rides on the row term a = x^2 + y^2
+        // (a is 0 or >= 2^-46, so (a + 2^-120) + z^2 == (a + z^2) + 2^-120 bit for bit).  A quad may cross a row end (S is odd:
+        // 37 % of the waves hold such a lane): its samples k with z + k >= S belong to the next row.  Only those lanes replace
+        // the z coordinate and the row term of the samples concerned, behind a branch the other waves skip; the arithmetic
+        // itself is one code path.  All the integers involved are < 2^24, so the float adds are exact.
         const float px = (float) x * h - 2.5f, py = (float) y * h - 2.5f;
-        const float px2 = px * px, a_cur = px2 + py * py;
 #if defined(SDM_HAVE_PAIRS)
-        float ny = (float) (y + 1u) * h - 2.5f, a_nxt = px2 + ny * ny;
-        if (z + 3u >= S && y + 1u == S) {                   // ... and the next row is the first of the next x plane (rare)
-            const float nx = (float) (x + 1u) * h - 2.5f;
-            a_nxt = nx * nx + 6.25f;                        // ny = 0 * h - 2.5f = -2.5f exactly; (-2.5f)^2 = 6.25f exactly
+        const float a_cur = (px * px + py * py) + SDM_SQRT_NUDGE;
+        const float zf = (float) z;
+        v2f q0 = mk2(zf, zf + 1.0f), q1 = mk2(zf + 2.0f, zf + 3.0f);
+        v2f a0 = mk2(a_cur, a_cur), a1 = a0;
+        if (__builtin_expect(z + 3u >= S, 0)) {
+            const bool ywrap = (y + 1u == S);
+            const float nx = (float) (ywrap ? x + 1u : x) * h - 2.5f, ny = (float) (ywrap ? 0u : y + 1u) * h - 2.5f;
+            const float a_nxt = (nx * nx + ny * ny) + SDM_SQRT_NUDGE;
+            const uint32_t rem = S - z;                      // 1 .. 3 samples left in this row
+            if (rem <= 1u) { q0.y = (float) (1u - rem); a0.y = a_nxt; }
+            if (rem <= 2u) { q1.x = (float) (2u - rem); a1.x = a_nxt; }
+            q1.y = (float) (3u - rem); a1.y = a_nxt;
         }
-        const float zf = (float) z, Sf = (float) S;
-        const bool w1 = z + 1u >= S, w2 = z + 2u >= S, w3 = z + 3u >= S;
-        const v2f q0 = mk2(zf, zf + 1.0f) - mk2(0.0f, w1 ? Sf : 0.0f), q1 = mk2(zf + 2.0f, zf + 3.0f) - mk2(w2 ? Sf : 0.0f, w3 ? Sf : 0.0f);
         const v2f p0 = q0 * h - 2.5f, p1 = q1 * h - 2.5f;
-        const v2f r0 = sqrt_rn_normal2(mk2(a_cur, w1 ? a_nxt : a_cur) + p0 * p0) - 1.0f;
-        const v2f r1 = sqrt_rn_normal2(mk2(w2 ? a_nxt : a_cur, w3 ? a_nxt : a_cur) + p1 * p1) - 1.0f;
-        v[0] = r0.x; v[1] = r0.y; v[2] = r1.x; v[3] = r1.y;
+        const v2f r0v = sqrt_rn_normal2_nonudge(a0 + p0 * p0) - 1.0f;
+        const v2f r1v = sqrt_rn_normal2_nonudge(a1 + p1 * p1) - 1.0f;
+        v[0] = r0v.x; v[1] = r0v.y; v[2] = r1v.x; v[3] = r1v.y;
 #else
         {
+            const float a_cur = px * px + py * py;
             const uint32_t rem = S - z;
             const bool ywrap = (y + 1u == S);
             const float nx = (float) (ywrap ? x + 1u : x) * h - 2.5f, ny = (float) (ywrap ? 0u : y + 1u) * h - 2.5f;

@@ -416,6 +416,17 @@ SDM_HD v2f sqrt_rn_normal2(v2f x) {
     return __builtin_elementwise_fma(e, h, g);
 #endif
 }
+// the same with the nudge already inside x (the caller added 2^-120 to a term of the sum, see k_sample_dense_q1)
+SDM_HD v2f sqrt_rn_normal2_nonudge(v2f xc) {
+#if defined(SDM_FAST_MATH)
+    return mk2(__builtin_amdgcn_sqrtf(xc.x), __builtin_amdgcn_sqrtf(xc.y));
+#else
+    const v2f y = mk2(__builtin_amdgcn_rsqf(xc.x), __builtin_amdgcn_rsqf(xc.y));
+    const v2f g = xc * y, h = 0.5f * y;
+    const v2f e = __builtin_elementwise_fma(-g, g, xc);
+    return __builtin_elementwise_fma(e, h, g);
+#endif
+}
 SDM_HD v2f smooth_min2(v2f a, v2f b, float k) {
     const v2f h = max2s(k - abs2(a - b), 0.0f) / k;
     return min2(a, b) - h * h * h * k * (1.0f / 6.0f);
