@@ -248,6 +248,50 @@ def one_mesh_legs(pkg, job, local_rank, scene, params, levels_list, base_levels,
                                                 **xslab}}
 
 
+def dense_p1_sharded_leg(pkg, job, local_rank, scene, params, grids=(512, 1024), launches=50):
+    """P1 (the north star's HBM pass) sharded over the ranks: rank r samples the x planes [r (N+1) / R, (r+1) (N+1) / R) of the same
+    dense lattice into its own HBM, no exchange of any kind (the parts are bit for bit the ranges of the whole volume: -m gpu
+    test_dense_slabs_concatenate_to_the_whole_volume).  Timed like a step: `launches` back-to-back launches per rank between
+    barrier + synchronize, max over ranks; aggregate = 4 (N+1)^3 bytes / that time, against R x 8 TB/s.  The 1-rank figure beside it
+    is the whole volume on rank 0 alone, same invocation."""
+    from bevy_signed_distance_mesh_generation_amd import partition as P
+    world, rank = job.world, job.rank
+    h = pkg.CudaHandler(local_rank, "sphere")
+    out = {"what": "dense (N+1)^3 f32 SDF-sample pass, one x-slab of lattice planes per GPU, no data-path collective; aggregate over all "
+                   "ranks, frac = aggregate / (n_gpus x 8 TB/s); t_1rank = the whole volume on rank 0 alone in the same invocation",
+           "n_gpus": world, "launches": launches}
+    for n in grids:
+        S = n + 1
+        x0, x1 = P.dense_slab_planes(n, rank, world)
+        alg = 4.0 * S ** 3
+        whole = torch.empty(S ** 3 if rank == 0 else 4, dtype=torch.float32, device="cuda")
+        mine = torch.empty(max(4, (x1 - x0) * S * S), dtype=torch.float32, device="cuda")
+        for sc in dict.fromkeys(("sphere", scene)):
+            h.set_scene(sc, params if sc == scene else None)
+            t1 = None
+            if rank == 0:
+                h.time_kernel(0, n, whole.data_ptr(), 200)                       # clocks settle under the new load (see roofline_legs)
+                t1 = h.time_kernel(0, n, whole.data_ptr(), launches)
+            job.sync()
+            h.sample_dense_slab(n, x0, x1, mine.data_ptr(), iters=200, timed=False)
+            dt, _ = job.timed(lambda: h.sample_dense_slab(n, x0, x1, mine.data_ptr(), iters=1, timed=False), launches, 20)
+            ms = dt / launches * 1e3
+            gbps = alg / (ms * 1e-3) / 1e9
+            row = {"ms_per_pass": round(ms, 5), "achieved": round(gbps, 1), "unit": "GB/s", "peak": HBM_PEAK_GBPS * world,
+                   "frac": round(gbps / (HBM_PEAK_GBPS * world), 4), "gsamples_per_s": round(S ** 3 / (ms * 1e-3) / 1e9, 1),
+                   "mvoxels_per_s": round(n ** 3 / ms / 1e3, 1), "bytes_per_pass": alg, "planes_of_rank0": [int(x0), int(x1)] if rank == 0 else None}
+            if world > 1:
+                box = [t1]
+                dist.broadcast_object_list(box, src=0)
+                t1 = box[0]
+            row["t_1rank_ms"] = round(t1, 5)
+            row["speedup_vs_1rank"] = round(t1 / ms, 3)
+            out.setdefault(f"{n}^3", {})[sc] = row
+        del whole, mine
+    h.close()
+    return out
+
+
 def roofline_legs(h, out, n_grid, scene, params, consts):
     """P1 / P2a / write ceiling, HIP-event timed on the handle's stream (N = 1 only)."""
     buf = torch.empty((n_grid + 1) ** 3, dtype=torch.float32, device="cuda")
@@ -454,6 +498,9 @@ def main():
             "mtris_per_s": round(tris * k / dt / 1e6, 2), "triangles": tris, "vertices": verts,
             "ranks_seen": one_mesh["ranks_seen"], "one_mesh": one_mesh,
         }
+        job.arm_watchdog(300, "sharded dense P1 leg")
+        out["dense_p1_sharded"] = dense_p1_sharded_leg(pkg, job, local_rank, args.scene, params)
+        job.disarm_watchdog()
         if not args.no_replicas:
             # extra: N independent regens, one per GPU, no exchange (objects / frames shard trivially) -- not the judged figure
             job.arm_watchdog(300, "replicas leg")

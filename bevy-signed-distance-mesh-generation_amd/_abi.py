@@ -122,6 +122,7 @@ SYMBOLS = {
     "sdmesh_download_voxels": (_i, [_vp, _vp]),
     "sdmesh_regen_dense": (_i, [_vp, _i, ctypes.POINTER(RegenInfo)]),
     "sdmesh_sample_dense": (_i, [_vp, _u32, _vp, ctypes.POINTER(ctypes.c_float)]),
+    "sdmesh_sample_dense_slab": (_i, [_vp, _u32, _u32, _u32, _vp, _i, ctypes.POINTER(ctypes.c_float)]),
     "sdmesh_time_kernel": (_i, [_vp, _i, _u32, _vp, _i, ctypes.POINTER(ctypes.c_float)]),
     "sdmesh_profile_stages": (_i, [_vp, _vp, _sz, _vp, _i, ctypes.POINTER(_i)]),
     "sdmesh_profile_rounds": (_i, [_vp, ctypes.POINTER(ctypes.c_uint64)]),

@@ -1483,16 +1483,18 @@ int sdmesh_download_voxels(sdmesh_handle *h, struct Point *voxels) {
     return SDMESH_OK;
 }
 
-static hipError_t launch_p1(sdmesh_handle *h, float *d_out, uint32_t N) {
+static hipError_t launch_p1(sdmesh_handle *h, float *d_out, uint32_t N, uint32_t x0, uint32_t x1) {
+    // planes [x0, x1) of the x-outer volume into d_out[0 ..); the whole volume is (0, N + 1)
     const int grid = h->dense_grid > 0 ? h->dense_grid : 8 * h->grid;
     // measured (round-1 sweep): the write-bound sphere wants whole 16-B aligned cache lines per store (flat
     // quads, 5.5 TB/s vs 3.9 with dword-aligned row stores); the VALU-bound scenes want the leaner row kernel
     const bool rows = h->dense_rows == 2 ? (h->scene != SDMESH_SCENE_SPHERE) : (h->dense_rows != 0);
     const uint64_t total = (uint64_t) (N + 1) * (N + 1) * (N + 1);
-    if (!rows && h->dense_q1 && N >= 1u && total < 0xFFFFFFF0ull) return launch_sample_dense_q1(h->stream, h->scene, h->d_sp, d_out, N, h->dense_nt != 0);
-    return rows ? launch_sample_dense_rows(h->stream, grid, h->scene, h->d_sp, d_out, N, h->dense_nt != 0)
-                         : launch_sample_dense(h->stream, grid, h->scene, h->d_sp, d_out, N, h->dense_nt != 0, h->dense_contig != 0);
+    if (!rows && h->dense_q1 && N >= 1u && total < 0xFFFFFFF0ull) return launch_sample_dense_q1(h->stream, h->scene, h->d_sp, d_out, N, h->dense_nt != 0, x0, x1);
+    return rows ? launch_sample_dense_rows(h->stream, grid, h->scene, h->d_sp, d_out, N, h->dense_nt != 0, x0, x1)
+                         : launch_sample_dense(h->stream, grid, h->scene, h->d_sp, d_out, N, h->dense_nt != 0, h->dense_contig != 0, x0, x1);
 }
+static hipError_t launch_p1(sdmesh_handle *h, float *d_out, uint32_t N) { return launch_p1(h, d_out, N, 0u, N + 1u); }
 
 int sdmesh_regen_dense(sdmesh_handle *h, int levels, sdmesh_regen_info *info) {
     if (!h) return SDMESH_ERR_INVALID;
@@ -1564,6 +1566,25 @@ int sdmesh_sample_dense(sdmesh_handle *h, uint32_t N, float *d_out, float *kerne
     HIPCHK(hipEventRecord(h->ev1, h->stream));
     HIPCHK(hipStreamSynchronize(h->stream));
     if (kernel_ms) HIPCHK(hipEventElapsedTime(kernel_ms, h->ev0, h->ev1));
+    return SDMESH_OK;
+}
+
+int sdmesh_sample_dense_slab(sdmesh_handle *h, uint32_t N, uint32_t x_begin, uint32_t x_end, float *d_out, int iters, float *avg_ms) {
+    if (!h || N == 0 || N > 4096 || iters < 1) return SDMESH_ERR_INVALID;
+    if (x_begin > x_end || x_end > N + 1u) return fail(h, SDMESH_ERR_INVALID, "x planes [%u, %u) outside the lattice [0, %u)", x_begin, x_end, N + 1u);
+    if (x_end > x_begin && !d_out) return SDMESH_ERR_INVALID;
+    HIPCHK(hipSetDevice(h->device));
+    SDCHK(sync_scene(h));
+    const bool timed = avg_ms != nullptr;
+    if (timed) HIPCHK(hipEventRecord(h->ev0, h->stream));
+    for (int i = 0; i < iters; i++) HIPCHK(launch_p1(h, d_out, N, x_begin, x_end));
+    if (timed) {
+        HIPCHK(hipEventRecord(h->ev1, h->stream));
+        HIPCHK(hipStreamSynchronize(h->stream));
+        float ms = 0.0f;
+        HIPCHK(hipEventElapsedTime(&ms, h->ev0, h->ev1));
+        *avg_ms = ms / (float) iters;
+    }
     return SDMESH_OK;
 }
 

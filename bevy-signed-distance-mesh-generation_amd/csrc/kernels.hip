@@ -2376,7 +2376,7 @@ __global__ void k_set_u32(uint32_t *p, uint32_t v) { *p = v; }
 // ------------------------------------------------------------------------------------------
 template <int SCENE, bool NT>
 __global__ __launch_bounds__(256) void k_sample_dense(float *__restrict__ out, uint32_t N, uint64_t total, const SceneParams *__restrict__ spp,
-                                                       uint32_t contig) {
+                                                       uint32_t contig, uint64_t first /* flat index of out[0] in the volume (x-slabs) */) {
     const SceneParams &sp = *spp;  // scene uniform in device memory (a captured graph replays with new values)
     // Flat quads (4 consecutive samples, 16-B aligned float4 store) over the x-outer / z-inner volume.
     // (x, y, z) of a thread's first quad comes from one division; every further grid-stride step adds
@@ -2398,8 +2398,8 @@ __global__ __launch_bounds__(256) void k_sample_dense(float *__restrict__ out, u
     }
     if (qd >= qlim) return;
     uint64_t i0 = qd << 2;
-    uint32_t z = (uint32_t) (i0 % S);
-    uint64_t r = i0 / S;
+    uint32_t z = (uint32_t) ((i0 + first) % S);
+    uint64_t r = (i0 + first) / S;
     uint32_t y = (uint32_t) (r % S), x = (uint32_t) (r / S);
     const uint64_t st4 = stride << 2;
     const uint32_t sz = (uint32_t) (st4 % S), sy = (uint32_t) ((st4 / S) % S), sx = (uint32_t) (st4 / S / S);
@@ -2484,7 +2484,8 @@ __device__ __forceinline__ uint32_t div_magic(uint32_t n, DivMagic d) {
 
 template <int SCENE, bool NT>
 __global__ __launch_bounds__(256) void k_sample_dense_q1(float *__restrict__ out, uint32_t N, uint32_t total, const SceneParams *__restrict__ spp,
-                                                          DivMagic dS, float h /* = 5.0f / (float) N, computed on the host: the same IEEE quotient */) {
+                                                          DivMagic dS, float h /* = 5.0f / (float) N, computed on the host: the same IEEE quotient */,
+                                                          uint32_t first /* flat index of out[0] in the volume (x-slabs); first + total < 2^32 */) {
     typedef float v4f __attribute__((ext_vector_type(4)));
     const SceneParams &sp = *spp;
     const uint32_t S = N + 1u;
@@ -2493,7 +2494,7 @@ __global__ __launch_bounds__(256) void k_sample_dense_q1(float *__restrict__ out
     // (x, y, z) of the WAVE's first sample on the scalar unit: two magic divisions of the workgroup's first index, then the wave's
     // offset and at most two row steps (a piece is 1 024 consecutive samples, a row has S >= 512 of them), all on uniform values.
     // A wave's 256 samples touch at most two rows, so a lane needs one compare and three selects.
-    const uint32_t iw = blockIdx.x << 10;
+    const uint32_t iw = first + (blockIdx.x << 10);
     const uint32_t r0 = div_magic(iw, dS), x0 = div_magic(r0, dS);
     uint32_t x, y, z;
     if (S >= 512u) {                                         // (the usual case: no loop)
@@ -2508,8 +2509,8 @@ __global__ __launch_bounds__(256) void k_sample_dense_q1(float *__restrict__ out
         const bool c = z >= S;
         z = c ? z - S : z; y = c ? ya : yw; x = c ? xa : xw;
     } else {
-        const uint32_t rr = div_magic(i0, dS);
-        z = i0 - rr * S; x = div_magic(rr, dS); y = rr - x * S;
+        const uint32_t rr = div_magic(first + i0, dS);
+        z = (first + i0) - rr * S; x = div_magic(rr, dS); y = rr - x * S;
     }
     float v[4];
     if (SCENE == SCENE_SPHERE) {
@@ -2576,14 +2577,15 @@ __global__ __launch_bounds__(256) void k_sample_dense_q1(float *__restrict__ out
 }
 
 template <int SCENE, bool NT>
-__global__ __launch_bounds__(256) void k_sample_dense_rows(float *__restrict__ out, uint32_t N, const SceneParams *__restrict__ spp) {
+__global__ __launch_bounds__(256) void k_sample_dense_rows(float *__restrict__ out, uint32_t N, const SceneParams *__restrict__ spp,
+                                                            uint32_t xb /* first x plane */, uint32_t xe /* one past the last: out[0] is sample (xb, 0, 0) */) {
     typedef float v4fu __attribute__((ext_vector_type(4), aligned(4)));
     const SceneParams &sp = *spp;
     const float h = 5.0f / (float) N;
-    const uint32_t S = N + 1u, nrows = S * S, nq = S >> 2, lane = lane_id();
+    const uint32_t S = N + 1u, nrows = S * (xe - xb), nq = S >> 2, lane = lane_id();
     const uint32_t nwaves = gridDim.x * (blockDim.x >> 6);
     for (uint32_t row = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6); row < nrows; row += nwaves) {
-        const uint32_t x = row / S, y = row - x * S;
+        const uint32_t xl = row / S, y = row - xl * S, x = xb + xl;
         RowCtx<SCENE> rc;
         rc.init((float) x * h - 2.5f, (float) y * h - 2.5f, sp);
         float *__restrict__ o = out + (uint64_t) row * S;
@@ -2842,18 +2844,21 @@ hipError_t launch_triangles_direct(hipStream_t st, int scene, const SceneParams 
     return hipGetLastError();
 }
 
-hipError_t launch_sample_dense_rows(hipStream_t st, int grid, int scene, const SceneParams *sp, float *out, uint32_t N, bool nt) {
-    if (nt) { SDM_DISPATCH(scene, hipLaunchKernelGGL((k_sample_dense_rows<S, true>), dim3(grid), dim3(256), 0, st, out, N, sp)); }
-    else { SDM_DISPATCH(scene, hipLaunchKernelGGL((k_sample_dense_rows<S, false>), dim3(grid), dim3(256), 0, st, out, N, sp)); }
+hipError_t launch_sample_dense_rows(hipStream_t st, int grid, int scene, const SceneParams *sp, float *out, uint32_t N, bool nt,
+                                    uint32_t x0, uint32_t x1) {
+    if (x1 <= x0) return hipSuccess;
+    if (nt) { SDM_DISPATCH(scene, hipLaunchKernelGGL((k_sample_dense_rows<S, true>), dim3(grid), dim3(256), 0, st, out, N, sp, x0, x1)); }
+    else { SDM_DISPATCH(scene, hipLaunchKernelGGL((k_sample_dense_rows<S, false>), dim3(grid), dim3(256), 0, st, out, N, sp, x0, x1)); }
     return hipGetLastError();
 }
 
 hipError_t launch_sample_dense(hipStream_t st, int grid, int scene, const SceneParams *sp, float *out, uint32_t N, bool nt,
-                               bool contig) {
-    const uint64_t total = (uint64_t) (N + 1) * (N + 1) * (N + 1);
+                               bool contig, uint32_t x0, uint32_t x1) {
+    const uint64_t plane = (uint64_t) (N + 1) * (N + 1), total = plane * (x1 - x0), first = plane * x0;
     const uint32_t cg = contig ? 1u : 0u;
-    if (nt) { SDM_DISPATCH(scene, hipLaunchKernelGGL((k_sample_dense<S, true>), dim3(grid), dim3(256), 0, st, out, N, total, sp, cg)); }
-    else { SDM_DISPATCH(scene, hipLaunchKernelGGL((k_sample_dense<S, false>), dim3(grid), dim3(256), 0, st, out, N, total, sp, cg)); }
+    if (total == 0) return hipSuccess;
+    if (nt) { SDM_DISPATCH(scene, hipLaunchKernelGGL((k_sample_dense<S, true>), dim3(grid), dim3(256), 0, st, out, N, total, sp, cg, first)); }
+    else { SDM_DISPATCH(scene, hipLaunchKernelGGL((k_sample_dense<S, false>), dim3(grid), dim3(256), 0, st, out, N, total, sp, cg, first)); }
     return hipGetLastError();
 }
 
@@ -2873,13 +2878,15 @@ static DivMagic make_div_magic(uint32_t d) {
     return r;
 }
 
-hipError_t launch_sample_dense_q1(hipStream_t st, int scene, const SceneParams *sp, float *out, uint32_t N, bool nt) {
-    const uint64_t total = (uint64_t) (N + 1) * (N + 1) * (N + 1);
-    if (total >= 0xFFFFFFF0ull || N < 1u) return hipErrorInvalidValue;
+hipError_t launch_sample_dense_q1(hipStream_t st, int scene, const SceneParams *sp, float *out, uint32_t N, bool nt, uint32_t x0, uint32_t x1) {
+    // planes x0 .. x1 - 1 of the volume into out[0 ..): the whole volume must index in 32 bits (the caller checks, so do we)
+    const uint64_t plane = (uint64_t) (N + 1) * (N + 1), total = plane * (x1 - x0), first = plane * x0;
+    if (plane * (N + 1) >= 0xFFFFFFF0ull || N < 1u || x1 < x0 || x1 > N + 1u) return hipErrorInvalidValue;
+    if (total == 0) return hipSuccess;
     const DivMagic dS = make_div_magic(N + 1u);
     const uint32_t grid = (uint32_t) (((total + 3ull) / 4ull + 255ull) / 256ull);
-    if (nt) { SDM_DISPATCH(scene, hipLaunchKernelGGL((k_sample_dense_q1<S, true>), dim3(grid), dim3(256), 0, st, out, N, (uint32_t) total, sp, dS, 5.0f / (float) N)); }
-    else { SDM_DISPATCH(scene, hipLaunchKernelGGL((k_sample_dense_q1<S, false>), dim3(grid), dim3(256), 0, st, out, N, (uint32_t) total, sp, dS, 5.0f / (float) N)); }
+    if (nt) { SDM_DISPATCH(scene, hipLaunchKernelGGL((k_sample_dense_q1<S, true>), dim3(grid), dim3(256), 0, st, out, N, (uint32_t) total, sp, dS, 5.0f / (float) N, (uint32_t) first)); }
+    else { SDM_DISPATCH(scene, hipLaunchKernelGGL((k_sample_dense_q1<S, false>), dim3(grid), dim3(256), 0, st, out, N, (uint32_t) total, sp, dS, 5.0f / (float) N, (uint32_t) first)); }
     return hipGetLastError();
 }
 

@@ -93,11 +93,12 @@ hipError_t launch_expand_raw(hipStream_t st, int grid, const Vertex *uverts, con
                              const uint8_t *cubeidx, const uint32_t *trioff, uint32_t n, Triangle *out);
 hipError_t launch_triangles_direct(hipStream_t st, int scene, const SceneParams *sp, const Point *vox, uint32_t n, Point vs,
                                    Triangle *out);
-hipError_t launch_sample_dense_q1(hipStream_t st, int scene, const SceneParams *sp, float *out, uint32_t N, bool nt);   // one quad per thread (< 2^32 samples)
+// (x0, x1: the x planes [x0, x1) of the volume, written to out[0 ..) -- the whole volume is (0, N + 1))
+hipError_t launch_sample_dense_q1(hipStream_t st, int scene, const SceneParams *sp, float *out, uint32_t N, bool nt, uint32_t x0, uint32_t x1);   // one quad per thread (< 2^32 samples in the volume)
 hipError_t launch_stream_fill(hipStream_t st, int grid, float *out, uint64_t total, float value);
-hipError_t launch_sample_dense_rows(hipStream_t st, int grid, int scene, const SceneParams *sp, float *out, uint32_t N, bool nt);
+hipError_t launch_sample_dense_rows(hipStream_t st, int grid, int scene, const SceneParams *sp, float *out, uint32_t N, bool nt, uint32_t x0, uint32_t x1);
 hipError_t launch_sample_dense(hipStream_t st, int grid, int scene, const SceneParams *sp, float *out, uint32_t N, bool nt,
-                               bool contig);
+                               bool contig, uint32_t x0, uint32_t x1);
 hipError_t launch_create_field(hipStream_t st, Point *vox, uint32_t x0, uint32_t x1, uint32_t z0, uint32_t z1, uint32_t *n_out,
                                uint32_t *zero = nullptr, uint32_t nzero = 0, void *ff = nullptr, size_t ff_bytes = 0);
 hipError_t launch_raw_count(hipStream_t st, int grid, const Triangle *raw, const uint32_t *n_ptr, uint32_t *tilecnt);

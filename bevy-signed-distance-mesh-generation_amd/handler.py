@@ -436,6 +436,14 @@ class CudaHandler:
         self._chk(self._lib.sdmesh_sample_dense(self._h, int(N), ctypes.c_void_p(dev_ptr), ctypes.byref(ms)))
         return ms.value
 
+    def sample_dense_slab(self, N, x_begin, x_end, dev_ptr, iters=1, timed=True):
+        """P1 of the x planes [x_begin, x_end) into a device buffer of (x_end - x_begin) (N+1)^2 floats; ms per launch when timed,
+        else the launches are only enqueued on the handle's stream (None)."""
+        ms = ctypes.c_float(0)
+        self._chk(self._lib.sdmesh_sample_dense_slab(self._h, int(N), int(x_begin), int(x_end), ctypes.c_void_p(dev_ptr), int(iters),
+                                                     ctypes.byref(ms) if timed else None))
+        return ms.value if timed else None
+
     def time_kernel(self, which, N, dev_ptr, iters):
         ms = ctypes.c_float(0)
         self._chk(self._lib.sdmesh_time_kernel(self._h, int(which), int(N), ctypes.c_void_p(dev_ptr), int(iters),

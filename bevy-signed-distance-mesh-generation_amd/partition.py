@@ -25,6 +25,12 @@ def slab_bounds(part, nparts):
     return INIT_FACTOR * part // nparts, INIT_FACTOR * (part + 1) // nparts
 
 
+def dense_slab_planes(N, part, nparts):
+    """x planes [x0, x1) of the dense (N+1)^3 lattice rank `part` samples (P1 shards with no exchange: x is the outermost index
+    of the volume, so a slab of planes is a contiguous range of it).  Same formula as the level-0 slabs, over N + 1 planes."""
+    return (N + 1) * part // nparts, (N + 1) * (part + 1) // nparts
+
+
 def merge_destinations(counts):
     """CPU restatement of the merge plan (k_merge_plan / k_merge_copy in csrc/kernels.hip), for the tests that run without a
     GPU and as the kernel's checker -- the product path calls `sdmesh_merge_by_column`, never this.

@@ -268,6 +268,14 @@ int sdmesh_regen_dense(sdmesh_handle *h, int levels, sdmesh_regen_info *info);
  * z inner, sample m at (float)m * (5/N) - 2.5.  *kernel_ms (optional) = HIP-event time. */
 int sdmesh_sample_dense(sdmesh_handle *h, uint32_t N, float *d_out, float *kernel_ms);
 
+/* P1 of one x-slab: the lattice planes x_begin <= x < x_end of the same volume into d_out[0 .. (x_end - x_begin) (N+1)^2), i.e. the
+ * contiguous range [x_begin (N+1)^2, x_end (N+1)^2) of what sdmesh_sample_dense writes (x is the outermost index) -- bit for bit
+ * the same samples, whatever the slab's phase against the 16-byte quads.  The dense pass shards over GPUs with no exchange at all:
+ * rank r of R takes the planes [r (N+1) / R, (r+1) (N+1) / R) (bench.py --gpus N, leg `dense_p1_sharded`).  `iters` launches are
+ * enqueued on the handle's stream; with avg_ms != NULL the call also synchronises and returns the HIP-event time per launch,
+ * with avg_ms == NULL it only enqueues (the caller owns the synchronisation).  An empty slab is a no-op. */
+int sdmesh_sample_dense_slab(sdmesh_handle *h, uint32_t N, uint32_t x_begin, uint32_t x_end, float *d_out, int iters, float *avg_ms);
+
 /* Time `iters` back-to-back launches of one internal kernel with HIP events on the handle's stream
  * (bench.py's live roofline measurement).  which: 0 = P1 sample_dense(N) into d_buf; 1 = P2a sign bits of d_buf;
  * 2 = write ceiling (P1's store stream over the same 4 (N+1)^3 bytes with no arithmetic). */

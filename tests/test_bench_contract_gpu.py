@@ -56,3 +56,9 @@ def test_one_mesh_line_keeps_the_contract_on_one_rank():
             row = j["one_mesh"][form][size]
             assert row["t_1rank_ms"] > 0 and row["ms_per_regen"] > 0 and row["triangles"] > 0
     assert (j["one_mesh"]["xslab_distributed_weld"]["512^3"]["triangles"], j["one_mesh"]["xslab_distributed_weld"]["512^3"]["vertices"]) == (530536, 265262)
+    d = j["dense_p1_sharded"]
+    for size in ("512^3", "1024^3"):
+        for sc in ("sphere", "sdobj"):
+            row = d[size][sc]
+            assert row["peak"] == 8000.0 and 0.0 < row["frac"] < 1.0 and row["t_1rank_ms"] > 0 and row["ms_per_pass"] > 0
+    assert d["512^3"]["sphere"]["planes_of_rank0"] == [0, 513]
