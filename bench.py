@@ -334,6 +334,20 @@ def roofline_legs(h, out, n_grid, scene, params, consts):
                                "bound, see roofline_step and DESIGN.md")
     if scene != "sphere":
         out["roofline_workload_scene"] = roofs[scene]
+    # the same pass over a volume eight times as large (BASELINE configs[3]'s grid): a launch is 0.6 ms instead of 0.08, so its
+    # ramp and drain (~8 us between dependent launches on one stream) weigh an eighth as much
+    try:
+        big = torch.empty((2 * n_grid + 1) ** 3, dtype=torch.float32, device="cuda")
+        h.set_scene("sphere")
+        h.time_kernel(0, 2 * n_grid, big.data_ptr(), 30)
+        msb = h.time_kernel(0, 2 * n_grid, big.data_ptr(), 20)
+        bb = 4.0 * (2 * n_grid + 1) ** 3
+        out["roofline"]["at_twice_the_grid"] = {"grid": 2 * n_grid, "bytes_per_launch": bb, "avg_launch_ms": round(msb, 5),
+                                                 "achieved": round(bb / (msb * 1e-3) / 1e9, 1), "unit": "GB/s",
+                                                 "frac": round(bb / (msb * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4)}
+        del big
+    finally:
+        h.set_scene(scene, params)
 
 
 def roofline_step_leg(pkg, local_rank, scene, params, levels, consts, info):
@@ -492,7 +506,9 @@ def main():
             "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"{args.scene} {n_grid}^3 (BASELINE configs[2]: reference scene sd_obj, 32^3 level-0 cells refined "
                                    f"x{args.levels}) as ONE mesh over {world} GPUs; the faster of the two one-mesh forms at this size is the "
-                                   f"headline: {form} (both are in one_mesh, each with its same-size 1-GPU time)",
+                                   f"headline: {form} (both are in one_mesh, each with its same-size 1-GPU time; they deliver different "
+                                   f"things: zslab_gather_root_weld leaves the whole indexed mesh on rank 0, xslab_distributed_weld leaves it "
+                                   f"distributed, every rank holding its slab's vertices and globally numbered triangles)",
                        "levels": args.levels, "grid": n_grid, "parallelism": f"{world} slabs of equal surface content, one per GPU",
                        "one_mesh_form": form},
             "mtris_per_s": round(tris * k / dt / 1e6, 2), "triangles": tris, "vertices": verts,
@@ -620,7 +636,8 @@ def main():
         for cy in (0.5, -0.5, 0.0):                  # widest frames first: one capacity plan covers the animation
             ha.set_scene("anim", [cy]); ha.regen(args.levels)
         anim = {"what": "120 frames, new scene uniform + full regen per frame (BASELINE configs[4]); hipGraph replay as the "
-                        "config names it, and plain eager launches of the same chain beside it", "grid": n_grid}
+                        "config names it, and plain eager launches of the same chain beside it; each mode is run twice (eager, graph, eager, "
+                        "graph) and the better pass of a mode is the one reported, frames_in_flight_3 likewise (best of 2 passes)", "grid": n_grid}
         for mode, flag in (("eager", 0), ("hipgraph", 1), ("eager", 0), ("hipgraph", 1)):   # two passes each, the better one counts
             ha.set_option("graph", flag)
             for f in range(20):
