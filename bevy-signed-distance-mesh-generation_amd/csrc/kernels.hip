@@ -2584,29 +2584,46 @@ __global__ __launch_bounds__(256) void k_sample_dense_rows(float *__restrict__ o
     const float h = 5.0f / (float) N;
     const uint32_t S = N + 1u, nrows = S * (xe - xb), nq = S >> 2, lane = lane_id();
     const uint32_t nwaves = gridDim.x * (blockDim.x >> 6);
-    for (uint32_t row = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6); row < nrows; row += nwaves) {
-        const uint32_t xl = row / S, y = row - xl * S, x = xb + xl;
-        RowCtx<SCENE> rc;
-        rc.init((float) x * h - 2.5f, (float) y * h - 2.5f, sp);
-        float *__restrict__ o = out + (uint64_t) row * S;
-        for (uint32_t q = lane; q < nq; q += 64) {
-            const uint32_t z = q << 2;
-            v4fu v;
+    // A wave takes ROWS_PER_WAVE consecutive rows at a time.  The S % 4 samples behind a row's last whole quad (one, for the odd
+    // S of a power-of-two grid) would cost the whole wave a full evaluation per row for one busy lane (a third on top of the two
+    // quad passes of a 513-sample row); they are evaluated for all rows of the group together instead, one lane per sample
+    // with its own row context.
+    constexpr uint32_t ROWS_PER_WAVE = 16;
+    const uint32_t tails = S & 3u, ngroups = (nrows + ROWS_PER_WAVE - 1u) / ROWS_PER_WAVE;
+    for (uint32_t g = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6); g < ngroups; g += nwaves) {
+        const uint32_t row0 = g * ROWS_PER_WAVE, rows = nrows - row0 < ROWS_PER_WAVE ? nrows - row0 : ROWS_PER_WAVE;
+        uint32_t xl = row0 / S, y = row0 - xl * S;                      // (uniform)
+        if (nq) {
+            for (uint32_t r = 0; r < rows; r++) {
+                RowCtx<SCENE> rc;
+                rc.init((float) (xb + xl) * h - 2.5f, (float) y * h - 2.5f, sp);
+                float *__restrict__ o = out + (uint64_t) (row0 + r) * S;
+                for (uint32_t q = lane; q < nq; q += 64) {
+                    const uint32_t z = q << 2;
+                    v4fu v;
 #if defined(SDM_HAVE_PAIRS)
-            const v2f lo = row_eval2<SCENE>(rc, mk2((float) z * h - 2.5f, (float) (z + 1u) * h - 2.5f), sp);
-            const v2f hi = row_eval2<SCENE>(rc, mk2((float) (z + 2u) * h - 2.5f, (float) (z + 3u) * h - 2.5f), sp);
-            v.x = lo.x; v.y = lo.y; v.z = hi.x; v.w = hi.y;
+                    const v2f lo = row_eval2<SCENE>(rc, mk2((float) z * h - 2.5f, (float) (z + 1u) * h - 2.5f), sp);
+                    const v2f hi = row_eval2<SCENE>(rc, mk2((float) (z + 2u) * h - 2.5f, (float) (z + 3u) * h - 2.5f), sp);
+                    v.x = lo.x; v.y = lo.y; v.z = hi.x; v.w = hi.y;
 #else
-            v.x = rc.eval((float) z * h - 2.5f, sp);
-            v.y = rc.eval((float) (z + 1u) * h - 2.5f, sp);
-            v.z = rc.eval((float) (z + 2u) * h - 2.5f, sp);
-            v.w = rc.eval((float) (z + 3u) * h - 2.5f, sp);
+                    v.x = rc.eval((float) z * h - 2.5f, sp);
+                    v.y = rc.eval((float) (z + 1u) * h - 2.5f, sp);
+                    v.z = rc.eval((float) (z + 2u) * h - 2.5f, sp);
+                    v.w = rc.eval((float) (z + 3u) * h - 2.5f, sp);
 #endif
-            if (NT) __builtin_nontemporal_store(v, reinterpret_cast<v4fu *>(o + z));
-            else *reinterpret_cast<v4fu *>(o + z) = v;
+                    if (NT) __builtin_nontemporal_store(v, reinterpret_cast<v4fu *>(o + z));
+                    else *reinterpret_cast<v4fu *>(o + z) = v;
+                }
+                if (++y == S) { y = 0; ++xl; }
+            }
         }
-        const uint32_t zt = (nq << 2) + lane;
-        if (zt < S) o[zt] = rc.eval((float) zt * h - 2.5f, sp);
+        if (lane < rows * tails) {                                      // (tails <= 3, so at most 48 lanes)
+            const uint32_t r = lane / tails, k = lane - r * tails, row = row0 + r;
+            const uint32_t tx = row / S, ty = row - tx * S, tz = (nq << 2) + k;
+            RowCtx<SCENE> rc;
+            rc.init((float) (xb + tx) * h - 2.5f, (float) ty * h - 2.5f, sp);
+            out[(uint64_t) row * S + tz] = rc.eval((float) tz * h - 2.5f, sp);
+        }
     }
 }
 
@@ -2847,6 +2864,10 @@ hipError_t launch_triangles_direct(hipStream_t st, int scene, const SceneParams 
 hipError_t launch_sample_dense_rows(hipStream_t st, int grid, int scene, const SceneParams *sp, float *out, uint32_t N, bool nt,
                                     uint32_t x0, uint32_t x1) {
     if (x1 <= x0) return hipSuccess;
+    if (grid <= 0) {       // one group of 16 rows per wave: the dispatcher balances the waves (a fixed grid leaves 2 or 3 groups per wave)
+        const uint64_t ngroups = ((uint64_t) (N + 1) * (x1 - x0) + 15ull) / 16ull;
+        grid = (int) std::min<uint64_t>((ngroups + 3ull) / 4ull, 0x7FFFFFFFull);
+    }
     if (nt) { SDM_DISPATCH(scene, hipLaunchKernelGGL((k_sample_dense_rows<S, true>), dim3(grid), dim3(256), 0, st, out, N, sp, x0, x1)); }
     else { SDM_DISPATCH(scene, hipLaunchKernelGGL((k_sample_dense_rows<S, false>), dim3(grid), dim3(256), 0, st, out, N, sp, x0, x1)); }
     return hipGetLastError();
