@@ -115,6 +115,7 @@ struct sdmesh_handle {
     bool wide_active = false;  // the wide form is in use (forced, or a vertex did not fit the packed 3 x 21-bit key)
     bool welded = false;       // tri_e holds the final corner order
     int dense_grid = 16384;    // workgroups for k_sample_dense
+    int dense_aligned = 1;     // option "dense_aligned": sd_obj family rows through k_sample_dense_rows_aligned (0 = the plain row kernel)
     int dense_nt = 1;          // nontemporal stores in k_sample_dense
     int dense_contig = 1;      // flat P1 kernel: every workgroup writes one contiguous run (measured best)
     int dense_q1 = 1;          // flat P1 kernel: one quad per thread, one 4 KiB piece per workgroup (the shape the write stream is fastest in)
@@ -1193,7 +1194,8 @@ int sdmesh_set_option(sdmesh_handle *h, const char *name, int value) {
         return SDMESH_OK;
     }
     if (!strcmp(name, "dense_grid")) { h->dense_grid = value; return SDMESH_OK; }
-    if (!strcmp(name, "dense_nt")) { h->dense_nt = value ? 1 : 0; return SDMESH_OK; }
+    if (!strcmp(name, "dense_aligned")) { h->dense_aligned = value != 0; return SDMESH_OK; }
+    if (!strcmp(name, "dense_nt")) { h->dense_nt = value < 0 ? 0 : (value > 2 ? 2 : value); return SDMESH_OK; }    // 2: also in the aligned row kernel
     if (!strcmp(name, "dense_rows")) { h->dense_rows = value; return SDMESH_OK; }
     if (!strcmp(name, "dense_q1")) { h->dense_q1 = value ? 1 : 0; return SDMESH_OK; }
     if (!strcmp(name, "dense_contig")) { h->dense_contig = value ? 1 : 0; return SDMESH_OK; }
@@ -1491,7 +1493,7 @@ static hipError_t launch_p1(sdmesh_handle *h, float *d_out, uint32_t N, uint32_t
     const bool rows = h->dense_rows == 2 ? (h->scene != SDMESH_SCENE_SPHERE) : (h->dense_rows != 0);
     const uint64_t total = (uint64_t) (N + 1) * (N + 1) * (N + 1);
     if (!rows && h->dense_q1 && N >= 1u && total < 0xFFFFFFF0ull) return launch_sample_dense_q1(h->stream, h->scene, h->d_sp, d_out, N, h->dense_nt != 0, x0, x1);
-    return rows ? launch_sample_dense_rows(h->stream, h->dense_grid, h->scene, h->d_sp, d_out, N, h->dense_nt != 0, x0, x1)
+    return rows ? launch_sample_dense_rows(h->stream, h->dense_grid, h->scene, h->d_sp, d_out, N, h->dense_nt != 0, x0, x1, h->dense_aligned != 0, h->dense_nt == 2)
                          : launch_sample_dense(h->stream, grid, h->scene, h->d_sp, d_out, N, h->dense_nt != 0, h->dense_contig != 0, x0, x1);
 }
 static hipError_t launch_p1(sdmesh_handle *h, float *d_out, uint32_t N) { return launch_p1(h, d_out, N, 0u, N + 1u); }

@@ -2627,6 +2627,111 @@ __global__ __launch_bounds__(256) void k_sample_dense_rows(float *__restrict__ o
     }
 }
 
+// P1 for sd_obj / its animated form, row-structured with WHOLE-LINE stores and the z terms out of the row loop.
+//
+// k_sample_dense_rows pays, per 513-sample row, two 117-instruction quad passes of which a third rebuilds terms that depend on z
+// alone (the lattice coordinate, the skeleton's three z residuals, z^2), a 50-instruction row context every lane computes
+// redundantly, and dword-aligned 16-byte stores that straddle cache lines (1.10x the bytes).  Here a wave takes ROWS rows whose
+// starts have the SAME phase against the 16-byte quads of the output (rows lr = c + 4 i: a row starts at lr * S floats), so that
+//   * one set of z terms per lane (two aligned quads = 8 samples x {sz, mz, az, z^2}) serves all the wave's rows;
+//   * every quad store is 16-byte aligned (nontemporal, whole lines across the wave);
+//   * the row contexts are computed once, one lane per row, and broadcast with v_readlane (4 scalars per row);
+//   * the <= 3 samples in front of a row's first aligned quad and the <= 3 behind its last are evaluated for the whole group
+//     together, one lane per sample.
+// Same operations in the same order per sample as RowCtx<SCENE>::eval (the 2^-120 nudge of the lean square roots rides on the
+// row terms: every term is 0 or >= 2^-60, so (a + 2^-120) + t == (a + t) + 2^-120 bit for bit) -> the same bits
+// (tests: test_dense_sample_matches_oracle, ..._at_full_size_..., test_dense_slabs_concatenate_to_the_whole_volume).
+template <int SCENE, bool NT, uint32_t ROWS>
+__global__ __launch_bounds__(256) void k_sample_dense_rows_aligned(float *__restrict__ out /* 16-byte aligned */, uint32_t N,
+                                                                    const SceneParams *__restrict__ spp, uint32_t xb, uint32_t xe) {
+    static_assert(SCENE == SCENE_SDOBJ || SCENE == SCENE_ANIM, "sd_obj family only");
+#if defined(SDM_HAVE_PAIRS)                      // (device pass only: the packed 2-vector helpers of sdf.hpp)
+    typedef float v4f __attribute__((ext_vector_type(4)));
+    const SceneParams &sp = *spp;
+    const float h = 5.0f / (float) N;
+    const uint32_t S = N + 1u, nrows = S * (xe - xb), lane = lane_id();
+#if defined(SDM_FAST_MATH)
+    const float nud = 0.0f;
+#else
+    const float nud = SDM_SQRT_NUDGE;
+#endif
+    const uint32_t per_class = (((nrows + 3u) >> 2) + ROWS - 1u) / ROWS;            // groups per phase class
+    const uint32_t g = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    if (g >= 4u * per_class) return;
+    const uint32_t c = g & 3u, i0 = (g >> 2) * ROWS;                                 // rows lr = c + 4 (i0 + j), j < 16
+    const uint32_t head = (4u - ((c * (S & 3u)) & 3u)) & 3u;                         // samples in front of the first aligned quad
+    const uint32_t nqa = (S - head) >> 2, tail0 = head + (nqa << 2), ht = head + (S - tail0);
+    // ---- the group's row contexts, one lane per row
+    float ca0 = 0.0f, ca1 = 0.0f, ca2 = 0.0f, cc = 0.0f;
+    {
+        const uint32_t lr = c + 4u * (i0 + (lane & (ROWS - 1u)));
+        const uint32_t xl = lr / S, y = lr - xl * S;
+        const float px = (float) (xb + xl) * h - 2.5f, py = (float) y * h - 2.5f;
+        const SkelX sx = skel_x(px);
+        const SkelY sy = skel_y(py);
+        float ay = py;
+        if (SCENE == SCENE_ANIM) ay = py - sp.p[0];
+        ca0 = (sx.ax + sy.sy) + nud; ca1 = (sx.sx15 + sy.ay) + nud; ca2 = (sx.mx + sy.sy) + nud;
+        cc = (px * px + ay * ay) + nud;
+    }
+    uint32_t rows = 0;                                                               // valid rows of the group (a prefix)
+    if (c + 4u * i0 < nrows) { rows = (nrows - 1u - c - 4u * i0) / 4u + 1u; if (rows > ROWS) rows = ROWS; }
+    // ---- aligned quads, 128 per chunk (two per lane), z terms hoisted over the rows
+    for (uint32_t qb = 0; qb < nqa; qb += 128u) {
+        v2f sz[4], mz[4], az[4], z2[4];
+        uint32_t zq[2];
+        bool on[2];
+#pragma unroll
+        for (int u = 0; u < 2; u++) {
+            const uint32_t q = qb + lane + 64u * u;
+            on[u] = q < nqa;
+            zq[u] = head + (q << 2);
+#pragma unroll
+            for (int p = 0; p < 2; p++) {
+                const v2f pz = mk2((float) (zq[u] + 2u * p) * h - 2.5f, (float) (zq[u] + 2u * p + 1u) * h - 2.5f);
+                az[2 * u + p] = along_sq2(pz, -0.25f, 0.5f);
+                sz[2 * u + p] = sq2(abs2(pz) - 0.25f);
+                mz[2 * u + p] = min2(sq2(pz - (-0.25f)), sq2(pz - 2.75f));
+                z2[2 * u + p] = pz * pz;
+            }
+        }
+        for (uint32_t j = 0; j < rows; j++) {
+            const float a0 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, ca0), j));
+            const float a1 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, ca1), j));
+            const float a2 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, ca2), j));
+            const float cs = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, cc), j));
+            float *__restrict__ o = out + (uint64_t) (c + 4u * (i0 + j)) * S;
+#pragma unroll
+            for (int u = 0; u < 2; u++) {
+                if (on[u]) {
+                    v2f r[2];
+#pragma unroll
+                    for (int p = 0; p < 2; p++) {
+                        const v2f m = min2(min2(a0 + sz[2 * u + p], a1 + mz[2 * u + p]), a2 + az[2 * u + p]);
+                        const v2f d1 = sqrt_rn_normal2_nonudge(m) - 0.1f;
+                        const v2f d2 = sqrt_rn_normal2_nonudge(cs + z2[2 * u + p]) - 1.0f;
+                        r[p] = smooth_min2(d1, d2, 0.5f);
+                    }
+                    const v4f v = {r[0].x, r[0].y, r[1].x, r[1].y};
+                    if (NT) __builtin_nontemporal_store(v, reinterpret_cast<v4f *>(o + zq[u]));
+                    else *reinterpret_cast<v4f *>(o + zq[u]) = v;
+                }
+            }
+        }
+    }
+    // ---- the rows' unaligned ends: ht <= 6 samples per row, one lane each
+    for (uint32_t u = lane; u < rows * ht; u += 64u) {
+        const uint32_t j = u / ht, k = u - j * ht;
+        const uint32_t z = k < head ? k : tail0 + (k - head);
+        const uint32_t lr = c + 4u * (i0 + j);
+        const uint32_t xl = lr / S, y = lr - xl * S;
+        RowCtx<SCENE> rc;
+        rc.init((float) (xb + xl) * h - 2.5f, (float) y * h - 2.5f, sp);
+        out[(uint64_t) lr * S + z] = rc.eval((float) z * h - 2.5f, sp);
+    }
+#endif
+}
+
 // ------------------------------------------------------------------------------------------
 // host-side launchers (scene dispatch)
 // ------------------------------------------------------------------------------------------
@@ -2862,8 +2967,28 @@ hipError_t launch_triangles_direct(hipStream_t st, int scene, const SceneParams 
 }
 
 hipError_t launch_sample_dense_rows(hipStream_t st, int grid, int scene, const SceneParams *sp, float *out, uint32_t N, bool nt,
-                                    uint32_t x0, uint32_t x1) {
+                                    uint32_t x0, uint32_t x1, bool aligned_rows, bool nt_rows) {
     if (x1 <= x0) return hipSuccess;
+#if defined(SDM_NO_PAIRS)
+    aligned_rows = false;                    // (the aligned kernel is written on the packed 2-vector helpers)
+#endif
+    if ((scene == SCENE_SDOBJ || scene == SCENE_ANIM) && aligned_rows && ((uintptr_t) out & 15u) == 0 && N >= 3u) {
+        // whole-line stores, z terms hoisted over 4 same-phase rows (k_sample_dense_rows_aligned): one group per wave.  Measured at
+        // 512^3 (sd_obj): 16 / 8 / 4 / 2 / 1 rows per wave 0.131 / 0.126 / 0.121 / 0.144 / 0.163 ms with plain stores (long waves
+        // leave the SIMDs two-thirds empty in their last round; short ones lose the hoisting), 0.151 / 0.152 / 0.127 / 0.147 / 0.166
+        // with nontemporal ones -- hence `nt_rows` (option dense_nt = 2) is off by default for this kernel
+        constexpr uint32_t R = 4;
+        const uint64_t nrows = (uint64_t) (N + 1) * (x1 - x0), ngroups = 4ull * ((((nrows + 3ull) >> 2) + R - 1ull) / R);
+        const int g2 = (int) std::min<uint64_t>((ngroups + 3ull) / 4ull, 0x7FFFFFFFull);
+        if (scene == SCENE_SDOBJ) {
+            if (nt_rows) hipLaunchKernelGGL((k_sample_dense_rows_aligned<SCENE_SDOBJ, true, R>), dim3(g2), dim3(256), 0, st, out, N, sp, x0, x1);
+            else hipLaunchKernelGGL((k_sample_dense_rows_aligned<SCENE_SDOBJ, false, R>), dim3(g2), dim3(256), 0, st, out, N, sp, x0, x1);
+        } else {
+            if (nt_rows) hipLaunchKernelGGL((k_sample_dense_rows_aligned<SCENE_ANIM, true, R>), dim3(g2), dim3(256), 0, st, out, N, sp, x0, x1);
+            else hipLaunchKernelGGL((k_sample_dense_rows_aligned<SCENE_ANIM, false, R>), dim3(g2), dim3(256), 0, st, out, N, sp, x0, x1);
+        }
+        return hipGetLastError();
+    }
     if (grid <= 0) {       // one group of 16 rows per wave: the dispatcher balances the waves (a fixed grid leaves 2 or 3 groups per wave)
         const uint64_t ngroups = ((uint64_t) (N + 1) * (x1 - x0) + 15ull) / 16ull;
         grid = (int) std::min<uint64_t>((ngroups + 3ull) / 4ull, 0x7FFFFFFFull);

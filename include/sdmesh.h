@@ -127,7 +127,10 @@ int sdmesh_use_own_stream(sdmesh_handle *h);
  *   "refine2" = 1, "mask_chunk" = 8|16|32   refine variants
  *   "dense_q1" = 0      dense sample pass (P1) of the flat kernels in the persistent shape (default 1: one float4 store per thread,
  *                       one 4 KiB piece per workgroup -- the shape the HBM write stream is fastest in; volumes of < 2^32 samples)
- *   "dense_grid", "dense_nt", "dense_rows", "dense_contig"   launch shape of the dense sample pass (P1)
+ *   "dense_grid", "dense_nt", "dense_rows", "dense_contig"   launch shape of the dense sample pass (P1); dense_nt = 0 | 1 | 2:
+ *                       nontemporal stores never / in the flat kernels and the plain row kernel (default) / in the aligned row kernel too
+ *   "dense_aligned" = 0 sd_obj family rows through the plain row kernel (default 1: k_sample_dense_rows_aligned -- four same-phase
+ *                       rows per wave, z terms hoisted, 16-byte aligned stores; needs a 16-byte aligned output, else falls back)
  *   "forget_plan" = 1   drop the capacity plan (the next regen discovers sizes again)
  *   "fast_math" = 0|1   confirms the numeric mode of the loaded library: libsdmesh.so is strict IEEE (bit-exact against the
  *                       CPU oracle), libsdmesh_fast.so is the same code built like the reference's `nvcc --use_fast_math`
