@@ -2631,7 +2631,7 @@ __global__ __launch_bounds__(256) void k_sample_dense_rows(float *__restrict__ o
 //
 // k_sample_dense_rows pays, per 513-sample row, two 117-instruction quad passes of which a third rebuilds terms that depend on z
 // alone (the lattice coordinate, the skeleton's three z residuals, z^2), a 50-instruction row context every lane computes
-// redundantly, and dword-aligned 16-byte stores that straddle cache lines (1.10x the bytes).  Here a wave takes ROWS rows whose
+// redundantly, and dword-aligned 16-byte stores that straddle cache lines (1.10x the bytes).  Here a wave takes ROWS (8) rows whose
 // starts have the SAME phase against the 16-byte quads of the output (rows lr = c + 4 i: a row starts at lr * S floats), so that
 //   * one set of z terms per lane (two aligned quads = 8 samples x {sz, mz, az, z^2}) serves all the wave's rows;
 //   * every quad store is 16-byte aligned (nontemporal, whole lines across the wave);
@@ -2641,10 +2641,11 @@ __global__ __launch_bounds__(256) void k_sample_dense_rows(float *__restrict__ o
 // Same operations in the same order per sample as RowCtx<SCENE>::eval (the 2^-120 nudge of the lean square roots rides on the
 // row terms: every term is 0 or >= 2^-60, so (a + 2^-120) + t == (a + t) + 2^-120 bit for bit) -> the same bits
 // (tests: test_dense_sample_matches_oracle, ..._at_full_size_..., test_dense_slabs_concatenate_to_the_whole_volume).
-template <int SCENE, bool NT, uint32_t ROWS>
+template <int SCENE, bool NT, uint32_t ROWS, int QPL /* aligned quads per lane: a wave covers 64 QPL quads of each of its rows */>
 __global__ __launch_bounds__(256) void k_sample_dense_rows_aligned(float *__restrict__ out /* 16-byte aligned */, uint32_t N,
                                                                     const SceneParams *__restrict__ spp, uint32_t xb, uint32_t xe) {
     static_assert(SCENE == SCENE_SDOBJ || SCENE == SCENE_ANIM, "sd_obj family only");
+    static_assert(ROWS <= 64 && (ROWS & (ROWS - 1u)) == 0, "one lane per row context");
 #if defined(SDM_HAVE_PAIRS)                      // (device pass only: the packed 2-vector helpers of sdf.hpp)
     typedef float v4f __attribute__((ext_vector_type(4)));
     const SceneParams &sp = *spp;
@@ -2655,14 +2656,18 @@ __global__ __launch_bounds__(256) void k_sample_dense_rows_aligned(float *__rest
 #else
     const float nud = SDM_SQRT_NUDGE;
 #endif
-    const uint32_t per_class = (((nrows + 3u) >> 2) + ROWS - 1u) / ROWS;            // groups per phase class
-    const uint32_t g = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
-    if (g >= 4u * per_class) return;
-    const uint32_t c = g & 3u, i0 = (g >> 2) * ROWS;                                 // rows lr = c + 4 (i0 + j), j < 16
+    // wave -> (chunk of 64 QPL quads along z, phase class, group of ROWS rows of that class)
+    const uint32_t per_class = (((nrows + 3u) >> 2) + ROWS - 1u) / ROWS;            // row groups per phase class
+    const uint32_t nchunks = ((S >> 2) + 64u * QPL - 1u) / (64u * QPL);               // (S >> 2 = the most aligned quads a row can have)
+    uint32_t g = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    if (g >= nchunks * 4u * per_class) return;
+    const uint32_t chunk = g % nchunks;
+    g /= nchunks;
+    const uint32_t c = g & 3u, i0 = (g >> 2) * ROWS;                                 // rows lr = c + 4 (i0 + j), j < ROWS
     const uint32_t head = (4u - ((c * (S & 3u)) & 3u)) & 3u;                         // samples in front of the first aligned quad
     const uint32_t nqa = (S - head) >> 2, tail0 = head + (nqa << 2), ht = head + (S - tail0);
-    // ---- the group's row contexts, one lane per row
-    float ca0 = 0.0f, ca1 = 0.0f, ca2 = 0.0f, cc = 0.0f;
+    // ---- the group's row contexts, one lane per row (2^-120 on every row term: see above)
+    float ca0, ca1, ca2, cc;
     {
         const uint32_t lr = c + 4u * (i0 + (lane & (ROWS - 1u)));
         const uint32_t xl = lr / S, y = lr - xl * S;
@@ -2676,14 +2681,14 @@ __global__ __launch_bounds__(256) void k_sample_dense_rows_aligned(float *__rest
     }
     uint32_t rows = 0;                                                               // valid rows of the group (a prefix)
     if (c + 4u * i0 < nrows) { rows = (nrows - 1u - c - 4u * i0) / 4u + 1u; if (rows > ROWS) rows = ROWS; }
-    // ---- aligned quads, 128 per chunk (two per lane), z terms hoisted over the rows
-    for (uint32_t qb = 0; qb < nqa; qb += 128u) {
-        v2f sz[4], mz[4], az[4], z2[4];
-        uint32_t zq[2];
-        bool on[2];
+    // ---- this wave's aligned quads, z terms hoisted over the rows
+    {
+        v2f sz[2 * QPL], mz[2 * QPL], az[2 * QPL], z2[2 * QPL];
+        uint32_t zq[QPL];
+        bool on[QPL];
 #pragma unroll
-        for (int u = 0; u < 2; u++) {
-            const uint32_t q = qb + lane + 64u * u;
+        for (int u = 0; u < QPL; u++) {
+            const uint32_t q = chunk * (64u * QPL) + lane + 64u * u;
             on[u] = q < nqa;
             zq[u] = head + (q << 2);
 #pragma unroll
@@ -2702,7 +2707,7 @@ __global__ __launch_bounds__(256) void k_sample_dense_rows_aligned(float *__rest
             const float cs = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, cc), j));
             float *__restrict__ o = out + (uint64_t) (c + 4u * (i0 + j)) * S;
 #pragma unroll
-            for (int u = 0; u < 2; u++) {
+            for (int u = 0; u < QPL; u++) {
                 if (on[u]) {
                     v2f r[2];
 #pragma unroll
@@ -2719,15 +2724,27 @@ __global__ __launch_bounds__(256) void k_sample_dense_rows_aligned(float *__rest
             }
         }
     }
-    // ---- the rows' unaligned ends: ht <= 6 samples per row, one lane each
-    for (uint32_t u = lane; u < rows * ht; u += 64u) {
-        const uint32_t j = u / ht, k = u - j * ht;
-        const uint32_t z = k < head ? k : tail0 + (k - head);
-        const uint32_t lr = c + 4u * (i0 + j);
-        const uint32_t xl = lr / S, y = lr - xl * S;
-        RowCtx<SCENE> rc;
-        rc.init((float) (xb + xl) * h - 2.5f, (float) y * h - 2.5f, sp);
-        out[(uint64_t) lr * S + z] = rc.eval((float) z * h - 2.5f, sp);
+    // ---- the rows' unaligned ends (ht <= 6 samples per row), by the wave of the first chunk: one lane per sample, two samples per
+    // packed evaluation, with the row contexts fetched from the lanes that hold them (ds_bpermute: no LDS memory involved)
+    if (chunk == 0) {
+        for (uint32_t u0 = 0; u0 < rows * ht; u0 += 128u) {
+            const uint32_t ua = u0 + lane, ub = ua + 64u;
+            const uint32_t ja = ua / ht, jb = ub / ht, ka = ua - ja * ht, kb = ub - jb * ht;
+            const uint32_t za = ka < head ? ka : tail0 + (ka - head), zb = kb < head ? kb : tail0 + (kb - head);
+            const int sa = (int) ((ja & (ROWS - 1u)) << 2), sb = (int) ((jb & (ROWS - 1u)) << 2);
+#define SDM_ROWCTX2(v) mk2(__builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(sa, __builtin_bit_cast(int, v))), \
+                           __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(sb, __builtin_bit_cast(int, v))))
+            const v2f a0 = SDM_ROWCTX2(ca0), a1 = SDM_ROWCTX2(ca1), a2 = SDM_ROWCTX2(ca2), cs = SDM_ROWCTX2(cc);
+#undef SDM_ROWCTX2
+            const v2f pz = mk2((float) za * h - 2.5f, (float) zb * h - 2.5f);
+            const v2f eaz = along_sq2(pz, -0.25f, 0.5f), esz = sq2(abs2(pz) - 0.25f), emz = min2(sq2(pz - (-0.25f)), sq2(pz - 2.75f));
+            const v2f m = min2(min2(a0 + esz, a1 + emz), a2 + eaz);
+            const v2f d1 = sqrt_rn_normal2_nonudge(m) - 0.1f;
+            const v2f d2 = sqrt_rn_normal2_nonudge(cs + pz * pz) - 1.0f;
+            const v2f r = smooth_min2(d1, d2, 0.5f);
+            if (ua < rows * ht) out[(uint64_t) (c + 4u * (i0 + ja)) * S + za] = r.x;
+            if (ub < rows * ht) out[(uint64_t) (c + 4u * (i0 + jb)) * S + zb] = r.y;
+        }
     }
 #endif
 }
@@ -2973,19 +2990,21 @@ hipError_t launch_sample_dense_rows(hipStream_t st, int grid, int scene, const S
     aligned_rows = false;                    // (the aligned kernel is written on the packed 2-vector helpers)
 #endif
     if ((scene == SCENE_SDOBJ || scene == SCENE_ANIM) && aligned_rows && ((uintptr_t) out & 15u) == 0 && N >= 3u) {
-        // whole-line stores, z terms hoisted over 4 same-phase rows (k_sample_dense_rows_aligned): one group per wave.  Measured at
-        // 512^3 (sd_obj): 16 / 8 / 4 / 2 / 1 rows per wave 0.131 / 0.126 / 0.121 / 0.144 / 0.163 ms with plain stores (long waves
-        // leave the SIMDs two-thirds empty in their last round; short ones lose the hoisting), 0.151 / 0.152 / 0.127 / 0.147 / 0.166
-        // with nontemporal ones -- hence `nt_rows` (option dense_nt = 2) is off by default for this kernel
-        constexpr uint32_t R = 4;
-        const uint64_t nrows = (uint64_t) (N + 1) * (x1 - x0), ngroups = 4ull * ((((nrows + 3ull) >> 2) + R - 1ull) / R);
+        // whole-line stores, z terms hoisted over the same-phase rows of a wave (k_sample_dense_rows_aligned), one wave per (chunk, group).
+        // Measured at 512^3 (sd_obj, plain stores, same box): 8 rows x 2 quads per lane 0.127-0.131 ms, 4 x 2: 0.134-0.147, 8 x 1: 0.133-0.140,
+        // 16 x 2: 0.125-0.133 on another box where 8 x 2 gave 0.120-0.126 (long waves leave the SIMDs half empty in their last round and
+        // hide their dependent chains badly; short ones lose the hoisting); nontemporal stores cost this kernel 5-15 %, hence
+        // `nt_rows` (option dense_nt = 2) is off by default here
+        constexpr uint32_t R = 8, Q = 2;
+        const uint64_t nrows = (uint64_t) (N + 1) * (x1 - x0), nchunks = (((N + 1) >> 2) + 64ull * Q - 1ull) / (64ull * Q);
+        const uint64_t ngroups = nchunks * 4ull * ((((nrows + 3ull) >> 2) + R - 1ull) / R);
         const int g2 = (int) std::min<uint64_t>((ngroups + 3ull) / 4ull, 0x7FFFFFFFull);
         if (scene == SCENE_SDOBJ) {
-            if (nt_rows) hipLaunchKernelGGL((k_sample_dense_rows_aligned<SCENE_SDOBJ, true, R>), dim3(g2), dim3(256), 0, st, out, N, sp, x0, x1);
-            else hipLaunchKernelGGL((k_sample_dense_rows_aligned<SCENE_SDOBJ, false, R>), dim3(g2), dim3(256), 0, st, out, N, sp, x0, x1);
+            if (nt_rows) hipLaunchKernelGGL((k_sample_dense_rows_aligned<SCENE_SDOBJ, true, R, Q>), dim3(g2), dim3(256), 0, st, out, N, sp, x0, x1);
+            else hipLaunchKernelGGL((k_sample_dense_rows_aligned<SCENE_SDOBJ, false, R, Q>), dim3(g2), dim3(256), 0, st, out, N, sp, x0, x1);
         } else {
-            if (nt_rows) hipLaunchKernelGGL((k_sample_dense_rows_aligned<SCENE_ANIM, true, R>), dim3(g2), dim3(256), 0, st, out, N, sp, x0, x1);
-            else hipLaunchKernelGGL((k_sample_dense_rows_aligned<SCENE_ANIM, false, R>), dim3(g2), dim3(256), 0, st, out, N, sp, x0, x1);
+            if (nt_rows) hipLaunchKernelGGL((k_sample_dense_rows_aligned<SCENE_ANIM, true, R, Q>), dim3(g2), dim3(256), 0, st, out, N, sp, x0, x1);
+            else hipLaunchKernelGGL((k_sample_dense_rows_aligned<SCENE_ANIM, false, R, Q>), dim3(g2), dim3(256), 0, st, out, N, sp, x0, x1);
         }
         return hipGetLastError();
     }
