@@ -118,6 +118,7 @@ SYMBOLS = {
     "sdmesh_sharded_regen": (_i, [_vp, _i, _i, ctypes.POINTER(RegenInfo)]),
     "sdmesh_distributed_regen": (_i, [_vp, _i, ctypes.POINTER(RegenInfo), ctypes.POINTER(_u32)]),
     "sdmesh_distributed_regen_rehearsal": (_i, [_vp, _i, _i, _vp, _vp]),
+    "sdmesh_sharded_regen_rehearsal": (_i, [_vp, _i, _i, _i, ctypes.POINTER(RegenInfo)]),
     "sdmesh_download_mesh": (_i, [_vp, _vp, _vp]),
     "sdmesh_download_voxels": (_i, [_vp, _vp]),
     "sdmesh_regen_dense": (_i, [_vp, _i, ctypes.POINTER(RegenInfo)]),

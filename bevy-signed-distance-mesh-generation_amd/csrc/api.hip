@@ -190,6 +190,11 @@ struct sdmesh_handle {
     ncclComm_t comm = nullptr;
     int comm_rank = 0, comm_nranks = 1;
     DevBuf shard_mine, shard_counts, shard_recv, shard_lists, shard_plan, shard_merged;
+    // z-slab INDEXED gather (root): the ranks' welded buffers concatenated, the merge's tables, its outputs (swapped into vertices / indices)
+    DevBuf zs_verts, zs_idx, zs_tables, zs_pervert, zs_tilecnt, zs_hkeys, zs_hmin, zs_vout, zs_iout, zs_ranks;
+    ZsRanks *h_zs = nullptr;       // pinned staging copy of the merge's rank table
+    int shard_indexed = 1;         // option "shard_indexed": sdmesh_sharded_regen gathers welded per-slab vertex / index buffers (0: raw triangle lists + root weld)
+    uint32_t zs_band_plan = 0;     // face-band vertices of the last indexed merge (sizes the band hash of the next one)
     uint32_t *h_counts = nullptr;      // pinned: nranks x SHARD_ROW words (column counts + status record of every rank)
     size_t h_counts_words = 0;
     void **h_lists = nullptr;          // pinned: nranks device pointers
@@ -1070,10 +1075,11 @@ void sdmesh_destroy(sdmesh_handle *h) {
                       &h->first_ord_buf, &h->uverts, &h->tri_e, &h->vslot, &h->tdesc, &h->tfirst, &h->tfpre, &h->tpre, &h->flip, &h->wvidx, &h->torder, &h->wrep_buf, &h->wfm_buf,
                       &h->vertices, &h->indices, &h->raw, &h->compact, &h->staging, &h->dense_samples, &h->dense_bits,
                       &h->cellcnt, &h->dist_upids, &h->dist_upkeys, &h->dist_loids, &h->dist_prevkeys, &h->dist_hkeys, &h->dist_hpos, &h->dist_dupof,
-                      &h->dist_newidx, &h->dist_tilecnt, &h->dist_counts, &h->dist_upg, &h->dist_prevg, &h->dist_verts, &h->dist_nups, &h->col_list1, &h->col_mask2, &h->col_mask3, &h->colinfo, &h->prof_rounds, &h->proj_diag, &h->shard_mine, &h->shard_counts, &h->shard_recv, &h->shard_lists, &h->shard_plan, &h->shard_merged};
+                      &h->dist_newidx, &h->dist_tilecnt, &h->dist_counts, &h->dist_upg, &h->dist_prevg, &h->dist_verts, &h->dist_nups, &h->col_list1, &h->col_mask2, &h->col_mask3, &h->colinfo, &h->prof_rounds, &h->proj_diag, &h->shard_mine, &h->shard_counts, &h->shard_recv, &h->shard_lists, &h->shard_plan, &h->shard_merged, &h->zs_verts, &h->zs_idx, &h->zs_tables, &h->zs_pervert, &h->zs_tilecnt, &h->zs_hkeys, &h->zs_hmin, &h->zs_vout, &h->zs_iout, &h->zs_ranks};
     (void) sdmesh_comm_destroy(h);
     if (h->h_counts) (void) hipHostFree(h->h_counts);
     if (h->h_lists) (void) hipHostFree(h->h_lists);
+    if (h->h_zs) (void) hipHostFree(h->h_zs);
     for (DevBuf *b : bufs) release(*b);
     if (h->h_pinned) (void) hipHostFree(h->h_pinned);
     if (h->d_sp) (void) hipFree(h->d_sp);
@@ -1170,6 +1176,7 @@ int sdmesh_set_option(sdmesh_handle *h, const char *name, int value) {
         h->tf_threads = value; drop_graph(h); return SDMESH_OK;
     }
     if (!strcmp(name, "inject_fail")) { h->inject_fail = value; return SDMESH_OK; }
+    if (!strcmp(name, "shard_indexed")) { h->shard_indexed = value != 0; return SDMESH_OK; }
     if (!strcmp(name, "project_prio")) { h->project_prio = value != 0; drop_graph(h); return SDMESH_OK; }
     if (!strcmp(name, "project_grid")) { h->project_grid = value < 0 ? 0 : (value > 65535 ? 65535 : value); drop_graph(h); return SDMESH_OK; }
     if (!strcmp(name, "project_batch")) { h->project_batch = value < 0 ? 0 : (value > 6 ? 6 : value); drop_graph(h); return SDMESH_OK; }
@@ -1951,6 +1958,211 @@ uint32_t cap_items(const DevBuf &b, size_t item) { return (uint32_t) std::min<si
 
 }  // namespace
 
+namespace {
+
+// ---- z-slab INDEXED gather, root side: the single-GPU mesh from the ranks' welded buffers, concatenated in rank order in
+// h->zs_verts / h->zs_idx (kernels.hip, "INDEXED gather").  d_counts: per-rank column triangle counts (`cstride` words per rank).
+int zs_ensure_inputs(sdmesh_handle *h, uint64_t vtot, uint64_t ttot) {
+    SDCHK(ensure_grow(h, h->zs_verts, sizeof(Vertex) * (size_t) std::max<uint64_t>(vtot, 64)));
+    SDCHK(ensure_grow(h, h->zs_idx, sizeof(IndexTriangle) * (size_t) std::max<uint64_t>(ttot, 64)));
+    return SDMESH_OK;
+}
+
+int zs_merge(sdmesh_handle *h, int R, const uint32_t *d_counts, uint32_t cstride, const uint32_t *Vr, const uint32_t *Tr, int levels,
+             Point voxel_size, sdmesh_regen_info *info) {
+    hipStream_t st = h->stream;
+    ZsRanks zr;
+    memset(&zr, 0, sizeof zr);
+    zr.nranks = (uint32_t) R;
+    uint64_t vtot = 0, ttot = 0;
+    for (int r = 0; r < R; r++) {
+        zr.vbase[r] = (uint32_t) vtot; zr.tbase[r] = (uint32_t) ttot;
+        vtot += Vr[r]; ttot += Tr[r];
+    }
+    if (vtot > 0x0FFFFFFFull || ttot > 0x0FFFFFFFull) return fail(h, SDMESH_ERR_INVALID, "too many vertices / triangles for one mesh");
+    zr.vbase[R] = (uint32_t) vtot; zr.tbase[R] = (uint32_t) ttot;
+    const uint32_t F = MESH_GENERATION_INIT_FACTOR;
+    for (int r = 0; r < R; r++) {
+        uint32_t lo = F * (uint32_t) r / (uint32_t) R, hi = F * (uint32_t) (r + 1) / (uint32_t) R;
+        if (h->slab_nparts == R && h->slab_mode == SDMESH_PART_ZSLAB) { lo = h->slab_bounds[r]; hi = h->slab_bounds[r + 1]; }
+        zr.zlo[r] = -MESH_GENERATION_BB_SIZE / 2.0f + MESH_GENERATION_BB_SIZE * (float) lo / (float) F;
+        zr.zhi[r] = -MESH_GENERATION_BB_SIZE / 2.0f + MESH_GENERATION_BB_SIZE * (float) hi / (float) F;
+    }
+    zr.zbot = -MESH_GENERATION_BB_SIZE / 2.0f; zr.ztop = MESH_GENERATION_BB_SIZE / 2.0f;
+    // a projected vertex stays within about a voxel of its lattice edge: 2.5 voxels of the finest level is a safe band
+    zr.band = 2.5f * ((MESH_GENERATION_BB_SIZE / (float) F) / (float) (1u << levels));
+    const uint32_t V = (uint32_t) vtot, T = (uint32_t) ttot, nseg = (uint32_t) R * 1024u;
+    // the rank table in device memory (the kernels index it per thread; pinned staging so that the copy is asynchronous)
+    if (!h->h_zs) HIPCHK(hipHostMalloc((void **) &h->h_zs, sizeof(ZsRanks), hipHostMallocDefault));
+    SDCHK(ensure(h, h->zs_ranks, sizeof(ZsRanks)));
+    HIPCHK(hipStreamSynchronize(st));                      // (a previous merge may still be reading the staging copy)
+    *h->h_zs = zr;
+    HIPCHK(hipMemcpyAsync(h->zs_ranks.p, h->h_zs, sizeof(ZsRanks), hipMemcpyHostToDevice, st));
+    const ZsRanks *d_zr = (const ZsRanks *) h->zs_ranks.p;
+    HIPCHK(hipEventRecord(h->ev0, st));                    // info->device_ms = the root's merge alone (the gathered buffers are in place)
+    // tables: tplan [2 nseg] | vplan [2 nseg] | segmax [nseg] | vstart [nseg] | newcnt [nseg]; per vertex: segof | redirect | kept_before | map
+    SDCHK(ensure(h, h->zs_tables, 4ull * 7 * nseg));
+    SDCHK(ensure_grow(h, h->zs_pervert, 4ull * 4 * std::max<uint32_t>(V, 64)));
+    SDCHK(ensure_grow(h, h->zs_tilecnt, 4ull * (tiles(std::max<uint32_t>(V, 64)) + 16)));
+    SDCHK(ensure_grow(h, h->zs_vout, sizeof(Vertex) * (size_t) std::max<uint32_t>(V, 64)));
+    SDCHK(ensure_grow(h, h->zs_iout, sizeof(IndexTriangle) * (size_t) std::max<uint32_t>(T, 64)));
+    uint32_t *tplan = (uint32_t *) h->zs_tables.p, *vplan = tplan + 2 * nseg, *segmax = vplan + 2 * nseg, *vstart = segmax + nseg, *newcnt = vstart + nseg;
+    const uint32_t vcap = std::max<uint32_t>(V, 64);
+    uint32_t *segof = (uint32_t *) h->zs_pervert.p, *redirect = segof + vcap, *kept = redirect + vcap, *map = kept + vcap;
+    for (int attempt = 0; attempt < 2; attempt++) {
+        // the band hash is sized from the last merge's band (25 % head-room), from the vertex total when nothing is known yet
+        uint32_t band_cap = V;
+        if (attempt == 0 && h->zs_band_plan && (uint64_t) h->zs_band_plan + h->zs_band_plan / 4 + 1024 < V) band_cap = h->zs_band_plan + h->zs_band_plan / 4 + 1024;
+        const uint32_t hsize = 2u * band_cap + 64u;
+        SDCHK(ensure_grow(h, h->zs_hkeys, 8ull * hsize));
+        SDCHK(ensure_grow(h, h->zs_hmin, 4ull * hsize));
+        SDCHK(zero_status(h));
+        HIPCHK(hipMemsetAsync(h->d_ctr + CTR_DIST_NUP, 0, 4, st));
+        if (R > 1) {
+            HIPCHK(hipMemsetAsync(h->zs_hkeys.p, 0xFF, 8ull * hsize, st));
+            HIPCHK(hipMemsetAsync(h->zs_hmin.p, 0xFF, 4ull * hsize, st));
+        }
+        HIPCHK(launch_merge_plan(st, d_counts, cstride, R, tplan, T, h->d_ctr + CTR_NTRI, h->d_status));
+        HIPCHK(launch_zs_front(st, h->grid, (const Vertex *) h->zs_verts.p, (const uint32_t *) h->zs_idx.p, d_counts, cstride, tplan, zr, d_zr, segmax, vstart,
+                               newcnt, segof, redirect, (uint64_t *) h->zs_hkeys.p, (uint32_t *) h->zs_hmin.p, hsize, h->d_ctr + CTR_DIST_NUP,
+                               h->d_status));
+        HIPCHK(launch_set_u32(st, h->d_ctr + CTR_DIST_V, V));
+        HIPCHK(launch_dist_number(st, h->tgrid, redirect, V, h->d_ctr + CTR_DIST_V, (uint32_t *) h->zs_tilecnt.p, h->d_ctr + CTR_NVERT, kept, h->d_status));
+        HIPCHK(launch_merge_plan(st, newcnt, 1024u, R, vplan, V, h->d_ctr + CTR_SCRATCH, h->d_status));
+        HIPCHK(launch_zs_back(st, h->grid, (const Vertex *) h->zs_verts.p, (const uint32_t *) h->zs_idx.p, d_counts, cstride, tplan, zr, d_zr, redirect, kept, segof,
+                              vstart, vplan, (Vertex *) h->zs_vout.p, V, map, (uint32_t *) h->zs_iout.p, T));
+        HIPCHK(hipEventRecord(h->ev1, st));
+        SDCHK(read_back(h));
+        h->zs_band_plan = h->h_pinned[CTR_DIST_NUP];
+        if (!(h->h_pinned[CTR_WORDS + ST_OVERFLOW] & 64u)) break;          // (64: the band outgrew its hash -> once more with room for every vertex)
+        if (attempt == 1) return fail(h, SDMESH_ERR_INTERNAL, "the face-band hash overflowed although it had room for every vertex");
+    }
+    if (h->h_pinned[CTR_WORDS + ST_WELD_RANGE]) return fail(h, SDMESH_ERR_WELD_RANGE, "the indexed gather needs vertices inside the packed key range (option shard_indexed = 0 welds on the root instead)");
+    SDCHK(status_to_error(h));
+    if (h->h_pinned[CTR_WORDS + ST_OVERFLOW]) return fail(h, SDMESH_ERR_INTERNAL, "indexed merge overflow (status %u)", h->h_pinned[CTR_WORDS + ST_OVERFLOW]);
+    if (h->h_pinned[CTR_NTRI] != T || h->h_pinned[CTR_SCRATCH] != h->h_pinned[CTR_NVERT])
+        return fail(h, SDMESH_ERR_INTERNAL, "indexed merge: %u triangles planned of %u, %u vertices planned of %u kept", h->h_pinned[CTR_NTRI], T,
+                    h->h_pinned[CTR_SCRATCH], h->h_pinned[CTR_NVERT]);
+    std::swap(h->vertices, h->zs_vout);                    // the merged mesh becomes the handle's mesh
+    std::swap(h->indices, h->zs_iout);
+    h->buf_gen++;
+    h->n_tris = T;
+    h->n_verts = h->h_pinned[CTR_NVERT];
+    h->n_unique = h->n_verts;
+    h->mesh_valid = true;
+    h->welded = true;
+    h->last_direct = false;
+    h->vox_valid = false;                                  // (the root's voxel list is its own slab's, not the mesh's)
+    if (info) {
+        float ms = 0.0f;
+        HIPCHK(hipEventElapsedTime(&ms, h->ev0, h->ev1));
+        fill_info(h, info, 0, false, ms);
+        info->levels = (uint32_t) levels;
+        info->voxel_size = voxel_size;
+    }
+    return SDMESH_OK;
+}
+
+// this rank's level-0 z-slab, meshed AND welded; its column triangle counts into d_row[0 .. 1024)
+int zs_local_phase(sdmesh_handle *h, int levels, int part, int nparts, uint32_t *d_row, sdmesh_regen_info *slab) {
+    hipStream_t st = h->stream;
+    const int saved_skip = h->skip_weld;
+    h->skip_weld = 0;
+    const int rc = regen_impl(h, levels, SDMESH_PART_ZSLAB, part, nparts, slab);
+    h->skip_weld = saved_skip;
+    SDCHK(rc);
+    if (h->last_direct || !h->welded) return fail(h, SDMESH_ERR_INTERNAL, "a slab took the direct path: no column counts");
+    if (h->wide_active) return fail(h, SDMESH_ERR_WELD_RANGE, "the indexed gather needs the packed weld keys (option shard_indexed = 0 welds on the root instead)");
+    HIPCHK(hipMemsetAsync(d_row, 0, 4096, st));
+    if (h->n_vox) {
+        HIPCHK(launch_set_u32(st, h->d_ctr + CTR_SCRATCH, h->n_vox));
+        HIPCHK(launch_column_counts(st, std::min(h->grid, (int) tiles(h->n_vox)), (const Point *) h->vox[h->cur].p, h->d_ctr + CTR_SCRATCH,
+                                    (const uint8_t *) h->cubeidx.p, d_row));
+    }
+    return SDMESH_OK;
+}
+
+int sharded_regen_indexed(sdmesh_handle *h, int levels, int root, sdmesh_regen_info *info) {
+    const int R = h->comm_nranks, me = h->comm_rank;
+    hipStream_t st = h->stream;
+    const int inject = h->inject_fail;
+    h->inject_fail = 0;
+    SDCHK(ensure(h, h->shard_counts, 4ull * (size_t) R * SHARD_ROW));
+    SDCHK(ensure_shard_host(h, R));
+    uint32_t *d_counts = (uint32_t *) h->shard_counts.p, *d_row = d_counts + (size_t) me * SHARD_ROW;
+    // 1. this rank's slab, welded locally; any failure in here becomes this rank's status word
+    sdmesh_regen_info slab;
+    memset(&slab, 0, sizeof slab);
+    const int lrc = inject == 1 ? fail(h, SDMESH_ERR_INTERNAL, "injected failure (option inject_fail)") : zs_local_phase(h, levels, me, R, d_row, &slab);
+    uint32_t t_mine = 0, v_mine = 0;
+    if (lrc == SDMESH_OK) { t_mine = h->n_tris; v_mine = h->n_verts; }
+    else HIPCHK(hipMemsetAsync(d_row, 0, 4096, st));
+    // 2. the all-gather of the counts -- ALWAYS entered; record = {status, triangles, room for vertices / triangles as a root, vertices, 1, 0, 0}
+    HIPCHK(launch_pack_record(st, d_row + 1024, nullptr, nullptr, (uint32_t) lrc, t_mine, cap_items(h->zs_verts, sizeof(Vertex)),
+                              cap_items(h->zs_idx, sizeof(IndexTriangle))));
+    HIPCHK(launch_pack_record(st, d_row + 1028, nullptr, nullptr, v_mine, 1u, 0u, 0u));
+    NCCLCHK(g_rccl.AllGather(d_row, d_counts, SHARD_ROW, ncclUint32, h->comm, st));                     // in place
+    HIPCHK(hipMemcpyAsync(h->h_counts, d_counts, 4ull * (size_t) R * SHARD_ROW, hipMemcpyDeviceToHost, st));
+    HIPCHK(hipStreamSynchronize(st));
+    // 3. every rank, on the same numbers
+    SDCHK(peer_failure(h, R, me, h->h_counts, SHARD_ROW, 1024, lrc));
+    std::vector<uint32_t> Tr((size_t) R, 0), Vr((size_t) R, 0);
+    uint64_t ttot = 0, vtot = 0;
+    for (int r = 0; r < R; r++) {
+        const uint32_t *row = h->h_counts + (size_t) r * SHARD_ROW;
+        uint64_t s = 0;
+        for (int c = 0; c < 1024; c++) s += row[c];
+        if (s != row[1025])
+            return fail(h, SDMESH_ERR_INTERNAL, "rank %d: column counts (%llu) disagree with the slab's triangle count (%u)", r, (unsigned long long) s, row[1025]);
+        if (row[1029] != 1u) return fail(h, SDMESH_ERR_INVALID, "rank %d runs the raw-list form of the z-slab gather (option shard_indexed differs between the ranks)", r);
+        Tr[r] = row[1025]; Vr[r] = row[1028];
+        ttot += Tr[r]; vtot += Vr[r];
+    }
+    if (ttot > 0x0FFFFFFFull || vtot > 0x0FFFFFFFull) return fail(h, SDMESH_ERR_INVALID, "too many triangles for one mesh");
+    // 4. the root's receive buffers; grown behind a second agreement only if its published capacity is too small
+    const uint32_t *root_row = h->h_counts + (size_t) root * SHARD_ROW;
+    if (vtot > root_row[1026] || ttot > root_row[1027] || root_row[1026] == 0u || inject == 2) {
+        int grc = SDMESH_OK;
+        if (me == root) grc = inject == 2 ? fail(h, SDMESH_ERR_HIP, "injected allocation failure (option inject_fail)") : zs_ensure_inputs(h, vtot, ttot);
+        uint32_t worst = 0;
+        SDCHK(agree_flag(h, grc == SDMESH_OK ? 0u : 1u, &worst));
+        if (grc != SDMESH_OK) return grc;
+        if (worst) return fail(h, SDMESH_ERR_PEER, "the root (rank %d) could not grow its receive buffers; every rank returns an error", root);
+    }
+    if (me != root) {
+        // 5a. peers: the slab's vertex and index buffers go straight to the root (each peer on its own xGMI link)
+        if (v_mine || t_mine) {
+            NCCLCHK(g_rccl.GroupStart());
+            if (v_mine) NCCLCHK(g_rccl.Send(h->vertices.p, (size_t) v_mine * 6, ncclFloat32, root, h->comm, st));
+            if (t_mine) NCCLCHK(g_rccl.Send(h->indices.p, (size_t) t_mine * 3, ncclUint32, root, h->comm, st));
+            NCCLCHK(g_rccl.GroupEnd());
+        }
+        HIPCHK(hipStreamSynchronize(st));
+        if (info) *info = slab;
+        return SDMESH_OK;
+    }
+    // 5b. root: its own slab into its place of the concatenated buffers, grouped receives for the others
+    uint64_t vb = 0, tb = 0;
+    NCCLCHK(g_rccl.GroupStart());
+    for (int r = 0; r < R; r++) {
+        Vertex *vd = (Vertex *) h->zs_verts.p + vb;
+        IndexTriangle *td = (IndexTriangle *) h->zs_idx.p + tb;
+        if (r == root) {
+            if (Vr[r]) HIPCHK(hipMemcpyAsync(vd, h->vertices.p, sizeof(Vertex) * (size_t) Vr[r], hipMemcpyDeviceToDevice, st));
+            if (Tr[r]) HIPCHK(hipMemcpyAsync(td, h->indices.p, sizeof(IndexTriangle) * (size_t) Tr[r], hipMemcpyDeviceToDevice, st));
+        } else {
+            if (Vr[r]) NCCLCHK(g_rccl.Recv(vd, (size_t) Vr[r] * 6, ncclFloat32, r, h->comm, st));
+            if (Tr[r]) NCCLCHK(g_rccl.Recv(td, (size_t) Tr[r] * 3, ncclUint32, r, h->comm, st));
+        }
+        vb += Vr[r]; tb += Tr[r];
+    }
+    NCCLCHK(g_rccl.GroupEnd());
+    // 6. the merge (from here on nobody waits for the root any more: a failure is the root's alone)
+    return zs_merge(h, R, d_counts, SHARD_ROW, Vr.data(), Tr.data(), levels, slab.voxel_size, info);
+}
+
+}  // namespace
+
 extern "C" {
 
 int sdmesh_sharded_regen(sdmesh_handle *h, int levels, int root, sdmesh_regen_info *info) {
@@ -1959,6 +2171,7 @@ int sdmesh_sharded_regen(sdmesh_handle *h, int levels, int root, sdmesh_regen_in
     if (!h->comm) return fail(h, SDMESH_ERR_INVALID, "no communicator (sdmesh_comm_init)");
     const int R = h->comm_nranks, me = h->comm_rank;
     if (root < 0 || root >= R) return fail(h, SDMESH_ERR_INVALID, "root %d outside the communicator", root);
+    if (h->shard_indexed) return sharded_regen_indexed(h, levels, root, info);
     hipStream_t st = h->stream;
     const int inject = h->inject_fail;
     h->inject_fail = 0;
@@ -1999,6 +2212,7 @@ int sdmesh_sharded_regen(sdmesh_handle *h, int levels, int root, sdmesh_regen_in
     HIPCHK(launch_pack_record(st, d_row + 1024, nullptr, nullptr, (uint32_t) lrc, n_mine, cap_items(h->shard_recv, sizeof(Triangle)),
                               cap_items(h->shard_merged, sizeof(Triangle))));
     // (k_pack_record writes {v0, v1 | status, v2, v3}: word 0 = status, word 1 = triangles here)
+    HIPCHK(launch_pack_record(st, d_row + 1028, nullptr, nullptr, 0u, 0u, 0u, 0u));                    // {vertices: none, raw form}
     NCCLCHK(g_rccl.AllGather(d_row, d_counts, SHARD_ROW, ncclUint32, h->comm, st));                     // in place
     HIPCHK(hipMemcpyAsync(h->h_counts, d_counts, 4ull * (size_t) R * SHARD_ROW, hipMemcpyDeviceToHost, st));
     HIPCHK(hipStreamSynchronize(st));
@@ -2011,6 +2225,7 @@ int sdmesh_sharded_regen(sdmesh_handle *h, int levels, int root, sdmesh_regen_in
         for (int c = 0; c < 1024; c++) tr[r] += row[c];
         if (tr[r] != row[1025])
             return fail(h, SDMESH_ERR_INTERNAL, "rank %d: column counts (%llu) disagree with the slab's triangle count (%u)", r, (unsigned long long) tr[r], row[1025]);
+        if (row[1029] != 0u) return fail(h, SDMESH_ERR_INVALID, "rank %d runs the indexed form of the z-slab gather (option shard_indexed differs between the ranks)", r);
         total += tr[r];
         if (r != root) foreign += tr[r];
     }
@@ -2061,6 +2276,42 @@ int sdmesh_sharded_regen(sdmesh_handle *h, int levels, int root, sdmesh_regen_in
 }
 
 }  // extern "C"
+
+extern "C" int sdmesh_sharded_regen_rehearsal(sdmesh_handle **hs, int nranks, int levels, int root, sdmesh_regen_info *info) {
+    // The indexed z-slab gather for `nranks` handles of ONE process on ONE device, device-to-device copies in place of the RCCL
+    // messages: every phase and kernel of sdmesh_sharded_regen's indexed form (tests and single-GPU measurements of the root's share)
+    if (!hs || nranks < 1 || nranks > 32 || root < 0 || root >= nranks) return SDMESH_ERR_INVALID;
+    for (int r = 0; r < nranks; r++)
+        if (!hs[r] || hs[r]->device != hs[0]->device) return SDMESH_ERR_INVALID;
+    sdmesh_handle *H = hs[root], *h = H;                   // (`h`: what the error macros report through)
+    const int R = nranks;
+    HIPCHK(hipSetDevice(H->device));
+    SDCHK(ensure(H, H->shard_counts, 4ull * (size_t) R * SHARD_ROW));
+    uint32_t *d_counts = (uint32_t *) H->shard_counts.p;
+    std::vector<uint32_t> Tr((size_t) R, 0), Vr((size_t) R, 0);
+    sdmesh_regen_info slab;
+    memset(&slab, 0, sizeof slab);
+    uint64_t vtot = 0, ttot = 0;
+    for (int r = 0; r < R; r++) {
+        h = hs[r];
+        if (h->slab_nparts != H->slab_nparts || (H->slab_nparts && (h->slab_mode != H->slab_mode || memcmp(h->slab_bounds, H->slab_bounds, sizeof(uint32_t) * (size_t) (H->slab_nparts + 1)))))
+            return fail(H, SDMESH_ERR_INVALID, "handle %d has other slab bounds than the root", r);
+        const int rc = zs_local_phase(h, levels, r, R, d_counts + (size_t) r * SHARD_ROW, &slab);
+        if (rc != SDMESH_OK) { if (h != H) (void) fail(H, rc, "slab %d: %s", r, h->err); return rc; }
+        HIPCHK(hipStreamSynchronize(h->stream));
+        Tr[r] = h->n_tris; Vr[r] = h->n_verts;
+        vtot += Vr[r]; ttot += Tr[r];
+    }
+    h = H;
+    SDCHK(zs_ensure_inputs(H, vtot, ttot));
+    uint64_t vb = 0, tb = 0;
+    for (int r = 0; r < R; r++) {
+        if (Vr[r]) HIPCHK(hipMemcpyAsync((Vertex *) H->zs_verts.p + vb, hs[r]->vertices.p, sizeof(Vertex) * (size_t) Vr[r], hipMemcpyDeviceToDevice, H->stream));
+        if (Tr[r]) HIPCHK(hipMemcpyAsync((IndexTriangle *) H->zs_idx.p + tb, hs[r]->indices.p, sizeof(IndexTriangle) * (size_t) Tr[r], hipMemcpyDeviceToDevice, H->stream));
+        vb += Vr[r]; tb += Tr[r];
+    }
+    return zs_merge(H, R, d_counts, SHARD_ROW, Vr.data(), Tr.data(), levels, slab.voxel_size, info);
+}
 
 // ================================================================================================
 // Multi-GPU: ONE mesh, x-slabs, DISTRIBUTED weld (the mesh stays distributed)

@@ -2231,6 +2231,190 @@ __global__ __launch_bounds__(256) void k_dist_finalize(const Vertex *__restrict_
 }
 
 // ------------------------------------------------------------------------------------------
+// Multi-GPU, z-slabs, INDEXED gather (the north star's "RCCL gather of per-slab vertex/index buffers").
+// Every rank meshes AND welds its own level-0 z-slab; the root receives the slabs' vertex and index buffers (24 B per vertex +
+// 12 B per triangle, against 72 B per triangle for the raw lists) and restores the single-GPU mesh from them WITHOUT welding
+// anything again -- no hash claim per corner, only streaming passes over the gathered buffers:
+//
+//   * a rank's welded vertices are numbered in its own first-seen order, so the number of distinct vertices in its first n
+//     triangles is 1 + the largest index among them: the largest index per (rank, column) segment (k_zs_segmax) gives, by a
+//     prefix maximum over the columns (k_zs_vplan), the range of local vertices FIRST SEEN in each column;
+//   * in the single-GPU order a level-0 column holds rank 0's triangles, then rank 1's, ...: so the single-GPU first-seen vertex
+//     order is, column by column and rank by rank, each segment's first-seen vertices in their local order -- the vertex buffers
+//     merge by (column, rank) segments exactly like the triangle lists (same plan kernel, k_merge_plan, on the vertex counts);
+//   * the only vertices two slabs can share lie within `band` of a slab face: those go through one small hash (k_zs_band_insert:
+//     key -> smallest concatenated vertex id) and look themselves up (k_zs_band_resolve); of a pair the copy whose first-seen
+//     segment comes first in the (column, rank) order is the single-GPU representative, the other one is dropped from its
+//     segment's count and redirected;
+//   * kept vertices are numbered by an ordered scan (the distributed weld's k_dist_keep_count / k_scan_tiles / k_dist_newidx),
+//     written to their merged places (k_zs_vertex_out), the dropped ones inherit their partner's number (k_zs_loser_map), and
+//     the index buffers are rewritten segment by segment into the merged triangle order (k_zs_index_out).
+// Inputs are the ranks' buffers CONCATENATED in rank order (vertex i of rank r at vbase[r] + i, triangle t at tbase[r] + t).
+// ------------------------------------------------------------------------------------------
+__device__ __forceinline__ uint32_t zs_rank_of(const ZsRanks &zr, uint32_t i) {
+    uint32_t r = 0;
+    while (r + 1u < zr.nranks && i >= zr.vbase[r + 1u]) r++;
+    return r;
+}
+
+// largest local vertex index + 1 of every (rank, column) segment of the index buffers (0 for an empty segment; segmax pre-zeroed).
+// Segments are very uneven (a column holds anything from nothing to tens of thousands of triangles): gridDim.y workgroups share one.
+__global__ __launch_bounds__(256) void k_zs_segmax(const uint32_t *__restrict__ idx_all, const uint32_t *__restrict__ counts, uint32_t cstride,
+                                                    const uint32_t *__restrict__ tplan, const ZsRanks *__restrict__ zrp, uint32_t *__restrict__ segmax) {
+    const ZsRanks &zr = *zrp;
+    const uint32_t nseg = zr.nranks * NCOL;
+    for (uint32_t seg = blockIdx.x; seg < nseg; seg += gridDim.x) {
+        const uint32_t r = seg / NCOL, n = counts[r * cstride + seg % NCOL];
+        if (n == 0) continue;
+        const uint32_t ne = 3u * n, per = (ne + gridDim.y - 1u) / gridDim.y, e0 = blockIdx.y * per, e1 = e0 + per < ne ? e0 + per : ne;
+        if (e0 >= e1) continue;
+        const uint32_t *__restrict__ s = idx_all + 3ull * (zr.tbase[r] + tplan[2u * seg]);
+        uint32_t m = 0;
+        for (uint32_t e = e0 + threadIdx.x; e < e1; e += 256) { const uint32_t v = s[e] + 1u; m = v > m ? v : m; }
+        for (int o = 32; o > 0; o >>= 1) { const uint32_t t = (uint32_t) __shfl_xor((int) m, o, 64); m = t > m ? t : m; }
+        if (lane_id() == 0 && m) atomicMax(&segmax[seg], m);
+    }
+}
+
+// per rank (one workgroup each): vstart[c] = local vertices first seen in the columns before c (prefix maximum of segmax), newcnt[c] = first seen in c
+__global__ __launch_bounds__(1024) void k_zs_vplan(const uint32_t *__restrict__ segmax, const ZsRanks *__restrict__ zrp, uint32_t *__restrict__ vstart,
+                                                    uint32_t *__restrict__ newcnt, uint32_t *__restrict__ status) {
+    const ZsRanks &zr = *zrp;
+    __shared__ uint32_t s[NCOL];
+    const uint32_t c = threadIdx.x, r = blockIdx.x;
+    s[c] = segmax[r * NCOL + c];
+    __syncthreads();
+    for (uint32_t o = 1; o < NCOL; o <<= 1) {                        // inclusive prefix maximum (Hillis-Steele: 10 steps)
+        const uint32_t a = s[c], b = c >= o ? s[c - o] : 0u;
+        __syncthreads();
+        s[c] = a > b ? a : b;
+        __syncthreads();
+    }
+    const uint32_t incl = s[c], excl = c ? s[c - 1u] : 0u;
+    vstart[r * NCOL + c] = excl;
+    newcnt[r * NCOL + c] = incl - excl;
+    if (c == NCOL - 1u && incl != zr.vbase[r + 1u] - zr.vbase[r]) atomicOr(&status[ST_INTERNAL], 256u);       // an unreferenced vertex
+}
+
+// every vertex learns its first-seen segment; its redirect starts as "kept"
+__global__ __launch_bounds__(256) void k_zs_segfill(const uint32_t *__restrict__ vstart, const uint32_t *__restrict__ newcnt, const ZsRanks *__restrict__ zrp,
+                                                     uint32_t *__restrict__ segof, uint32_t *__restrict__ redirect) {
+    const ZsRanks &zr = *zrp;
+    const uint32_t nseg = zr.nranks * NCOL;
+    for (uint32_t seg = blockIdx.x; seg < nseg; seg += gridDim.x) {
+        const uint32_t n = newcnt[seg], first = zr.vbase[seg / NCOL] + vstart[seg];
+        for (uint32_t i = threadIdx.x; i < n; i += 256) { segof[first + i] = seg; redirect[first + i] = U32_NONE; }
+    }
+}
+
+__device__ __forceinline__ bool zs_in_band(const ZsRanks &zr, uint32_t r, float z) {
+    return (zr.zhi[r] < zr.ztop && z >= zr.zhi[r] - zr.band) || (zr.zlo[r] > zr.zbot && z <= zr.zlo[r] + zr.band);
+}
+
+__global__ __launch_bounds__(256) void k_zs_band_insert(const Vertex *__restrict__ v, uint32_t V, const ZsRanks *__restrict__ zrp, uint64_t *__restrict__ hkeys,
+                                                         uint32_t *__restrict__ hmin, uint32_t hsize, uint32_t *__restrict__ nband,
+                                                         uint32_t *__restrict__ status) {
+    // (the band is counted per workgroup at the END of its grid-stride loop: one counter add per wave that holds a band vertex --
+    // nearly every wave does, every column crosses the slab faces -- would queue tens of thousands of atomics on one word.  The table
+    // has room for twice the keys it was planned for; a probe sequence that gets long anyway means the plan was too small.)
+    const ZsRanks &zr = *zrp;
+    __shared__ uint32_t s_n;
+    if (threadIdx.x == 0) s_n = 0;
+    __syncthreads();
+    uint32_t mine = 0;
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < V; i += gridDim.x * blockDim.x) {
+        const Point p = v[i].position;
+        if (!zs_in_band(zr, zs_rank_of(zr, i), p.z)) continue;
+        mine++;
+        uint64_t key;
+        if (!packed_weld_key(p, key)) { atomicOr(&status[ST_WELD_RANGE], 1u); continue; }
+        uint32_t s = hash_home(key, hsize);
+        bool placed = false;
+        for (uint32_t probe = 0; probe < 512u && probe < hsize; probe++) {
+            const uint64_t prev = atomicCAS((unsigned long long *) &hkeys[s], (unsigned long long) KEY_EMPTY, (unsigned long long) key);
+            if (prev == KEY_EMPTY || prev == key) { atomicMin(&hmin[s], i); placed = true; break; }
+            s = hash_next(s, hsize);
+        }
+        if (!placed) atomicOr(&status[ST_OVERFLOW], 64u);
+    }
+    const uint32_t ws = wave_sum(mine);
+    if (lane_id() == 0 && ws) atomicAdd(&s_n, ws);
+    __syncthreads();
+    if (threadIdx.x == 0 && s_n) atomicAdd(nband, s_n);
+}
+
+__global__ __launch_bounds__(256) void k_zs_band_resolve(const Vertex *__restrict__ v, uint32_t V, const ZsRanks *__restrict__ zrp, const uint64_t *__restrict__ hkeys,
+                                                          const uint32_t *__restrict__ hmin, uint32_t hsize, const uint32_t *__restrict__ segof,
+                                                          uint32_t *__restrict__ redirect, uint32_t *__restrict__ newcnt) {
+    const ZsRanks &zr = *zrp;
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < V; i += gridDim.x * blockDim.x) {
+        const Point p = v[i].position;
+        if (!zs_in_band(zr, zs_rank_of(zr, i), p.z)) continue;
+        uint64_t key;
+        if (!packed_weld_key(p, key)) continue;
+        uint32_t s = hash_home(key, hsize);
+        for (uint32_t probe = 0; probe < 512u && probe < hsize; probe++) {
+            const uint64_t k = hkeys[s];
+            if (k == KEY_EMPTY) break;
+            if (k == key) {
+                const uint32_t a = hmin[s];
+                if (a != i) {                                            // (a < i: the copy of a lower rank -- a rank's own keys are distinct)
+                    const uint32_t sa = segof[a], si = segof[i];
+                    // single-GPU order of the two first occurrences: by column, then by rank
+                    const bool a_first = (sa % NCOL) < (si % NCOL) || ((sa % NCOL) == (si % NCOL) && sa < si);
+                    const uint32_t win = a_first ? a : i, lose = a_first ? i : a;
+                    redirect[lose] = win;
+                    atomicSub(&newcnt[a_first ? si : sa], 1u);
+                }
+                break;
+            }
+            s = hash_next(s, hsize);
+        }
+    }
+}
+
+// kept vertices to their merged places; map[i] = merged number
+__global__ __launch_bounds__(256) void k_zs_vertex_out(const Vertex *__restrict__ v, uint32_t V, const ZsRanks *__restrict__ zrp, const uint32_t *__restrict__ redirect,
+                                                        const uint32_t *__restrict__ kept_before, const uint32_t *__restrict__ segof,
+                                                        const uint32_t *__restrict__ vstart, const uint32_t *__restrict__ vplan,
+                                                        Vertex *__restrict__ out, uint32_t cap, uint32_t *__restrict__ map) {
+    const ZsRanks &zr = *zrp;
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < V; i += gridDim.x * blockDim.x) {
+        if (redirect[i] != U32_NONE) continue;
+        const uint32_t seg = segof[i], first = zr.vbase[seg / NCOL] + vstart[seg];
+        const uint32_t g = vplan[2u * seg + 1u] + (kept_before[i] - kept_before[first]);
+        map[i] = g;
+        if (g < cap) out[g] = v[i];
+    }
+}
+
+__global__ __launch_bounds__(256) void k_zs_loser_map(uint32_t V, const uint32_t *__restrict__ redirect, uint32_t *__restrict__ map) {
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < V; i += gridDim.x * blockDim.x) {
+        const uint32_t w = redirect[i];
+        if (w != U32_NONE) map[i] = map[w];                            // (the partner is kept: its number is final)
+    }
+}
+
+// the index buffers, segment by segment (gridDim.y workgroups share one), into the merged triangle order with merged vertex numbers
+__global__ __launch_bounds__(256) void k_zs_index_out(const uint32_t *__restrict__ idx_all, const uint32_t *__restrict__ counts, uint32_t cstride,
+                                                       const uint32_t *__restrict__ tplan, const ZsRanks *__restrict__ zrp, const uint32_t *__restrict__ map,
+                                                       uint32_t *__restrict__ out, uint32_t cap_tris) {
+    const ZsRanks &zr = *zrp;
+    const uint32_t nseg = zr.nranks * NCOL;
+    for (uint32_t seg = blockIdx.x; seg < nseg; seg += gridDim.x) {
+        const uint32_t r = seg / NCOL, n = counts[r * cstride + seg % NCOL];
+        if (n == 0) continue;
+        const uint32_t dst = tplan[2u * seg + 1u];
+        if (dst + n > cap_tris) continue;                              // flagged by k_merge_plan
+        const uint32_t ne = 3u * n, per = (ne + gridDim.y - 1u) / gridDim.y, e0 = blockIdx.y * per, e1 = e0 + per < ne ? e0 + per : ne;
+        const uint32_t *__restrict__ s = idx_all + 3ull * (zr.tbase[r] + tplan[2u * seg]);
+        uint32_t *__restrict__ d = out + 3ull * dst;
+        const uint32_t vb = zr.vbase[r];
+        for (uint32_t e = e0 + threadIdx.x; e < e1; e += 256) d[e] = map[vb + s[e]];
+    }
+}
+
+// ------------------------------------------------------------------------------------------
 // Dense mode: the same voxel list as the hierarchical refine, derived from
 // the dense (N+1)^3 sample lattice.
 //   P2a k_sign_bits      one bit per sample (sd <= 0): a pure streaming read, 4 B x (N+1)^3 -> HBM-bound
@@ -3118,6 +3302,43 @@ hipError_t launch_dist_pack_up(hipStream_t st, int grid, const uint32_t *up_ids,
 hipError_t launch_dist_finalize(hipStream_t st, int grid, const Vertex *v, uint32_t V, uint32_t T, const uint32_t *dup_of, const uint32_t *newidx,
                                 const uint32_t *prev_g, const uint32_t *counts, uint32_t me, uint32_t *indices, Vertex *out_v) {
     hipLaunchKernelGGL(k_dist_finalize, dim3(grid), dim3(256), 0, st, v, V, T, dup_of, newidx, prev_g, counts, me, indices, out_v);
+    return hipGetLastError();
+}
+
+hipError_t launch_merge_plan(hipStream_t st, const uint32_t *d_counts, uint32_t cstride, int nranks, uint32_t *d_plan, uint32_t cap,
+                             uint32_t *total_out, uint32_t *status) {
+    hipLaunchKernelGGL(k_merge_plan, dim3(1), dim3(1024), 0, st, d_counts, cstride, (uint32_t) nranks, d_plan, cap, total_out, status);
+    return hipGetLastError();
+}
+
+// z-slab indexed merge, first half: the segments' first-seen vertex ranges, every vertex's segment, the face-band pairs
+hipError_t launch_zs_front(hipStream_t st, int grid, const Vertex *v_all, const uint32_t *idx_all, const uint32_t *counts, uint32_t cstride,
+                           const uint32_t *tplan, const ZsRanks &zr, const ZsRanks *d_zr, uint32_t *segmax, uint32_t *vstart, uint32_t *newcnt, uint32_t *segof,
+                           uint32_t *redirect, uint64_t *hkeys, uint32_t *hmin, uint32_t hsize, uint32_t *nband, uint32_t *status) {
+    const uint32_t V = zr.vbase[zr.nranks];
+    const int nseg = (int) (zr.nranks * 1024u);
+    (void) hipMemsetAsync(segmax, 0, 4ull * (size_t) nseg, st);
+    hipLaunchKernelGGL(k_zs_segmax, dim3(nseg, 2), dim3(256), 0, st, idx_all, counts, cstride, tplan, d_zr, segmax);
+    hipLaunchKernelGGL(k_zs_vplan, dim3(zr.nranks), dim3(1024), 0, st, (const uint32_t *) segmax, d_zr, vstart, newcnt, status);
+    hipLaunchKernelGGL(k_zs_segfill, dim3(nseg), dim3(256), 0, st, (const uint32_t *) vstart, (const uint32_t *) newcnt, d_zr, segof, redirect);
+    if (zr.nranks > 1 && V) {
+        hipLaunchKernelGGL(k_zs_band_insert, dim3(grid), dim3(256), 0, st, v_all, V, d_zr, hkeys, hmin, hsize, nband, status);
+        hipLaunchKernelGGL(k_zs_band_resolve, dim3(grid), dim3(256), 0, st, v_all, V, d_zr, (const uint64_t *) hkeys, (const uint32_t *) hmin, hsize,
+                           (const uint32_t *) segof, redirect, newcnt);
+    }
+    return hipGetLastError();
+}
+
+// second half: merged vertices and indices (kept_before = the ordered numbering of the kept vertices, vplan = k_merge_plan of newcnt)
+hipError_t launch_zs_back(hipStream_t st, int grid, const Vertex *v_all, const uint32_t *idx_all, const uint32_t *counts, uint32_t cstride,
+                          const uint32_t *tplan, const ZsRanks &zr, const ZsRanks *d_zr, const uint32_t *redirect, const uint32_t *kept_before, const uint32_t *segof,
+                          const uint32_t *vstart, const uint32_t *vplan, Vertex *v_out, uint32_t cap_verts, uint32_t *map, uint32_t *i_out, uint32_t cap_tris) {
+    const uint32_t V = zr.vbase[zr.nranks];
+    if (V) {
+        hipLaunchKernelGGL(k_zs_vertex_out, dim3(grid), dim3(256), 0, st, v_all, V, d_zr, redirect, kept_before, segof, vstart, vplan, v_out, cap_verts, map);
+        if (zr.nranks > 1) hipLaunchKernelGGL(k_zs_loser_map, dim3(grid), dim3(256), 0, st, V, redirect, map);
+    }
+    hipLaunchKernelGGL(k_zs_index_out, dim3(zr.nranks * 1024u, 2), dim3(256), 0, st, idx_all, counts, cstride, tplan, d_zr, (const uint32_t *) map, i_out, cap_tris);
     return hipGetLastError();
 }
 

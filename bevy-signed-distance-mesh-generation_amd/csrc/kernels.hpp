@@ -23,9 +23,10 @@ enum StatusWord : int {
 };
 
 // Multi-GPU agreement records (every rank learns every rank's status in the all-gather that moves the sizes anyway):
-//   z-slab gather   SHARD_ROW words per rank: 1024 column counts, then {status, triangles, receive capacity, merged capacity}
+//   z-slab gather   SHARD_ROW words per rank: 1024 column counts, then {status, triangles, two receive capacities of this rank as a
+//                   root (raw form: received / merged triangles; indexed form: vertices / triangles), vertices, indexed form?, 0, 0}
 //   x-slab weld     DIST_REC words per rank: {band size or kept count, status, capacity for the neighbour's band, 0}
-static constexpr uint32_t SHARD_ROW = 1024 + 4;
+static constexpr uint32_t SHARD_ROW = 1024 + 8;
 static constexpr uint32_t DIST_REC = 4;
 
 hipError_t launch_refine_mask(hipStream_t st, int grid, int scene, const SceneParams *sp, const Point *vox,
@@ -110,6 +111,21 @@ hipError_t launch_column_counts(hipStream_t st, int grid, const Point *vox, cons
                                 uint32_t *colcnt);
 hipError_t launch_tile_tricount(hipStream_t st, int grid, const uint8_t *cubeidx, const uint32_t *n_ptr, uint32_t *tilecnt);
 // multi-GPU distributed weld (x-slabs)
+// z-slab indexed gather: the ranks' welded buffers concatenated in rank order (csrc/kernels.hip, "INDEXED gather")
+struct ZsRanks {
+    uint32_t nranks;
+    uint32_t vbase[33], tbase[33];      // first vertex / triangle of rank r in the concatenated buffers; [nranks] = totals
+    float zlo[32], zhi[32];             // the slabs' z extents
+    float zbot, ztop, band;             // the domain's z extent (a face on it is no slab face), half-width of the face bands
+};
+hipError_t launch_merge_plan(hipStream_t st, const uint32_t *d_counts, uint32_t cstride, int nranks, uint32_t *d_plan, uint32_t cap,
+                             uint32_t *total_out, uint32_t *status);
+hipError_t launch_zs_front(hipStream_t st, int grid, const Vertex *v_all, const uint32_t *idx_all, const uint32_t *counts, uint32_t cstride,
+                           const uint32_t *tplan, const ZsRanks &zr /* host copy */, const ZsRanks *d_zr /* the same in device memory */, uint32_t *segmax, uint32_t *vstart, uint32_t *newcnt, uint32_t *segof,
+                           uint32_t *redirect, uint64_t *hkeys, uint32_t *hmin, uint32_t hsize, uint32_t *nband, uint32_t *status);
+hipError_t launch_zs_back(hipStream_t st, int grid, const Vertex *v_all, const uint32_t *idx_all, const uint32_t *counts, uint32_t cstride,
+                          const uint32_t *tplan, const ZsRanks &zr, const ZsRanks *d_zr, const uint32_t *redirect, const uint32_t *kept_before, const uint32_t *segof,
+                          const uint32_t *vstart, const uint32_t *vplan, Vertex *v_out, uint32_t cap_verts, uint32_t *map, uint32_t *i_out, uint32_t cap_tris);
 hipError_t launch_band_select(hipStream_t st, int grid, const Vertex *v, uint32_t V, float up_thr, float lo_thr, bool has_up, bool has_lo,
                               uint32_t *up_ids, uint64_t *up_keys, uint32_t *lo_ids, uint32_t *ctr, uint32_t *dup_of, uint32_t *status);
 hipError_t launch_dist_match(hipStream_t st, int grid, const uint64_t *prev_keys, uint32_t n_prev, uint64_t *hkeys, uint32_t *hpos, uint32_t hsize,

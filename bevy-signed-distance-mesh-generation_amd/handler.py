@@ -392,6 +392,19 @@ class CudaHandler:
             raise SdMeshError(rc, " | ".join(m for m in msgs if m))
         return [infos[i] for i in range(n)], [int(first[i]) for i in range(n)]
 
+    @staticmethod
+    def sharded_regen_rehearsal(handlers, levels, root=0):
+        """The indexed z-slab gather for several handlers of THIS process on one GPU (copies instead of RCCL messages): handler r meshes
+        and welds z-slab r, handlers[root] merges the slabs' vertex / index buffers into the single-GPU mesh, which becomes ITS mesh."""
+        n = len(handlers)
+        arr = (ctypes.c_void_p * n)(*[h._h for h in handlers])
+        info = RegenInfo()
+        rc = handlers[0]._lib.sdmesh_sharded_regen_rehearsal(arr, n, int(levels), int(root), ctypes.byref(info))
+        if rc != 0:
+            msgs = [h._lib.sdmesh_last_error(h._h).decode(errors="replace") for h in handlers]
+            raise SdMeshError(rc, " | ".join(m for m in msgs if m))
+        return info
+
     def weld_device_triangles(self, dev_ptr, nslots):
         info = RegenInfo()
         self._chk(self._lib.sdmesh_weld_device_triangles(self._h, ctypes.c_void_p(dev_ptr), int(nslots),

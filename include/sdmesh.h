@@ -262,6 +262,14 @@ int sdmesh_comm_ranks(sdmesh_handle *h, int *ranks_seen);
  * small (never in steady state).  Only an SDMESH_ERR_RCCL / SDMESH_ERR_HIP from a collective itself is not agreed upon. */
 int sdmesh_sharded_regen(sdmesh_handle *h, int levels, int root, sdmesh_regen_info *info);
 
+/* The indexed form of sdmesh_sharded_regen (its default; option "shard_indexed" = 0 selects the raw-list form described above) for
+ * `nranks` handles of ONE process on ONE device, with device-to-device copies in place of the RCCL messages: handle r meshes and
+ * welds level-0 z-slab r; the root handle concatenates the slabs' vertex / index buffers and merges them (csrc/kernels.hip,
+ * "INDEXED gather": no second weld, streaming passes only) into the single-GPU mesh, bit for bit, which becomes the root handle's
+ * mesh (sdmesh_device_mesh / sdmesh_download_mesh).  Every kernel and phase of the collective form runs; tests and single-GPU
+ * measurements of the root's share use it.  All handles need the same slab bounds (sdmesh_set_slab_bounds / sdmesh_balance_slabs). */
+int sdmesh_sharded_regen_rehearsal(sdmesh_handle **handles, int nranks, int levels, int root, sdmesh_regen_info *info);
+
 /* Dense mode: the same regen through the dense (N+1)^3 lattice -- P1 sample, P2a sign bits, P2b
  * LDS-tiled classify with the hierarchical ancestor criterion (A2'), then the usual mesh stage.  O(N^3) work; it
  * exists as the cross-check that "dense == hierarchical" and to measure the two HBM passes, not as the fast path. */
