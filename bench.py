@@ -178,7 +178,7 @@ def single_gpu_step_times(pkg, local_rank, scene, params, levels_list, graph, re
 
 
 def one_mesh_legs(pkg, job, local_rank, scene, params, levels_list, base_levels, steps, warmup, graph):
-    """ONE mesh over all ranks, both forms, every size; plus the primary timing (z-slab form at the workload size)."""
+    """ONE mesh over all ranks, both forms, every size; plus the primary timing (the faster form at the workload size)."""
     from bevy_signed_distance_mesh_generation_amd import partition as P
     world, rank = job.world, job.rank
     dev = torch.device("cuda", local_rank)
@@ -187,7 +187,7 @@ def one_mesh_legs(pkg, job, local_rank, scene, params, levels_list, base_levels,
         box = [t1]
         dist.broadcast_object_list(box, src=0)
         t1 = box[0]
-    # --- z-slabs, RCCL gather to rank 0, merge + weld there: all inside sdmesh_sharded_regen
+    # --- z-slabs welded per rank, RCCL gather of the vertex / index buffers to rank 0, indexed merge there: all inside sdmesh_sharded_regen
     h = pkg.CudaHandler(local_rank, scene, params)
     mesher = P.ShardedMesher(pkg, h, base_levels, rank, world, dev, transport="rccl")
     ranks_seen = mesher.ranks_seen
@@ -211,7 +211,7 @@ def one_mesh_legs(pkg, job, local_rank, scene, params, levels_list, base_levels,
                            "speedup_vs_1rank": round(t1[lv]["ms"] / ms, 3), "mvoxels_per_s": round(n ** 3 / ms / 1e3, 1),
                            "mtris_per_s": round(int(tri[0]) / ms / 1e3, 1), "triangles": int(tri[0]), "vertices": int(tri[1]), "steps": k}
         if lv == base_levels:
-            primary = (dt, k, int(tri[0]), int(tri[1]), "zslab_gather_root_weld")
+            primary = (dt, k, int(tri[0]), int(tri[1]), "zslab_indexed_gather")
     mesher.close()
     h.close()
     # --- x-slabs, every rank welds its slab, neighbours unify the shared faces, the mesh stays distributed
@@ -238,10 +238,11 @@ def one_mesh_legs(pkg, job, local_rank, scene, params, levels_list, base_levels,
             primary = (dt, k, int(cnt[1]), int(cnt[0]), "xslab_distributed_weld")
     h.close()
     return primary, {"n_gpus": world, "ranks_seen": ranks_seen, "slab_bounds": {"z": zbounds, "x": xbounds},
-                     "zslab_gather_root_weld": {"what": "sdmesh_sharded_regen: level-0 z-slab per rank, ncclAllGather of 1024 column "
-                                                        "counts, ncclSend/ncclRecv of compact triangle lists to rank 0, merge kernel + "
-                                                        "first-seen weld there; mesh identical to 1 GPU (counts checked here, bits in tests)",
-                                                **zslab},
+                     "zslab_indexed_gather": {"what": "sdmesh_sharded_regen (indexed form): level-0 z-slab per rank, meshed AND welded there; ncclAllGather of "
+                                                      "1024 column counts + sizes + status; ncclSend/ncclRecv of the slabs' vertex and index buffers "
+                                                      "(24 B per vertex + 12 B per triangle) to rank 0; there the buffers are merged by (column, rank) "
+                                                      "segments without welding again; mesh identical to 1 GPU (counts checked here, bits in tests)",
+                                              **zslab},
                      "xslab_distributed_weld": {"what": "sdmesh_distributed_regen: level-0 x-slab per rank, every rank welds its slab, x-neighbours unify "
                                                         "the vertices of their shared face by weld key (two ncclSend/ncclRecv of the face band + two 4-byte "
                                                         "ncclAllGather), indices become global, the mesh stays distributed",
@@ -507,7 +508,7 @@ def main():
             "config": {"workload": f"{args.scene} {n_grid}^3 (BASELINE configs[2]: reference scene sd_obj, 32^3 level-0 cells refined "
                                    f"x{args.levels}) as ONE mesh over {world} GPUs; the faster of the two one-mesh forms at this size is the "
                                    f"headline: {form} (both are in one_mesh, each with its same-size 1-GPU time; they deliver different "
-                                   f"things: zslab_gather_root_weld leaves the whole indexed mesh on rank 0, xslab_distributed_weld leaves it "
+                                   f"things: zslab_indexed_gather leaves the whole indexed mesh on rank 0, xslab_distributed_weld leaves it "
                                    f"distributed, every rank holding its slab's vertices and globally numbered triangles)",
                        "levels": args.levels, "grid": n_grid, "parallelism": f"{world} slabs of equal surface content, one per GPU",
                        "one_mesh_form": form},

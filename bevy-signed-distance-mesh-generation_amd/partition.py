@@ -69,14 +69,17 @@ class ShardedMesher:
     """ONE mesh across all ranks (strong scaling) -- a thin caller of the C ABI.
 
     With RCCL available to the job (process group backend "nccl", or a single rank) the whole step is ONE library call,
-    `sdmesh_sharded_regen`: z-slab regen per rank (weld skipped), ncclAllGather of the 1024 per-column triangle counts,
-    grouped ncclSend / ncclRecv of the compact per-slab lists to the root (each peer on its own xGMI link), the
-    order-restoring merge kernel and the first-seen weld on the root.  The communicator is the library's own
-    (`sdmesh_comm_init`); torch.distributed only carries the 128-byte unique id to the ranks.
+    `sdmesh_sharded_regen`, by default in its INDEXED form: z-slab regen AND weld per rank, ncclAllGather of the 1024 per-column
+    triangle counts (+ sizes and a status word), grouped ncclSend / ncclRecv of the slabs' vertex and index buffers to the root
+    (24 B per vertex + 12 B per triangle, each peer on its own xGMI link), and on the root the merge of those buffers by
+    (column, rank) segments -- no second weld (csrc/kernels.hip, "INDEXED gather").  Option "shard_indexed" = 0 selects the
+    raw form (unwelded slabs, 72 B per triangle, order-restoring merge kernel + first-seen weld of every corner on the root).
+    The communicator is the library's own (`sdmesh_comm_init`); torch.distributed only carries the 128-byte unique id to the ranks.
 
     Under "gloo" (the rehearsals that put several ranks on one GPU, where RCCL refuses duplicate devices) only the
-    TRANSPORT differs: counts and triangle lists are staged through host memory by torch.distributed, everything else
-    -- slab regen, column counts, `sdmesh_merge_by_column`, `sdmesh_weld_device_triangles` -- is the same C ABI."""
+    TRANSPORT differs, and the raw form is the one rehearsed: counts and triangle lists are staged through host memory by
+    torch.distributed, everything else -- slab regen, column counts, `sdmesh_merge_by_column`, `sdmesh_weld_device_triangles` --
+    is the same C ABI.  (The indexed form is rehearsed in one process by `sdmesh_sharded_regen_rehearsal`.)"""
 
     def __init__(self, pkg, handler, levels, rank, world, device, transport=None, balance=True):
         import torch.distributed as dist

@@ -148,6 +148,7 @@ int sdmesh_use_own_stream(sdmesh_handle *h);
  *   "publish_ctl" = 0   read the counters back with a device-to-host copy behind the chain (default 1: the chain's last
  *                       kernel writes them to the handle's pinned host block itself)
  *   "profile" = 1       time every stage of the planned chain with HIP events (sdmesh_profile_stages)
+ *   "shard_indexed" = 0 sdmesh_sharded_regen in its raw form (unwelded slabs, triangle lists to the root, weld there); default 1: indexed form
  *   "weld_wide" = 1     always weld with the unbounded key form (default 0: packed 3 x 21-bit keys, and the wide form
  *                       automatically from the first vertex that does not fit them) */
 int sdmesh_set_option(sdmesh_handle *h, const char *name, int value);
@@ -249,12 +250,17 @@ int sdmesh_comm_destroy(sdmesh_handle *h);
 /* ncclAllReduce(sum) of 1 over the communicator: how many ranks really took part */
 int sdmesh_comm_ranks(sdmesh_handle *h, int *ranks_seen);
 
-/* ONE regen of ONE mesh over all ranks of the communicator, entirely behind this call: rank r meshes level-0 z-slab r
- * (no weld), ncclAllGather of the 1024 per-column triangle counts (4 KB), grouped ncclSend / ncclRecv of the compact
- * per-slab triangle lists straight to `root` (each peer on its own xGMI link), order-restoring merge kernel and first-seen
- * weld on the root.  On the root *info describes the welded mesh (identical to a single-GPU sdmesh_regen, fetch it with
- * sdmesh_device_mesh / sdmesh_download_mesh); on the other ranks it describes their slab.  Collective: every rank of
- * the communicator must call it with the same levels and root.
+/* ONE regen of ONE mesh over all ranks of the communicator, entirely behind this call.
+ * Indexed form (default): rank r meshes AND welds level-0 z-slab r, ncclAllGather of the 1024 per-column triangle counts + sizes +
+ * status (4 KB), grouped ncclSend / ncclRecv of the slab's vertex and index buffers (24 B per vertex + 12 B per triangle) straight to
+ * `root` (each peer on its own xGMI link); the root merges the buffers by (column, rank) segments WITHOUT welding again (only vertices
+ * near a slab face are looked up, in one small hash).
+ * Raw form (option "shard_indexed" = 0, also the way out for wide weld keys: the indexed form fails with SDMESH_ERR_WELD_RANGE then):
+ * no weld on the ranks, the compact per-slab triangle lists (72 B per triangle) go to the root, order-restoring merge kernel and
+ * first-seen weld of every corner there.  Every rank must use the same form (checked in the all-gather).
+ * On the root *info describes the welded mesh (identical to a single-GPU sdmesh_regen, fetch it with sdmesh_device_mesh /
+ * sdmesh_download_mesh; in the indexed form info->device_ms is the time of the root's merge, and the root's voxel list is not kept);
+ * on the other ranks it describes their slab.  Collective: every rank of the communicator must call it with the same levels and root.
  * Failure is collective too: the all-gather carries a status word per rank and is entered even by a rank whose slab
  * failed, so when any rank fails (its regen, an allocation, a count mismatch) every rank returns from this call with an
  * error -- the failing one with its own code, the others with SDMESH_ERR_PEER -- and none is left waiting in a collective.

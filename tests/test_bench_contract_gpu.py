@@ -50,8 +50,8 @@ def test_one_mesh_line_keeps_the_contract_on_one_rank():
     for k in REQUIRED:
         assert k in j, k
     assert j["n_gpus"] == 1 and j["scaling"] == "strong" and j["ranks_seen"] == 1
-    assert j["config"]["one_mesh_form"] in ("zslab_gather_root_weld", "xslab_distributed_weld")
-    for form in ("zslab_gather_root_weld", "xslab_distributed_weld"):
+    assert j["config"]["one_mesh_form"] in ("zslab_indexed_gather", "xslab_distributed_weld")
+    for form in ("zslab_indexed_gather", "xslab_distributed_weld"):
         for size in ("256^3", "512^3", "1024^3"):
             row = j["one_mesh"][form][size]
             assert row["t_1rank_ms"] > 0 and row["ms_per_regen"] > 0 and row["triangles"] > 0
