@@ -209,7 +209,8 @@ def one_mesh_legs(pkg, job, local_rank, scene, params, levels_list, base_levels,
                                f"{t1[lv]['triangles']} / {t1[lv]['vertices']}")
         zslab[f"{n}^3"] = {"ms_per_regen": round(ms, 4), "t_1rank_ms": round(t1[lv]["ms"], 4),
                            "speedup_vs_1rank": round(t1[lv]["ms"] / ms, 3), "mvoxels_per_s": round(n ** 3 / ms / 1e3, 1),
-                           "mtris_per_s": round(int(tri[0]) / ms / 1e3, 1), "triangles": int(tri[0]), "vertices": int(tri[1]), "steps": k}
+                           "mtris_per_s": round(int(tri[0]) / ms / 1e3, 1), "triangles": int(tri[0]), "vertices": int(tri[1]), "steps": k,
+                           "root_merge_ms": round(float(info.device_ms), 4) if info is not None else None}      # (HIP events on rank 0: the merge alone)
         if lv == base_levels:
             primary = (dt, k, int(tri[0]), int(tri[1]), "zslab_indexed_gather")
     mesher.close()
