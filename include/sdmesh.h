@@ -31,8 +31,10 @@ enum {
     SDMESH_ERR_HIP = 2,          /* a HIP runtime call failed (sdmesh_last_error has the text) */
     SDMESH_ERR_NO_DEVICE = 3,    /* no usable gfx950 device */
     SDMESH_ERR_CAPACITY = 4,     /* caller-provided output buffer too small */
-    SDMESH_ERR_WELD_RANGE = 5,   /* kept for ABI stability; no longer returned: vertices outside the packed +-10.48 unit key
-                                    are welded with the wide key form, like the reference's [i64; 3] (src/cuda/mod.rs:268-273) */
+    SDMESH_ERR_WELD_RANGE = 5,   /* single-GPU calls never return it: vertices outside the packed +-10.48 unit key are welded with the
+                                    wide key form, like the reference's [i64; 3] (src/cuda/mod.rs:268-273).  Only the multi-GPU forms
+                                    that match vertices across ranks by the packed key return it (the distributed weld, the indexed
+                                    z-slab gather -- whose raw form, option "shard_indexed" = 0, is the way out) */
     SDMESH_ERR_INTERNAL = 6,     /* invariant violated on the device (bug) */
     SDMESH_ERR_RCCL = 7,         /* librccl missing or a collective failed (sdmesh_last_error has the text); the communicator is
                                     unusable afterwards */
