@@ -17,7 +17,11 @@
  * tris/voxel histogram for sd_obj k=0..5 and the sphere k=0..4) -- this oracle reproduces
  * every row; the FNV hash columns of that table could not be reproduced by any FNV variant
  * (not even for the scene-independent level-0 field) and are not used;
- * (2) closed-mesh invariants (V - T/2 = chi, every edge shared by exactly two triangles).
+ * (2) closed-mesh invariants (V - T/2 = chi, every edge shared by exactly two triangles);
+ * (3) the DATA the reference itself holds for the path, parsed from its files as text by tools/pin_mc_tables.py into
+ * tests/golden/*_ref.json and checked against this file and the product by tests/test_reference_pins.py: the
+ * marching-cubes tables, the FFI header (constants, struct fields) and the path's numeric literals (stencil step and
+ * weights, Newton threshold and cap, midpoint factor, inside / flip tests, sd_obj's parameters, weld quantum).
  *
  * Arithmetic model: GLM 1.0.1 generic scalar paths, no FMA
  * contraction (compile with -ffp-contract=off), IEEE division and sqrt:

@@ -116,3 +116,46 @@ def test_bindings_struct_fields_equal_the_reference_header():
     assert set(ref) <= set(ours), set(ref) - set(ours)
     for name, fields in ref.items():
         assert ours[name] == fields, name
+
+
+def test_path_constants_of_oracle_and_product_equal_the_reference_text():
+    """The numeric literals of the hot path as the reference's own source text holds them (tests/golden/path_constants_ref.json,
+    parsed by tools/pin_mc_tables.py: numbers, not code) against the oracle's C restatement AND the product's device code -- the two
+    are written independently of each other here, but both from the survey, so a misread constant would otherwise be common-mode."""
+    ref = json.load(open(os.path.join(GOLD, "path_constants_ref.json")))
+    oracle = open(os.path.join(ROOT, "oracle", "sdmesh_oracle.c")).read()
+    sdf = open(os.path.join(ROOT, "bevy-signed-distance-mesh-generation_amd", "csrc", "sdf.hpp")).read()
+    kern = open(os.path.join(ROOT, "bevy-signed-distance-mesh-generation_amd", "csrc", "kernels.hip")).read()
+    meshdev = open(os.path.join(ROOT, "bevy-signed-distance-mesh-generation_amd", "csrc", "mesh_device.hpp")).read()
+    f = lambda s: float(s)                                                       # noqa: E731
+    # finite-difference stencil: step, 8x inner weight, +-2 eps outer offsets
+    eps = f(ref["normal_epsilon"])
+    assert f(re.search(r"#define NORMAL_EPSILON ([0-9.]+)f", oracle).group(1)) == eps
+    assert f(re.search(r"#define SDM_NORMAL_EPS ([0-9.]+)f", sdf).group(1)) == eps
+    assert ref["stencil_weights"] == ["8.0"] and ref["stencil_offsets_in_epsilons"] == ["-2.0", "2.0"]
+    assert "8.0f * F(NORMAL_EPSILON, 0.0f, 0.0f)" in oracle and "F(2.0f * NORMAL_EPSILON, 0.0f, 0.0f)" in oracle
+    assert "e2 = 2.0f * SDM_NORMAL_EPS" in sdf and re.search(r"8\.0f \* \w+\.x - 8\.0f \* \w+\.y", sdf)
+    # Newton projection: threshold (inclusive), iteration cap
+    thr, cap = f(ref["newton_threshold"]), int(ref["newton_iteration_cap"])
+    m = re.search(r"i < (\d+); i\+\+\) \{.*?collision = gabs\(sd\) <= ([0-9.]+)f;", oracle, flags=re.S)
+    assert int(m.group(1)) == cap and f(m.group(2)) == thr
+    assert int(re.search(r"#define SDM_MAX_NEWTON (\d+)", sdf).group(1)) == cap
+    got = {f(v) for v in re.findall(r"fabsf\(sd\) <= ([0-9.]+)f", sdf + kern)}
+    assert got == {thr}, got
+    # marching cubes: midpoint, `<= 0` inside tests, 5 triangle slots per voxel, flip when the dot product is `<= 0`, centroid / 3
+    assert f(ref["mc_midpoint_factor"]) == 0.5 and ref["mc_inside_test"] == "<=" and ref["refine_inside_test"] == "<="
+    assert ref["orientation_flip_test"] == "<=" and f(ref["centroid_divisor"]) == 3.0 and int(ref["triangles_per_voxel_slot"]) == 5
+    assert re.search(r"<= 0\.0f\) bits \|=", kern) and "sdf_eval(scene, params, " in oracle and re.search(r"<= 0\.0f", oracle)
+    assert "a / 3.0f" in sdf and "vdivs(vadd(vadd(v0, v1), v2), 3.0f)" in oracle and "dot3(tn, an) <= 0.0f" in oracle
+    assert re.search(r"5u? \* ", meshdev + kern) and re.search(r"5 \* ", oracle)
+    # sd_obj: skeleton (3, 1, 0.5) with line width 0.1, unit sphere, smooth minimum k = 0.5 with h^3 k / 6
+    sk = [f(v) for v in ref["sd_obj"]["skeleton_size"]]
+    assert sk == [3.0, 1.0, 0.5] and f(ref["sd_obj"]["skeleton_line_width"]) == 0.1 and f(ref["sd_obj"]["sphere_radius"]) == 1.0
+    assert f(ref["sd_obj"]["smooth_k"]) == 0.5 and ref["smooth_min"]["sixth"] == ["1.0", "6.0"]
+    assert "sd_box_skeleton(p, 0, (3, 1, 0.5), 0.1)" in sdf and "h * h * h * k * (1.0f / 6.0f)" in sdf and "h * h * h * k * (1.0f / 6.0f)" in oracle
+    assert re.search(r"smooth_min\(a1, a2, 0\.5f\)", sdf) and re.search(r"- 0\.1f", sdf) and re.search(r"\) - 1\.0f;", sdf)
+    assert re.search(r"3\.0f,\s*1\.0f,\s*0\.5f", oracle) and re.search(r"0\.1f", oracle)
+    # weld: key = round(x * 10e4) per coordinate, triangles dropped on a non-finite x of their first vertex
+    q = f(ref["weld_quantum_factor"])
+    assert q == 1e5 and ref["weld_finite_test"] == "x"
+    assert f(re.search(r"roundf\(x \* ([0-9.e]+)f\)", oracle).group(1)) == q and f(re.search(r"roundf\(x \* ([0-9.e]+)f\)", sdf).group(1)) == q
