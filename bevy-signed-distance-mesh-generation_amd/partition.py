@@ -65,6 +65,74 @@ def merge_triangles(tri_lists, counts):
     return out
 
 
+def indexed_merge_reference(parts, counts, z_faces, band):
+    """CPU restatement (numpy) of the root's share of the INDEXED z-slab gather (zs_merge / k_zs_* in csrc), for the tests that
+    run without a GPU -- the product path calls `sdmesh_sharded_regen`, never this.
+
+    parts: per rank (verts [V_r, 6] f32 = position | normal in the rank's own first-seen order, idx [T_r, 3] local indices in the
+    rank's emission order); counts [R, 1024] triangles per level-0 column; z_faces: per rank (z_lo, z_hi) of its slab; band: half
+    width of the face bands.  Returns (verts, idx) of the single-GPU mesh."""
+    import numpy as np
+    R = len(parts)
+    counts = np.asarray(counts, dtype=np.int64).reshape(R, NCOLS)
+    tstart = np.concatenate([np.zeros((R, 1), np.int64), np.cumsum(counts, 1)], 1)        # [R, 1025] segment starts in the rank's list
+    # (1) local vertices first seen per (rank, column): prefix maximum of the segments' largest index + 1
+    vstart = np.zeros((R, NCOLS + 1), np.int64)
+    for r, (v, t) in enumerate(parts):
+        run = 0
+        for c in range(NCOLS):
+            seg = t[tstart[r, c]:tstart[r, c + 1]]
+            if len(seg):
+                run = max(run, int(seg.max()) + 1)
+            vstart[r, c + 1] = run
+        assert run == len(v), "an unreferenced vertex"
+    segof = [np.searchsorted(vstart[r, 1:], np.arange(len(parts[r][0])), side="right") for r in range(R)]   # first-seen column
+    # (2) face-band pairs by weld key; of a pair the copy whose first-seen (column, rank) comes first stays
+    key_of = lambda p: np.round(p.astype(np.float32) * np.float32(10e4)).astype(np.int64)      # noqa: E731  (src/cuda/mod.rs:268)
+    redirect = [np.full(len(parts[r][0]), -1, np.int64) for r in range(R)]                    # -1 = kept, else (rank << 32 | vertex)
+    seen = {}
+    for r, (v, t) in enumerate(parts):
+        z = v[:, 2]
+        lo, hi = z_faces[r]
+        near = ((hi < 2.5) & (z >= hi - band)) | ((lo > -2.5) & (z <= lo + band))
+        for i in np.nonzero(near)[0]:
+            k = tuple(key_of(v[i, :3]))
+            if k not in seen:
+                seen[k] = (r, int(i))
+                continue
+            ra, ia = seen[k]
+            a_first = (segof[ra][ia], ra) <= (segof[r][i], r)
+            if a_first:
+                redirect[r][i] = (ra << 32) | ia
+            else:
+                redirect[ra][ia] = (r << 32) | int(i)
+                seen[k] = (r, int(i))
+    # (3) kept vertices numbered segment by segment in (column, rank) order, local order inside a segment
+    gid = [np.full(len(parts[r][0]), -1, np.int64) for r in range(R)]
+    out_v, n = [], 0
+    for c in range(NCOLS):
+        for r in range(R):
+            a, b = vstart[r, c], vstart[r, c + 1]
+            keep = np.nonzero(redirect[r][a:b] < 0)[0] + a
+            gid[r][keep] = n + np.arange(len(keep))
+            out_v.append(parts[r][0][keep])
+            n += len(keep)
+    for r in range(R):
+        for i in np.nonzero(redirect[r] >= 0)[0]:
+            w = int(redirect[r][i])
+            gid[r][i] = gid[w >> 32][w & 0xFFFFFFFF]
+    # (4) index buffers, segment by segment, into the merged triangle order
+    out_t = []
+    for c in range(NCOLS):
+        for r in range(R):
+            seg = parts[r][1][tstart[r, c]:tstart[r, c + 1]]
+            if len(seg):
+                out_t.append(gid[r][seg])
+    verts = np.concatenate(out_v) if out_v else np.zeros((0, 6), np.float32)
+    idx = np.concatenate(out_t) if out_t else np.zeros((0, 3), np.int64)
+    return verts, idx
+
+
 class ShardedMesher:
     """ONE mesh across all ranks (strong scaling) -- a thin caller of the C ABI.
 

@@ -106,6 +106,70 @@ def test_gloo_slab_gather_merge_weld_equals_single(world, levels):
     assert ok and nt == nref
 
 
+def _indexed_worker(rank, world, port, levels, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    sys.path.insert(0, ROOT)
+    from oracle import oracle as O
+    from tests.partition_util import oracle_slab_triangles
+    P = _partition()
+    O.set_threads(2)
+    # this rank's z-slab with the oracle, meshed AND welded locally (its own first-seen order), + its per-column triangle counts
+    tris, _, counts = oracle_slab_triangles(O, "sdobj", levels, rank, world)
+    if len(tris):
+        pos, nrm, idx = O.weld(tris.reshape(-1, 3, 2, 3))
+    else:
+        pos = nrm = np.zeros((0, 3), np.float32); idx = np.zeros((0, 3), np.uint32)
+    verts = torch.from_numpy(np.concatenate([pos, nrm], axis=1).astype(np.float32))
+    tri = torch.from_numpy(idx.astype(np.int64))
+    # 1) all-gather of the counts and the sizes; 2) the slabs' vertex / index buffers straight to the root
+    rec = torch.cat([torch.from_numpy(counts), torch.tensor([len(verts), len(tri)], dtype=torch.int64)])
+    allr = [torch.zeros_like(rec) for _ in range(world)]
+    dist.all_gather(allr, rec)
+    allr = torch.stack(allr).numpy()
+    if rank == 0:
+        parts = [(verts.numpy(), tri.numpy())]
+        for r in range(1, world):
+            v = torch.empty((int(allr[r, 1024]), 6), dtype=torch.float32); i = torch.empty((int(allr[r, 1025]), 3), dtype=torch.int64)
+            if v.numel():
+                dist.recv(v, src=r)
+            if i.numel():
+                dist.recv(i, src=r)
+            parts.append((v.numpy(), i.numpy()))
+        faces = [(-2.5 + 5.0 * P.slab_bounds(r, world)[0] / 32, -2.5 + 5.0 * P.slab_bounds(r, world)[1] / 32) for r in range(world)]
+        band = 2.5 * (5.0 / 32) / (1 << levels)
+        v, t = P.indexed_merge_reference(parts, allr[:, :1024], faces, band)
+        ref = O.regen("sdobj", levels)
+        ok = (np.array_equal(t.astype(np.uint32), ref["idx"])
+              and np.array_equal(np.ascontiguousarray(v[:, :3]).view(np.uint32), ref["pos"].view(np.uint32))
+              and np.array_equal(np.ascontiguousarray(v[:, 3:]).view(np.uint32), ref["nrm"].view(np.uint32)))
+        dups = sum(len(p[0]) for p in parts) - len(v)
+        q.put((ok, len(t), len(ref["idx"]), len(v), len(ref["pos"]), dups))
+    else:
+        if verts.numel():
+            dist.send(verts, dst=0)
+        if tri.numel():
+            dist.send(tri, dst=0)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,levels", [(2, 1), (3, 2), (4, 1)])
+def test_gloo_indexed_zslab_gather_equals_single(world, levels):
+    """The INDEXED z-slab gather (every rank welds its slab, the per-slab vertex / index buffers go to the root, which merges them by
+    (column, rank) segments without welding again) as a gloo job on CPU tensors, the oracle standing in for each rank's kernels and
+    partition.indexed_merge_reference for the root's: the result is the single-GPU mesh, bit for bit, and the slabs did share vertices."""
+    ctx = mp.get_context("spawn")
+    q = ctx.SimpleQueue()
+    port = 29100 + (os.getpid() % 2000) + 10 * world + levels
+    procs = [ctx.Process(target=_indexed_worker, args=(r, world, port, levels, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    _join_all(procs, 300)
+    ok, nt, nref, nv, nvref, dups = q.get()
+    assert ok and (nt, nv) == (nref, nvref) and dups > 0
+
+
 def _dist_worker(rank, world, port, levels, q):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     dist.init_process_group("gloo", rank=rank, world_size=world)
