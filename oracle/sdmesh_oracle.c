@@ -19,7 +19,7 @@
  * (not even for the scene-independent level-0 field) and are not used;
  * (2) closed-mesh invariants (V - T/2 = chi, every edge shared by exactly two triangles);
  * (3) the DATA the reference itself holds for the path, parsed from its files as text by tools/pin_mc_tables.py into
- * tests/golden/*_ref.json and checked against this file and the product by tests/test_reference_pins.py: the
+ * tests/golden/NAME_ref.json (mc_tables, bindings, path_constants) and checked against this file and the product by tests/test_reference_pins.py: the
  * marching-cubes tables, the FFI header (constants, struct fields) and the path's numeric literals (stencil step and
  * weights, Newton threshold and cap, midpoint factor, inside / flip tests, sd_obj's parameters, weld quantum).
  *
