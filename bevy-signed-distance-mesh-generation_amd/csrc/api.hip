@@ -191,7 +191,7 @@ struct sdmesh_handle {
     int comm_rank = 0, comm_nranks = 1;
     DevBuf shard_mine, shard_counts, shard_recv, shard_lists, shard_plan, shard_merged;
     // z-slab INDEXED gather (root): the ranks' welded buffers concatenated, the merge's tables, its outputs (swapped into vertices / indices)
-    DevBuf zs_verts, zs_idx, zs_tables, zs_pervert, zs_tilecnt, zs_hkeys, zs_hmin, zs_vout, zs_iout, zs_ranks;
+    DevBuf zs_verts, zs_idx, zs_tables, zs_pervert, zs_tilecnt, zs_hkeys, zs_hmin, zs_vout, zs_iout, zs_ranks, zs_local;
     ZsRanks *h_zs = nullptr;       // pinned staging copy of the merge's rank table
     int shard_indexed = 1;         // option "shard_indexed": sdmesh_sharded_regen gathers welded per-slab vertex / index buffers (0: raw triangle lists + root weld)
     uint32_t zs_band_plan = 0;     // face-band vertices of the last indexed merge (sizes the band hash of the next one)
@@ -1075,7 +1075,7 @@ void sdmesh_destroy(sdmesh_handle *h) {
                       &h->first_ord_buf, &h->uverts, &h->tri_e, &h->vslot, &h->tdesc, &h->tfirst, &h->tfpre, &h->tpre, &h->flip, &h->wvidx, &h->torder, &h->wrep_buf, &h->wfm_buf,
                       &h->vertices, &h->indices, &h->raw, &h->compact, &h->staging, &h->dense_samples, &h->dense_bits,
                       &h->cellcnt, &h->dist_upids, &h->dist_upkeys, &h->dist_loids, &h->dist_prevkeys, &h->dist_hkeys, &h->dist_hpos, &h->dist_dupof,
-                      &h->dist_newidx, &h->dist_tilecnt, &h->dist_counts, &h->dist_upg, &h->dist_prevg, &h->dist_verts, &h->dist_nups, &h->col_list1, &h->col_mask2, &h->col_mask3, &h->colinfo, &h->prof_rounds, &h->proj_diag, &h->shard_mine, &h->shard_counts, &h->shard_recv, &h->shard_lists, &h->shard_plan, &h->shard_merged, &h->zs_verts, &h->zs_idx, &h->zs_tables, &h->zs_pervert, &h->zs_tilecnt, &h->zs_hkeys, &h->zs_hmin, &h->zs_vout, &h->zs_iout, &h->zs_ranks};
+                      &h->dist_newidx, &h->dist_tilecnt, &h->dist_counts, &h->dist_upg, &h->dist_prevg, &h->dist_verts, &h->dist_nups, &h->col_list1, &h->col_mask2, &h->col_mask3, &h->colinfo, &h->prof_rounds, &h->proj_diag, &h->shard_mine, &h->shard_counts, &h->shard_recv, &h->shard_lists, &h->shard_plan, &h->shard_merged, &h->zs_verts, &h->zs_idx, &h->zs_tables, &h->zs_pervert, &h->zs_tilecnt, &h->zs_hkeys, &h->zs_hmin, &h->zs_vout, &h->zs_iout, &h->zs_ranks, &h->zs_local};
     (void) sdmesh_comm_destroy(h);
     if (h->h_counts) (void) hipHostFree(h->h_counts);
     if (h->h_lists) (void) hipHostFree(h->h_lists);
@@ -1961,7 +1961,7 @@ uint32_t cap_items(const DevBuf &b, size_t item) { return (uint32_t) std::min<si
 namespace {
 
 // ---- z-slab INDEXED gather, root side: the single-GPU mesh from the ranks' welded buffers, concatenated in rank order in
-// h->zs_verts / h->zs_idx (kernels.hip, "INDEXED gather").  d_counts: per-rank column triangle counts (`cstride` words per rank).
+// h->zs_verts / h->zs_idx (kernels.hip, "INDEXED gather").  d_counts: per rank (`cstride` words each) 1024 column triangle counts, then the 1024 first-seen vertex counts zs_local_phase computed there.
 int zs_ensure_inputs(sdmesh_handle *h, uint64_t vtot, uint64_t ttot) {
     SDCHK(ensure_grow(h, h->zs_verts, sizeof(Vertex) * (size_t) std::max<uint64_t>(vtot, 64)));
     SDCHK(ensure_grow(h, h->zs_idx, sizeof(IndexTriangle) * (size_t) std::max<uint64_t>(ttot, 64)));
@@ -2000,13 +2000,13 @@ int zs_merge(sdmesh_handle *h, int R, const uint32_t *d_counts, uint32_t cstride
     HIPCHK(hipMemcpyAsync(h->zs_ranks.p, h->h_zs, sizeof(ZsRanks), hipMemcpyHostToDevice, st));
     const ZsRanks *d_zr = (const ZsRanks *) h->zs_ranks.p;
     HIPCHK(hipEventRecord(h->ev0, st));                    // info->device_ms = the root's merge alone (the gathered buffers are in place)
-    // tables: tplan [2 nseg] | vplan [2 nseg] | segmax [nseg] | vstart [nseg] | newcnt [nseg]; per vertex: segof | redirect | kept_before | map
-    SDCHK(ensure(h, h->zs_tables, 4ull * 7 * nseg));
+    // tables: tplan [2 nseg] | vplan [2 nseg] | vstart [nseg] | newcnt [nseg]; per vertex: segof | redirect | kept_before | map
+    SDCHK(ensure(h, h->zs_tables, 4ull * 6 * nseg));
     SDCHK(ensure_grow(h, h->zs_pervert, 4ull * 4 * std::max<uint32_t>(V, 64)));
     SDCHK(ensure_grow(h, h->zs_tilecnt, 4ull * (tiles(std::max<uint32_t>(V, 64)) + 16)));
     SDCHK(ensure_grow(h, h->zs_vout, sizeof(Vertex) * (size_t) std::max<uint32_t>(V, 64)));
     SDCHK(ensure_grow(h, h->zs_iout, sizeof(IndexTriangle) * (size_t) std::max<uint32_t>(T, 64)));
-    uint32_t *tplan = (uint32_t *) h->zs_tables.p, *vplan = tplan + 2 * nseg, *segmax = vplan + 2 * nseg, *vstart = segmax + nseg, *newcnt = vstart + nseg;
+    uint32_t *tplan = (uint32_t *) h->zs_tables.p, *vplan = tplan + 2 * nseg, *vstart = vplan + 2 * nseg, *newcnt = vstart + nseg;
     const uint32_t vcap = std::max<uint32_t>(V, 64);
     uint32_t *segof = (uint32_t *) h->zs_pervert.p, *redirect = segof + vcap, *kept = redirect + vcap, *map = kept + vcap;
     for (int attempt = 0; attempt < 2; attempt++) {
@@ -2023,8 +2023,8 @@ int zs_merge(sdmesh_handle *h, int R, const uint32_t *d_counts, uint32_t cstride
             HIPCHK(hipMemsetAsync(h->zs_hmin.p, 0xFF, 4ull * hsize, st));
         }
         HIPCHK(launch_merge_plan(st, d_counts, cstride, R, tplan, T, h->d_ctr + CTR_NTRI, h->d_status));
-        HIPCHK(launch_zs_front(st, h->grid, (const Vertex *) h->zs_verts.p, (const uint32_t *) h->zs_idx.p, d_counts, cstride, tplan, zr, d_zr, segmax, vstart,
-                               newcnt, segof, redirect, (uint64_t *) h->zs_hkeys.p, (uint32_t *) h->zs_hmin.p, hsize, h->d_ctr + CTR_DIST_NUP,
+        HIPCHK(launch_zs_front(st, h->grid, (const Vertex *) h->zs_verts.p, d_counts, cstride, d_counts + 1024 /* the ranks' first-seen vertex counts */, zr, d_zr,
+                               vstart, newcnt, segof, redirect, (uint64_t *) h->zs_hkeys.p, (uint32_t *) h->zs_hmin.p, hsize, h->d_ctr + CTR_DIST_NUP,
                                h->d_status));
         HIPCHK(launch_set_u32(st, h->d_ctr + CTR_DIST_V, V));
         HIPCHK(launch_dist_number(st, h->tgrid, redirect, V, h->d_ctr + CTR_DIST_V, (uint32_t *) h->zs_tilecnt.p, h->d_ctr + CTR_NVERT, kept, h->d_status));
@@ -2073,11 +2073,24 @@ int zs_local_phase(sdmesh_handle *h, int levels, int part, int nparts, uint32_t 
     SDCHK(rc);
     if (h->last_direct || !h->welded) return fail(h, SDMESH_ERR_INTERNAL, "a slab took the direct path: no column counts");
     if (h->wide_active) return fail(h, SDMESH_ERR_WELD_RANGE, "the indexed gather needs the packed weld keys (option shard_indexed = 0 welds on the root instead)");
-    HIPCHK(hipMemsetAsync(d_row, 0, 4096, st));
+    HIPCHK(hipMemsetAsync(d_row, 0, 8192, st));
     if (h->n_vox) {
         HIPCHK(launch_set_u32(st, h->d_ctr + CTR_SCRATCH, h->n_vox));
         HIPCHK(launch_column_counts(st, std::min(h->grid, (int) tiles(h->n_vox)), (const Point *) h->vox[h->cur].p, h->d_ctr + CTR_SCRATCH,
                                     (const uint8_t *) h->cubeidx.p, d_row));
+    }
+    // the vertices FIRST SEEN per column of this slab's own first-seen order -> d_row[1024 .. 2048): this rank's share of the merge
+    if (h->n_tris) {
+        if (!h->h_zs) HIPCHK(hipHostMalloc((void **) &h->h_zs, sizeof(ZsRanks), hipHostMallocDefault));
+        SDCHK(ensure(h, h->zs_ranks, sizeof(ZsRanks)));
+        SDCHK(ensure(h, h->zs_local, 4ull * 4 * 1024));
+        HIPCHK(hipStreamSynchronize(st));                  // (the staging copy may still be in flight from a previous call)
+        memset(h->h_zs, 0, sizeof(ZsRanks));
+        h->h_zs->nranks = 1; h->h_zs->vbase[1] = h->n_verts; h->h_zs->tbase[1] = h->n_tris;
+        HIPCHK(hipMemcpyAsync(h->zs_ranks.p, h->h_zs, sizeof(ZsRanks), hipMemcpyHostToDevice, st));
+        uint32_t *loc = (uint32_t *) h->zs_local.p;
+        HIPCHK(launch_zs_local_vcnt(st, (const uint32_t *) h->indices.p, d_row, (const ZsRanks *) h->zs_ranks.p, loc, loc + 2048, loc + 3072, d_row + 1024,
+                                    h->d_ctr + CTR_SCRATCH, h->d_status));
     }
     return SDMESH_OK;
 }
@@ -2096,32 +2109,32 @@ int sharded_regen_indexed(sdmesh_handle *h, int levels, int root, sdmesh_regen_i
     const int lrc = inject == 1 ? fail(h, SDMESH_ERR_INTERNAL, "injected failure (option inject_fail)") : zs_local_phase(h, levels, me, R, d_row, &slab);
     uint32_t t_mine = 0, v_mine = 0;
     if (lrc == SDMESH_OK) { t_mine = h->n_tris; v_mine = h->n_verts; }
-    else HIPCHK(hipMemsetAsync(d_row, 0, 4096, st));
+    else HIPCHK(hipMemsetAsync(d_row, 0, 8192, st));
     // 2. the all-gather of the counts -- ALWAYS entered; record = {status, triangles, room for vertices / triangles as a root, vertices, 1, 0, 0}
-    HIPCHK(launch_pack_record(st, d_row + 1024, nullptr, nullptr, (uint32_t) lrc, t_mine, cap_items(h->zs_verts, sizeof(Vertex)),
+    HIPCHK(launch_pack_record(st, d_row + SHARD_REC, nullptr, nullptr, (uint32_t) lrc, t_mine, cap_items(h->zs_verts, sizeof(Vertex)),
                               cap_items(h->zs_idx, sizeof(IndexTriangle))));
-    HIPCHK(launch_pack_record(st, d_row + 1028, nullptr, nullptr, v_mine, 1u, 0u, 0u));
+    HIPCHK(launch_pack_record(st, d_row + SHARD_REC + 4, nullptr, nullptr, v_mine, 1u, 0u, 0u));
     NCCLCHK(g_rccl.AllGather(d_row, d_counts, SHARD_ROW, ncclUint32, h->comm, st));                     // in place
     HIPCHK(hipMemcpyAsync(h->h_counts, d_counts, 4ull * (size_t) R * SHARD_ROW, hipMemcpyDeviceToHost, st));
     HIPCHK(hipStreamSynchronize(st));
     // 3. every rank, on the same numbers
-    SDCHK(peer_failure(h, R, me, h->h_counts, SHARD_ROW, 1024, lrc));
+    SDCHK(peer_failure(h, R, me, h->h_counts, SHARD_ROW, SHARD_REC, lrc));
     std::vector<uint32_t> Tr((size_t) R, 0), Vr((size_t) R, 0);
     uint64_t ttot = 0, vtot = 0;
     for (int r = 0; r < R; r++) {
         const uint32_t *row = h->h_counts + (size_t) r * SHARD_ROW;
         uint64_t s = 0;
         for (int c = 0; c < 1024; c++) s += row[c];
-        if (s != row[1025])
-            return fail(h, SDMESH_ERR_INTERNAL, "rank %d: column counts (%llu) disagree with the slab's triangle count (%u)", r, (unsigned long long) s, row[1025]);
-        if (row[1029] != 1u) return fail(h, SDMESH_ERR_INVALID, "rank %d runs the raw-list form of the z-slab gather (option shard_indexed differs between the ranks)", r);
-        Tr[r] = row[1025]; Vr[r] = row[1028];
+        if (s != row[SHARD_REC + 1])
+            return fail(h, SDMESH_ERR_INTERNAL, "rank %d: column counts (%llu) disagree with the slab's triangle count (%u)", r, (unsigned long long) s, row[SHARD_REC + 1]);
+        if (row[SHARD_REC + 5] != 1u) return fail(h, SDMESH_ERR_INVALID, "rank %d runs the raw-list form of the z-slab gather (option shard_indexed differs between the ranks)", r);
+        Tr[r] = row[SHARD_REC + 1]; Vr[r] = row[SHARD_REC + 4];
         ttot += Tr[r]; vtot += Vr[r];
     }
     if (ttot > 0x0FFFFFFFull || vtot > 0x0FFFFFFFull) return fail(h, SDMESH_ERR_INVALID, "too many triangles for one mesh");
     // 4. the root's receive buffers; grown behind a second agreement only if its published capacity is too small
     const uint32_t *root_row = h->h_counts + (size_t) root * SHARD_ROW;
-    if (vtot > root_row[1026] || ttot > root_row[1027] || root_row[1026] == 0u || inject == 2) {
+    if (vtot > root_row[SHARD_REC + 2] || ttot > root_row[SHARD_REC + 3] || root_row[SHARD_REC + 2] == 0u || inject == 2) {
         int grc = SDMESH_OK;
         if (me == root) grc = inject == 2 ? fail(h, SDMESH_ERR_HIP, "injected allocation failure (option inject_fail)") : zs_ensure_inputs(h, vtot, ttot);
         uint32_t worst = 0;
@@ -2198,7 +2211,7 @@ int sdmesh_sharded_regen(sdmesh_handle *h, int levels, int root, sdmesh_regen_in
         if (n_mine)
             HIPCHK(launch_expand_compact(st, h->grid, (const Vertex *) h->uverts.p, (const uint32_t *) h->tri_e.p, (const uint8_t *) h->flip.p,
                                          h->d_ctr + CTR_NTRI, (Triangle *) h->shard_mine.p, n_mine));
-        HIPCHK(hipMemsetAsync(d_row, 0, 4096, st));
+        HIPCHK(hipMemsetAsync(d_row, 0, 8192, st));                        // (column triangle counts | vertex counts: none in the raw form)
         if (h->n_vox) {
             HIPCHK(launch_set_u32(st, h->d_ctr + CTR_SCRATCH, h->n_vox));
             HIPCHK(launch_column_counts(st, std::min(h->grid, (int) tiles(h->n_vox)), (const Point *) h->vox[h->cur].p,
@@ -2207,32 +2220,32 @@ int sdmesh_sharded_regen(sdmesh_handle *h, int levels, int root, sdmesh_regen_in
         return SDMESH_OK;
     };
     const int lrc = local_phase();
-    if (lrc != SDMESH_OK) { n_mine = 0; HIPCHK(hipMemsetAsync(d_row, 0, 4096, st)); }
+    if (lrc != SDMESH_OK) { n_mine = 0; HIPCHK(hipMemsetAsync(d_row, 0, 8192, st)); }
     // 2. the all-gather of the counts -- ALWAYS entered; record = {status, triangles, what this rank could receive / merge}
-    HIPCHK(launch_pack_record(st, d_row + 1024, nullptr, nullptr, (uint32_t) lrc, n_mine, cap_items(h->shard_recv, sizeof(Triangle)),
+    HIPCHK(launch_pack_record(st, d_row + SHARD_REC, nullptr, nullptr, (uint32_t) lrc, n_mine, cap_items(h->shard_recv, sizeof(Triangle)),
                               cap_items(h->shard_merged, sizeof(Triangle))));
     // (k_pack_record writes {v0, v1 | status, v2, v3}: word 0 = status, word 1 = triangles here)
-    HIPCHK(launch_pack_record(st, d_row + 1028, nullptr, nullptr, 0u, 0u, 0u, 0u));                    // {vertices: none, raw form}
+    HIPCHK(launch_pack_record(st, d_row + SHARD_REC + 4, nullptr, nullptr, 0u, 0u, 0u, 0u));                    // {vertices: none, raw form}
     NCCLCHK(g_rccl.AllGather(d_row, d_counts, SHARD_ROW, ncclUint32, h->comm, st));                     // in place
     HIPCHK(hipMemcpyAsync(h->h_counts, d_counts, 4ull * (size_t) R * SHARD_ROW, hipMemcpyDeviceToHost, st));
     HIPCHK(hipStreamSynchronize(st));
     // 3. every rank, on the same numbers: did anybody fail, do the counts add up, does the mesh fit one weld
-    SDCHK(peer_failure(h, R, me, h->h_counts, SHARD_ROW, 1024, lrc));
+    SDCHK(peer_failure(h, R, me, h->h_counts, SHARD_ROW, SHARD_REC, lrc));
     std::vector<uint64_t> tr((size_t) R, 0);
     uint64_t total = 0, foreign = 0;
     for (int r = 0; r < R; r++) {
         const uint32_t *row = h->h_counts + (size_t) r * SHARD_ROW;
         for (int c = 0; c < 1024; c++) tr[r] += row[c];
-        if (tr[r] != row[1025])
-            return fail(h, SDMESH_ERR_INTERNAL, "rank %d: column counts (%llu) disagree with the slab's triangle count (%u)", r, (unsigned long long) tr[r], row[1025]);
-        if (row[1029] != 0u) return fail(h, SDMESH_ERR_INVALID, "rank %d runs the indexed form of the z-slab gather (option shard_indexed differs between the ranks)", r);
+        if (tr[r] != row[SHARD_REC + 1])
+            return fail(h, SDMESH_ERR_INTERNAL, "rank %d: column counts (%llu) disagree with the slab's triangle count (%u)", r, (unsigned long long) tr[r], row[SHARD_REC + 1]);
+        if (row[SHARD_REC + 5] != 0u) return fail(h, SDMESH_ERR_INVALID, "rank %d runs the indexed form of the z-slab gather (option shard_indexed differs between the ranks)", r);
         total += tr[r];
         if (r != root) foreign += tr[r];
     }
     if (total > 0x0FFFFFFFull) return fail(h, SDMESH_ERR_INVALID, "too many triangles for one weld");
     // 4. the root's receive / merge buffers; grown behind a second agreement only if its published capacity is too small
     const uint32_t *root_row = h->h_counts + (size_t) root * SHARD_ROW;
-    if (foreign > root_row[1026] || total > root_row[1027] || inject == 2) {
+    if (foreign > root_row[SHARD_REC + 2] || total > root_row[SHARD_REC + 3] || inject == 2) {
         int grc = SDMESH_OK;
         if (me == root) {
             grc = inject == 2 ? fail(h, SDMESH_ERR_HIP, "injected allocation failure (option inject_fail)")

@@ -2237,8 +2237,9 @@ __global__ __launch_bounds__(256) void k_dist_finalize(const Vertex *__restrict_
 // anything again -- no hash claim per corner, only streaming passes over the gathered buffers:
 //
 //   * a rank's welded vertices are numbered in its own first-seen order, so the number of distinct vertices in its first n
-//     triangles is 1 + the largest index among them: the largest index per (rank, column) segment (k_zs_segmax) gives, by a
-//     prefix maximum over the columns (k_zs_vplan), the range of local vertices FIRST SEEN in each column;
+//     triangles is 1 + the largest index among them: the largest index per column segment (k_zs_segmax) gives, by a prefix
+//     maximum over the columns (k_zs_vplan), the number of local vertices FIRST SEEN in each column -- computed by every rank
+//     for its own slab (launch_zs_local_vcnt) and carried to the root in the all-gather beside the triangle counts;
 //   * in the single-GPU order a level-0 column holds rank 0's triangles, then rank 1's, ...: so the single-GPU first-seen vertex
 //     order is, column by column and rank by rank, each segment's first-seen vertices in their local order -- the vertex buffers
 //     merge by (column, rank) segments exactly like the triangle lists (same plan kernel, k_merge_plan, on the vertex counts);
@@ -2294,6 +2295,20 @@ __global__ __launch_bounds__(1024) void k_zs_vplan(const uint32_t *__restrict__ 
     vstart[r * NCOL + c] = excl;
     newcnt[r * NCOL + c] = incl - excl;
     if (c == NCOL - 1u && incl != zr.vbase[r + 1u] - zr.vbase[r]) atomicOr(&status[ST_INTERNAL], 256u);       // an unreferenced vertex
+}
+
+// root: vstart[r][c] = exclusive prefix over the columns of rank r's first-seen vertex counts (gathered with the column counts), newcnt = a
+// private copy of them (the band pairs decrement it)
+__global__ __launch_bounds__(1024) void k_zs_vstart(const uint32_t *__restrict__ vcounts, uint32_t cstride, const ZsRanks *__restrict__ zrp,
+                                                     uint32_t *__restrict__ vstart, uint32_t *__restrict__ newcnt, uint32_t *__restrict__ status) {
+    const ZsRanks &zr = *zrp;
+    __shared__ uint32_t lds[17];
+    const uint32_t c = threadIdx.x, r = blockIdx.x;
+    const uint32_t n = vcounts[r * cstride + c];
+    uint32_t total;
+    vstart[r * NCOL + c] = block_excl_scan(n, total, lds);
+    newcnt[r * NCOL + c] = n;
+    if (c == 0 && total != zr.vbase[r + 1u] - zr.vbase[r]) atomicOr(&status[ST_INTERNAL], 512u);   // the counts do not add up to the rank's vertices
 }
 
 // every vertex learns its first-seen segment; its redirect starts as "kept"
@@ -3319,15 +3334,24 @@ hipError_t launch_merge_plan(hipStream_t st, const uint32_t *d_counts, uint32_t 
     return hipGetLastError();
 }
 
+// a rank's own first-seen vertex counts per column (carried to the root in the all-gather: the work stays where it is parallel)
+hipError_t launch_zs_local_vcnt(hipStream_t st, const uint32_t *idx, const uint32_t *colcnt, const ZsRanks *d_zr1, uint32_t *tplan1, uint32_t *segmax,
+                                uint32_t *vstart, uint32_t *vcnt, uint32_t *scratch_total, uint32_t *status) {
+    hipLaunchKernelGGL(k_merge_plan, dim3(1), dim3(1024), 0, st, colcnt, 1024u, 1u, tplan1, 0xFFFFFFFFu, scratch_total, status);
+    (void) hipMemsetAsync(segmax, 0, 4096, st);
+    hipLaunchKernelGGL(k_zs_segmax, dim3(1024, 2), dim3(256), 0, st, idx, colcnt, 1024u, (const uint32_t *) tplan1, d_zr1, segmax);
+    hipLaunchKernelGGL(k_zs_vplan, dim3(1), dim3(1024), 0, st, (const uint32_t *) segmax, d_zr1, vstart, vcnt, status);
+    return hipGetLastError();
+}
+
 // z-slab indexed merge, first half: the segments' first-seen vertex ranges, every vertex's segment, the face-band pairs
-hipError_t launch_zs_front(hipStream_t st, int grid, const Vertex *v_all, const uint32_t *idx_all, const uint32_t *counts, uint32_t cstride,
-                           const uint32_t *tplan, const ZsRanks &zr, const ZsRanks *d_zr, uint32_t *segmax, uint32_t *vstart, uint32_t *newcnt, uint32_t *segof,
+hipError_t launch_zs_front(hipStream_t st, int grid, const Vertex *v_all, const uint32_t *counts, uint32_t cstride, const uint32_t *vcounts,
+                           const ZsRanks &zr, const ZsRanks *d_zr, uint32_t *vstart, uint32_t *newcnt, uint32_t *segof,
                            uint32_t *redirect, uint64_t *hkeys, uint32_t *hmin, uint32_t hsize, uint32_t *nband, uint32_t *status) {
     const uint32_t V = zr.vbase[zr.nranks];
     const int nseg = (int) (zr.nranks * 1024u);
-    (void) hipMemsetAsync(segmax, 0, 4ull * (size_t) nseg, st);
-    hipLaunchKernelGGL(k_zs_segmax, dim3(nseg, 2), dim3(256), 0, st, idx_all, counts, cstride, tplan, d_zr, segmax);
-    hipLaunchKernelGGL(k_zs_vplan, dim3(zr.nranks), dim3(1024), 0, st, (const uint32_t *) segmax, d_zr, vstart, newcnt, status);
+    (void) counts;
+    hipLaunchKernelGGL(k_zs_vstart, dim3(zr.nranks), dim3(1024), 0, st, vcounts, cstride, d_zr, vstart, newcnt, status);
     hipLaunchKernelGGL(k_zs_segfill, dim3(nseg), dim3(256), 0, st, (const uint32_t *) vstart, (const uint32_t *) newcnt, d_zr, segof, redirect);
     if (zr.nranks > 1 && V) {
         hipLaunchKernelGGL(k_zs_band_insert, dim3(grid), dim3(256), 0, st, v_all, V, d_zr, hkeys, hmin, hsize, nband, status);

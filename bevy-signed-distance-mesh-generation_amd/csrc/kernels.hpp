@@ -23,10 +23,11 @@ enum StatusWord : int {
 };
 
 // Multi-GPU agreement records (every rank learns every rank's status in the all-gather that moves the sizes anyway):
-//   z-slab gather   SHARD_ROW words per rank: 1024 column counts, then {status, triangles, two receive capacities of this rank as a
-//                   root (raw form: received / merged triangles; indexed form: vertices / triangles), vertices, indexed form?, 0, 0}
-//   x-slab weld     DIST_REC words per rank: {band size or kept count, status, capacity for the neighbour's band, 0}
-static constexpr uint32_t SHARD_ROW = 1024 + 8;
+//   z-slab gather   SHARD_ROW words per rank: 1024 column triangle counts, 1024 column first-seen VERTEX counts (indexed form; zeros in the
+//                   raw form), then {status, triangles, two receive capacities of this rank as a root (raw form: received / merged
+//                   triangles; indexed form: vertices / triangles), vertices, indexed form?, 0, 0}
+static constexpr uint32_t SHARD_ROW = 2048 + 8;
+static constexpr uint32_t SHARD_REC = 2048;        // first word of the record inside a row
 static constexpr uint32_t DIST_REC = 4;
 
 hipError_t launch_refine_mask(hipStream_t st, int grid, int scene, const SceneParams *sp, const Point *vox,
@@ -120,8 +121,12 @@ struct ZsRanks {
 };
 hipError_t launch_merge_plan(hipStream_t st, const uint32_t *d_counts, uint32_t cstride, int nranks, uint32_t *d_plan, uint32_t cap,
                              uint32_t *total_out, uint32_t *status);
-hipError_t launch_zs_front(hipStream_t st, int grid, const Vertex *v_all, const uint32_t *idx_all, const uint32_t *counts, uint32_t cstride,
-                           const uint32_t *tplan, const ZsRanks &zr /* host copy */, const ZsRanks *d_zr /* the same in device memory */, uint32_t *segmax, uint32_t *vstart, uint32_t *newcnt, uint32_t *segof,
+// this rank's share of the indexed merge: vertices FIRST SEEN per level-0 column of its own welded slab (vcnt[1024]), from its index buffer
+hipError_t launch_zs_local_vcnt(hipStream_t st, const uint32_t *idx, const uint32_t *colcnt, const ZsRanks *d_zr1 /* one rank: {0, V}, {0, T} */,
+                                uint32_t *tplan1 /* [2048] */, uint32_t *segmax /* [1024] */, uint32_t *vstart /* [1024] */, uint32_t *vcnt /* [1024] */,
+                                uint32_t *scratch_total, uint32_t *status);
+hipError_t launch_zs_front(hipStream_t st, int grid, const Vertex *v_all, const uint32_t *counts, uint32_t cstride, const uint32_t *vcounts,
+                           const ZsRanks &zr /* host copy */, const ZsRanks *d_zr /* the same in device memory */, uint32_t *vstart, uint32_t *newcnt, uint32_t *segof,
                            uint32_t *redirect, uint64_t *hkeys, uint32_t *hmin, uint32_t hsize, uint32_t *nband, uint32_t *status);
 hipError_t launch_zs_back(hipStream_t st, int grid, const Vertex *v_all, const uint32_t *idx_all, const uint32_t *counts, uint32_t cstride,
                           const uint32_t *tplan, const ZsRanks &zr, const ZsRanks *d_zr, const uint32_t *redirect, const uint32_t *kept_before, const uint32_t *segof,

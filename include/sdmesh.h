@@ -253,8 +253,8 @@ int sdmesh_comm_destroy(sdmesh_handle *h);
 int sdmesh_comm_ranks(sdmesh_handle *h, int *ranks_seen);
 
 /* ONE regen of ONE mesh over all ranks of the communicator, entirely behind this call.
- * Indexed form (default): rank r meshes AND welds level-0 z-slab r, ncclAllGather of the 1024 per-column triangle counts + sizes +
- * status (4 KB), grouped ncclSend / ncclRecv of the slab's vertex and index buffers (24 B per vertex + 12 B per triangle) straight to
+ * Indexed form (default): rank r meshes AND welds level-0 z-slab r, ncclAllGather of the 1024 per-column triangle counts, the 1024
+ * per-column first-seen vertex counts, sizes and status (8 KB), grouped ncclSend / ncclRecv of the slab's vertex and index buffers (24 B per vertex + 12 B per triangle) straight to
  * `root` (each peer on its own xGMI link); the root merges the buffers by (column, rank) segments WITHOUT welding again (only vertices
  * near a slab face are looked up, in one small hash).
  * Raw form (option "shard_indexed" = 0, also the way out for wide weld keys: the indexed form fails with SDMESH_ERR_WELD_RANGE then):
