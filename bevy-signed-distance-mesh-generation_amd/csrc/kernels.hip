@@ -2922,7 +2922,7 @@ __global__ __launch_bounds__(256) void k_sample_dense_rows_aligned(float *__rest
                         const v2f m = min2(min2(a0 + sz[2 * u + p], a1 + mz[2 * u + p]), a2 + az[2 * u + p]);
                         const v2f d1 = sqrt_rn_normal2_nonudge(m) - 0.1f;
                         const v2f d2 = sqrt_rn_normal2_nonudge(cs + z2[2 * u + p]) - 1.0f;
-                        r[p] = smooth_min2(d1, d2, 0.5f);
+                        r[p] = smooth_min_half2(d1, d2);
                     }
                     const v4f v = {r[0].x, r[0].y, r[1].x, r[1].y};
                     if (NT) __builtin_nontemporal_store(v, reinterpret_cast<v4f *>(o + zq[u]));
@@ -2948,7 +2948,7 @@ __global__ __launch_bounds__(256) void k_sample_dense_rows_aligned(float *__rest
             const v2f m = min2(min2(a0 + esz, a1 + emz), a2 + eaz);
             const v2f d1 = sqrt_rn_normal2_nonudge(m) - 0.1f;
             const v2f d2 = sqrt_rn_normal2_nonudge(cs + pz * pz) - 1.0f;
-            const v2f r = smooth_min2(d1, d2, 0.5f);
+            const v2f r = smooth_min_half2(d1, d2);
             if (ua < rows * ht) out[(uint64_t) (c + 4u * (i0 + ja)) * S + za] = r.x;
             if (ub < rows * ht) out[(uint64_t) (c + 4u * (i0 + jb)) * S + zb] = r.y;
         }

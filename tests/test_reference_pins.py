@@ -9,6 +9,8 @@ import os
 import re
 import sys
 
+import numpy as np
+
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "tools"))
 import gen_mc_tables as G  # noqa: E402
@@ -153,7 +155,10 @@ def test_path_constants_of_oracle_and_product_equal_the_reference_text():
     assert sk == [3.0, 1.0, 0.5] and f(ref["sd_obj"]["skeleton_line_width"]) == 0.1 and f(ref["sd_obj"]["sphere_radius"]) == 1.0
     assert f(ref["sd_obj"]["smooth_k"]) == 0.5 and ref["smooth_min"]["sixth"] == ["1.0", "6.0"]
     assert "sd_box_skeleton(p, 0, (3, 1, 0.5), 0.1)" in sdf and "h * h * h * k * (1.0f / 6.0f)" in sdf and "h * h * h * k * (1.0f / 6.0f)" in oracle
-    assert re.search(r"smooth_min\(a1, a2, 0\.5f\)", sdf) and re.search(r"- 0\.1f", sdf) and re.search(r"\) - 1\.0f;", sdf)
+    # (the product evaluates smooth_min(a1, a2, 0.5f) as smooth_min_half: h^3 * (fl(1/6) / 2), the same value with one multiplication fewer)
+    assert "smooth_min_half(a1, a2)" in sdf and "fmax1(0.5f - fabsf(a - b), 0.0f) / 0.5f" in sdf
+    assert np.float32(float(re.search(r"#define SDM_SIXTH_HALF ([0-9.]+)f", sdf).group(1))) == np.float32(1.0) / np.float32(6.0) / np.float32(2.0)
+    assert re.search(r"- 0\.1f", sdf) and re.search(r"\) - 1\.0f;", sdf)
     assert re.search(r"3\.0f,\s*1\.0f,\s*0\.5f", oracle) and re.search(r"0\.1f", oracle)
     # weld: key = round(x * 10e4) per coordinate, triangles dropped on a non-finite x of their first vertex
     q = f(ref["weld_quantum_factor"])
