@@ -170,6 +170,53 @@ def test_gloo_indexed_zslab_gather_equals_single(world, levels):
     assert ok and (nt, nv) == (nref, nvref) and dups > 0
 
 
+def test_indexed_merge_keeps_the_copy_first_seen_in_the_earlier_column():
+    """csg3 at 128^3 in 5 uniform z-slabs has shared face vertices whose single-GPU representative is the HIGHER rank's copy (that
+    rank first sees them in an earlier column): the restatement of the indexed merge handles them (the GPU kernels run the same
+    case in test_indexed_zslab_gather_behind_the_c_abi[csg3-2-5-False-0])."""
+    from oracle import oracle as O
+    from tests.partition_util import oracle_slab_triangles
+    P = _partition()
+    O.set_threads(4)
+    world, levels, scene = 5, 2, "csg3"
+    parts, counts = [], []
+    for r in range(world):
+        tris, _, c = oracle_slab_triangles(O, scene, levels, r, world)
+        if len(tris):
+            pos, nrm, idx = O.weld(tris.reshape(-1, 3, 2, 3))
+        else:
+            pos = nrm = np.zeros((0, 3), np.float32); idx = np.zeros((0, 3), np.uint32)
+        parts.append((np.concatenate([pos, nrm], 1).astype(np.float32), idx.astype(np.int64)))
+        counts.append(c)
+    # the case really occurs: a key shared by two ranks whose first-seen column is earlier on the higher rank
+    tstart = np.concatenate([np.zeros((world, 1), np.int64), np.cumsum(np.array(counts), 1)], 1)
+    first_col = []
+    for r, (v, t) in enumerate(parts):
+        vs, run = np.zeros(P.NCOLS + 1, np.int64), 0
+        for c in range(P.NCOLS):
+            seg = t[tstart[r, c]:tstart[r, c + 1]]
+            if len(seg):
+                run = max(run, int(seg.max()) + 1)
+            vs[c + 1] = run
+        first_col.append(np.searchsorted(vs[1:], np.arange(len(v)), side="right"))
+    seen, higher_wins = {}, 0
+    for r, (v, t) in enumerate(parts):
+        keys = np.round(v[:, :3].astype(np.float32) * np.float32(10e4)).astype(np.int64)
+        for i, k in enumerate(map(tuple, keys)):
+            if k in seen:
+                ra, ia = seen[k]
+                higher_wins += not ((first_col[ra][ia], ra) <= (first_col[r][i], r))
+            else:
+                seen[k] = (r, i)
+    assert higher_wins > 0
+    faces = [(-2.5 + 5.0 * P.slab_bounds(r, world)[0] / 32, -2.5 + 5.0 * P.slab_bounds(r, world)[1] / 32) for r in range(world)]
+    v, t = P.indexed_merge_reference(parts, np.array(counts), faces, 2.5 * (5.0 / 32) / (1 << levels))
+    ref = O.regen(scene, levels)
+    assert np.array_equal(t.astype(np.uint32), ref["idx"])
+    assert np.array_equal(np.ascontiguousarray(v[:, :3]).view(np.uint32), ref["pos"].view(np.uint32))
+    assert np.array_equal(np.ascontiguousarray(v[:, 3:]).view(np.uint32), ref["nrm"].view(np.uint32))
+
+
 def _dist_worker(rank, world, port, levels, q):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     dist.init_process_group("gloo", rank=rank, world_size=world)
