@@ -294,6 +294,80 @@ def dense_p1_sharded_leg(pkg, job, local_rank, scene, params, grids=(512, 1024),
     return out
 
 
+def reference_abi_leg(pkg, local_rank, scene, params, levels):
+    """The reference's own launch structure on this GPU: its two kernels -- one thread per voxel, raw 8n / 5n slot layouts, by-value
+    VoxelField kernargs (src/cuda/mod.rs:149-177,226-250) -- as the B1 code object exports them, launched through the HIP module API
+    on voxel lists that are already on the device.  Kernel time only (HIP events): no upload / download of the 8n / 5n slot buffers,
+    no host-side retain, no host weld, all of which the reference pays on top.  Reported beside the native chain, never `value`."""
+    import ctypes
+    hip = None
+    for name in ("libamdhip64.so", "libamdhip64.so.7", os.path.join(os.path.dirname(torch.__file__), "lib", "libamdhip64.so")):
+        try:
+            hip = ctypes.CDLL(name)
+            break
+        except OSError:
+            continue
+    if hip is None:
+        return {"error": "HIP runtime library not found for the module API"}
+    A = pkg._abi
+    mod, f_ref, f_tri = ctypes.c_void_p(), ctypes.c_void_p(), ctypes.c_void_p()
+    blob = open(pkg.HSACO_PATH, "rb").read()
+    if hip.hipModuleLoadData(ctypes.byref(mod), blob) != 0:
+        return {"error": "hipModuleLoadData failed"}
+    hip.hipModuleGetFunction(ctypes.byref(f_ref), mod, b"compute_refine_voxel_field_by_sdf")
+    hip.hipModuleGetFunction(ctypes.byref(f_tri), mod, b"compute_surface_triangles_from_voxel_field_by_sdf")
+    e0, e1 = ctypes.c_void_p(), ctypes.c_void_p()
+    hip.hipEventCreate(ctypes.byref(e0)); hip.hipEventCreate(ctypes.byref(e1))
+
+    def timed_launch(fn, n, *args):
+        arr = (ctypes.c_void_p * len(args))(*[ctypes.cast(ctypes.pointer(a), ctypes.c_void_p) for a in args])
+        grid = (n + A.BLOCK_SIZE - 1) // A.BLOCK_SIZE
+        ms = []
+        for _ in range(4):
+            hip.hipEventRecord(e0, None)
+            if hip.hipModuleLaunchKernel(fn, grid, 1, 1, A.BLOCK_SIZE, 1, 1, 0, None, arr, None) != 0:
+                raise RuntimeError("hipModuleLaunchKernel failed")
+            hip.hipEventRecord(e1, None)
+            hip.hipEventSynchronize(e1)
+            t = ctypes.c_float(0)
+            hip.hipEventElapsedTime(ctypes.byref(t), e0, e1)
+            ms.append(t.value)
+        return min(ms[1:])
+
+    h = pkg.CudaHandler(local_rank, scene, params)
+    refine_ms, rows = 0.0, []
+    tri_ms, n_last = None, 0
+    for lv in range(levels + 1):
+        h.regen(lv)
+        f = h.download_voxels()                                     # level-lv voxel list (the reference keeps it on the host between steps)
+        n = len(f.voxels)
+        d_in = torch.from_numpy(np.ascontiguousarray(f.voxels)).to("cuda")
+        fin = A.VoxelField(A.Point(*map(float, f.voxel_size)), d_in.data_ptr(), n)
+        if lv < levels:
+            d_out = torch.empty((8 * n, 3), dtype=torch.float32, device="cuda")
+            fout = A.VoxelField(A.Point(0.0, 0.0, 0.0), d_out.data_ptr(), 8 * n)
+            torch.cuda.synchronize()
+            ms = timed_launch(f_ref, n, fin, fout)
+            refine_ms += ms
+            rows.append({"level": lv, "voxels": n, "refine_kernel_ms": round(ms, 4)})
+            del d_out
+        else:
+            d_tri = torch.empty((5 * n, 18), dtype=torch.float32, device="cuda")
+            torch.cuda.synchronize()
+            tri_ms = timed_launch(f_tri, n, fin, ctypes.c_void_p(d_tri.data_ptr()))
+            n_last = n
+            del d_tri
+        del d_in
+    h.close()
+    hip.hipEventDestroy(e0); hip.hipEventDestroy(e1); hip.hipModuleUnload(mod)
+    return {"what": "the reference's launch structure on this GPU: its two kernels as this build's reference-ABI code object restates them (B1: one thread per voxel, "
+                    "every voxel projects all its own triangle corners, raw 8n / 5n slot layouts, by-value kernargs), launched as src/cuda/mod.rs launches them, "
+                    "on device-resident voxel lists: kernel time only (HIP events) -- the reference also pays the upload / download of the slot buffers, "
+                    "the host-side retain and the host HashMap weld on top; beside it the native chain's device time for the same work incl. the weld",
+            "refine_kernels_ms": round(refine_ms, 4), "triangles_kernel_ms": round(tri_ms, 4), "kernels_total_ms": round(refine_ms + tri_ms, 4),
+            "voxels_meshed": n_last, "triangle_slots_written_MB": round(5 * n_last * 72 / 1e6, 1), "per_level": rows}
+
+
 def roofline_legs(h, out, n_grid, scene, params, consts):
     """P1 / P2a / write ceiling, HIP-event timed on the handle's stream (N = 1 only)."""
     buf = torch.empty((n_grid + 1) ** 3, dtype=torch.float32, device="cuda")
@@ -457,6 +531,7 @@ def main():
     ap.add_argument("--scene", default="sdobj")
     ap.add_argument("--levels", type=int, default=4)          # N = 32 * 2^levels = 512
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-ref-abi", action="store_true", help="skip the leg that times the reference-ABI code object's kernels")
     ap.add_argument("--no-anim", action="store_true")
     ap.add_argument("--no-pipelined", action="store_true")
     ap.add_argument("--no-sizes", action="store_true")
@@ -696,6 +771,12 @@ def main():
                               "mvoxels_per_s": round(n_grid ** 3 * 100 / fdt / 1e6, 1), "triangles": int(finfo.triangles), "vertices": int(finfo.vertices)}
     hf.close()
 
+    if not args.no_ref_abi:
+        ra = reference_abi_leg(pkg, local_rank, args.scene, params, args.levels)
+        if "kernels_total_ms" in ra:
+            ra["native_chain_device_ms"] = out["device_ms_per_step"]
+            ra["native_speedup_over_reference_shaped_kernels"] = round(ra["kernels_total_ms"] / out["device_ms_per_step"], 1)
+        out["reference_abi_kernels"] = ra
     roofline_legs(h, out, n_grid, args.scene, params, consts)
     out["roofline_step"] = roofline_step_leg(pkg, local_rank, args.scene, params, args.levels, consts, info)
     if not args.no_cpu_baseline:

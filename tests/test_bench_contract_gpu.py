@@ -42,6 +42,8 @@ def test_single_gpu_line_keeps_the_contract():
     assert s["project"]["wave_instr"] > 0 and 0.0 < s["project"]["frac"] < 1.0
     assert s["project"].get("frac_of_issue_bound") is None or 0.0 < s["project"]["frac_of_issue_bound"] <= 1.0
     assert set(s["hbm_passes"]) >= {"P3_emit_active_list", "P4_triangles", "P5_weld"}
+    ra = j["reference_abi_kernels"]
+    assert ra["voxels_meshed"] == 265256 and ra["kernels_total_ms"] > ra["native_chain_device_ms"] > 0 and len(ra["per_level"]) == 4
 
 
 @pytest.mark.gpu
