@@ -191,8 +191,8 @@ struct sdmesh_handle {
     int comm_rank = 0, comm_nranks = 1;
     DevBuf shard_mine, shard_counts, shard_recv, shard_lists, shard_plan, shard_merged;
     // z-slab INDEXED gather (root): the ranks' welded buffers concatenated, the merge's tables, its outputs (swapped into vertices / indices)
-    DevBuf zs_verts, zs_idx, zs_tables, zs_pervert, zs_tilecnt, zs_hkeys, zs_hmin, zs_vout, zs_iout, zs_ranks, zs_local;
-    ZsRanks *h_zs = nullptr;       // pinned staging copy of the merge's rank table
+    DevBuf zs_verts, zs_idx, zs_tables, zs_pervert, zs_tilecnt, zs_hkeys, zs_hmin, zs_vout, zs_iout, zs_ranks, zs_ranks1, zs_local;
+    ZsRanks *h_zs = nullptr, *h_zs1 = nullptr;       // pinned staging copies of the merge's rank table / of the local phase's one-rank table
     int shard_indexed = 1;         // option "shard_indexed": sdmesh_sharded_regen gathers welded per-slab vertex / index buffers (0: raw triangle lists + root weld)
     uint32_t zs_band_plan = 0;     // face-band vertices of the last indexed merge (sizes the band hash of the next one)
     uint32_t *h_counts = nullptr;      // pinned: nranks x SHARD_ROW words (column counts + status record of every rank)
@@ -1075,11 +1075,12 @@ void sdmesh_destroy(sdmesh_handle *h) {
                       &h->first_ord_buf, &h->uverts, &h->tri_e, &h->vslot, &h->tdesc, &h->tfirst, &h->tfpre, &h->tpre, &h->flip, &h->wvidx, &h->torder, &h->wrep_buf, &h->wfm_buf,
                       &h->vertices, &h->indices, &h->raw, &h->compact, &h->staging, &h->dense_samples, &h->dense_bits,
                       &h->cellcnt, &h->dist_upids, &h->dist_upkeys, &h->dist_loids, &h->dist_prevkeys, &h->dist_hkeys, &h->dist_hpos, &h->dist_dupof,
-                      &h->dist_newidx, &h->dist_tilecnt, &h->dist_counts, &h->dist_upg, &h->dist_prevg, &h->dist_verts, &h->dist_nups, &h->col_list1, &h->col_mask2, &h->col_mask3, &h->colinfo, &h->prof_rounds, &h->proj_diag, &h->shard_mine, &h->shard_counts, &h->shard_recv, &h->shard_lists, &h->shard_plan, &h->shard_merged, &h->zs_verts, &h->zs_idx, &h->zs_tables, &h->zs_pervert, &h->zs_tilecnt, &h->zs_hkeys, &h->zs_hmin, &h->zs_vout, &h->zs_iout, &h->zs_ranks, &h->zs_local};
+                      &h->dist_newidx, &h->dist_tilecnt, &h->dist_counts, &h->dist_upg, &h->dist_prevg, &h->dist_verts, &h->dist_nups, &h->col_list1, &h->col_mask2, &h->col_mask3, &h->colinfo, &h->prof_rounds, &h->proj_diag, &h->shard_mine, &h->shard_counts, &h->shard_recv, &h->shard_lists, &h->shard_plan, &h->shard_merged, &h->zs_verts, &h->zs_idx, &h->zs_tables, &h->zs_pervert, &h->zs_tilecnt, &h->zs_hkeys, &h->zs_hmin, &h->zs_vout, &h->zs_iout, &h->zs_ranks, &h->zs_ranks1, &h->zs_local};
     (void) sdmesh_comm_destroy(h);
     if (h->h_counts) (void) hipHostFree(h->h_counts);
     if (h->h_lists) (void) hipHostFree(h->h_lists);
     if (h->h_zs) (void) hipHostFree(h->h_zs);
+    if (h->h_zs1) (void) hipHostFree(h->h_zs1);
     for (DevBuf *b : bufs) release(*b);
     if (h->h_pinned) (void) hipHostFree(h->h_pinned);
     if (h->d_sp) (void) hipFree(h->d_sp);
@@ -1993,9 +1994,9 @@ int zs_merge(sdmesh_handle *h, int R, const uint32_t *d_counts, uint32_t cstride
     zr.band = 2.5f * ((MESH_GENERATION_BB_SIZE / (float) F) / (float) (1u << levels));
     const uint32_t V = (uint32_t) vtot, T = (uint32_t) ttot, nseg = (uint32_t) R * 1024u;
     // the rank table in device memory (the kernels index it per thread; pinned staging so that the copy is asynchronous)
+    // (the staging copy is rewritten only here, and the previous merge ended with a wait for the stream: nothing can still be reading it)
     if (!h->h_zs) HIPCHK(hipHostMalloc((void **) &h->h_zs, sizeof(ZsRanks), hipHostMallocDefault));
     SDCHK(ensure(h, h->zs_ranks, sizeof(ZsRanks)));
-    HIPCHK(hipStreamSynchronize(st));                      // (a previous merge may still be reading the staging copy)
     *h->h_zs = zr;
     HIPCHK(hipMemcpyAsync(h->zs_ranks.p, h->h_zs, sizeof(ZsRanks), hipMemcpyHostToDevice, st));
     const ZsRanks *d_zr = (const ZsRanks *) h->zs_ranks.p;
@@ -2081,15 +2082,16 @@ int zs_local_phase(sdmesh_handle *h, int levels, int part, int nparts, uint32_t 
     }
     // the vertices FIRST SEEN per column of this slab's own first-seen order -> d_row[1024 .. 2048): this rank's share of the merge
     if (h->n_tris) {
-        if (!h->h_zs) HIPCHK(hipHostMalloc((void **) &h->h_zs, sizeof(ZsRanks), hipHostMallocDefault));
-        SDCHK(ensure(h, h->zs_ranks, sizeof(ZsRanks)));
+        // (its own one-rank table, device copy and pinned staging: the staging is only rewritten here, and every call that reaches
+        // this point has waited for the stream at the end of the previous one -- no copy of it can still be in flight)
+        if (!h->h_zs1) HIPCHK(hipHostMalloc((void **) &h->h_zs1, sizeof(ZsRanks), hipHostMallocDefault));
+        SDCHK(ensure(h, h->zs_ranks1, sizeof(ZsRanks)));
         SDCHK(ensure(h, h->zs_local, 4ull * 4 * 1024));
-        HIPCHK(hipStreamSynchronize(st));                  // (the staging copy may still be in flight from a previous call)
-        memset(h->h_zs, 0, sizeof(ZsRanks));
-        h->h_zs->nranks = 1; h->h_zs->vbase[1] = h->n_verts; h->h_zs->tbase[1] = h->n_tris;
-        HIPCHK(hipMemcpyAsync(h->zs_ranks.p, h->h_zs, sizeof(ZsRanks), hipMemcpyHostToDevice, st));
+        memset(h->h_zs1, 0, sizeof(ZsRanks));
+        h->h_zs1->nranks = 1; h->h_zs1->vbase[1] = h->n_verts; h->h_zs1->tbase[1] = h->n_tris;
+        HIPCHK(hipMemcpyAsync(h->zs_ranks1.p, h->h_zs1, sizeof(ZsRanks), hipMemcpyHostToDevice, st));
         uint32_t *loc = (uint32_t *) h->zs_local.p;
-        HIPCHK(launch_zs_local_vcnt(st, (const uint32_t *) h->indices.p, d_row, (const ZsRanks *) h->zs_ranks.p, loc, loc + 2048, loc + 3072, d_row + 1024,
+        HIPCHK(launch_zs_local_vcnt(st, (const uint32_t *) h->indices.p, d_row, (const ZsRanks *) h->zs_ranks1.p, loc, loc + 2048, loc + 3072, d_row + 1024,
                                     h->d_ctr + CTR_SCRATCH, h->d_status));
     }
     return SDMESH_OK;
