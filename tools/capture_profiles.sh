@@ -13,7 +13,7 @@ run regen_fetch --kernel-trace --pmc FETCH_SIZE --output-format csv -d $O/regen_
 run regen_write --kernel-trace --pmc WRITE_SIZE --output-format csv -d $O/regen_write -- $P $R/tools/prof_regen.py sdobj 4 3 || exit 1
 run dense_write --kernel-trace --pmc WRITE_SIZE --output-format csv -d $O/dense_write -- $P $R/tools/dense_once.py || exit 1
 run dense_fetch --kernel-trace --pmc FETCH_SIZE --output-format csv -d $O/dense_fetch -- $P $R/tools/dense_once.py || exit 1
-run bench_trace --kernel-trace --stats --output-format csv -d $O/bench_trace -- $P $R/bench.py --steps 100 --warmup 10 --no-cpu-baseline --no-sizes --no-pipelined --no-anim || exit 1
+run bench_trace --kernel-trace --stats --output-format csv -d $O/bench_trace -- $P $R/bench.py --steps 100 --warmup 10 --no-cpu-baseline --no-sizes --no-pipelined --no-anim --no-ref-abi || exit 1
 cd $R
 for u in valu_rate valu_issue; do      # (built in-tree by the builder; a fresh clone compiles them here)
   [ -x tools/ubench/$u ] || /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -w $([ $u = valu_rate ] && echo -ffp-contract=off) tools/ubench/$u.hip -o tools/ubench/$u
