@@ -191,7 +191,7 @@ struct sdmesh_handle {
     int comm_rank = 0, comm_nranks = 1;
     DevBuf shard_mine, shard_counts, shard_recv, shard_lists, shard_plan, shard_merged;
     // z-slab INDEXED gather (root): the ranks' welded buffers concatenated, the merge's tables, its outputs (swapped into vertices / indices)
-    DevBuf zs_verts, zs_idx, zs_tables, zs_pervert, zs_tilecnt, zs_hkeys, zs_hmin, zs_vout, zs_iout, zs_ranks, zs_ranks1, zs_local;
+    DevBuf zs_verts, zs_idx, zs_tables, zs_pervert, zs_tilecnt, zs_hkeys, zs_vout, zs_iout, zs_ranks, zs_ranks1, zs_local;
     ZsRanks *h_zs = nullptr, *h_zs1 = nullptr;       // pinned staging copies of the merge's rank table / of the local phase's one-rank table
     int shard_indexed = 1;         // option "shard_indexed": sdmesh_sharded_regen gathers welded per-slab vertex / index buffers (0: raw triangle lists + root weld)
     uint32_t zs_band_plan = 0;     // face-band vertices of the last indexed merge (sizes the band hash of the next one)
@@ -1075,7 +1075,7 @@ void sdmesh_destroy(sdmesh_handle *h) {
                       &h->first_ord_buf, &h->uverts, &h->tri_e, &h->vslot, &h->tdesc, &h->tfirst, &h->tfpre, &h->tpre, &h->flip, &h->wvidx, &h->torder, &h->wrep_buf, &h->wfm_buf,
                       &h->vertices, &h->indices, &h->raw, &h->compact, &h->staging, &h->dense_samples, &h->dense_bits,
                       &h->cellcnt, &h->dist_upids, &h->dist_upkeys, &h->dist_loids, &h->dist_prevkeys, &h->dist_hkeys, &h->dist_hpos, &h->dist_dupof,
-                      &h->dist_newidx, &h->dist_tilecnt, &h->dist_counts, &h->dist_upg, &h->dist_prevg, &h->dist_verts, &h->dist_nups, &h->col_list1, &h->col_mask2, &h->col_mask3, &h->colinfo, &h->prof_rounds, &h->proj_diag, &h->shard_mine, &h->shard_counts, &h->shard_recv, &h->shard_lists, &h->shard_plan, &h->shard_merged, &h->zs_verts, &h->zs_idx, &h->zs_tables, &h->zs_pervert, &h->zs_tilecnt, &h->zs_hkeys, &h->zs_hmin, &h->zs_vout, &h->zs_iout, &h->zs_ranks, &h->zs_ranks1, &h->zs_local};
+                      &h->dist_newidx, &h->dist_tilecnt, &h->dist_counts, &h->dist_upg, &h->dist_prevg, &h->dist_verts, &h->dist_nups, &h->col_list1, &h->col_mask2, &h->col_mask3, &h->colinfo, &h->prof_rounds, &h->proj_diag, &h->shard_mine, &h->shard_counts, &h->shard_recv, &h->shard_lists, &h->shard_plan, &h->shard_merged, &h->zs_verts, &h->zs_idx, &h->zs_tables, &h->zs_pervert, &h->zs_tilecnt, &h->zs_hkeys, &h->zs_vout, &h->zs_iout, &h->zs_ranks, &h->zs_ranks1, &h->zs_local};
     (void) sdmesh_comm_destroy(h);
     if (h->h_counts) (void) hipHostFree(h->h_counts);
     if (h->h_lists) (void) hipHostFree(h->h_lists);
@@ -2015,20 +2015,17 @@ int zs_merge(sdmesh_handle *h, int R, const uint32_t *d_counts, uint32_t cstride
         uint32_t band_cap = V;
         if (attempt == 0 && h->zs_band_plan && (uint64_t) h->zs_band_plan + h->zs_band_plan / 4 + 1024 < V) band_cap = h->zs_band_plan + h->zs_band_plan / 4 + 1024;
         const uint32_t hsize = 2u * band_cap + 64u;
-        SDCHK(ensure_grow(h, h->zs_hkeys, 8ull * hsize));
-        SDCHK(ensure_grow(h, h->zs_hmin, 4ull * hsize));
+        SDCHK(ensure_grow(h, h->zs_hkeys, 12ull * hsize));                    // keys (8 B per slot), then the slots' smallest vertex ids (4 B)
+        uint64_t *hkeys = (uint64_t *) h->zs_hkeys.p;
+        uint32_t *hmin = (uint32_t *) (hkeys + hsize);
         SDCHK(zero_status(h));
-        HIPCHK(hipMemsetAsync(h->d_ctr + CTR_DIST_NUP, 0, 4, st));
-        if (R > 1) {
-            HIPCHK(hipMemsetAsync(h->zs_hkeys.p, 0xFF, 8ull * hsize, st));
-            HIPCHK(hipMemsetAsync(h->zs_hmin.p, 0xFF, 4ull * hsize, st));
-        }
+        if (R > 1) HIPCHK(hipMemsetAsync(hkeys, 0xFF, 12ull * hsize, st));    // (all-ones = empty key = no vertex yet)
         HIPCHK(launch_merge_plan(st, d_counts, cstride, R, tplan, T, h->d_ctr + CTR_NTRI, h->d_status));
         HIPCHK(launch_zs_front(st, h->grid, (const Vertex *) h->zs_verts.p, d_counts, cstride, d_counts + 1024 /* the ranks' first-seen vertex counts */, zr, d_zr,
-                               vstart, newcnt, segof, redirect, (uint64_t *) h->zs_hkeys.p, (uint32_t *) h->zs_hmin.p, hsize, h->d_ctr + CTR_DIST_NUP,
+                               vstart, newcnt, segof, redirect, hkeys, hmin, hsize, h->d_ctr + CTR_DIST_NUP,
                                h->d_status));
-        HIPCHK(launch_set_u32(st, h->d_ctr + CTR_DIST_V, V));
-        HIPCHK(launch_dist_number(st, h->tgrid, redirect, V, h->d_ctr + CTR_DIST_V, (uint32_t *) h->zs_tilecnt.p, h->d_ctr + CTR_NVERT, kept, h->d_status));
+        HIPCHK(launch_dist_number(st, h->tgrid, redirect, V, &d_zr->vbase[R] /* = V, in device memory */, (uint32_t *) h->zs_tilecnt.p, h->d_ctr + CTR_NVERT, kept,
+                                  h->d_status));
         HIPCHK(launch_merge_plan(st, newcnt, 1024u, R, vplan, V, h->d_ctr + CTR_SCRATCH, h->d_status));
         HIPCHK(launch_zs_back(st, h->grid, (const Vertex *) h->zs_verts.p, (const uint32_t *) h->zs_idx.p, d_counts, cstride, tplan, zr, d_zr, redirect, kept, segof,
                               vstart, vplan, (Vertex *) h->zs_vout.p, V, map, (uint32_t *) h->zs_iout.p, T));
@@ -2075,11 +2072,9 @@ int zs_local_phase(sdmesh_handle *h, int levels, int part, int nparts, uint32_t 
     if (h->last_direct || !h->welded) return fail(h, SDMESH_ERR_INTERNAL, "a slab took the direct path: no column counts");
     if (h->wide_active) return fail(h, SDMESH_ERR_WELD_RANGE, "the indexed gather needs the packed weld keys (option shard_indexed = 0 welds on the root instead)");
     HIPCHK(hipMemsetAsync(d_row, 0, 8192, st));
-    if (h->n_vox) {
-        HIPCHK(launch_set_u32(st, h->d_ctr + CTR_SCRATCH, h->n_vox));
-        HIPCHK(launch_column_counts(st, std::min(h->grid, (int) tiles(h->n_vox)), (const Point *) h->vox[h->cur].p, h->d_ctr + CTR_SCRATCH,
+    if (h->n_vox)         // (the voxel count is still in the chain's own counter)
+        HIPCHK(launch_column_counts(st, std::min(h->grid, (int) tiles(h->n_vox)), (const Point *) h->vox[h->cur].p, h->d_ctr + CTR_LEVEL0 + levels,
                                     (const uint8_t *) h->cubeidx.p, d_row));
-    }
     // the vertices FIRST SEEN per column of this slab's own first-seen order -> d_row[1024 .. 2048): this rank's share of the merge
     if (h->n_tris) {
         // (its own one-rank table, device copy and pinned staging: the staging is only rewritten here, and every call that reaches

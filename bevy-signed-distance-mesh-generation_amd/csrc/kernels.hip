@@ -2248,8 +2248,8 @@ __global__ __launch_bounds__(256) void k_dist_finalize(const Vertex *__restrict_
 //     segment comes first in the (column, rank) order is the single-GPU representative, the other one is dropped from its
 //     segment's count and redirected;
 //   * kept vertices are numbered by an ordered scan (the distributed weld's k_dist_keep_count / k_scan_tiles / k_dist_newidx),
-//     written to their merged places (k_zs_vertex_out), the dropped ones inherit their partner's number (k_zs_loser_map), and
-//     the index buffers are rewritten segment by segment into the merged triangle order (k_zs_index_out).
+//     written to their merged places (k_zs_vertex_out), and the index buffers are rewritten segment by segment into the merged
+//     triangle order, a dropped copy taking its partner's number (k_zs_index_out).
 // Inputs are the ranks' buffers CONCATENATED in rank order (vertex i of rank r at vbase[r] + i, triangle t at tbase[r] + t).
 // ------------------------------------------------------------------------------------------
 __device__ __forceinline__ uint32_t zs_rank_of(const ZsRanks &zr, uint32_t i) {
@@ -2300,7 +2300,8 @@ __global__ __launch_bounds__(1024) void k_zs_vplan(const uint32_t *__restrict__ 
 // root: vstart[r][c] = exclusive prefix over the columns of rank r's first-seen vertex counts (gathered with the column counts), newcnt = a
 // private copy of them (the band pairs decrement it)
 __global__ __launch_bounds__(1024) void k_zs_vstart(const uint32_t *__restrict__ vcounts, uint32_t cstride, const ZsRanks *__restrict__ zrp,
-                                                     uint32_t *__restrict__ vstart, uint32_t *__restrict__ newcnt, uint32_t *__restrict__ status) {
+                                                     uint32_t *__restrict__ vstart, uint32_t *__restrict__ newcnt, uint32_t *__restrict__ nband,
+                                                     uint32_t *__restrict__ status) {
     const ZsRanks &zr = *zrp;
     __shared__ uint32_t lds[17];
     const uint32_t c = threadIdx.x, r = blockIdx.x;
@@ -2309,6 +2310,7 @@ __global__ __launch_bounds__(1024) void k_zs_vstart(const uint32_t *__restrict__
     vstart[r * NCOL + c] = block_excl_scan(n, total, lds);
     newcnt[r * NCOL + c] = n;
     if (c == 0 && total != zr.vbase[r + 1u] - zr.vbase[r]) atomicOr(&status[ST_INTERNAL], 512u);   // the counts do not add up to the rank's vertices
+    if (c == 0 && r == 0) *nband = 0;                                 // (the band counter of k_zs_band_insert, two launches on)
 }
 
 // every vertex learns its first-seen segment; its redirect starts as "kept"
@@ -2403,17 +2405,10 @@ __global__ __launch_bounds__(256) void k_zs_vertex_out(const Vertex *__restrict_
     }
 }
 
-__global__ __launch_bounds__(256) void k_zs_loser_map(uint32_t V, const uint32_t *__restrict__ redirect, uint32_t *__restrict__ map) {
-    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < V; i += gridDim.x * blockDim.x) {
-        const uint32_t w = redirect[i];
-        if (w != U32_NONE) map[i] = map[w];                            // (the partner is kept: its number is final)
-    }
-}
-
 // the index buffers, segment by segment (gridDim.y workgroups share one), into the merged triangle order with merged vertex numbers
 __global__ __launch_bounds__(256) void k_zs_index_out(const uint32_t *__restrict__ idx_all, const uint32_t *__restrict__ counts, uint32_t cstride,
                                                        const uint32_t *__restrict__ tplan, const ZsRanks *__restrict__ zrp, const uint32_t *__restrict__ map,
-                                                       uint32_t *__restrict__ out, uint32_t cap_tris) {
+                                                       const uint32_t *__restrict__ redirect, uint32_t *__restrict__ out, uint32_t cap_tris) {
     const ZsRanks &zr = *zrp;
     const uint32_t nseg = zr.nranks * NCOL;
     for (uint32_t seg = blockIdx.x; seg < nseg; seg += gridDim.x) {
@@ -2425,7 +2420,10 @@ __global__ __launch_bounds__(256) void k_zs_index_out(const uint32_t *__restrict
         const uint32_t *__restrict__ s = idx_all + 3ull * (zr.tbase[r] + tplan[2u * seg]);
         uint32_t *__restrict__ d = out + 3ull * dst;
         const uint32_t vb = zr.vbase[r];
-        for (uint32_t e = e0 + threadIdx.x; e < e1; e += 256) d[e] = map[vb + s[e]];
+        for (uint32_t e = e0 + threadIdx.x; e < e1; e += 256) {
+            const uint32_t i = vb + s[e], w = redirect[i];
+            d[e] = map[w == U32_NONE ? i : w];                          // (a dropped copy takes its partner's number: the partner is kept)
+        }
     }
 }
 
@@ -3351,7 +3349,7 @@ hipError_t launch_zs_front(hipStream_t st, int grid, const Vertex *v_all, const 
     const uint32_t V = zr.vbase[zr.nranks];
     const int nseg = (int) (zr.nranks * 1024u);
     (void) counts;
-    hipLaunchKernelGGL(k_zs_vstart, dim3(zr.nranks), dim3(1024), 0, st, vcounts, cstride, d_zr, vstart, newcnt, status);
+    hipLaunchKernelGGL(k_zs_vstart, dim3(zr.nranks), dim3(1024), 0, st, vcounts, cstride, d_zr, vstart, newcnt, nband, status);
     hipLaunchKernelGGL(k_zs_segfill, dim3(nseg), dim3(256), 0, st, (const uint32_t *) vstart, (const uint32_t *) newcnt, d_zr, segof, redirect);
     if (zr.nranks > 1 && V) {
         hipLaunchKernelGGL(k_zs_band_insert, dim3(grid), dim3(256), 0, st, v_all, V, d_zr, hkeys, hmin, hsize, nband, status);
@@ -3366,11 +3364,8 @@ hipError_t launch_zs_back(hipStream_t st, int grid, const Vertex *v_all, const u
                           const uint32_t *tplan, const ZsRanks &zr, const ZsRanks *d_zr, const uint32_t *redirect, const uint32_t *kept_before, const uint32_t *segof,
                           const uint32_t *vstart, const uint32_t *vplan, Vertex *v_out, uint32_t cap_verts, uint32_t *map, uint32_t *i_out, uint32_t cap_tris) {
     const uint32_t V = zr.vbase[zr.nranks];
-    if (V) {
-        hipLaunchKernelGGL(k_zs_vertex_out, dim3(grid), dim3(256), 0, st, v_all, V, d_zr, redirect, kept_before, segof, vstart, vplan, v_out, cap_verts, map);
-        if (zr.nranks > 1) hipLaunchKernelGGL(k_zs_loser_map, dim3(grid), dim3(256), 0, st, V, redirect, map);
-    }
-    hipLaunchKernelGGL(k_zs_index_out, dim3(zr.nranks * 1024u, 2), dim3(256), 0, st, idx_all, counts, cstride, tplan, d_zr, (const uint32_t *) map, i_out, cap_tris);
+    if (V) hipLaunchKernelGGL(k_zs_vertex_out, dim3(grid), dim3(256), 0, st, v_all, V, d_zr, redirect, kept_before, segof, vstart, vplan, v_out, cap_verts, map);
+    hipLaunchKernelGGL(k_zs_index_out, dim3(zr.nranks * 1024u, 2), dim3(256), 0, st, idx_all, counts, cstride, tplan, d_zr, (const uint32_t *) map, redirect, i_out, cap_tris);
     return hipGetLastError();
 }
 
