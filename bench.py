@@ -250,7 +250,7 @@ def one_mesh_legs(pkg, job, local_rank, scene, params, levels_list, base_levels,
                                                 **xslab}}
 
 
-def dense_p1_sharded_leg(pkg, job, local_rank, scene, params, grids=(512, 1024), launches=50):
+def dense_p1_sharded_leg(pkg, job, local_rank, scene, params, grids=(256, 512, 1024), launches=50):
     """P1 (the north star's HBM pass) sharded over the ranks: rank r samples the x planes [r (N+1) / R, (r+1) (N+1) / R) of the same
     dense lattice into its own HBM, no exchange of any kind (the parts are bit for bit the ranges of the whole volume: -m gpu
     test_dense_slabs_concatenate_to_the_whole_volume).  Timed like a step: `launches` back-to-back launches per rank between
@@ -411,16 +411,25 @@ def roofline_legs(h, out, n_grid, scene, params, consts):
     if scene != "sphere":
         out["roofline_workload_scene"] = roofs[scene]
     # the same pass over a volume eight times as large (BASELINE configs[3]'s grid): a launch is 0.6 ms instead of 0.08, so its
-    # ramp and drain (~8 us between dependent launches on one stream) weigh an eighth as much
+    # ramp and drain (~8 us between dependent launches on one stream) weigh an eighth as much -- and over one an eighth as large
+    # (256^3: a 0.012 ms launch, mostly ramp and drain).  roofline_by_grid: the three grids the north star names, both scenes.
+    by_grid = {}
     try:
         big = torch.empty((2 * n_grid + 1) ** 3, dtype=torch.float32, device="cuda")
-        h.set_scene("sphere")
-        h.time_kernel(0, 2 * n_grid, big.data_ptr(), 30)
-        msb = h.time_kernel(0, 2 * n_grid, big.data_ptr(), 20)
-        bb = 4.0 * (2 * n_grid + 1) ** 3
-        out["roofline"]["at_twice_the_grid"] = {"grid": 2 * n_grid, "bytes_per_launch": bb, "avg_launch_ms": round(msb, 5),
-                                                 "achieved": round(bb / (msb * 1e-3) / 1e9, 1), "unit": "GB/s",
-                                                 "frac": round(bb / (msb * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4)}
+        for sc in dict.fromkeys(("sphere", scene)):
+            h.set_scene(sc, [0.25] if sc == "anim" else None)
+            rows = {}
+            for g, warm, reps in ((n_grid // 2, 300, 100), (2 * n_grid, 30, 20)):
+                h.time_kernel(0, g, big.data_ptr(), warm)
+                msg = h.time_kernel(0, g, big.data_ptr(), reps)
+                bb = 4.0 * (g + 1) ** 3
+                rows[str(g)] = {"bytes_per_launch": bb, "avg_launch_ms": round(msg, 5), "achieved": round(bb / (msg * 1e-3) / 1e9, 1), "unit": "GB/s",
+                                "frac": round(bb / (msg * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4), "mvoxels_per_s": round(g ** 3 / msg / 1e3, 1)}
+            rows[str(n_grid)] = {k: roofs[sc][k] for k in ("bytes_per_launch", "avg_launch_ms", "achieved", "unit", "frac")}
+            rows[str(n_grid)]["mvoxels_per_s"] = round(n_grid ** 3 / roofs[sc]["avg_launch_ms"] / 1e3, 1)
+            by_grid[sc] = dict(sorted(rows.items(), key=lambda kv: int(kv[0])))
+        out["roofline"]["at_twice_the_grid"] = dict(by_grid["sphere"][str(2 * n_grid)], grid=2 * n_grid)
+        out["roofline_by_grid"] = by_grid
         del big
     finally:
         h.set_scene(scene, params)

@@ -42,6 +42,8 @@ def test_single_gpu_line_keeps_the_contract():
     assert s["project"]["wave_instr"] > 0 and 0.0 < s["project"]["frac"] < 1.0
     assert s["project"].get("frac_of_issue_bound") is None or 0.0 < s["project"]["frac_of_issue_bound"] <= 1.0
     assert set(s["hbm_passes"]) >= {"P3_emit_active_list", "P4_triangles", "P5_weld"}
+    for sc in ("sphere", "sdobj"):
+        assert set(j["roofline_by_grid"][sc]) == {"256", "512", "1024"} and all(0.0 < r["frac"] < 1.0 for r in j["roofline_by_grid"][sc].values())
     ra = j["reference_abi_kernels"]
     assert ra["voxels_meshed"] == 265256 and ra["kernels_total_ms"] > ra["native_chain_device_ms"] > 0 and len(ra["per_level"]) == 4
 
@@ -59,7 +61,7 @@ def test_one_mesh_line_keeps_the_contract_on_one_rank():
             assert row["t_1rank_ms"] > 0 and row["ms_per_regen"] > 0 and row["triangles"] > 0
     assert (j["one_mesh"]["xslab_distributed_weld"]["512^3"]["triangles"], j["one_mesh"]["xslab_distributed_weld"]["512^3"]["vertices"]) == (530536, 265262)
     d = j["dense_p1_sharded"]
-    for size in ("512^3", "1024^3"):
+    for size in ("256^3", "512^3", "1024^3"):
         for sc in ("sphere", "sdobj"):
             row = d[size][sc]
             assert row["peak"] == 8000.0 and 0.0 < row["frac"] < 1.0 and row["t_1rank_ms"] > 0 and row["ms_per_pass"] > 0
