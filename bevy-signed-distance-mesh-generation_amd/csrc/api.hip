@@ -2086,7 +2086,7 @@ int zs_local_phase(sdmesh_handle *h, int levels, int part, int nparts, uint32_t 
         h->h_zs1->nranks = 1; h->h_zs1->vbase[1] = h->n_verts; h->h_zs1->tbase[1] = h->n_tris;
         HIPCHK(hipMemcpyAsync(h->zs_ranks1.p, h->h_zs1, sizeof(ZsRanks), hipMemcpyHostToDevice, st));
         uint32_t *loc = (uint32_t *) h->zs_local.p;
-        HIPCHK(launch_zs_local_vcnt(st, (const uint32_t *) h->indices.p, d_row, (const ZsRanks *) h->zs_ranks1.p, loc, loc + 2048, loc + 3072, d_row + 1024,
+        HIPCHK(launch_zs_local_vcnt(st, (const uint32_t *) h->indices.p, h->n_tris, d_row, (const ZsRanks *) h->zs_ranks1.p, loc, loc + 2048, loc + 3072, d_row + 1024,
                                     h->d_ctr + CTR_SCRATCH, h->d_status));
     }
     return SDMESH_OK;

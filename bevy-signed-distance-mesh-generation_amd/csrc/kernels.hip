@@ -2248,8 +2248,8 @@ __global__ __launch_bounds__(256) void k_dist_finalize(const Vertex *__restrict_
 //     segment comes first in the (column, rank) order is the single-GPU representative, the other one is dropped from its
 //     segment's count and redirected;
 //   * kept vertices are numbered by an ordered scan (the distributed weld's k_dist_keep_count / k_scan_tiles / k_dist_newidx),
-//     written to their merged places (k_zs_vertex_out), and the index buffers are rewritten segment by segment into the merged
-//     triangle order, a dropped copy taking its partner's number (k_zs_index_out).
+//     written to their merged places (k_zs_vertex_out), the dropped ones inherit their partner's number (k_zs_loser_map), and
+//     the index buffers are rewritten segment by segment into the merged triangle order (k_zs_index_out).
 // Inputs are the ranks' buffers CONCATENATED in rank order (vertex i of rank r at vbase[r] + i, triangle t at tbase[r] + t).
 // ------------------------------------------------------------------------------------------
 __device__ __forceinline__ uint32_t zs_rank_of(const ZsRanks &zr, uint32_t i) {
@@ -2405,10 +2405,19 @@ __global__ __launch_bounds__(256) void k_zs_vertex_out(const Vertex *__restrict_
     }
 }
 
+// a dropped copy takes its partner's number (the partner is kept: its number is final).  Its own pass over the vertices: folded into the
+// index rewrite it would cost every one of the 3T index lookups a second gather (measured: +40 us at 2048^3, +0.2 ms at 4096^3)
+__global__ __launch_bounds__(256) void k_zs_loser_map(uint32_t V, const uint32_t *__restrict__ redirect, uint32_t *__restrict__ map) {
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < V; i += gridDim.x * blockDim.x) {
+        const uint32_t w = redirect[i];
+        if (w != U32_NONE) map[i] = map[w];
+    }
+}
+
 // the index buffers, segment by segment (gridDim.y workgroups share one), into the merged triangle order with merged vertex numbers
 __global__ __launch_bounds__(256) void k_zs_index_out(const uint32_t *__restrict__ idx_all, const uint32_t *__restrict__ counts, uint32_t cstride,
                                                        const uint32_t *__restrict__ tplan, const ZsRanks *__restrict__ zrp, const uint32_t *__restrict__ map,
-                                                       const uint32_t *__restrict__ redirect, uint32_t *__restrict__ out, uint32_t cap_tris) {
+                                                       uint32_t *__restrict__ out, uint32_t cap_tris) {
     const ZsRanks &zr = *zrp;
     const uint32_t nseg = zr.nranks * NCOL;
     for (uint32_t seg = blockIdx.x; seg < nseg; seg += gridDim.x) {
@@ -2420,10 +2429,7 @@ __global__ __launch_bounds__(256) void k_zs_index_out(const uint32_t *__restrict
         const uint32_t *__restrict__ s = idx_all + 3ull * (zr.tbase[r] + tplan[2u * seg]);
         uint32_t *__restrict__ d = out + 3ull * dst;
         const uint32_t vb = zr.vbase[r];
-        for (uint32_t e = e0 + threadIdx.x; e < e1; e += 256) {
-            const uint32_t i = vb + s[e], w = redirect[i];
-            d[e] = map[w == U32_NONE ? i : w];                          // (a dropped copy takes its partner's number: the partner is kept)
-        }
+        for (uint32_t e = e0 + threadIdx.x; e < e1; e += 256) d[e] = map[vb + s[e]];
     }
 }
 
@@ -3333,11 +3339,19 @@ hipError_t launch_merge_plan(hipStream_t st, const uint32_t *d_counts, uint32_t 
 }
 
 // a rank's own first-seen vertex counts per column (carried to the root in the all-gather: the work stays where it is parallel)
-hipError_t launch_zs_local_vcnt(hipStream_t st, const uint32_t *idx, const uint32_t *colcnt, const ZsRanks *d_zr1, uint32_t *tplan1, uint32_t *segmax,
+// workgroups that share one (rank, column) segment: enough for one element per thread in the occupied segments (about a third of the
+// columns hold surface), so that a segment's dependent loads are ONE round trip deep in small meshes; large meshes are bandwidth-bound anyway
+static uint32_t zs_seg_split(uint32_t tris, uint32_t nseg) {
+    const uint64_t per_seg = (9ull * tris + nseg - 1) / nseg;               // 3 indices per triangle, ~3x the average in the occupied segments
+    const uint64_t by_work = std::max<uint64_t>(1, (per_seg + 255) / 256), by_grid = std::max<uint64_t>(2, 16384 / nseg);   // (dispatching mostly
+    return (uint32_t) std::min<uint64_t>(16, std::min(by_work, by_grid));                                                      //  empty workgroups costs too)
+}
+
+hipError_t launch_zs_local_vcnt(hipStream_t st, const uint32_t *idx, uint32_t tris, const uint32_t *colcnt, const ZsRanks *d_zr1, uint32_t *tplan1, uint32_t *segmax,
                                 uint32_t *vstart, uint32_t *vcnt, uint32_t *scratch_total, uint32_t *status) {
     hipLaunchKernelGGL(k_merge_plan, dim3(1), dim3(1024), 0, st, colcnt, 1024u, 1u, tplan1, 0xFFFFFFFFu, scratch_total, status);
     (void) hipMemsetAsync(segmax, 0, 4096, st);
-    hipLaunchKernelGGL(k_zs_segmax, dim3(1024, 2), dim3(256), 0, st, idx, colcnt, 1024u, (const uint32_t *) tplan1, d_zr1, segmax);
+    hipLaunchKernelGGL(k_zs_segmax, dim3(1024, zs_seg_split(tris, 1024u)), dim3(256), 0, st, idx, colcnt, 1024u, (const uint32_t *) tplan1, d_zr1, segmax);
     hipLaunchKernelGGL(k_zs_vplan, dim3(1), dim3(1024), 0, st, (const uint32_t *) segmax, d_zr1, vstart, vcnt, status);
     return hipGetLastError();
 }
@@ -3364,8 +3378,11 @@ hipError_t launch_zs_back(hipStream_t st, int grid, const Vertex *v_all, const u
                           const uint32_t *tplan, const ZsRanks &zr, const ZsRanks *d_zr, const uint32_t *redirect, const uint32_t *kept_before, const uint32_t *segof,
                           const uint32_t *vstart, const uint32_t *vplan, Vertex *v_out, uint32_t cap_verts, uint32_t *map, uint32_t *i_out, uint32_t cap_tris) {
     const uint32_t V = zr.vbase[zr.nranks];
-    if (V) hipLaunchKernelGGL(k_zs_vertex_out, dim3(grid), dim3(256), 0, st, v_all, V, d_zr, redirect, kept_before, segof, vstart, vplan, v_out, cap_verts, map);
-    hipLaunchKernelGGL(k_zs_index_out, dim3(zr.nranks * 1024u, 2), dim3(256), 0, st, idx_all, counts, cstride, tplan, d_zr, (const uint32_t *) map, redirect, i_out, cap_tris);
+    if (V) {
+        hipLaunchKernelGGL(k_zs_vertex_out, dim3(grid), dim3(256), 0, st, v_all, V, d_zr, redirect, kept_before, segof, vstart, vplan, v_out, cap_verts, map);
+        if (zr.nranks > 1) hipLaunchKernelGGL(k_zs_loser_map, dim3(grid), dim3(256), 0, st, V, redirect, map);
+    }
+    hipLaunchKernelGGL(k_zs_index_out, dim3(zr.nranks * 1024u, zs_seg_split(zr.tbase[zr.nranks], zr.nranks * 1024u)), dim3(256), 0, st, idx_all, counts, cstride, tplan, d_zr, (const uint32_t *) map, i_out, cap_tris);
     return hipGetLastError();
 }
 

@@ -122,7 +122,7 @@ struct ZsRanks {
 hipError_t launch_merge_plan(hipStream_t st, const uint32_t *d_counts, uint32_t cstride, int nranks, uint32_t *d_plan, uint32_t cap,
                              uint32_t *total_out, uint32_t *status);
 // this rank's share of the indexed merge: vertices FIRST SEEN per level-0 column of its own welded slab (vcnt[1024]), from its index buffer
-hipError_t launch_zs_local_vcnt(hipStream_t st, const uint32_t *idx, const uint32_t *colcnt, const ZsRanks *d_zr1 /* one rank: {0, V}, {0, T} */,
+hipError_t launch_zs_local_vcnt(hipStream_t st, const uint32_t *idx, uint32_t tris, const uint32_t *colcnt, const ZsRanks *d_zr1 /* one rank: {0, V}, {0, T} */,
                                 uint32_t *tplan1 /* [2048] */, uint32_t *segmax /* [1024] */, uint32_t *vstart /* [1024] */, uint32_t *vcnt /* [1024] */,
                                 uint32_t *scratch_total, uint32_t *status);
 hipError_t launch_zs_front(hipStream_t st, int grid, const Vertex *v_all, const uint32_t *counts, uint32_t cstride, const uint32_t *vcounts,
