@@ -1499,8 +1499,7 @@ static hipError_t launch_p1(sdmesh_handle *h, float *d_out, uint32_t N, uint32_t
     // measured (round-1 sweep): the write-bound sphere wants whole 16-B aligned cache lines per store (flat
     // quads, 5.5 TB/s vs 3.9 with dword-aligned row stores); the VALU-bound scenes want the leaner row kernel
     const bool rows = h->dense_rows == 2 ? (h->scene != SDMESH_SCENE_SPHERE) : (h->dense_rows != 0);
-    const uint64_t total = (uint64_t) (N + 1) * (N + 1) * (N + 1);
-    if (!rows && h->dense_q1 && N >= 1u && total < 0xFFFFFFF0ull) return launch_sample_dense_q1(h->stream, h->scene, h->d_sp, d_out, N, h->dense_nt != 0, x0, x1);
+    if (!rows && h->dense_q1 && N >= 1u) return launch_sample_dense_q1(h->stream, h->scene, h->d_sp, d_out, N, h->dense_nt != 0, x0, x1);
     return rows ? launch_sample_dense_rows(h->stream, h->dense_grid, h->scene, h->d_sp, d_out, N, h->dense_nt != 0, x0, x1, h->dense_aligned != 0, h->dense_nt == 2)
                          : launch_sample_dense(h->stream, grid, h->scene, h->d_sp, d_out, N, h->dense_nt != 0, h->dense_contig != 0, x0, x1);
 }

@@ -2686,7 +2686,7 @@ __global__ __launch_bounds__(256) void k_stream_fill(float *__restrict__ out, ui
 // arithmetic cannot be amortised over a loop, so (x, y, z) comes from two exact 32-bit divisions by S = N + 1 done with a
 // host-computed magic number (mulhi + shift + fixup: 6 instructions each), and the sphere's four samples are evaluated
 // as two packed pairs (pz = (float) z * h - 2.5f etc. on v_pk_*; same operations in the same order per component).
-// Volumes of 2^32 samples or more keep the persistent kernel.
+// Volumes of 2^32 samples or more go out as several launches of whole planes (the kernel indexes relative to its launch's first plane).
 struct DivMagic { uint32_t m, add, sh; };           // q = add ? (((n - hi) >> 1) + hi) >> sh : hi >> sh,  hi = mulhi(n, m)
 __device__ __forceinline__ uint32_t div_magic(uint32_t n, DivMagic d) {
     const uint32_t hi = __umulhi(n, d.m);
@@ -2696,7 +2696,7 @@ __device__ __forceinline__ uint32_t div_magic(uint32_t n, DivMagic d) {
 template <int SCENE, bool NT>
 __global__ __launch_bounds__(256) void k_sample_dense_q1(float *__restrict__ out, uint32_t N, uint32_t total, const SceneParams *__restrict__ spp,
                                                           DivMagic dS, float h /* = 5.0f / (float) N, computed on the host: the same IEEE quotient */,
-                                                          uint32_t first /* flat index of out[0] in the volume (x-slabs); first + total < 2^32 */) {
+                                                          uint32_t xplane0 /* out[0] is sample (xplane0, 0, 0): x-slabs, and volumes of >= 2^32 samples in batches of planes */) {
     typedef float v4f __attribute__((ext_vector_type(4)));
     const SceneParams &sp = *spp;
     const uint32_t S = N + 1u;
@@ -2705,12 +2705,12 @@ __global__ __launch_bounds__(256) void k_sample_dense_q1(float *__restrict__ out
     // (x, y, z) of the WAVE's first sample on the scalar unit: two magic divisions of the workgroup's first index, then the wave's
     // offset and at most two row steps (a piece is 1 024 consecutive samples, a row has S >= 512 of them), all on uniform values.
     // A wave's 256 samples touch at most two rows, so a lane needs one compare and three selects.
-    const uint32_t iw = first + (blockIdx.x << 10);
-    const uint32_t r0 = div_magic(iw, dS), x0 = div_magic(r0, dS);
+    const uint32_t iw = blockIdx.x << 10;                      // (indices relative to the slab: it starts on a plane, so x = xplane0 + the quotient)
+    const uint32_t r0 = div_magic(iw, dS), x0 = xplane0 + div_magic(r0, dS);
     uint32_t x, y, z;
     if (S >= 512u) {                                         // (the usual case: no loop)
         const uint32_t wv = __builtin_amdgcn_readfirstlane(threadIdx.x) & ~63u;
-        uint32_t zw = (iw - r0 * S) + (wv << 2), yw = r0 - x0 * S, xw = x0;
+        uint32_t zw = (iw - r0 * S) + (wv << 2), yw = r0 - (x0 - xplane0) * S, xw = x0;
         if (zw >= S) { zw -= S; yw++; }
         if (zw >= S) { zw -= S; yw++; }
         if (yw >= S) { yw -= S; xw++; }
@@ -2720,8 +2720,8 @@ __global__ __launch_bounds__(256) void k_sample_dense_q1(float *__restrict__ out
         const bool c = z >= S;
         z = c ? z - S : z; y = c ? ya : yw; x = c ? xa : xw;
     } else {
-        const uint32_t rr = div_magic(first + i0, dS);
-        z = (first + i0) - rr * S; x = div_magic(rr, dS); y = rr - x * S;
+        const uint32_t rr = div_magic(i0, dS), xl = div_magic(rr, dS);
+        z = i0 - rr * S; y = rr - xl * S; x = xplane0 + xl;
     }
     float v[4];
     if (SCENE == SCENE_SPHERE) {
@@ -3206,17 +3206,23 @@ hipError_t launch_sample_dense_rows(hipStream_t st, int grid, int scene, const S
         // 16 x 2: 0.125-0.133 on another box where 8 x 2 gave 0.120-0.126 (long waves leave the SIMDs half empty in their last round and
         // hide their dependent chains badly; short ones lose the hoisting); nontemporal stores cost this kernel 5-15 %, hence
         // `nt_rows` (option dense_nt = 2) is off by default here
-        constexpr uint32_t R = 8, Q = 2;
+        // Rows longer than 512 samples: FOUR quads per lane, so that a wave still writes whole rows (1024^3, sd_obj: 8 x 4 0.844 ms = 64 % of the HBM
+        // peak against 1.084 ms = 50 % for 8 x 2, 0.89-0.94 for 4 x 4 / 4 x 2 / 16 x 4: half-row pieces from twice as many waves cost the write path more
+        // than the 64 extra registers cost occupancy; at 512^3, where a row is one 8 x 2 piece anyway, both shapes time the same).
+        constexpr uint32_t R = 8;
+        const uint32_t Q = ((N + 1) >> 2) > 128u ? 4u : 2u;
         const uint64_t nrows = (uint64_t) (N + 1) * (x1 - x0), nchunks = (((N + 1) >> 2) + 64ull * Q - 1ull) / (64ull * Q);
         const uint64_t ngroups = nchunks * 4ull * ((((nrows + 3ull) >> 2) + R - 1ull) / R);
         const int g2 = (int) std::min<uint64_t>((ngroups + 3ull) / 4ull, 0x7FFFFFFFull);
+#define SDM_AL(SC, NTF, QQ) hipLaunchKernelGGL((k_sample_dense_rows_aligned<SC, NTF, R, QQ>), dim3(g2), dim3(256), 0, st, out, N, sp, x0, x1)
         if (scene == SCENE_SDOBJ) {
-            if (nt_rows) hipLaunchKernelGGL((k_sample_dense_rows_aligned<SCENE_SDOBJ, true, R, Q>), dim3(g2), dim3(256), 0, st, out, N, sp, x0, x1);
-            else hipLaunchKernelGGL((k_sample_dense_rows_aligned<SCENE_SDOBJ, false, R, Q>), dim3(g2), dim3(256), 0, st, out, N, sp, x0, x1);
+            if (Q == 4) { if (nt_rows) SDM_AL(SCENE_SDOBJ, true, 4); else SDM_AL(SCENE_SDOBJ, false, 4); }
+            else { if (nt_rows) SDM_AL(SCENE_SDOBJ, true, 2); else SDM_AL(SCENE_SDOBJ, false, 2); }
         } else {
-            if (nt_rows) hipLaunchKernelGGL((k_sample_dense_rows_aligned<SCENE_ANIM, true, R, Q>), dim3(g2), dim3(256), 0, st, out, N, sp, x0, x1);
-            else hipLaunchKernelGGL((k_sample_dense_rows_aligned<SCENE_ANIM, false, R, Q>), dim3(g2), dim3(256), 0, st, out, N, sp, x0, x1);
+            if (Q == 4) { if (nt_rows) SDM_AL(SCENE_ANIM, true, 4); else SDM_AL(SCENE_ANIM, false, 4); }
+            else { if (nt_rows) SDM_AL(SCENE_ANIM, true, 2); else SDM_AL(SCENE_ANIM, false, 2); }
         }
+#undef SDM_AL
         return hipGetLastError();
     }
     if (grid <= 0) {       // one group of 16 rows per wave: the dispatcher balances the waves (a fixed grid leaves 2 or 3 groups per wave)
@@ -3255,14 +3261,21 @@ static DivMagic make_div_magic(uint32_t d) {
 }
 
 hipError_t launch_sample_dense_q1(hipStream_t st, int scene, const SceneParams *sp, float *out, uint32_t N, bool nt, uint32_t x0, uint32_t x1) {
-    // planes x0 .. x1 - 1 of the volume into out[0 ..): the whole volume must index in 32 bits (the caller checks, so do we)
-    const uint64_t plane = (uint64_t) (N + 1) * (N + 1), total = plane * (x1 - x0), first = plane * x0;
-    if (plane * (N + 1) >= 0xFFFFFFF0ull || N < 1u || x1 < x0 || x1 > N + 1u) return hipErrorInvalidValue;
-    if (total == 0) return hipSuccess;
+    // planes x0 .. x1 - 1 of the volume into out[0 ..).  The kernel indexes relative to its launch's first plane in 32 bits: a range of
+    // 2^32 samples or more goes out as several launches of whole planes (2048^3: three) -- every one in the shape the store stream likes.
+    if (N < 1u || x1 < x0 || x1 > N + 1u) return hipErrorInvalidValue;
+    const uint64_t plane = (uint64_t) (N + 1) * (N + 1);
+    // planes per launch: a multiple of four, so that every launch's first sample is 16-byte aligned in `out` whatever the parity of N + 1
+    const uint32_t batch = (uint32_t) std::max<uint64_t>(4, (0xFFFFF000ull / plane) & ~3ull);
     const DivMagic dS = make_div_magic(N + 1u);
-    const uint32_t grid = (uint32_t) (((total + 3ull) / 4ull + 255ull) / 256ull);
-    if (nt) { SDM_DISPATCH(scene, hipLaunchKernelGGL((k_sample_dense_q1<S, true>), dim3(grid), dim3(256), 0, st, out, N, (uint32_t) total, sp, dS, 5.0f / (float) N, (uint32_t) first)); }
-    else { SDM_DISPATCH(scene, hipLaunchKernelGGL((k_sample_dense_q1<S, false>), dim3(grid), dim3(256), 0, st, out, N, (uint32_t) total, sp, dS, 5.0f / (float) N, (uint32_t) first)); }
+    for (uint32_t xa = x0; xa < x1; xa += batch) {
+        const uint32_t xb = std::min(x1, xa + batch);
+        const uint64_t total = plane * (xb - xa);
+        float *o = out + plane * (xa - x0);
+        const uint32_t grid = (uint32_t) (((total + 3ull) / 4ull + 255ull) / 256ull);
+        if (nt) { SDM_DISPATCH(scene, hipLaunchKernelGGL((k_sample_dense_q1<S, true>), dim3(grid), dim3(256), 0, st, o, N, (uint32_t) total, sp, dS, 5.0f / (float) N, xa)); }
+        else { SDM_DISPATCH(scene, hipLaunchKernelGGL((k_sample_dense_q1<S, false>), dim3(grid), dim3(256), 0, st, o, N, (uint32_t) total, sp, dS, 5.0f / (float) N, xa)); }
+    }
     return hipGetLastError();
 }
 
