@@ -3209,19 +3209,18 @@ hipError_t launch_sample_dense_rows(hipStream_t st, int grid, int scene, const S
         // Rows longer than 512 samples: FOUR quads per lane, so that a wave still writes whole rows (1024^3, sd_obj: 8 x 4 0.844 ms = 64 % of the HBM
         // peak against 1.084 ms = 50 % for 8 x 2, 0.89-0.94 for 4 x 4 / 4 x 2 / 16 x 4: half-row pieces from twice as many waves cost the write path more
         // than the 64 extra registers cost occupancy; at 512^3, where a row is one 8 x 2 piece anyway, both shapes time the same).
+        // (Balancing the chunks of a longer row instead -- 1449-sample rows as two chunks of 3 x 64 quads rather than 4 x 64 + a 41 % full one -- was
+        // slower, 2.97 against 2.84 ms: as few pieces per row as possible is what counts.)
         constexpr uint32_t R = 8;
-        const uint32_t Q = ((N + 1) >> 2) > 128u ? 4u : 2u;
-        const uint64_t nrows = (uint64_t) (N + 1) * (x1 - x0), nchunks = (((N + 1) >> 2) + 64ull * Q - 1ull) / (64ull * Q);
+        const uint32_t nq = (N + 1) >> 2, Q = nq <= 128u ? 2u : 4u;
+        const uint64_t nrows = (uint64_t) (N + 1) * (x1 - x0), nchunks = ((uint64_t) nq + 64ull * Q - 1ull) / (64ull * Q);
         const uint64_t ngroups = nchunks * 4ull * ((((nrows + 3ull) >> 2) + R - 1ull) / R);
         const int g2 = (int) std::min<uint64_t>((ngroups + 3ull) / 4ull, 0x7FFFFFFFull);
 #define SDM_AL(SC, NTF, QQ) hipLaunchKernelGGL((k_sample_dense_rows_aligned<SC, NTF, R, QQ>), dim3(g2), dim3(256), 0, st, out, N, sp, x0, x1)
-        if (scene == SCENE_SDOBJ) {
-            if (Q == 4) { if (nt_rows) SDM_AL(SCENE_SDOBJ, true, 4); else SDM_AL(SCENE_SDOBJ, false, 4); }
-            else { if (nt_rows) SDM_AL(SCENE_SDOBJ, true, 2); else SDM_AL(SCENE_SDOBJ, false, 2); }
-        } else {
-            if (Q == 4) { if (nt_rows) SDM_AL(SCENE_ANIM, true, 4); else SDM_AL(SCENE_ANIM, false, 4); }
-            else { if (nt_rows) SDM_AL(SCENE_ANIM, true, 2); else SDM_AL(SCENE_ANIM, false, 2); }
-        }
+#define SDM_ALQ(SC, NTF) { if (Q == 4) SDM_AL(SC, NTF, 4); else SDM_AL(SC, NTF, 2); }
+        if (scene == SCENE_SDOBJ) { if (nt_rows) SDM_ALQ(SCENE_SDOBJ, true) else SDM_ALQ(SCENE_SDOBJ, false) }
+        else { if (nt_rows) SDM_ALQ(SCENE_ANIM, true) else SDM_ALQ(SCENE_ANIM, false) }
+#undef SDM_ALQ
 #undef SDM_AL
         return hipGetLastError();
     }
