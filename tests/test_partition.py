@@ -43,6 +43,17 @@ def test_merge_restores_column_major_interleave(R):
     assert [P.slab_bounds(p, R) for p in range(R)][0][0] == 0 and P.slab_bounds(R - 1, R)[1] == 32
 
 
+@pytest.mark.parametrize("N,R", [(2, 5), (64, 3), (511, 8), (512, 8), (1024, 7), (4096, 32)])
+def test_dense_slab_planes_tile_the_lattice(N, R):
+    """P1 shards by x planes: the ranks' ranges tile [0, N + 1) in order, no gap, no overlap, sizes within one plane of each other."""
+    P = _partition()
+    spans = [P.dense_slab_planes(N, r, R) for r in range(R)]
+    assert spans[0][0] == 0 and spans[-1][1] == N + 1
+    assert all(spans[r][1] == spans[r + 1][0] for r in range(R - 1))
+    sizes = [b - a for a, b in spans]
+    assert min(sizes) >= 0 and max(sizes) - min(sizes) <= 1
+
+
 def _join_all(procs, timeout):
     """Join the workers; none of them outlives the test (a stuck rank would keep the rendezvous port)."""
     try:
