@@ -1,9 +1,9 @@
 // The renderer's call pattern (src/renderer/mod.rs:159-171,197-217) against the C++ mirror of CudaHandler: one handler for the
 // application, a level-0 field, then per user step `refine_voxel_field` followed by `voxel_field_to_mesh`; the last mesh is
 // saved as Wavefront OBJ like the reference's `obj.save` (src/renderer/mod.rs:204).
-//   usage: example_scene LEVELS OUT.obj      prints one line per step: voxels, vertices, triangles
-// build:  g++ -std=c++17 -O2 -I include integration/cpp/example_scene.cpp -L bevy-signed-distance-mesh-generation_amd -lsdmesh
-//             -Wl,-rpath,$PWD/bevy-signed-distance-mesh-generation_amd -o example_scene        (tests/test_cpp_host.py does exactly this)
+//   usage: regen_steps LEVELS OUT.obj      prints one line per step: voxels, vertices, triangles
+// build:  g++ -std=c++17 -O2 -I include integration/cpp/regen_steps.cpp -L bevy-signed-distance-mesh-generation_amd -lsdmesh
+//             -Wl,-rpath,$PWD/bevy-signed-distance-mesh-generation_amd -o regen_steps        (tests/test_cpp_host.py does exactly this)
 #include <cstdio>
 #include <cstdlib>
 
