@@ -686,12 +686,12 @@ def main():
 
     # --- several regens in flight (one handle each): most kernels of the chain are latency-bound, so they overlap
     if not args.no_pipelined:
-        depth = 4
+        depth = 3          # (measured, tools/pipeline_depth.py: 1 / 2 / 3 / 4 / 6 / 8 in flight = 0.129 / 0.083 / 0.070 / 0.085 / 0.087 / 0.088 ms per regen at 512^3)
         hs = [pkg.CudaHandler(local_rank, args.scene, params) for _ in range(depth)]
         for hh in hs:
             hh.regen(args.levels); hh.set_option("graph", 1 if args.graph else 0); hh.regen(args.levels); hh.regen(args.levels)
         torch.cuda.synchronize()
-        psteps = max(args.steps, depth)
+        psteps = max(args.steps, 60)
         tp = time.perf_counter()
         for hh in hs:
             hh.regen_begin(args.levels)
