@@ -210,7 +210,7 @@ def one_mesh_legs(pkg, job, local_rank, scene, params, levels_list, base_levels,
         zslab[f"{n}^3"] = {"ms_per_regen": round(ms, 4), "t_1rank_ms": round(t1[lv]["ms"], 4),
                            "speedup_vs_1rank": round(t1[lv]["ms"] / ms, 3), "mvoxels_per_s": round(n ** 3 / ms / 1e3, 1),
                            "mtris_per_s": round(int(tri[0]) / ms / 1e3, 1), "triangles": int(tri[0]), "vertices": int(tri[1]), "steps": k,
-                           "root_merge_ms": round(float(info.device_ms), 4) if info is not None else None}      # (HIP events on rank 0: the merge alone)
+                           "route": {1: "planned (one host synchronisation)", 2: "synchronous", 3: "planned, repeated synchronously"}.get(h.sharded_route())}
         if lv == base_levels:
             primary = (dt, k, int(tri[0]), int(tri[1]), "zslab_indexed_gather")
     mesher.close()
@@ -223,8 +223,8 @@ def one_mesh_legs(pkg, job, local_rank, scene, params, levels_list, base_levels,
         xbounds = dm.bounds
         dm.step()
         k, w = (steps, warmup) if lv == base_levels else (max(3, min(20, steps // 4)), 2)
-        dt, part = job.timed(dm.step, k, w)
-        cnt = torch.tensor([part[0].shape[0], part[1].shape[0]], dtype=torch.int64, device=dev)
+        dt, dinfo = job.timed(lambda: h.distributed_regen(lv)[0], k, w)     # (the library call alone: dm.step also wraps the part in torch tensors)
+        cnt = torch.tensor([int(dinfo.vertices), int(dinfo.triangles)], dtype=torch.int64, device=dev)
         if world > 1:
             dist.all_reduce(cnt)
         n = 32 << lv
@@ -235,8 +235,6 @@ def one_mesh_legs(pkg, job, local_rank, scene, params, levels_list, base_levels,
         xslab[f"{n}^3"] = {"ms_per_regen": round(ms, 4), "t_1rank_ms": round(t1[lv]["ms"], 4),
                            "speedup_vs_1rank": round(t1[lv]["ms"] / ms, 3), "mvoxels_per_s": round(n ** 3 / ms / 1e3, 1),
                            "triangles": int(cnt[1]), "vertices": int(cnt[0]), "steps": k}
-        if lv == base_levels and dt / k < primary[0] / primary[1]:
-            primary = (dt, k, int(cnt[1]), int(cnt[0]), "xslab_distributed_weld")
     h.close()
     return primary, {"n_gpus": world, "ranks_seen": ranks_seen, "slab_bounds": {"z": zbounds, "x": xbounds},
                      "zslab_indexed_gather": {"what": "sdmesh_sharded_regen (indexed form): level-0 z-slab per rank, meshed AND welded there; ncclAllGather of "
@@ -368,71 +366,78 @@ def reference_abi_leg(pkg, local_rank, scene, params, levels):
             "voxels_meshed": n_last, "triangle_slots_written_MB": round(5 * n_last * 72 / 1e6, 1), "per_level": rows}
 
 
+def steady_ms(h, which, n, ptr, reps, warm_ms=40.0, windows=3):
+    """HIP-event time per launch of one kernel in steady state: at least `warm_ms` of THAT kernel first (the chip's clock and power
+    management settle over ~25 ms under a new load; a fixed number of warm-up launches is 3 ms at 256^3 and 120 ms at 1024^3), then
+    `windows` windows of `reps` back-to-back launches.  Returns (median window, the windows)."""
+    t = h.time_kernel(which, n, ptr, 5)
+    done = 5 * t
+    while done < warm_ms:
+        k = int(min(4000, max(10, (warm_ms - done) / max(t, 1e-4) + 1)))
+        t = h.time_kernel(which, n, ptr, k)
+        done += t * k
+    ws = [h.time_kernel(which, n, ptr, reps) for _ in range(windows)]
+    return float(np.median(ws)), ws
+
+
 def roofline_legs(h, out, n_grid, scene, params, consts):
-    """P1 / P2a / write ceiling, HIP-event timed on the handle's stream (N = 1 only)."""
-    buf = torch.empty((n_grid + 1) ** 3, dtype=torch.float32, device="cuda")
-    alg_bytes = 4.0 * (n_grid + 1) ** 3
+    """P1 / P2a / write ceiling, HIP-event timed on the handle's stream (N = 1 only).  One buffer for every grid, allocated before the
+    first leg; every figure = the median of three windows behind a time-based warm-up of the kernel under test (steady_ms)."""
+    big = torch.empty((2 * n_grid + 1) ** 3, dtype=torch.float32, device="cuda")
+    torch.cuda.synchronize()
+    ptr = big.data_ptr()
+    window = "median of 3 windows of back-to-back launches (HIP events) behind >= 40 ms of the same kernel; `windows_ms` = the three"
     traffic = (consts.get("p1_traffic_bytes") or {}).get(str(n_grid), {})
-    roofs = {}
-    for sc in ("sphere", scene):
-        h.set_scene(sc, [0.25] if sc == "anim" else None)
-        h.time_kernel(0, n_grid, buf.data_ptr(), 20)                 # warm-up launches (instruction cache, clocks)
-        ms_first = h.time_kernel(0, n_grid, buf.data_ptr(), 50)      # the first 50 of a burst ...
-        h.time_kernel(0, n_grid, buf.data_ptr(), 200)
-        ms = h.time_kernel(0, n_grid, buf.data_ptr(), 50)            # ... and 50 in steady state (the quoted figure)
-        gbps = alg_bytes / (ms * 1e-3) / 1e9
-        roofs[sc] = {"bound": "hbm", "kernel": f"k_sample_dense<{sc}>", "achieved": round(gbps, 1), "peak": HBM_PEAK_GBPS,
-                     "unit": "GB/s", "frac": round(gbps / HBM_PEAK_GBPS, 4),
-                     "traffic": traffic.get(sc),
-                     "bytes_per_launch": alg_bytes, "avg_launch_ms": round(ms, 5),
-                     "first_50_of_burst": {"avg_launch_ms": round(ms_first, 5), "frac": round(alg_bytes / (ms_first * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4)},
-                     "gsamples_per_s": round((n_grid + 1) ** 3 / (ms * 1e-3) / 1e9, 1)}
-    # P2a: sign bits of the dense lattice -- the streaming-READ pass (4 B x (N+1)^3 in, 1 bit per sample out)
-    h.set_scene("sphere")
-    ms2 = h.time_kernel(1, n_grid, buf.data_ptr(), 50)
-    gb2 = alg_bytes / (ms2 * 1e-3) / 1e9
-    out["roofline_p2_sign_bits"] = {"bound": "hbm", "kernel": "k_sign_bits", "achieved": round(gb2, 1), "peak": HBM_PEAK_GBPS,
-                                    "unit": "GB/s", "frac": round(gb2 / HBM_PEAK_GBPS, 4), "traffic": None,
-                                    "bytes_per_launch": alg_bytes + alg_bytes / 32, "avg_launch_ms": round(ms2, 5)}
-    # write ceiling on THIS box: P1's store stream (same bytes, same launch shape: one float4 store per thread, one 4 KiB piece
-    # per workgroup) with no arithmetic in front.  The sphere pass itself stops at its own VALU issue (four correctly rounded
-    # square roots per quad), see DESIGN.md 6.
-    ms3 = h.time_kernel(2, n_grid, buf.data_ptr(), 50)
-    gb3 = alg_bytes / (ms3 * 1e-3) / 1e9
-    h.set_scene(scene, params)
-    del buf
+
+    def row(sc, g, reps, burst=False):
+        bb = 4.0 * (g + 1) ** 3
+        r = {}
+        if burst:
+            h.time_kernel(0, g, ptr, 20)                                     # (instruction cache)
+            ms_first = h.time_kernel(0, g, ptr, 50)                          # the first 50 of a burst, clocks not settled yet
+            r["first_50_of_burst"] = {"avg_launch_ms": round(ms_first, 5), "frac": round(bb / (ms_first * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4)}
+        ms, ws = steady_ms(h, 0, g, ptr, reps)
+        gbps = bb / (ms * 1e-3) / 1e9
+        r.update({"bytes_per_launch": bb, "avg_launch_ms": round(ms, 5), "achieved": round(gbps, 1), "unit": "GB/s", "frac": round(gbps / HBM_PEAK_GBPS, 4),
+                  "mvoxels_per_s": round(g ** 3 / ms / 1e3, 1), "gsamples_per_s": round((g + 1) ** 3 / (ms * 1e-3) / 1e9, 1),
+                  "windows_ms": [round(w, 5) for w in ws], "window_spread": round((max(ws) - min(ws)) / ms, 4)})
+        return r
+
+    roofs, by_grid = {}, {}
+    try:
+        for sc in dict.fromkeys(("sphere", scene)):
+            h.set_scene(sc, [0.25] if sc == "anim" else None)
+            rows = {str(n_grid): row(sc, n_grid, 50, burst=True), str(n_grid // 2): row(sc, n_grid // 2, 200), str(2 * n_grid): row(sc, 2 * n_grid, 20)}
+            by_grid[sc] = dict(sorted(rows.items(), key=lambda kv: int(kv[0])))
+            roofs[sc] = dict({"bound": "hbm", "kernel": f"k_sample_dense<{sc}>", "peak": HBM_PEAK_GBPS, "traffic": traffic.get(sc), "window": window},
+                             **rows[str(n_grid)])
+        # P2a: sign bits of the dense lattice -- the streaming-READ pass (4 B x (N+1)^3 in, 1 bit per sample out)
+        alg_bytes = 4.0 * (n_grid + 1) ** 3
+        h.set_scene("sphere")
+        ms2, ws2 = steady_ms(h, 1, n_grid, ptr, 50)
+        gb2 = alg_bytes / (ms2 * 1e-3) / 1e9
+        out["roofline_p2_sign_bits"] = {"bound": "hbm", "kernel": "k_sign_bits", "achieved": round(gb2, 1), "peak": HBM_PEAK_GBPS,
+                                        "unit": "GB/s", "frac": round(gb2 / HBM_PEAK_GBPS, 4), "traffic": None,
+                                        "bytes_per_launch": alg_bytes + alg_bytes / 32, "avg_launch_ms": round(ms2, 5), "windows_ms": [round(w, 5) for w in ws2]}
+        # write ceiling on THIS box: P1's store stream (same bytes, same launch shape: one float4 store per thread, one 4 KiB piece
+        # per workgroup) with no arithmetic in front
+        ms3, ws3 = steady_ms(h, 2, n_grid, ptr, 50)
+        gb3 = alg_bytes / (ms3 * 1e-3) / 1e9
+    finally:
+        h.set_scene(scene, params)
+        del big
     out["roofline"] = roofs["sphere"]
-    out["roofline"]["write_ceiling"] = {"kernel": "k_stream_fill", "achieved": round(gb3, 1), "unit": "GB/s",
-                                        "avg_launch_ms": round(ms3, 5),
-                                        "p1_frac_of_ceiling": round(roofs["sphere"]["achieved"] / gb3, 4)}
+    out["roofline"]["write_ceiling"] = {"kernel": "k_stream_fill", "achieved": round(gb3, 1), "unit": "GB/s", "avg_launch_ms": round(ms3, 5),
+                                        "windows_ms": [round(w, 5) for w in ws3], "p1_frac_of_ceiling": round(roofs["sphere"]["achieved"] / gb3, 4)}
     out["roofline"]["note"] = ("P1 dense (N+1)^3 f32 SDF-sample pass, the HBM pass the north star names; claimed on the "
                                "sphere scene (SURVEY 8(d) caveat i); the regen itself is O(surface) and VALU/latency "
                                "bound, see roofline_step and DESIGN.md")
     if scene != "sphere":
         out["roofline_workload_scene"] = roofs[scene]
-    # the same pass over a volume eight times as large (BASELINE configs[3]'s grid): a launch is 0.6 ms instead of 0.08, so its
-    # ramp and drain (~8 us between dependent launches on one stream) weigh an eighth as much -- and over one an eighth as large
-    # (256^3: a 0.012 ms launch, mostly ramp and drain).  roofline_by_grid: the three grids the north star names, both scenes.
-    by_grid = {}
-    try:
-        big = torch.empty((2 * n_grid + 1) ** 3, dtype=torch.float32, device="cuda")
-        for sc in dict.fromkeys(("sphere", scene)):
-            h.set_scene(sc, [0.25] if sc == "anim" else None)
-            rows = {}
-            for g, warm, reps in ((n_grid // 2, 300, 100), (2 * n_grid, 30, 20)):
-                h.time_kernel(0, g, big.data_ptr(), warm)
-                msg = h.time_kernel(0, g, big.data_ptr(), reps)
-                bb = 4.0 * (g + 1) ** 3
-                rows[str(g)] = {"bytes_per_launch": bb, "avg_launch_ms": round(msg, 5), "achieved": round(bb / (msg * 1e-3) / 1e9, 1), "unit": "GB/s",
-                                "frac": round(bb / (msg * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4), "mvoxels_per_s": round(g ** 3 / msg / 1e3, 1)}
-            rows[str(n_grid)] = {k: roofs[sc][k] for k in ("bytes_per_launch", "avg_launch_ms", "achieved", "unit", "frac")}
-            rows[str(n_grid)]["mvoxels_per_s"] = round(n_grid ** 3 / roofs[sc]["avg_launch_ms"] / 1e3, 1)
-            by_grid[sc] = dict(sorted(rows.items(), key=lambda kv: int(kv[0])))
-        out["roofline"]["at_twice_the_grid"] = dict(by_grid["sphere"][str(2 * n_grid)], grid=2 * n_grid)
-        out["roofline_by_grid"] = by_grid
-        del big
-    finally:
-        h.set_scene(scene, params)
+    # the same pass over a volume eight times as large (BASELINE configs[3]'s grid: a launch is 0.6 ms instead of 0.08, so its ramp and
+    # drain weigh an eighth as much) and over one an eighth as large (256^3: a 0.012 ms launch, mostly ramp and drain)
+    out["roofline"]["at_twice_the_grid"] = dict(by_grid["sphere"][str(2 * n_grid)], grid=2 * n_grid)
+    out["roofline_by_grid"] = by_grid
 
 
 def roofline_step_leg(pkg, local_rank, scene, params, levels, consts, info):
@@ -591,10 +596,9 @@ def main():
             "ms_per_step": round(dt / k * 1e3, 4), "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"{args.scene} {n_grid}^3 (BASELINE configs[2]: reference scene sd_obj, 32^3 level-0 cells refined "
-                                   f"x{args.levels}) as ONE mesh over {world} GPUs; the faster of the two one-mesh forms at this size is the "
-                                   f"headline: {form} (both are in one_mesh, each with its same-size 1-GPU time; they deliver different "
-                                   f"things: zslab_indexed_gather leaves the whole indexed mesh on rank 0, xslab_distributed_weld leaves it "
-                                   f"distributed, every rank holding its slab's vertices and globally numbered triangles)",
+                                   f"x{args.levels}) as ONE mesh over {world} GPUs, the form the north star names: level-0 z-slabs, RCCL gather of "
+                                   f"the slabs' vertex / index buffers to rank 0, whole indexed mesh there ({form}); the x-slab form that leaves "
+                                   f"the mesh distributed is in one_mesh beside it, each with its same-size 1-GPU time",
                        "levels": args.levels, "grid": n_grid, "parallelism": f"{world} slabs of equal surface content, one per GPU",
                        "one_mesh_form": form},
             "mtris_per_s": round(tris * k / dt / 1e6, 2), "triangles": tris, "vertices": verts,

@@ -191,10 +191,36 @@ struct sdmesh_handle {
     int comm_rank = 0, comm_nranks = 1;
     DevBuf shard_mine, shard_counts, shard_recv, shard_lists, shard_plan, shard_merged;
     // z-slab INDEXED gather (root): the ranks' welded buffers concatenated, the merge's tables, its outputs (swapped into vertices / indices)
-    DevBuf zs_verts, zs_idx, zs_tables, zs_pervert, zs_tilecnt, zs_hkeys, zs_vout, zs_iout, zs_ranks, zs_ranks1, zs_local;
-    ZsRanks *h_zs = nullptr, *h_zs1 = nullptr;       // pinned staging copies of the merge's rank table / of the local phase's one-rank table
+    // z-slab INDEXED gather: the ranks' welded buffers in SLOTS of zs_verts / zs_idx (root), the merge's tables, its outputs
+    DevBuf zs_verts, zs_idx, zs_tables, zs_pervert, zs_hkeys, zs_vout, zs_iout, zs_ranks, zs_ctl, shard_counts2;
+    ZsRanks *h_zs = nullptr;       // pinned staging copy of the merge's slot table
+    ZsRanks zs_uploaded{};         // what zs_ranks holds (uploaded again only when the table changes: never in steady state)
+    bool zs_uploaded_valid = false;
+    uint32_t *h_zs_pub = nullptr;  // pinned: what a step publishes (ZC_WORDS control words, then the ranks' records)
     int shard_indexed = 1;         // option "shard_indexed": sdmesh_sharded_regen gathers welded per-slab vertex / index buffers (0: raw triangle lists + root weld)
+    int shard_planned = 1;         // option "shard_planned": 0 = every indexed step takes the synchronous route (three host synchronisations)
+    int shard_slack = 1;           // option "shard_slack": 0 = the plan's slots have no head-room (any growth makes the next planned step repeat: tests)
     uint32_t zs_band_plan = 0;     // face-band vertices of the last indexed merge (sizes the band hash of the next one)
+    // The PLANNED indexed step (steady state: one host synchronisation).  The plan is COLLECTIVE state: every rank derives it from the
+    // same gathered records at the end of a synchronous step and invalidates it on the same evidence, so all ranks always agree on
+    // which route a call takes (message sizes are the plan's, not the step's).
+    struct ZsPlan {
+        bool valid = false;
+        int levels = -1, root = -1, R = 0, scene = -1;
+        uint32_t slab_sig = 0, sig = 0;
+        uint32_t cap_v[32] = {0}, cap_t[32] = {0};      // slot = message size of rank r, in vertices / triangles
+    } zsp;
+    int zs_cur = 0;                // which of the two count buffers (shard_counts / shard_counts2) the next step uses
+    uint32_t zs_seq = 0;           // step number, published with the step's results (a stale host copy is told apart)
+    uint32_t zs_last_route = 0;    // 1 = the last indexed step ran planned, 2 = synchronous, 3 = planned, then repeated synchronously
+    // hooks of a sharded local phase into the ordinary chain
+    uint32_t *colcnt = nullptr;    // != nullptr: k_tile_dedupe adds the triangles per level-0 column into this (pre-zeroed) row
+    Vertex *out_v = nullptr;       // != nullptr: the weld writes the mesh here (the root's slot of the gather buffers) instead of h->vertices / h->indices
+    uint32_t *out_i = nullptr;
+    uint32_t out_vcap = 0;
+    // where the last mesh lies when it is not in h->vertices / h->indices (a merged or compacted mesh); nullptr = there
+    Vertex *res_v = nullptr;
+    uint32_t *res_i = nullptr;
     uint32_t *h_counts = nullptr;      // pinned: nranks x SHARD_ROW words (column counts + status record of every rank)
     size_t h_counts_words = 0;
     void **h_lists = nullptr;          // pinned: nranks device pointers
@@ -357,6 +383,7 @@ int mesh_front(sdmesh_handle *h, const Point *d_vox, const uint32_t *n_ptr, Poin
     if (!ff_done) HIPCHK(hipMemsetAsync(h->ff_arena.p, 0xFF, ff_bytes(h), st));
     else if (h->ff_fork == 1) HIPCHK(hipStreamWaitEvent(st, h->ev_ff, 0));   // table was cleared on the side stream during the refine
     if (zero_counters) HIPCHK(hipMemsetAsync(h->d_ctr + CTR_NUNIQ, 0, 4 * sizeof(uint32_t), st));
+    if (zero_counters && h->colcnt) HIPCHK(hipMemsetAsync(h->colcnt, 0, 4096, st));      // (a mesh stage run again: its column counts start over)
     if (have_tilecnt) { /* nothing to launch */ }
     else if (have_cubeidx) HIPCHK(launch_tile_tricount(st, h->tgrid, (const uint8_t *) h->cubeidx.p, n_ptr, tilecnt));
     else HIPCHK(launch_classify(st, h->tgrid, h->scene, h->d_sp, d_vox, n_ptr, vs, (uint8_t *) h->cubeidx.p, tilecnt));
@@ -370,7 +397,7 @@ int mesh_front(sdmesh_handle *h, const Point *d_vox, const uint32_t *n_ptr, Poin
     HIPCHK(launch_tile_dedupe(st, h->tgrid, d_vox, n_ptr, vs, (const uint8_t *) h->cubeidx.p, (const uint32_t *) tilecnt,
                               (uint32_t *) h->trioff.p, (uint32_t *) h->tri_e.p, (Vertex *) h->uverts.p, (uint4 *) h->tdesc.p,
                               h->ucap, h->tcap, h->d_ctr + CTR_NTRI, h->d_ctr + CTR_NTILES, h->d_status, d_tile_dbg,
-                              tiles(h->cap_vox) > PRESCAN_TILES));
+                              tiles(h->cap_vox) > PRESCAN_TILES, h->colcnt));
     SDCHK(prof_mark(h, "tile_dedupe"));
     // few tiles: the projection's workgroups prefix the tile counts themselves (no k_tile_prefix launch)
     const bool local_pre = h->local_prefix && tiles(h->cap_vox) <= SDM_LOCAL_TILES;
@@ -459,14 +486,15 @@ int mesh_weld(sdmesh_handle *h, const Vertex *uverts, uint32_t max_tiles, bool p
     hipStream_t st = h->stream;
     const bool local_pre = h->local_prefix && max_tiles <= SDM_LOCAL_TILES;       // k_tile_finish prefixes the tile counts itself
     h->ctl_published = publish;             // the last kernel writes the control block to the pinned host copy itself
+    h->res_v = nullptr; h->res_i = nullptr; // (whatever mesh a merge left elsewhere is superseded)
     const int flip_scene = h->flip_pending ? h->scene : -1;
     h->flip_pending = false;
     for (int part = h->profile ? 1 : 0; part <= (h->profile ? 2 : 0); part++) {        // profiling: a stage marker behind k_tile_first
         HIPCHK(launch_weld(st, h->tgrid, uverts, (const uint4 *) h->tdesc.p, h->d_ctr + CTR_NTILES, (uint32_t *) h->tri_e.p,
                            (const uint8_t *) h->flip.p, h->first_ord, h->wfm, (const uint32_t *) h->wrep_buf.p, (uint32_t *) h->vslot.p,
                            (uint32_t *) h->wvidx.p, (uint32_t *) h->torder.p, (uint32_t *) h->tfirst.p, local_pre ? nullptr : (uint32_t *) h->tfpre.p,
-                           (Vertex *) h->vertices.p, (uint32_t) (h->vertices.cap / sizeof(Vertex)), h->d_ctr + CTR_NVERT,
-                           (uint32_t *) h->indices.p, h->d_status, flip_scene, h->d_sp, part,
+                           h->out_v ? h->out_v : (Vertex *) h->vertices.p, h->out_v ? h->out_vcap : (uint32_t) (h->vertices.cap / sizeof(Vertex)), h->d_ctr + CTR_NVERT,
+                           h->out_v ? h->out_i : (uint32_t *) h->indices.p, h->d_status, flip_scene, h->d_sp, part,
                            publish ? h->d_ctr : nullptr, publish ? h->h_pinned : nullptr, CTR_WORDS + ST_WORDS, CTR_WORDS + ST_OVERFLOW, CTR_NVERT,
                            flip_scene >= 0 ? h->tf_threads : 256));
         if (part == 1) SDCHK(prof_mark(h, flip_scene >= 0 ? "tile_first_flip" : "tile_first"));
@@ -549,6 +577,7 @@ int weld_raw_device(sdmesh_handle *h, const Triangle *d_raw, uint32_t nslots, bo
     hipStream_t st = h->stream;
     if (nslots == 0) {
         h->n_tris = h->n_verts = 0;
+        h->res_v = nullptr; h->res_i = nullptr;
         h->mesh_valid = true;
         return SDMESH_OK;
     }
@@ -798,6 +827,8 @@ int regen_impl(sdmesh_handle *h, int levels, int mode, int part, int nparts, sdm
         const bool async = resumed || (h->plan_valid && h->plan_scene == h->scene && h->plan_levels == levels && h->plan_mode == mode &&
                                        h->plan_part == part && h->plan_nparts == nparts && attempt == 0);
         h->mesh_valid = h->vox_valid = false;
+        h->res_v = nullptr; h->res_i = nullptr;
+        if (h->colcnt && attempt > 0) HIPCHK(hipMemsetAsync(h->colcnt, 0, 4096, st));     // (a sharded local phase: the column counts of the attempt before)
         Point vs;
         vs.x = vs.y = vs.z = MESH_GENERATION_BB_SIZE / (float) MESH_GENERATION_INIT_FACTOR;
         uint32_t n_cap = n0;
@@ -823,7 +854,7 @@ int regen_impl(sdmesh_handle *h, int levels, int mode, int part, int nparts, sdm
             SDCHK(presize_planned_chain(h, levels, n0, box[3] - box[2], &lvl_words));
             n_cap = padded(h->plan_counts[levels]);
             poison_pinned(h);
-            if (h->use_graph && st != nullptr && !h->profile && !h->project_diag) {   // (the legacy null stream cannot be captured: eager launches there)
+            if (h->use_graph && st != nullptr && !h->profile && !h->project_diag && !h->colcnt && !h->out_v) {   // (a sharded local phase's hooks alternate: eager there)   // (the legacy null stream cannot be captured: eager launches there)
                 uint64_t key[8] = {h->buf_gen, (uint64_t) h->scene, (uint64_t) levels, ((uint64_t) mode << 40) | ((uint64_t) part << 20) | (uint64_t) nparts,
                                    (uint64_t) h->skip_weld | ((uint64_t) h->wide_active << 1) | ((uint64_t) h->col_refine << 2) | ((uint64_t) h->claim_in_project << 3) | ((uint64_t) h->fuse_flip << 4) | ((uint64_t) h->publish_ctl << 6) | ((uint64_t) h->local_prefix << 7) | ((uint64_t) h->project_batch << 8) | ((uint64_t) h->project_grid << 12) | ((uint64_t) h->project_prio << 30) | ((uint64_t) h->tf_threads << 32) | ((uint64_t) h->col_segs << 44), (uint64_t) (uintptr_t) st, (uint64_t) h->grid | ((uint64_t) h->tgrid << 20) | ((uint64_t) h->project_mult << 40) | ((uint64_t) h->flip_mult << 48) | ((uint64_t) h->refine2 << 56) | ((uint64_t) h->emit_ci << 57) | ((uint64_t) h->project_lanes << 58) | ((uint64_t) h->flip_lanes << 61), 0};
                 for (int i = 0; i <= levels; i++) key[7] = key[7] * 1000003ull + h->plan_counts[i];
@@ -1075,12 +1106,12 @@ void sdmesh_destroy(sdmesh_handle *h) {
                       &h->first_ord_buf, &h->uverts, &h->tri_e, &h->vslot, &h->tdesc, &h->tfirst, &h->tfpre, &h->tpre, &h->flip, &h->wvidx, &h->torder, &h->wrep_buf, &h->wfm_buf,
                       &h->vertices, &h->indices, &h->raw, &h->compact, &h->staging, &h->dense_samples, &h->dense_bits,
                       &h->cellcnt, &h->dist_upids, &h->dist_upkeys, &h->dist_loids, &h->dist_prevkeys, &h->dist_hkeys, &h->dist_hpos, &h->dist_dupof,
-                      &h->dist_newidx, &h->dist_tilecnt, &h->dist_counts, &h->dist_upg, &h->dist_prevg, &h->dist_verts, &h->dist_nups, &h->col_list1, &h->col_mask2, &h->col_mask3, &h->colinfo, &h->prof_rounds, &h->proj_diag, &h->shard_mine, &h->shard_counts, &h->shard_recv, &h->shard_lists, &h->shard_plan, &h->shard_merged, &h->zs_verts, &h->zs_idx, &h->zs_tables, &h->zs_pervert, &h->zs_tilecnt, &h->zs_hkeys, &h->zs_vout, &h->zs_iout, &h->zs_ranks, &h->zs_ranks1, &h->zs_local};
+                      &h->dist_newidx, &h->dist_tilecnt, &h->dist_counts, &h->dist_upg, &h->dist_prevg, &h->dist_verts, &h->dist_nups, &h->col_list1, &h->col_mask2, &h->col_mask3, &h->colinfo, &h->prof_rounds, &h->proj_diag, &h->shard_mine, &h->shard_counts, &h->shard_recv, &h->shard_lists, &h->shard_plan, &h->shard_merged, &h->zs_verts, &h->zs_idx, &h->zs_tables, &h->zs_pervert, &h->zs_hkeys, &h->zs_vout, &h->zs_iout, &h->zs_ranks, &h->zs_ctl, &h->shard_counts2};
     (void) sdmesh_comm_destroy(h);
     if (h->h_counts) (void) hipHostFree(h->h_counts);
     if (h->h_lists) (void) hipHostFree(h->h_lists);
     if (h->h_zs) (void) hipHostFree(h->h_zs);
-    if (h->h_zs1) (void) hipHostFree(h->h_zs1);
+    if (h->h_zs_pub) (void) hipHostFree(h->h_zs_pub);
     for (DevBuf *b : bufs) release(*b);
     if (h->h_pinned) (void) hipHostFree(h->h_pinned);
     if (h->d_sp) (void) hipFree(h->d_sp);
@@ -1177,7 +1208,9 @@ int sdmesh_set_option(sdmesh_handle *h, const char *name, int value) {
         h->tf_threads = value; drop_graph(h); return SDMESH_OK;
     }
     if (!strcmp(name, "inject_fail")) { h->inject_fail = value; return SDMESH_OK; }
-    if (!strcmp(name, "shard_indexed")) { h->shard_indexed = value != 0; return SDMESH_OK; }
+    if (!strcmp(name, "shard_indexed")) { h->shard_indexed = value != 0; h->zsp.valid = false; return SDMESH_OK; }
+    if (!strcmp(name, "shard_slack")) { h->shard_slack = value != 0; h->zsp.valid = false; return SDMESH_OK; }
+    if (!strcmp(name, "shard_planned")) { h->shard_planned = value != 0; h->zsp.valid = false; return SDMESH_OK; }   // (like every option of a collective call: the same on all ranks)
     if (!strcmp(name, "project_prio")) { h->project_prio = value != 0; drop_graph(h); return SDMESH_OK; }
     if (!strcmp(name, "project_grid")) { h->project_grid = value < 0 ? 0 : (value > 65535 ? 65535 : value); drop_graph(h); return SDMESH_OK; }
     if (!strcmp(name, "project_batch")) { h->project_batch = value < 0 ? 0 : (value > 6 ? 6 : value); drop_graph(h); return SDMESH_OK; }
@@ -1314,6 +1347,7 @@ int sdmesh_voxel_field_to_mesh(sdmesh_handle *h, const struct Point *voxels, siz
     *n_verts = *n_tris = 0;
     if (n == 0) {                                  // src/cuda/mod.rs:327-344: empty mesh
         h->n_tris = h->n_verts = 0;
+        h->res_v = nullptr; h->res_i = nullptr;
         h->mesh_valid = true;
         return SDMESH_OK;
     }
@@ -1424,9 +1458,9 @@ int sdmesh_regen_end(sdmesh_handle *h, sdmesh_regen_info *info) {
 int sdmesh_device_mesh(sdmesh_handle *h, struct Mesh *mesh, uint32_t *n_tris) {
     if (!h || !mesh) return SDMESH_ERR_INVALID;
     if (!h->mesh_valid || !h->welded) return fail(h, SDMESH_ERR_INVALID, "no welded mesh on the device");
-    mesh->vertices = (Vertex *) h->vertices.p;
+    mesh->vertices = h->res_v ? h->res_v : (Vertex *) h->vertices.p;
     mesh->vertex_count = h->n_verts;
-    mesh->triangles = (IndexTriangle *) h->indices.p;
+    mesh->triangles = h->res_i ? (IndexTriangle *) h->res_i : (IndexTriangle *) h->indices.p;
     if (n_tris) *n_tris = h->n_tris;
     return SDMESH_OK;
 }
@@ -1477,9 +1511,9 @@ int sdmesh_download_mesh(sdmesh_handle *h, struct Vertex *verts, struct IndexTri
     if (!h) return SDMESH_ERR_INVALID;
     if (!h->mesh_valid) return fail(h, SDMESH_ERR_INVALID, "no mesh on the device");
     if (verts && h->n_verts)
-        HIPCHK(hipMemcpyAsync(verts, h->vertices.p, sizeof(Vertex) * (size_t) h->n_verts, hipMemcpyDeviceToHost, h->stream));
+        HIPCHK(hipMemcpyAsync(verts, h->res_v ? (const void *) h->res_v : h->vertices.p, sizeof(Vertex) * (size_t) h->n_verts, hipMemcpyDeviceToHost, h->stream));
     if (tris && h->n_tris)
-        HIPCHK(hipMemcpyAsync(tris, h->indices.p, sizeof(IndexTriangle) * (size_t) h->n_tris, hipMemcpyDeviceToHost, h->stream));
+        HIPCHK(hipMemcpyAsync(tris, h->res_i ? (const void *) h->res_i : h->indices.p, sizeof(IndexTriangle) * (size_t) h->n_tris, hipMemcpyDeviceToHost, h->stream));
     HIPCHK(hipStreamSynchronize(h->stream));
     return SDMESH_OK;
 }
@@ -1960,219 +1994,376 @@ uint32_t cap_items(const DevBuf &b, size_t item) { return (uint32_t) std::min<si
 
 namespace {
 
-// ---- z-slab INDEXED gather, root side: the single-GPU mesh from the ranks' welded buffers, concatenated in rank order in
-// h->zs_verts / h->zs_idx (kernels.hip, "INDEXED gather").  d_counts: per rank (`cstride` words each) 1024 column triangle counts, then the 1024 first-seen vertex counts zs_local_phase computed there.
-int zs_ensure_inputs(sdmesh_handle *h, uint64_t vtot, uint64_t ttot) {
-    SDCHK(ensure_grow(h, h->zs_verts, sizeof(Vertex) * (size_t) std::max<uint64_t>(vtot, 64)));
-    SDCHK(ensure_grow(h, h->zs_idx, sizeof(IndexTriangle) * (size_t) std::max<uint64_t>(ttot, 64)));
+// ---- z-slab INDEXED gather behind sdmesh_sharded_regen (kernels: csrc/zslab.hip) --------------------------------------------------
+// Two routes through the same kernels:
+//   synchronous  (first call, after any change, after a planned step that did not fit): slab regen with its own read-back, all-gather of
+//                the rows, read-back of the rows (message sizes must be host values), exact-size messages into slots, merge, read-back:
+//                three host synchronisations.  It ends by committing the PLAN: per-rank slot sizes with head-room, identical on every
+//                rank because they all derive it from the same gathered records.
+//   planned      (steady state): the slab's chain enqueued from its capacity plan, its two count kernels, the all-gather, plan-sized
+//                messages into plan-sized slots, the merge -- all enqueued blind, ONE host synchronisation at the end.  The real counts
+//                ride in the gathered records; the kernels read them on the device, the host verifies them afterwards.  A step whose counts
+//                did not fit (or in which any rank reported a failure) is repeated on the synchronous route -- by every rank, because every
+//                rank sees the same records.
+constexpr int ZS_REDO = -1000;                     // (internal: the planned step asks for the synchronous route)
+uint32_t zs_padded(const sdmesh_handle *h, uint32_t n) { return h->shard_slack ? n + n / 8u + 2048u : n + 1u; }   // (option "shard_slack" = 0: tests of the repeat)
+
+uint32_t zs_slab_sig(const sdmesh_handle *h, int R) {
+    uint32_t s = 2166136261u;
+    const bool own = h->slab_nparts == R && h->slab_mode == SDMESH_PART_ZSLAB;
+    for (int i = 0; own && i <= R; i++) s = (s ^ h->slab_bounds[i]) * 16777619u;
+    return s ^ (own ? 0x9e3779b9u : 0u);
+}
+
+uint32_t *zs_counts(sdmesh_handle *h, int which) { return (uint32_t *) (which ? h->shard_counts2.p : h->shard_counts.p); }
+
+// the fixed-size scratch of the exchange: two count buffers (rows of every rank; they alternate, the count areas of the idle one are
+// cleared by the running step), the merge's control block, pinned landing zones
+int zs_scratch(sdmesh_handle *h, int R) {
+    const bool fresh = !h->shard_counts.p || !h->shard_counts2.p || h->shard_counts.cap < 4ull * (size_t) R * SHARD_ROW || h->shard_counts2.cap < 4ull * (size_t) R * SHARD_ROW;
+    SDCHK(ensure(h, h->shard_counts, 4ull * (size_t) R * SHARD_ROW));
+    SDCHK(ensure(h, h->shard_counts2, 4ull * (size_t) R * SHARD_ROW));
+    if (fresh) h->zsp.valid = false;               // (only ever on a handle's first sharded call or after the communicator grew: the same call on every rank)
+    SDCHK(ensure(h, h->zs_ctl, 4ull * ZC_WORDS));
+    SDCHK(ensure(h, h->zs_ranks, sizeof(ZsRanks)));
+    SDCHK(ensure(h, h->zs_tables, 4ull * 6 * (size_t) R * 1024));   // tplan [2 nseg] | vplan [2 nseg] | vstart [nseg] | newcnt [nseg]
+    SDCHK(ensure_shard_host(h, R));
+    if (!h->h_zs) HIPCHK(hipHostMalloc((void **) &h->h_zs, sizeof(ZsRanks), hipHostMallocDefault));
+    if (!h->h_zs_pub) HIPCHK(hipHostMalloc((void **) &h->h_zs_pub, 4ull * (ZC_WORDS + 32 * 8), hipHostMallocDefault));
     return SDMESH_OK;
 }
 
-int zs_merge(sdmesh_handle *h, int R, const uint32_t *d_counts, uint32_t cstride, const uint32_t *Vr, const uint32_t *Tr, int levels,
-             Point voxel_size, sdmesh_regen_info *info) {
-    hipStream_t st = h->stream;
-    ZsRanks zr;
+// everything the root's merge touches, for slots of vslots vertices / tslots triangles in all
+int zs_root_ensure(sdmesh_handle *h, int R, uint64_t vslots, uint64_t tslots) {
+    const size_t v = (size_t) std::max<uint64_t>(vslots, 64), t = (size_t) std::max<uint64_t>(tslots, 64);
+    (void) R;
+    SDCHK(ensure_grow(h, h->zs_verts, sizeof(Vertex) * v));
+    SDCHK(ensure_grow(h, h->zs_idx, sizeof(IndexTriangle) * t));
+    SDCHK(ensure_grow(h, h->zs_pervert, 4ull * 3 * v));            // per slot vertex: segof | redirect | map
+    SDCHK(ensure_grow(h, h->zs_vout, sizeof(Vertex) * v));
+    SDCHK(ensure_grow(h, h->zs_iout, sizeof(IndexTriangle) * t));
+    return SDMESH_OK;
+}
+uint32_t zs_root_capacity_v(const sdmesh_handle *h) {               // what this rank could take as a root without allocating
+    const size_t a = cap_items(h->zs_verts, sizeof(Vertex)), b = cap_items(h->zs_pervert, 12), c = cap_items(h->zs_vout, sizeof(Vertex));
+    return (uint32_t) std::min(a, std::min(b, c));
+}
+uint32_t zs_root_capacity_t(const sdmesh_handle *h) {
+    return std::min(cap_items(h->zs_idx, sizeof(IndexTriangle)), cap_items(h->zs_iout, sizeof(IndexTriangle)));
+}
+
+void zs_slot_table(const sdmesh_handle *h, int R, const uint32_t *cap_v, const uint32_t *cap_t, int levels, ZsRanks &zr) {
     memset(&zr, 0, sizeof zr);
     zr.nranks = (uint32_t) R;
-    uint64_t vtot = 0, ttot = 0;
-    for (int r = 0; r < R; r++) {
-        zr.vbase[r] = (uint32_t) vtot; zr.tbase[r] = (uint32_t) ttot;
-        vtot += Vr[r]; ttot += Tr[r];
-    }
-    if (vtot > 0x0FFFFFFFull || ttot > 0x0FFFFFFFull) return fail(h, SDMESH_ERR_INVALID, "too many vertices / triangles for one mesh");
-    zr.vbase[R] = (uint32_t) vtot; zr.tbase[R] = (uint32_t) ttot;
+    uint32_t vb = 0, tb = 0;
     const uint32_t F = MESH_GENERATION_INIT_FACTOR;
     for (int r = 0; r < R; r++) {
+        zr.vbase[r] = vb; zr.tbase[r] = tb;
+        vb += cap_v[r]; tb += cap_t[r];
         uint32_t lo = F * (uint32_t) r / (uint32_t) R, hi = F * (uint32_t) (r + 1) / (uint32_t) R;
         if (h->slab_nparts == R && h->slab_mode == SDMESH_PART_ZSLAB) { lo = h->slab_bounds[r]; hi = h->slab_bounds[r + 1]; }
         zr.zlo[r] = -MESH_GENERATION_BB_SIZE / 2.0f + MESH_GENERATION_BB_SIZE * (float) lo / (float) F;
         zr.zhi[r] = -MESH_GENERATION_BB_SIZE / 2.0f + MESH_GENERATION_BB_SIZE * (float) hi / (float) F;
     }
+    zr.vbase[R] = vb; zr.tbase[R] = tb;
     zr.zbot = -MESH_GENERATION_BB_SIZE / 2.0f; zr.ztop = MESH_GENERATION_BB_SIZE / 2.0f;
     // a projected vertex stays within about a voxel of its lattice edge: 2.5 voxels of the finest level is a safe band
     zr.band = 2.5f * ((MESH_GENERATION_BB_SIZE / (float) F) / (float) (1u << levels));
-    const uint32_t V = (uint32_t) vtot, T = (uint32_t) ttot, nseg = (uint32_t) R * 1024u;
-    // the rank table in device memory (the kernels index it per thread; pinned staging so that the copy is asynchronous)
-    // (the staging copy is rewritten only here, and the previous merge ended with a wait for the stream: nothing can still be reading it)
-    if (!h->h_zs) HIPCHK(hipHostMalloc((void **) &h->h_zs, sizeof(ZsRanks), hipHostMallocDefault));
-    SDCHK(ensure(h, h->zs_ranks, sizeof(ZsRanks)));
-    *h->h_zs = zr;
-    HIPCHK(hipMemcpyAsync(h->zs_ranks.p, h->h_zs, sizeof(ZsRanks), hipMemcpyHostToDevice, st));
-    const ZsRanks *d_zr = (const ZsRanks *) h->zs_ranks.p;
-    HIPCHK(hipEventRecord(h->ev0, st));                    // info->device_ms = the root's merge alone (the gathered buffers are in place)
-    // tables: tplan [2 nseg] | vplan [2 nseg] | vstart [nseg] | newcnt [nseg]; per vertex: segof | redirect | kept_before | map
-    SDCHK(ensure(h, h->zs_tables, 4ull * 6 * nseg));
-    SDCHK(ensure_grow(h, h->zs_pervert, 4ull * 4 * std::max<uint32_t>(V, 64)));
-    SDCHK(ensure_grow(h, h->zs_tilecnt, 4ull * (tiles(std::max<uint32_t>(V, 64)) + 16)));
-    SDCHK(ensure_grow(h, h->zs_vout, sizeof(Vertex) * (size_t) std::max<uint32_t>(V, 64)));
-    SDCHK(ensure_grow(h, h->zs_iout, sizeof(IndexTriangle) * (size_t) std::max<uint32_t>(T, 64)));
-    uint32_t *tplan = (uint32_t *) h->zs_tables.p, *vplan = tplan + 2 * nseg, *vstart = vplan + 2 * nseg, *newcnt = vstart + nseg;
-    const uint32_t vcap = std::max<uint32_t>(V, 64);
-    uint32_t *segof = (uint32_t *) h->zs_pervert.p, *redirect = segof + vcap, *kept = redirect + vcap, *map = kept + vcap;
-    for (int attempt = 0; attempt < 2; attempt++) {
-        // the band hash is sized from the last merge's band (25 % head-room), from the vertex total when nothing is known yet
-        uint32_t band_cap = V;
-        if (attempt == 0 && h->zs_band_plan && (uint64_t) h->zs_band_plan + h->zs_band_plan / 4 + 1024 < V) band_cap = h->zs_band_plan + h->zs_band_plan / 4 + 1024;
-        const uint32_t hsize = 2u * band_cap + 64u;
+}
+
+// enqueue the merge of the slots described by zr (root).  Nothing here waits; the band hash is sized from the last merge's band.
+int zs_merge_enqueue(sdmesh_handle *h, const ZsRanks &zr, const uint32_t *d_counts, bool whole_band, uint32_t seq) {
+    hipStream_t st = h->stream;
+    const uint32_t R = zr.nranks, V = zr.vbase[R], T = zr.tbase[R], nseg = R * 1024u;
+    if (!h->zs_uploaded_valid || memcmp(&h->zs_uploaded, &zr, sizeof zr) != 0) {
+        // (the pinned staging copy is rewritten only here; every step ends with a wait for the stream, so no copy of it is in flight)
+        *h->h_zs = zr;
+        HIPCHK(hipMemcpyAsync(h->zs_ranks.p, h->h_zs, sizeof(ZsRanks), hipMemcpyHostToDevice, st));
+        h->zs_uploaded = zr; h->zs_uploaded_valid = true;
+    }
+    uint32_t hsize = 0;
+    if (R > 1) {
+        uint32_t band_cap = std::max<uint32_t>(V, 64u);
+        if (!whole_band && h->zs_band_plan && (uint64_t) h->zs_band_plan + h->zs_band_plan / 4 + 1024 < V) band_cap = h->zs_band_plan + h->zs_band_plan / 4 + 1024;
+        hsize = 2u * band_cap + 64u;
         SDCHK(ensure_grow(h, h->zs_hkeys, 12ull * hsize));                    // keys (8 B per slot), then the slots' smallest vertex ids (4 B)
-        uint64_t *hkeys = (uint64_t *) h->zs_hkeys.p;
-        uint32_t *hmin = (uint32_t *) (hkeys + hsize);
-        SDCHK(zero_status(h));
-        if (R > 1) HIPCHK(hipMemsetAsync(hkeys, 0xFF, 12ull * hsize, st));    // (all-ones = empty key = no vertex yet)
-        HIPCHK(launch_merge_plan(st, d_counts, cstride, R, tplan, T, h->d_ctr + CTR_NTRI, h->d_status));
-        HIPCHK(launch_zs_front(st, h->grid, (const Vertex *) h->zs_verts.p, d_counts, cstride, d_counts + 1024 /* the ranks' first-seen vertex counts */, zr, d_zr,
-                               vstart, newcnt, segof, redirect, hkeys, hmin, hsize, h->d_ctr + CTR_DIST_NUP,
-                               h->d_status));
-        HIPCHK(launch_dist_number(st, h->tgrid, redirect, V, &d_zr->vbase[R] /* = V, in device memory */, (uint32_t *) h->zs_tilecnt.p, h->d_ctr + CTR_NVERT, kept,
-                                  h->d_status));
-        HIPCHK(launch_merge_plan(st, newcnt, 1024u, R, vplan, V, h->d_ctr + CTR_SCRATCH, h->d_status));
-        HIPCHK(launch_zs_back(st, h->grid, (const Vertex *) h->zs_verts.p, (const uint32_t *) h->zs_idx.p, d_counts, cstride, tplan, zr, d_zr, redirect, kept, segof,
-                              vstart, vplan, (Vertex *) h->zs_vout.p, V, map, (uint32_t *) h->zs_iout.p, T));
-        HIPCHK(hipEventRecord(h->ev1, st));
-        SDCHK(read_back(h));
-        h->zs_band_plan = h->h_pinned[CTR_DIST_NUP];
-        if (!(h->h_pinned[CTR_WORDS + ST_OVERFLOW] & 64u)) break;          // (64: the band outgrew its hash -> once more with room for every vertex)
-        if (attempt == 1) return fail(h, SDMESH_ERR_INTERNAL, "the face-band hash overflowed although it had room for every vertex");
     }
-    if (h->h_pinned[CTR_WORDS + ST_WELD_RANGE]) return fail(h, SDMESH_ERR_WELD_RANGE, "the indexed gather needs vertices inside the packed key range (option shard_indexed = 0 welds on the root instead)");
-    SDCHK(status_to_error(h));
-    if (h->h_pinned[CTR_WORDS + ST_OVERFLOW]) return fail(h, SDMESH_ERR_INTERNAL, "indexed merge overflow (status %u)", h->h_pinned[CTR_WORDS + ST_OVERFLOW]);
-    if (h->h_pinned[CTR_NTRI] != T || h->h_pinned[CTR_SCRATCH] != h->h_pinned[CTR_NVERT])
-        return fail(h, SDMESH_ERR_INTERNAL, "indexed merge: %u triangles planned of %u, %u vertices planned of %u kept", h->h_pinned[CTR_NTRI], T,
-                    h->h_pinned[CTR_SCRATCH], h->h_pinned[CTR_NVERT]);
-    std::swap(h->vertices, h->zs_vout);                    // the merged mesh becomes the handle's mesh
-    std::swap(h->indices, h->zs_iout);
-    h->buf_gen++;
-    h->n_tris = T;
-    h->n_verts = h->h_pinned[CTR_NVERT];
-    h->n_unique = h->n_verts;
-    h->mesh_valid = true;
-    h->welded = true;
-    h->last_direct = false;
-    h->vox_valid = false;                                  // (the root's voxel list is its own slab's, not the mesh's)
-    if (info) {
-        float ms = 0.0f;
-        HIPCHK(hipEventElapsedTime(&ms, h->ev0, h->ev1));
-        fill_info(h, info, 0, false, ms);
-        info->levels = (uint32_t) levels;
-        info->voxel_size = voxel_size;
-    }
+    uint32_t *tplan = (uint32_t *) h->zs_tables.p, *vplan = tplan + 2 * nseg, *vstart = vplan + 2 * nseg, *newcnt = vstart + nseg;
+    const uint32_t vcap = std::max<uint32_t>(V, 64u);
+    uint32_t *segof = (uint32_t *) h->zs_pervert.p, *redirect = segof + vcap, *map = redirect + vcap;
+    HIPCHK(launch_zs_merge(st, h->grid, (const Vertex *) h->zs_verts.p, (const uint32_t *) h->zs_idx.p, d_counts, SHARD_ROW, zr, (const ZsRanks *) h->zs_ranks.p,
+                           tplan, vplan, vstart, newcnt, segof, redirect, map, (uint64_t *) h->zs_hkeys.p, hsize, (Vertex *) h->zs_vout.p,
+                           (uint32_t) std::min<size_t>(h->zs_vout.cap / sizeof(Vertex), 0xFFFFFFFFu), (uint32_t *) h->zs_iout.p,
+                           (uint32_t) std::min<size_t>(h->zs_iout.cap / sizeof(IndexTriangle), 0xFFFFFFFFu), (uint32_t *) h->zs_ctl.p, seq, h->h_zs_pub));
+    (void) T;
     return SDMESH_OK;
 }
 
-// this rank's level-0 z-slab, meshed AND welded; its column triangle counts into d_row[0 .. 1024)
-int zs_local_phase(sdmesh_handle *h, int levels, int part, int nparts, uint32_t *d_row, sdmesh_regen_info *slab) {
-    hipStream_t st = h->stream;
+// after the stream has been waited for: the merge's verdict (root).  May run the merge once more with a hash that holds every vertex.
+int zs_merge_finish(sdmesh_handle *h, const ZsRanks &zr, const uint32_t *d_counts, uint32_t seq, int levels, Point voxel_size, sdmesh_regen_info *info) {
+    for (int attempt = 0; attempt < 2; attempt++) {
+        const uint32_t *pub = h->h_zs_pub;
+        if (pub[ZC_SEQ] != seq) return fail(h, SDMESH_ERR_INTERNAL, "the indexed merge did not publish its results (step %u, found %u)", seq, pub[ZC_SEQ]);
+        h->zs_band_plan = pub[ZC_NBAND];
+        if (pub[ZC_BANDFLAGS] & 1u) return fail(h, SDMESH_ERR_WELD_RANGE, "the indexed gather needs vertices inside the packed key range (option shard_indexed = 0 welds on the root instead)");
+        if (pub[ZC_BANDFLAGS] & 64u) {                                       // the band outgrew its hash -> once more with room for every vertex
+            if (attempt == 1) return fail(h, SDMESH_ERR_INTERNAL, "the face-band hash overflowed although it had room for every vertex");
+            SDCHK(zs_merge_enqueue(h, zr, d_counts, true, seq));
+            HIPCHK(hipStreamSynchronize(h->stream));
+            continue;
+        }
+        if (pub[ZC_PLANFLAGS]) return fail(h, SDMESH_ERR_INTERNAL, "indexed merge: plan flags 0x%x (rows invalid or an output buffer too small)", pub[ZC_PLANFLAGS]);
+        for (uint32_t r = 0; r < zr.nranks; r++)
+            if (pub[ZC_RANKBAD + r]) return fail(h, SDMESH_ERR_INTERNAL, "indexed merge: the first-seen vertex counts of rank %u do not add up to its vertices", r);
+        h->res_v = (Vertex *) h->zs_vout.p;                                  // the merged mesh is the handle's mesh now
+        h->res_i = (uint32_t *) h->zs_iout.p;
+        h->n_tris = pub[ZC_TRIS];
+        h->n_verts = pub[ZC_VERTS];
+        h->n_unique = h->n_verts;
+        h->mesh_valid = true;
+        h->welded = true;
+        h->last_direct = false;
+        h->vox_valid = false;                                              // (the root's voxel list is its own slab's, not the mesh's)
+        if (info) {
+            fill_info(h, info, 0, false, 0.0f);
+            info->levels = (uint32_t) levels;
+            info->voxel_size = voxel_size;
+        }
+        return SDMESH_OK;
+    }
+    return SDMESH_ERR_INTERNAL;
+}
+
+// grouped messages of one step (no HIP call and no early return between GroupStart and GroupEnd: a group is always closed)
+struct ZsMsg { void *p; size_t count; ncclDataType_t type; int peer; bool send; };
+int zs_exchange(sdmesh_handle *h, const std::vector<ZsMsg> &msgs) {
+    if (msgs.empty()) return SDMESH_OK;
+    ncclResult_t first = g_rccl.GroupStart();
+    if (first != ncclSuccess) return fail(h, SDMESH_ERR_RCCL, "ncclGroupStart failed: %s", g_rccl.GetErrorString(first));
+    for (const ZsMsg &m : msgs) {
+        const ncclResult_t r = m.send ? g_rccl.Send(m.p, m.count, m.type, m.peer, h->comm, h->stream) : g_rccl.Recv(m.p, m.count, m.type, m.peer, h->comm, h->stream);
+        if (r != ncclSuccess) { first = r; break; }
+    }
+    const ncclResult_t end = g_rccl.GroupEnd();
+    if (first == ncclSuccess) first = end;
+    if (first != ncclSuccess) return fail(h, SDMESH_ERR_RCCL, "z-slab gather: an RCCL message failed: %s", g_rccl.GetErrorString(first));
+    return SDMESH_OK;
+}
+
+// this rank's slab, meshed AND welded with the ordinary synchronous regen; the column triangle counts land in `row` (pre-zeroed) on the way
+int zs_local_sync(sdmesh_handle *h, int levels, int part, int nparts, uint32_t *row, sdmesh_regen_info *slab) {
     const int saved_skip = h->skip_weld;
     h->skip_weld = 0;
+    h->colcnt = row;
     const int rc = regen_impl(h, levels, SDMESH_PART_ZSLAB, part, nparts, slab);
+    h->colcnt = nullptr;
     h->skip_weld = saved_skip;
     SDCHK(rc);
     if (h->last_direct || !h->welded) return fail(h, SDMESH_ERR_INTERNAL, "a slab took the direct path: no column counts");
     if (h->wide_active) return fail(h, SDMESH_ERR_WELD_RANGE, "the indexed gather needs the packed weld keys (option shard_indexed = 0 welds on the root instead)");
-    HIPCHK(hipMemsetAsync(d_row, 0, 8192, st));
-    if (h->n_vox)         // (the voxel count is still in the chain's own counter)
-        HIPCHK(launch_column_counts(st, std::min(h->grid, (int) tiles(h->n_vox)), (const Point *) h->vox[h->cur].p, h->d_ctr + CTR_LEVEL0 + levels,
-                                    (const uint8_t *) h->cubeidx.p, d_row));
-    // the vertices FIRST SEEN per column of this slab's own first-seen order -> d_row[1024 .. 2048): this rank's share of the merge
-    if (h->n_tris) {
-        // (its own one-rank table, device copy and pinned staging: the staging is only rewritten here, and every call that reaches
-        // this point has waited for the stream at the end of the previous one -- no copy of it can still be in flight)
-        if (!h->h_zs1) HIPCHK(hipHostMalloc((void **) &h->h_zs1, sizeof(ZsRanks), hipHostMallocDefault));
-        SDCHK(ensure(h, h->zs_ranks1, sizeof(ZsRanks)));
-        SDCHK(ensure(h, h->zs_local, 4ull * 4 * 1024));
-        memset(h->h_zs1, 0, sizeof(ZsRanks));
-        h->h_zs1->nranks = 1; h->h_zs1->vbase[1] = h->n_verts; h->h_zs1->tbase[1] = h->n_tris;
-        HIPCHK(hipMemcpyAsync(h->zs_ranks1.p, h->h_zs1, sizeof(ZsRanks), hipMemcpyHostToDevice, st));
-        uint32_t *loc = (uint32_t *) h->zs_local.p;
-        HIPCHK(launch_zs_local_vcnt(st, (const uint32_t *) h->indices.p, h->n_tris, d_row, (const ZsRanks *) h->zs_ranks1.p, loc, loc + 2048, loc + 3072, d_row + 1024,
-                                    h->d_ctr + CTR_SCRATCH, h->d_status));
-    }
     return SDMESH_OK;
 }
 
-int sharded_regen_indexed(sdmesh_handle *h, int levels, int root, sdmesh_regen_info *info) {
+int zs_step_sync(sdmesh_handle *h, int levels, int root, int inject, sdmesh_regen_info *info) {
     const int R = h->comm_nranks, me = h->comm_rank;
     hipStream_t st = h->stream;
-    const int inject = h->inject_fail;
-    h->inject_fail = 0;
-    SDCHK(ensure(h, h->shard_counts, 4ull * (size_t) R * SHARD_ROW));
-    SDCHK(ensure_shard_host(h, R));
-    uint32_t *d_counts = (uint32_t *) h->shard_counts.p, *d_row = d_counts + (size_t) me * SHARD_ROW;
+    h->zsp.valid = false;
+    h->zs_cur = 0;
+    uint32_t *d_counts = zs_counts(h, 0), *d_row = d_counts + (size_t) me * SHARD_ROW, *d_next = zs_counts(h, 1) + (size_t) me * SHARD_ROW;
+    HIPCHK(hipMemsetAsync(d_row, 0, 8192, st));
+    HIPCHK(hipMemsetAsync(d_next, 0, 8192, st));
     // 1. this rank's slab, welded locally; any failure in here becomes this rank's status word
     sdmesh_regen_info slab;
     memset(&slab, 0, sizeof slab);
-    const int lrc = inject == 1 ? fail(h, SDMESH_ERR_INTERNAL, "injected failure (option inject_fail)") : zs_local_phase(h, levels, me, R, d_row, &slab);
-    uint32_t t_mine = 0, v_mine = 0;
-    if (lrc == SDMESH_OK) { t_mine = h->n_tris; v_mine = h->n_verts; }
-    else HIPCHK(hipMemsetAsync(d_row, 0, 8192, st));
-    // 2. the all-gather of the counts -- ALWAYS entered; record = {status, triangles, room for vertices / triangles as a root, vertices, 1, 0, 0}
-    HIPCHK(launch_pack_record(st, d_row + SHARD_REC, nullptr, nullptr, (uint32_t) lrc, t_mine, cap_items(h->zs_verts, sizeof(Vertex)),
-                              cap_items(h->zs_idx, sizeof(IndexTriangle))));
-    HIPCHK(launch_pack_record(st, d_row + SHARD_REC + 4, nullptr, nullptr, v_mine, 1u, 0u, 0u));
+    const int lrc = inject == 1 ? fail(h, SDMESH_ERR_INTERNAL, "injected failure (option inject_fail)") : zs_local_sync(h, levels, me, R, d_row, &slab);
+    const uint32_t t_mine = lrc == SDMESH_OK ? h->n_tris : 0u, v_mine = lrc == SDMESH_OK ? h->n_verts : 0u;
+    // 2. the row's vertex counts and record, then the all-gather -- ALWAYS entered
+    HIPCHK(launch_zs_local(st, (const uint32_t *) h->indices.p, t_mine, cap_items(h->indices, sizeof(IndexTriangle)), d_row, nullptr, h->d_ctr + CTR_NTRI,
+                           h->d_ctr + CTR_NVERT, h->d_status, (uint32_t) lrc, zs_root_capacity_v(h), zs_root_capacity_t(h), (uint32_t) inject, 0u));
     NCCLCHK(g_rccl.AllGather(d_row, d_counts, SHARD_ROW, ncclUint32, h->comm, st));                     // in place
     HIPCHK(hipMemcpyAsync(h->h_counts, d_counts, 4ull * (size_t) R * SHARD_ROW, hipMemcpyDeviceToHost, st));
     HIPCHK(hipStreamSynchronize(st));
     // 3. every rank, on the same numbers
-    SDCHK(peer_failure(h, R, me, h->h_counts, SHARD_ROW, SHARD_REC, lrc));
-    std::vector<uint32_t> Tr((size_t) R, 0), Vr((size_t) R, 0);
-    uint64_t ttot = 0, vtot = 0;
+    SDCHK(peer_failure(h, R, me, h->h_counts, SHARD_ROW, SHARD_REC + ZR_STATUS, lrc));
+    uint32_t cap_v[32] = {0}, cap_t[32] = {0}, Vr[32] = {0}, Tr[32] = {0};
+    uint64_t tslots = 0, vslots = 0;
+    bool any_inject2 = false;
     for (int r = 0; r < R; r++) {
-        const uint32_t *row = h->h_counts + (size_t) r * SHARD_ROW;
-        uint64_t s = 0;
-        for (int c = 0; c < 1024; c++) s += row[c];
-        if (s != row[SHARD_REC + 1])
-            return fail(h, SDMESH_ERR_INTERNAL, "rank %d: column counts (%llu) disagree with the slab's triangle count (%u)", r, (unsigned long long) s, row[SHARD_REC + 1]);
-        if (row[SHARD_REC + 5] != 1u) return fail(h, SDMESH_ERR_INVALID, "rank %d runs the raw-list form of the z-slab gather (option shard_indexed differs between the ranks)", r);
-        Tr[r] = row[SHARD_REC + 1]; Vr[r] = row[SHARD_REC + 4];
-        ttot += Tr[r]; vtot += Vr[r];
+        const uint32_t *row = h->h_counts + (size_t) r * SHARD_ROW, *rec = row + SHARD_REC;
+        if (rec[ZR_STATUS]) return fail(h, SDMESH_ERR_INTERNAL, "rank %d: its own row reports status 0x%x", r, rec[ZR_STATUS]);      // (me: the device-side checks of the row)
+        if (rec[ZR_FORM] != 1u) return fail(h, SDMESH_ERR_INVALID, "rank %d runs the raw-list form of the z-slab gather (option shard_indexed differs between the ranks)", r);
+        Tr[r] = rec[ZR_TRIS]; Vr[r] = rec[ZR_VERTS];
+        cap_v[r] = zs_padded(h, Vr[r]); cap_t[r] = zs_padded(h, Tr[r]);
+        tslots += cap_t[r]; vslots += cap_v[r];
+        any_inject2 = any_inject2 || rec[ZR_INJECT] == 2u;
     }
-    if (ttot > 0x0FFFFFFFull || vtot > 0x0FFFFFFFull) return fail(h, SDMESH_ERR_INVALID, "too many triangles for one mesh");
-    // 4. the root's receive buffers; grown behind a second agreement only if its published capacity is too small
-    const uint32_t *root_row = h->h_counts + (size_t) root * SHARD_ROW;
-    if (vtot > root_row[SHARD_REC + 2] || ttot > root_row[SHARD_REC + 3] || root_row[SHARD_REC + 2] == 0u || inject == 2) {
+    if (tslots > 0x0FFFFFFFull || vslots > 0x0FFFFFFFull) return fail(h, SDMESH_ERR_INVALID, "too many triangles for one mesh");
+    // 4. the root's buffers (the slots are plan-sized already: the next step may be a planned one); grown behind a second agreement only if
+    //    its published capacity is too small
+    const uint32_t *root_rec = h->h_counts + (size_t) root * SHARD_ROW + SHARD_REC;
+    if (vslots > root_rec[ZR_CAP_V] || tslots > root_rec[ZR_CAP_T] || root_rec[ZR_CAP_V] == 0u || any_inject2) {
         int grc = SDMESH_OK;
-        if (me == root) grc = inject == 2 ? fail(h, SDMESH_ERR_HIP, "injected allocation failure (option inject_fail)") : zs_ensure_inputs(h, vtot, ttot);
+        if (me == root) grc = inject == 2 ? fail(h, SDMESH_ERR_HIP, "injected allocation failure (option inject_fail)") : zs_root_ensure(h, R, vslots, tslots);
+        else if (inject == 2) grc = fail(h, SDMESH_ERR_HIP, "injected allocation failure (option inject_fail)");
         uint32_t worst = 0;
         SDCHK(agree_flag(h, grc == SDMESH_OK ? 0u : 1u, &worst));
         if (grc != SDMESH_OK) return grc;
-        if (worst) return fail(h, SDMESH_ERR_PEER, "the root (rank %d) could not grow its receive buffers; every rank returns an error", root);
+        if (worst) return fail(h, SDMESH_ERR_PEER, "a rank (the root is rank %d) could not grow its buffers; every rank returns an error", root);
     }
+    // 5. the plan of the next steps: the same on every rank (from here on all of them hold every buffer a planned step needs, or will
+    //    find out before they enqueue anything)
+    sdmesh_handle::ZsPlan &pl = h->zsp;
+    pl.levels = levels; pl.root = root; pl.R = R; pl.scene = h->scene; pl.slab_sig = zs_slab_sig(h, R);
+    uint32_t sig = 2166136261u;
+    for (int r = 0; r < R; r++) { pl.cap_v[r] = cap_v[r]; pl.cap_t[r] = cap_t[r]; sig = ((sig ^ cap_v[r]) * 16777619u ^ cap_t[r]) * 16777619u; }
+    pl.sig = sig | 1u;
+    pl.valid = h->shard_planned != 0;
+    h->zs_cur = 1;                                   // (buffer 1's row of mine was cleared above and nothing has touched it)
+    ZsRanks zr;
+    zs_slot_table(h, R, cap_v, cap_t, levels, zr);
+    // 6. payload: exact sizes (they are host values here)
+    std::vector<ZsMsg> msgs;
     if (me != root) {
-        // 5a. peers: the slab's vertex and index buffers go straight to the root (each peer on its own xGMI link)
-        if (v_mine || t_mine) {
-            NCCLCHK(g_rccl.GroupStart());
-            if (v_mine) NCCLCHK(g_rccl.Send(h->vertices.p, (size_t) v_mine * 6, ncclFloat32, root, h->comm, st));
-            if (t_mine) NCCLCHK(g_rccl.Send(h->indices.p, (size_t) t_mine * 3, ncclUint32, root, h->comm, st));
-            NCCLCHK(g_rccl.GroupEnd());
-        }
+        if (v_mine) msgs.push_back({h->vertices.p, (size_t) v_mine * 6, ncclFloat32, root, true});
+        if (t_mine) msgs.push_back({h->indices.p, (size_t) t_mine * 3, ncclUint32, root, true});
+        SDCHK(zs_exchange(h, msgs));
         HIPCHK(hipStreamSynchronize(st));
         if (info) *info = slab;
         return SDMESH_OK;
     }
-    // 5b. root: its own slab into its place of the concatenated buffers, grouped receives for the others
-    uint64_t vb = 0, tb = 0;
-    NCCLCHK(g_rccl.GroupStart());
+    if (Vr[me]) HIPCHK(hipMemcpyAsync((Vertex *) h->zs_verts.p + zr.vbase[me], h->vertices.p, sizeof(Vertex) * (size_t) Vr[me], hipMemcpyDeviceToDevice, st));
+    if (Tr[me]) HIPCHK(hipMemcpyAsync((IndexTriangle *) h->zs_idx.p + zr.tbase[me], h->indices.p, sizeof(IndexTriangle) * (size_t) Tr[me], hipMemcpyDeviceToDevice, st));
     for (int r = 0; r < R; r++) {
-        Vertex *vd = (Vertex *) h->zs_verts.p + vb;
-        IndexTriangle *td = (IndexTriangle *) h->zs_idx.p + tb;
-        if (r == root) {
-            if (Vr[r]) HIPCHK(hipMemcpyAsync(vd, h->vertices.p, sizeof(Vertex) * (size_t) Vr[r], hipMemcpyDeviceToDevice, st));
-            if (Tr[r]) HIPCHK(hipMemcpyAsync(td, h->indices.p, sizeof(IndexTriangle) * (size_t) Tr[r], hipMemcpyDeviceToDevice, st));
-        } else {
-            if (Vr[r]) NCCLCHK(g_rccl.Recv(vd, (size_t) Vr[r] * 6, ncclFloat32, r, h->comm, st));
-            if (Tr[r]) NCCLCHK(g_rccl.Recv(td, (size_t) Tr[r] * 3, ncclUint32, r, h->comm, st));
-        }
-        vb += Vr[r]; tb += Tr[r];
+        if (r == me) continue;
+        if (Vr[r]) msgs.push_back({(Vertex *) h->zs_verts.p + zr.vbase[r], (size_t) Vr[r] * 6, ncclFloat32, r, false});
+        if (Tr[r]) msgs.push_back({(IndexTriangle *) h->zs_idx.p + zr.tbase[r], (size_t) Tr[r] * 3, ncclUint32, r, false});
     }
-    NCCLCHK(g_rccl.GroupEnd());
-    // 6. the merge (from here on nobody waits for the root any more: a failure is the root's alone)
-    return zs_merge(h, R, d_counts, SHARD_ROW, Vr.data(), Tr.data(), levels, slab.voxel_size, info);
+    SDCHK(zs_exchange(h, msgs));
+    // 7. the merge (from here on nobody waits for the root any more: a failure is the root's alone)
+    const uint32_t seq = ++h->zs_seq;
+    HIPCHK(hipEventRecord(h->ev0, st));
+    SDCHK(zs_merge_enqueue(h, zr, d_counts, false, seq));
+    HIPCHK(hipEventRecord(h->ev1, st));
+    HIPCHK(hipStreamSynchronize(st));
+    SDCHK(zs_merge_finish(h, zr, d_counts, seq, levels, slab.voxel_size, info));
+    if (info) HIPCHK(hipEventElapsedTime(&info->device_ms, h->ev0, h->ev1));          // the root's merge alone
+    return SDMESH_OK;
+}
+
+// planned route, local part of rank `me` (handle h): buffers, the slab's chain from its capacity plan with the column counts on the way
+// (a handle without a plan runs its regen synchronously here: still no exchange of host values between the ranks), the two count kernels.
+// slot_v / slot_i != nullptr: the weld writes straight into that slot of the root's gather buffers (the root itself).  Returns what the host
+// knows about the local phase when everything is enqueued; *pending = the chain's own verdict is still outstanding (zs_planned_local_end).
+int zs_planned_local(sdmesh_handle *h, int levels, int me, int R, const sdmesh_handle::ZsPlan &pl, Vertex *slot_v, IndexTriangle *slot_i, int inject,
+                     uint32_t *d_row, uint32_t *d_next, sdmesh_regen_info *slab) {
+    hipStream_t st = h->stream;
+    if (!slot_v) {            // peers send plan-sized messages out of their own mesh buffers (nothing may allocate once the chain is in flight)
+        SDCHK(ensure(h, h->vertices, sizeof(Vertex) * (size_t) pl.cap_v[me]));
+        SDCHK(ensure(h, h->indices, sizeof(IndexTriangle) * (size_t) pl.cap_t[me]));
+    }
+    const int saved_skip = h->skip_weld;
+    h->skip_weld = 0;
+    h->colcnt = d_row;
+    if (slot_v) { h->out_v = slot_v; h->out_i = (uint32_t *) slot_i; h->out_vcap = pl.cap_v[me]; }
+    int lrc = inject == 1 ? fail(h, SDMESH_ERR_INTERNAL, "injected failure (option inject_fail)") : regen_impl(h, levels, SDMESH_PART_ZSLAB, me, R, nullptr, 1);
+    bool ended = false;
+    if (lrc == SDMESH_OK && !h->pend_async) { lrc = regen_impl(h, 0, 0, 0, 1, slab, 2); ended = true; }      // no plan: the synchronous regen, now
+    h->colcnt = nullptr;
+    h->out_v = nullptr; h->out_i = nullptr; h->out_vcap = 0;
+    h->skip_weld = saved_skip;
+    if (lrc == SDMESH_OK && ended && (h->last_direct || !h->welded || h->wide_active)) lrc = fail(h, SDMESH_ERR_INTERNAL, "a slab left the packed-key lattice path");
+    if (lrc != SDMESH_OK && h->pend_active) { sdmesh_regen_info tmp; (void) regen_impl(h, 0, 0, 0, 1, &tmp, 2); }
+    const uint32_t *idx = slot_i ? (const uint32_t *) slot_i : (const uint32_t *) h->indices.p;
+    HIPCHK(launch_zs_local(st, idx, std::max<uint32_t>(h->plan_tris, 1u), slot_i ? pl.cap_t[me] : cap_items(h->indices, sizeof(IndexTriangle)), d_row, d_next,
+                           h->d_ctr + CTR_NTRI, h->d_ctr + CTR_NVERT, h->d_status, (uint32_t) lrc, zs_root_capacity_v(h), zs_root_capacity_t(h), (uint32_t) inject, pl.sig));
+    return lrc;
+}
+
+// after the step's wait: the chain's own verdict (a chain that overflowed its plan is repeated in there; its row said so already)
+int zs_planned_local_end(sdmesh_handle *h, sdmesh_regen_info *slab) {
+    if (!h->pend_active) return SDMESH_OK;
+    return regen_impl(h, 0, 0, 0, 1, slab, 2);
+}
+
+// the records a planned step published: does every rank fit the plan?
+bool zs_records_fit(const uint32_t *pub, int R, const sdmesh_handle::ZsPlan &pl) {
+    for (int r = 0; r < R; r++) {
+        const uint32_t *rec = pub + ZC_WORDS + 8 * r;
+        if (rec[ZR_STATUS] != 0u || rec[ZR_FORM] != 1u || rec[ZR_VERTS] > pl.cap_v[r] || rec[ZR_TRIS] > pl.cap_t[r] || rec[ZR_INJECT] != 0u || rec[ZR_SIG] != pl.sig) return false;
+    }
+    return true;
+}
+
+int zs_step_planned(sdmesh_handle *h, int levels, int root, int inject, sdmesh_regen_info *info) {
+    const int R = h->comm_nranks, me = h->comm_rank;
+    hipStream_t st = h->stream;
+    const sdmesh_handle::ZsPlan &pl = h->zsp;
+    const int cur = h->zs_cur;
+    uint32_t *d_counts = zs_counts(h, cur), *d_row = d_counts + (size_t) me * SHARD_ROW, *d_next = zs_counts(h, cur ^ 1) + (size_t) me * SHARD_ROW;
+    ZsRanks zr;
+    zs_slot_table(h, R, pl.cap_v, pl.cap_t, levels, zr);
+    const bool is_root = me == root;
+    if (is_root) SDCHK(zs_root_ensure(h, R, zr.vbase[R], zr.tbase[R]));
+    // 1. the slab's chain + 2. vertex counts and record; 3. all-gather; 4. plan-sized payload; 5. merge / publish -- all enqueued blind
+    sdmesh_regen_info slab;
+    memset(&slab, 0, sizeof slab);
+    const int lrc = zs_planned_local(h, levels, me, R, pl, is_root ? (Vertex *) h->zs_verts.p + zr.vbase[me] : nullptr,
+                                     is_root ? (IndexTriangle *) h->zs_idx.p + zr.tbase[me] : nullptr, inject, d_row, d_next, &slab);
+    if (lrc == SDMESH_ERR_HIP) return lrc;                                  // (the enqueue itself failed: nothing sane can follow)
+    const uint32_t seq = ++h->zs_seq;
+    NCCLCHK(g_rccl.AllGather(d_row, d_counts, SHARD_ROW, ncclUint32, h->comm, st));                     // in place
+    std::vector<ZsMsg> msgs;
+    if (!is_root) {
+        msgs.push_back({h->vertices.p, (size_t) pl.cap_v[me] * 6, ncclFloat32, root, true});
+        msgs.push_back({h->indices.p, (size_t) pl.cap_t[me] * 3, ncclUint32, root, true});
+        SDCHK(zs_exchange(h, msgs));
+        HIPCHK(launch_zs_publish(st, d_counts, SHARD_ROW, (uint32_t) R, nullptr, seq, h->h_zs_pub));
+    } else {
+        for (int r = 0; r < R; r++) {
+            if (r == me) continue;
+            msgs.push_back({(Vertex *) h->zs_verts.p + zr.vbase[r], (size_t) pl.cap_v[r] * 6, ncclFloat32, r, false});
+            msgs.push_back({(IndexTriangle *) h->zs_idx.p + zr.tbase[r], (size_t) pl.cap_t[r] * 3, ncclUint32, r, false});
+        }
+        SDCHK(zs_exchange(h, msgs));
+        SDCHK(zs_merge_enqueue(h, zr, d_counts, false, seq));
+    }
+    // 6. the step's one host synchronisation
+    HIPCHK(hipStreamSynchronize(st));
+    h->zs_cur = cur ^ 1;
+    const int erc = zs_planned_local_end(h, &slab);
+    const uint32_t *pub = h->h_zs_pub;
+    if (pub[ZC_SEQ] != seq) return fail(h, SDMESH_ERR_INTERNAL, "the planned z-slab step did not publish its records (step %u, found %u)", seq, pub[ZC_SEQ]);
+    // (erc / lrc are this rank's alone, but they imply a non-zero status in this rank's record, which every rank sees: the decision is collective)
+    if (erc != SDMESH_OK || lrc != SDMESH_OK || !zs_records_fit(pub, R, pl)) return ZS_REDO;
+    if (!is_root) {
+        if (info) *info = slab;
+        return SDMESH_OK;
+    }
+    return zs_merge_finish(h, zr, d_counts, seq, levels, slab.voxel_size, info);
+}
+
+int sharded_regen_indexed(sdmesh_handle *h, int levels, int root, sdmesh_regen_info *info) {
+    const int R = h->comm_nranks;
+    const int inject = h->inject_fail;
+    h->inject_fail = 0;
+    SDCHK(zs_scratch(h, R));                                   // (a rank that cannot even get these few KB cannot tell anybody)
+    const sdmesh_handle::ZsPlan &pl = h->zsp;
+    if (h->shard_planned && pl.valid && pl.levels == levels && pl.root == root && pl.R == R && pl.scene == h->scene && pl.slab_sig == zs_slab_sig(h, R)) {
+        const int rc = zs_step_planned(h, levels, root, inject, info);
+        if (rc != ZS_REDO) { h->zs_last_route = 1; return rc; }
+        h->zs_last_route = 3;
+        h->mesh_valid = false;
+        return zs_step_sync(h, levels, root, inject, info);
+    }
+    h->zs_last_route = 2;
+    return zs_step_sync(h, levels, root, inject, info);
 }
 
 }  // namespace
 
 extern "C" {
+
+int sdmesh_sharded_route(const sdmesh_handle *h) { return h ? (int) h->zs_last_route : 0; }
 
 int sdmesh_sharded_regen(sdmesh_handle *h, int levels, int root, sdmesh_regen_info *info) {
     if (!h) return SDMESH_ERR_INVALID;
@@ -2286,40 +2477,124 @@ int sdmesh_sharded_regen(sdmesh_handle *h, int levels, int root, sdmesh_regen_in
 
 }  // extern "C"
 
+namespace {
+
+// the rehearsal's planned route: the planned step's kernels for every handle (slots with head-room, counts read on the device, the root's
+// weld writing into its slot, the alternating count buffers), copies of the PLAN's sizes in place of the messages.  ZS_REDO like the real one.
+int zs_rehearsal_planned(sdmesh_handle **hs, int R, int levels, int root, sdmesh_regen_info *info) {
+    sdmesh_handle *H = hs[root], *h = H;
+    const sdmesh_handle::ZsPlan &pl = H->zsp;
+    const int cur = H->zs_cur;
+    uint32_t *d_counts = zs_counts(H, cur), *d_nextbuf = zs_counts(H, cur ^ 1);
+    ZsRanks zr;
+    zs_slot_table(H, R, pl.cap_v, pl.cap_t, levels, zr);
+    SDCHK(zs_root_ensure(H, R, zr.vbase[R], zr.tbase[R]));
+    std::vector<sdmesh_regen_info> slab((size_t) R);
+    std::vector<int> lrc((size_t) R, SDMESH_OK);
+    for (int r = 0; r < R; r++) {
+        h = hs[r];
+        const int inject = h->inject_fail;
+        h->inject_fail = 0;
+        memset(&slab[(size_t) r], 0, sizeof(sdmesh_regen_info));
+        lrc[(size_t) r] = zs_planned_local(h, levels, r, R, pl, r == root ? (Vertex *) H->zs_verts.p + zr.vbase[r] : nullptr,
+                                           r == root ? (IndexTriangle *) H->zs_idx.p + zr.tbase[r] : nullptr, inject, d_counts + (size_t) r * SHARD_ROW,
+                                           d_nextbuf + (size_t) r * SHARD_ROW, &slab[(size_t) r]);
+        HIPCHK(hipStreamSynchronize(h->stream));
+    }
+    h = H;
+    for (int r = 0; r < R; r++) {
+        if (r == root) continue;
+        HIPCHK(hipMemcpyAsync((Vertex *) H->zs_verts.p + zr.vbase[r], hs[r]->vertices.p, sizeof(Vertex) * (size_t) pl.cap_v[r], hipMemcpyDeviceToDevice, H->stream));
+        HIPCHK(hipMemcpyAsync((IndexTriangle *) H->zs_idx.p + zr.tbase[r], hs[r]->indices.p, sizeof(IndexTriangle) * (size_t) pl.cap_t[r], hipMemcpyDeviceToDevice, H->stream));
+    }
+    const uint32_t seq = ++H->zs_seq;
+    SDCHK(zs_merge_enqueue(H, zr, d_counts, false, seq));
+    HIPCHK(hipStreamSynchronize(H->stream));
+    H->zs_cur = cur ^ 1;
+    bool redo = false;
+    for (int r = 0; r < R; r++) redo = (zs_planned_local_end(hs[r], &slab[(size_t) r]) != SDMESH_OK) || lrc[(size_t) r] != SDMESH_OK || redo;
+    const uint32_t *pub = H->h_zs_pub;
+    if (pub[ZC_SEQ] != seq) return fail(H, SDMESH_ERR_INTERNAL, "the planned z-slab step did not publish its records (step %u, found %u)", seq, pub[ZC_SEQ]);
+    if (redo || !zs_records_fit(pub, R, pl)) return ZS_REDO;
+    return zs_merge_finish(H, zr, d_counts, seq, levels, slab[(size_t) root].voxel_size, info);
+}
+
+}  // namespace
+
 extern "C" int sdmesh_sharded_regen_rehearsal(sdmesh_handle **hs, int nranks, int levels, int root, sdmesh_regen_info *info) {
     // The indexed z-slab gather for `nranks` handles of ONE process on ONE device, device-to-device copies in place of the RCCL
-    // messages: every phase and kernel of sdmesh_sharded_regen's indexed form (tests and single-GPU measurements of the root's share)
+    // messages: every kernel of sdmesh_sharded_regen's indexed form on BOTH its routes -- the first call (and any call whose sizes,
+    // root, scene or slabs differ from the plan the root handle holds) takes the synchronous route and commits the plan, a repeat
+    // takes the planned one (tests and single-GPU measurements of the root's share)
     if (!hs || nranks < 1 || nranks > 32 || root < 0 || root >= nranks) return SDMESH_ERR_INVALID;
     for (int r = 0; r < nranks; r++)
         if (!hs[r] || hs[r]->device != hs[0]->device) return SDMESH_ERR_INVALID;
     sdmesh_handle *H = hs[root], *h = H;                   // (`h`: what the error macros report through)
     const int R = nranks;
     HIPCHK(hipSetDevice(H->device));
-    SDCHK(ensure(H, H->shard_counts, 4ull * (size_t) R * SHARD_ROW));
-    uint32_t *d_counts = (uint32_t *) H->shard_counts.p;
-    std::vector<uint32_t> Tr((size_t) R, 0), Vr((size_t) R, 0);
+    SDCHK(zs_scratch(H, R));
+    for (int r = 0; r < R; r++)
+        if (hs[r]->slab_nparts != H->slab_nparts || (H->slab_nparts && (hs[r]->slab_mode != H->slab_mode || memcmp(hs[r]->slab_bounds, H->slab_bounds, sizeof(uint32_t) * (size_t) (H->slab_nparts + 1)))))
+            return fail(H, SDMESH_ERR_INVALID, "handle %d has other slab bounds than the root", r);
+    {
+        const sdmesh_handle::ZsPlan &pl = H->zsp;
+        bool planned = H->shard_planned && pl.valid && pl.levels == levels && pl.root == root && pl.R == R && pl.slab_sig == zs_slab_sig(H, R);
+        for (int r = 0; planned && r < R; r++) planned = hs[r]->scene == pl.scene;
+        if (planned) {
+            const int rc = zs_rehearsal_planned(hs, R, levels, root, info);
+            if (rc != ZS_REDO) { H->zs_last_route = 1; return rc; }
+            H->zs_last_route = 3;
+        } else {
+            H->zs_last_route = 2;
+        }
+    }
+    H->zsp.valid = false;
+    uint32_t *d_counts = zs_counts(H, 0);
+    HIPCHK(hipMemsetAsync(d_counts, 0, 4ull * (size_t) R * SHARD_ROW, H->stream));
+    HIPCHK(hipMemsetAsync(zs_counts(H, 1), 0, 4ull * (size_t) R * SHARD_ROW, H->stream));
+    HIPCHK(hipStreamSynchronize(H->stream));
+    uint32_t Tr[32] = {0}, Vr[32] = {0}, cap_v[32] = {0}, cap_t[32] = {0};
     sdmesh_regen_info slab;
     memset(&slab, 0, sizeof slab);
-    uint64_t vtot = 0, ttot = 0;
+    uint64_t vslots = 0, tslots = 0;
     for (int r = 0; r < R; r++) {
         h = hs[r];
-        if (h->slab_nparts != H->slab_nparts || (H->slab_nparts && (h->slab_mode != H->slab_mode || memcmp(h->slab_bounds, H->slab_bounds, sizeof(uint32_t) * (size_t) (H->slab_nparts + 1)))))
-            return fail(H, SDMESH_ERR_INVALID, "handle %d has other slab bounds than the root", r);
-        const int rc = zs_local_phase(h, levels, r, R, d_counts + (size_t) r * SHARD_ROW, &slab);
+        const int inject = h->inject_fail;
+        h->inject_fail = 0;
+        uint32_t *row = d_counts + (size_t) r * SHARD_ROW;
+        const int rc = inject == 1 ? fail(h, SDMESH_ERR_INTERNAL, "injected failure (option inject_fail)") : zs_local_sync(h, levels, r, R, row, &slab);
         if (rc != SDMESH_OK) { if (h != H) (void) fail(H, rc, "slab %d: %s", r, h->err); return rc; }
+        HIPCHK(launch_zs_local(h->stream, (const uint32_t *) h->indices.p, h->n_tris, cap_items(h->indices, sizeof(IndexTriangle)), row, nullptr, h->d_ctr + CTR_NTRI,
+                               h->d_ctr + CTR_NVERT, h->d_status, 0u, 0u, 0u, 0u, 0u));
         HIPCHK(hipStreamSynchronize(h->stream));
         Tr[r] = h->n_tris; Vr[r] = h->n_verts;
-        vtot += Vr[r]; ttot += Tr[r];
+        cap_v[r] = zs_padded(H, Vr[r]); cap_t[r] = zs_padded(H, Tr[r]);
+        vslots += cap_v[r]; tslots += cap_t[r];
     }
     h = H;
-    SDCHK(zs_ensure_inputs(H, vtot, ttot));
-    uint64_t vb = 0, tb = 0;
+    if (vslots > 0x0FFFFFFFull || tslots > 0x0FFFFFFFull) return fail(h, SDMESH_ERR_INVALID, "too many vertices / triangles for one mesh");
+    SDCHK(zs_root_ensure(H, R, vslots, tslots));
+    sdmesh_handle::ZsPlan &pl = H->zsp;                    // the plan, committed as sdmesh_sharded_regen's synchronous route commits it
+    pl.levels = levels; pl.root = root; pl.R = R; pl.scene = H->scene; pl.slab_sig = zs_slab_sig(H, R);
+    uint32_t sig = 2166136261u;
+    for (int r = 0; r < R; r++) { pl.cap_v[r] = cap_v[r]; pl.cap_t[r] = cap_t[r]; sig = ((sig ^ cap_v[r]) * 16777619u ^ cap_t[r]) * 16777619u; }
+    pl.sig = sig | 1u;
+    pl.valid = H->shard_planned != 0;
+    H->zs_cur = 1;
+    ZsRanks zr;
+    zs_slot_table(H, R, cap_v, cap_t, levels, zr);
     for (int r = 0; r < R; r++) {
-        if (Vr[r]) HIPCHK(hipMemcpyAsync((Vertex *) H->zs_verts.p + vb, hs[r]->vertices.p, sizeof(Vertex) * (size_t) Vr[r], hipMemcpyDeviceToDevice, H->stream));
-        if (Tr[r]) HIPCHK(hipMemcpyAsync((IndexTriangle *) H->zs_idx.p + tb, hs[r]->indices.p, sizeof(IndexTriangle) * (size_t) Tr[r], hipMemcpyDeviceToDevice, H->stream));
-        vb += Vr[r]; tb += Tr[r];
+        if (Vr[r]) HIPCHK(hipMemcpyAsync((Vertex *) H->zs_verts.p + zr.vbase[r], hs[r]->vertices.p, sizeof(Vertex) * (size_t) Vr[r], hipMemcpyDeviceToDevice, H->stream));
+        if (Tr[r]) HIPCHK(hipMemcpyAsync((IndexTriangle *) H->zs_idx.p + zr.tbase[r], hs[r]->indices.p, sizeof(IndexTriangle) * (size_t) Tr[r], hipMemcpyDeviceToDevice, H->stream));
     }
-    return zs_merge(H, R, d_counts, SHARD_ROW, Vr.data(), Tr.data(), levels, slab.voxel_size, info);
+    const uint32_t seq = ++H->zs_seq;
+    HIPCHK(hipEventRecord(H->ev0, H->stream));
+    SDCHK(zs_merge_enqueue(H, zr, d_counts, false, seq));
+    HIPCHK(hipEventRecord(H->ev1, H->stream));
+    HIPCHK(hipStreamSynchronize(H->stream));
+    SDCHK(zs_merge_finish(H, zr, d_counts, seq, levels, slab.voxel_size, info));
+    if (info) HIPCHK(hipEventElapsedTime(&info->device_ms, H->ev0, H->ev1));          // the root's merge alone
+    return SDMESH_OK;
 }
 
 // ================================================================================================
@@ -2412,8 +2687,8 @@ int dist_phase_final(sdmesh_handle *h, int me) {
     HIPCHK(launch_dist_finalize(h->stream, h->grid, (const Vertex *) h->vertices.p, h->dist_V, h->dist_T, (const uint32_t *) h->dist_dupof.p,
                                 (const uint32_t *) h->dist_newidx.p, (const uint32_t *) h->dist_prevg.p, (const uint32_t *) h->dist_counts.p,
                                 (uint32_t) me, (uint32_t *) h->indices.p, (Vertex *) h->dist_verts.p));
-    std::swap(h->vertices, h->dist_verts);                 // the compacted list becomes the handle's vertex buffer
-    h->buf_gen++;
+    h->res_v = (Vertex *) h->dist_verts.p;                 // the compacted list is the handle's vertex buffer now (the indices were rewritten in place)
+    h->res_i = nullptr;
     return SDMESH_OK;
 }
 

@@ -22,6 +22,7 @@
 
 #include "../../include/sdmesh/bindings.h"
 #include "kernels.hpp"
+#include "prims.hpp"
 #include "mc_tables.hpp"
 #include "mesh_device.hpp"
 #include "sdf.hpp"
@@ -32,101 +33,6 @@
 #endif
 
 namespace sdm {
-
-static constexpr uint32_t TILE = 256;
-static constexpr uint64_t KEY_EMPTY = ~0ull;
-static constexpr uint32_t U32_NONE = 0xffffffffu;
-
-// ------------------------------------------------------------------------------------------
-// wave / block primitives (wave64)
-// ------------------------------------------------------------------------------------------
-__device__ __forceinline__ uint32_t lane_id() { return threadIdx.x & 63u; }
-
-// Wave-wide inclusive prefix sum with DPP row shifts / row broadcasts (gfx9 data-parallel primitives: ~6 VALU operations)
-// instead of six __shfl_up steps, each of which is a ds_bpermute_b32 round trip through the LDS crossbar.
-template <int CTRL, int ROW_MASK>
-__device__ __forceinline__ uint32_t dpp_add(uint32_t v) {
-    // lanes whose DPP source is out of range (or whose row is masked off) contribute `old` = 0
-    return v + (uint32_t) __builtin_amdgcn_update_dpp(0, (int) v, CTRL, ROW_MASK, 0xf, false);
-}
-
-__device__ __forceinline__ uint32_t wave_incl_scan(uint32_t v) {
-    v = dpp_add<0x111, 0xf>(v);      // row_shr:1
-    v = dpp_add<0x112, 0xf>(v);      // row_shr:2
-    v = dpp_add<0x114, 0xf>(v);      // row_shr:4
-    v = dpp_add<0x118, 0xf>(v);      // row_shr:8   -> inclusive sums inside each row of 16 lanes
-    v = dpp_add<0x142, 0xa>(v);      // row_bcast:15 into rows 1 and 3
-    v = dpp_add<0x143, 0xc>(v);      // row_bcast:31 into rows 2 and 3
-    return v;
-}
-
-__device__ __forceinline__ uint32_t wave_sum(uint32_t v) {
-    return (uint32_t) __builtin_amdgcn_readlane((int) wave_incl_scan(v), 63);
-}
-
-// Exclusive scan over the workgroup (blockDim.x multiple of 64, <= 1024).  `lds` needs 17 words.
-// All threads must call.  Returns the exclusive prefix of `v`; `total` = workgroup sum.
-__device__ __forceinline__ uint32_t block_excl_scan(uint32_t v, uint32_t &total, uint32_t *lds) {
-    const uint32_t lane = lane_id(), wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
-    const uint32_t incl = wave_incl_scan(v);
-    __syncthreads();                       // protect lds from the previous use
-    if (lane == 63) lds[wave] = incl;
-    __syncthreads();
-    if (wave == 0) {
-        uint32_t w = lane < nw ? lds[lane] : 0;
-        uint32_t wi = wave_incl_scan(w);
-        if (lane < nw) lds[lane] = wi - w;
-        if (lane == 63) lds[16] = wi;
-    }
-    __syncthreads();
-    total = lds[16];
-    return lds[wave] + incl - v;
-}
-
-// Tile counts that a 256-thread workgroup prefixes for itself in LDS (api.hip: LOCAL_TILES).  A single-workgroup scan kernel
-// between two per-tile kernels is a whole dependent launch (~4.7 us at 512^3: dispatch, two dependent loads, the scan, the
-// stores) for ~1 000 numbers; every consumer workgroup re-deriving the prefix costs it one 8-load step instead.
-static constexpr uint32_t LOCAL_TILES = SDM_LOCAL_TILES;
-
-// exclusive prefix of n <= LOCAL_TILES counts (count i at base[i * stride]) -> s_pre[0 .. n]; returns the total.
-// blockDim.x == 256, all threads must call; s_scan needs 17 words.
-__device__ __forceinline__ uint32_t local_prefix(const uint32_t *__restrict__ base, uint32_t stride, uint32_t n,
-                                                 uint32_t *__restrict__ s_pre, uint32_t *__restrict__ s_scan) {
-    constexpr uint32_t PER = LOCAL_TILES / 256;
-    uint32_t v[PER], sum = 0;
-#pragma unroll
-    for (uint32_t k = 0; k < PER; k++) {
-        const uint32_t i = threadIdx.x * PER + k;
-        v[k] = i < n ? base[(size_t) i * stride] : 0u;
-        sum += v[k];
-    }
-    uint32_t total;
-    uint32_t ex = block_excl_scan(sum, total, s_scan);
-#pragma unroll
-    for (uint32_t k = 0; k < PER; k++) {
-        const uint32_t i = threadIdx.x * PER + k;
-        if (i < n) s_pre[i] = ex;
-        ex += v[k];
-    }
-    if (threadIdx.x == 0) s_pre[n] = total;
-    __syncthreads();
-    return total;
-}
-
-// the tile lo in [0, n) with s_pre[lo] <= item < s_pre[lo + 1]   (item < s_pre[n])
-__device__ __forceinline__ uint32_t local_find(const uint32_t *__restrict__ s_pre, uint32_t n, uint32_t item) {
-    uint32_t lo = 0, hi = n;
-    while (hi - lo > 1u) {
-        const uint32_t mid = (lo + hi) >> 1;
-        if (s_pre[mid] <= item) lo = mid; else hi = mid;
-    }
-    return lo;
-}
-
-__device__ __forceinline__ uint64_t mix64(uint64_t h) {
-    h ^= h >> 33; h *= 0xff51afd7ed558ccdull; h ^= h >> 33; h *= 0xc4ceb9fe1a85ec53ull; h ^= h >> 33;
-    return h;
-}
 
 // ------------------------------------------------------------------------------------------
 // lattice addressing
@@ -153,24 +59,6 @@ __device__ __forceinline__ uint64_t edge_key(int mx, int my, int mz, int e) {
     const uint32_t ox = (0x281919u >> (2 * e)) & 3u, oy = (0xa06464u >> (2 * e)) & 3u, oz = (0x55aa00u >> (2 * e)) & 3u;
     const uint64_t kx = (uint64_t) (2 * mx) + ox, ky = (uint64_t) (2 * my) + oy, kz = (uint64_t) (2 * mz) + oz;
     return kx | (ky << 21) | (kz << 42);
-}
-
-// open-addressing tables have an arbitrary (non power-of-two) size: home slot by fast range
-// reduction of the mixed key, linear probing with wrap-around
-__device__ __forceinline__ uint32_t hash_home(uint64_t key, uint32_t hsize) {
-    return (uint32_t) (((mix64(key) >> 32) * (uint64_t) hsize) >> 32);
-}
-__device__ __forceinline__ uint32_t hash_next(uint32_t s, uint32_t hsize) { return s + 1 == hsize ? 0u : s + 1; }
-
-__device__ __forceinline__ uint32_t hash_find(const uint64_t *__restrict__ keys, uint32_t hsize, uint64_t key) {
-    uint32_t s = hash_home(key, hsize);
-    for (uint32_t probe = 0; probe < hsize; probe++) {
-        uint64_t k = keys[s];
-        if (k == key) return s;
-        if (k == KEY_EMPTY) return U32_NONE;
-        s = hash_next(s, hsize);
-    }
-    return U32_NONE;
 }
 
 // ------------------------------------------------------------------------------------------
@@ -943,7 +831,8 @@ __global__ __launch_bounds__(256) void k_tile_dedupe(const Point *__restrict__ v
                                                       uint32_t tcap, uint32_t *__restrict__ ntri_out,
                                                       uint32_t *__restrict__ ntiles_out, uint32_t *__restrict__ status,
                                                       uint64_t *__restrict__ dbg /* optional: 8 s_memtime stamps per tile (tools/tile_phases.py) */,
-                                                      uint32_t prescanned /* tilecnt = exclusive prefix, *ntri_out = total (k_scan_tiles in front) */) {
+                                                      uint32_t prescanned /* tilecnt = exclusive prefix, *ntri_out = total (k_scan_tiles in front) */,
+                                                      uint32_t *__restrict__ colcnt /* optional (multi-GPU z-slabs): += triangles per level-0 (x0, y0) column; pre-zeroed */) {
 #define SDM_STAMP(k) do { if (dbg && tid == 0) dbg[8ull * tile + (k)] = __builtin_amdgcn_s_memtime(); } while (0)
     __shared__ uint64_t s_keys[T_HASH];
     __shared__ uint64_t s_aux[2 * TILE];                    // insert phase: per-voxel lattice coordinates + triangle row;
@@ -983,6 +872,21 @@ __global__ __launch_bounds__(256) void k_tile_dedupe(const Point *__restrict__ v
         if (ntri) {
             const bool okx = lattice_coord(b.x, vs.x, mx), oky = lattice_coord(b.y, vs.y, my), okz = lattice_coord(b.z, vs.z, mz);
             lat_ok = okx && oky && okz;
+        }
+        if (colcnt) {
+            // triangles per level-0 column (the z-slab gather's order restoration): a column is a contiguous range of the
+            // list, so a wave's voxels nearly always share one -> one atomic per wave; the few waves on a boundary add per lane
+            const float cell = MESH_GENERATION_BB_SIZE / (float) MESH_GENERATION_INIT_FACTOR;
+            const uint32_t F = MESH_GENERATION_INIT_FACTOR;
+            uint32_t cx = (uint32_t) floorf((b.x + 2.5f) / cell), cy = (uint32_t) floorf((b.y + 2.5f) / cell);
+            cx = cx < F ? cx : F - 1; cy = cy < F ? cy : F - 1;
+            const uint32_t col = cx * F + cy, col0 = (uint32_t) __builtin_amdgcn_readfirstlane((int) col);
+            if (__ballot(ntri != 0u && col != col0) == 0ull) {
+                const uint32_t ws = wave_sum(ntri);
+                if (lane_id() == 0 && ws) atomicAdd(&colcnt[col0], ws);
+            } else if (ntri) {
+                atomicAdd(&colcnt[col], ntri);
+            }
         }
         SDM_STAMP(1);
         uint32_t ttri;
@@ -1094,11 +998,6 @@ static constexpr uint32_t VS_SLOT = 0x7fffffffu;
 // hammer a few cache lines at a time and atomics to one line serialise (512^3: claim 25 -> 157 us at 8-voxel cells;
 // milliseconds once a cell holds more keys than a block).  What the locality was wanted for -- the per-slot gathers of
 // the later weld kernels -- is obtained instead by indexing those arrays with the key's representative VERTEX (below).
-__device__ __forceinline__ bool packed_weld_key(const Point p, uint64_t &key) {
-    const long long qx = weld_quant(p.x) + 1048576LL, qy = weld_quant(p.y) + 1048576LL, qz = weld_quant(p.z) + 1048576LL;
-    key = (uint64_t) qx | ((uint64_t) qy << 21) | ((uint64_t) qz << 42);
-    return (((unsigned long long) qx | (unsigned long long) qy | (unsigned long long) qz) >> 21) == 0ull;
-}
 
 static constexpr uint32_t WELD_BLOCK = 256;
 
@@ -2231,209 +2130,6 @@ __global__ __launch_bounds__(256) void k_dist_finalize(const Vertex *__restrict_
 }
 
 // ------------------------------------------------------------------------------------------
-// Multi-GPU, z-slabs, INDEXED gather (the north star's "RCCL gather of per-slab vertex/index buffers").
-// Every rank meshes AND welds its own level-0 z-slab; the root receives the slabs' vertex and index buffers (24 B per vertex +
-// 12 B per triangle, against 72 B per triangle for the raw lists) and restores the single-GPU mesh from them WITHOUT welding
-// anything again -- no hash claim per corner, only streaming passes over the gathered buffers:
-//
-//   * a rank's welded vertices are numbered in its own first-seen order, so the number of distinct vertices in its first n
-//     triangles is 1 + the largest index among them: the largest index per column segment (k_zs_segmax) gives, by a prefix
-//     maximum over the columns (k_zs_vplan), the number of local vertices FIRST SEEN in each column -- computed by every rank
-//     for its own slab (launch_zs_local_vcnt) and carried to the root in the all-gather beside the triangle counts;
-//   * in the single-GPU order a level-0 column holds rank 0's triangles, then rank 1's, ...: so the single-GPU first-seen vertex
-//     order is, column by column and rank by rank, each segment's first-seen vertices in their local order -- the vertex buffers
-//     merge by (column, rank) segments exactly like the triangle lists (same plan kernel, k_merge_plan, on the vertex counts);
-//   * the only vertices two slabs can share lie within `band` of a slab face: those go through one small hash (k_zs_band_insert:
-//     key -> smallest concatenated vertex id) and look themselves up (k_zs_band_resolve); of a pair the copy whose first-seen
-//     segment comes first in the (column, rank) order is the single-GPU representative, the other one is dropped from its
-//     segment's count and redirected;
-//   * kept vertices are numbered by an ordered scan (the distributed weld's k_dist_keep_count / k_scan_tiles / k_dist_newidx),
-//     written to their merged places (k_zs_vertex_out), the dropped ones inherit their partner's number (k_zs_loser_map), and
-//     the index buffers are rewritten segment by segment into the merged triangle order (k_zs_index_out).
-// Inputs are the ranks' buffers CONCATENATED in rank order (vertex i of rank r at vbase[r] + i, triangle t at tbase[r] + t).
-// ------------------------------------------------------------------------------------------
-__device__ __forceinline__ uint32_t zs_rank_of(const ZsRanks &zr, uint32_t i) {
-    uint32_t r = 0;
-    while (r + 1u < zr.nranks && i >= zr.vbase[r + 1u]) r++;
-    return r;
-}
-
-// largest local vertex index + 1 of every (rank, column) segment of the index buffers (0 for an empty segment; segmax pre-zeroed).
-// Segments are very uneven (a column holds anything from nothing to tens of thousands of triangles): gridDim.y workgroups share one.
-__global__ __launch_bounds__(256) void k_zs_segmax(const uint32_t *__restrict__ idx_all, const uint32_t *__restrict__ counts, uint32_t cstride,
-                                                    const uint32_t *__restrict__ tplan, const ZsRanks *__restrict__ zrp, uint32_t *__restrict__ segmax) {
-    const ZsRanks &zr = *zrp;
-    const uint32_t nseg = zr.nranks * NCOL;
-    for (uint32_t seg = blockIdx.x; seg < nseg; seg += gridDim.x) {
-        const uint32_t r = seg / NCOL, n = counts[r * cstride + seg % NCOL];
-        if (n == 0) continue;
-        const uint32_t ne = 3u * n, per = (ne + gridDim.y - 1u) / gridDim.y, e0 = blockIdx.y * per, e1 = e0 + per < ne ? e0 + per : ne;
-        if (e0 >= e1) continue;
-        const uint32_t *__restrict__ s = idx_all + 3ull * (zr.tbase[r] + tplan[2u * seg]);
-        uint32_t m = 0;
-        for (uint32_t e = e0 + threadIdx.x; e < e1; e += 256) { const uint32_t v = s[e] + 1u; m = v > m ? v : m; }
-        for (int o = 32; o > 0; o >>= 1) { const uint32_t t = (uint32_t) __shfl_xor((int) m, o, 64); m = t > m ? t : m; }
-        if (lane_id() == 0 && m) atomicMax(&segmax[seg], m);
-    }
-}
-
-// per rank (one workgroup each): vstart[c] = local vertices first seen in the columns before c (prefix maximum of segmax), newcnt[c] = first seen in c
-__global__ __launch_bounds__(1024) void k_zs_vplan(const uint32_t *__restrict__ segmax, const ZsRanks *__restrict__ zrp, uint32_t *__restrict__ vstart,
-                                                    uint32_t *__restrict__ newcnt, uint32_t *__restrict__ status) {
-    const ZsRanks &zr = *zrp;
-    __shared__ uint32_t s[NCOL];
-    const uint32_t c = threadIdx.x, r = blockIdx.x;
-    s[c] = segmax[r * NCOL + c];
-    __syncthreads();
-    for (uint32_t o = 1; o < NCOL; o <<= 1) {                        // inclusive prefix maximum (Hillis-Steele: 10 steps)
-        const uint32_t a = s[c], b = c >= o ? s[c - o] : 0u;
-        __syncthreads();
-        s[c] = a > b ? a : b;
-        __syncthreads();
-    }
-    const uint32_t incl = s[c], excl = c ? s[c - 1u] : 0u;
-    vstart[r * NCOL + c] = excl;
-    newcnt[r * NCOL + c] = incl - excl;
-    if (c == NCOL - 1u && incl != zr.vbase[r + 1u] - zr.vbase[r]) atomicOr(&status[ST_INTERNAL], 256u);       // an unreferenced vertex
-}
-
-// root: vstart[r][c] = exclusive prefix over the columns of rank r's first-seen vertex counts (gathered with the column counts), newcnt = a
-// private copy of them (the band pairs decrement it)
-__global__ __launch_bounds__(1024) void k_zs_vstart(const uint32_t *__restrict__ vcounts, uint32_t cstride, const ZsRanks *__restrict__ zrp,
-                                                     uint32_t *__restrict__ vstart, uint32_t *__restrict__ newcnt, uint32_t *__restrict__ nband,
-                                                     uint32_t *__restrict__ status) {
-    const ZsRanks &zr = *zrp;
-    __shared__ uint32_t lds[17];
-    const uint32_t c = threadIdx.x, r = blockIdx.x;
-    const uint32_t n = vcounts[r * cstride + c];
-    uint32_t total;
-    vstart[r * NCOL + c] = block_excl_scan(n, total, lds);
-    newcnt[r * NCOL + c] = n;
-    if (c == 0 && total != zr.vbase[r + 1u] - zr.vbase[r]) atomicOr(&status[ST_INTERNAL], 512u);   // the counts do not add up to the rank's vertices
-    if (c == 0 && r == 0) *nband = 0;                                 // (the band counter of k_zs_band_insert, two launches on)
-}
-
-// every vertex learns its first-seen segment; its redirect starts as "kept"
-__global__ __launch_bounds__(256) void k_zs_segfill(const uint32_t *__restrict__ vstart, const uint32_t *__restrict__ newcnt, const ZsRanks *__restrict__ zrp,
-                                                     uint32_t *__restrict__ segof, uint32_t *__restrict__ redirect) {
-    const ZsRanks &zr = *zrp;
-    const uint32_t nseg = zr.nranks * NCOL;
-    for (uint32_t seg = blockIdx.x; seg < nseg; seg += gridDim.x) {
-        const uint32_t n = newcnt[seg], first = zr.vbase[seg / NCOL] + vstart[seg];
-        for (uint32_t i = threadIdx.x; i < n; i += 256) { segof[first + i] = seg; redirect[first + i] = U32_NONE; }
-    }
-}
-
-__device__ __forceinline__ bool zs_in_band(const ZsRanks &zr, uint32_t r, float z) {
-    return (zr.zhi[r] < zr.ztop && z >= zr.zhi[r] - zr.band) || (zr.zlo[r] > zr.zbot && z <= zr.zlo[r] + zr.band);
-}
-
-__global__ __launch_bounds__(256) void k_zs_band_insert(const Vertex *__restrict__ v, uint32_t V, const ZsRanks *__restrict__ zrp, uint64_t *__restrict__ hkeys,
-                                                         uint32_t *__restrict__ hmin, uint32_t hsize, uint32_t *__restrict__ nband,
-                                                         uint32_t *__restrict__ status) {
-    // (the band is counted per workgroup at the END of its grid-stride loop: one counter add per wave that holds a band vertex --
-    // nearly every wave does, every column crosses the slab faces -- would queue tens of thousands of atomics on one word.  The table
-    // has room for twice the keys it was planned for; a probe sequence that gets long anyway means the plan was too small.)
-    const ZsRanks &zr = *zrp;
-    __shared__ uint32_t s_n;
-    if (threadIdx.x == 0) s_n = 0;
-    __syncthreads();
-    uint32_t mine = 0;
-    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < V; i += gridDim.x * blockDim.x) {
-        const Point p = v[i].position;
-        if (!zs_in_band(zr, zs_rank_of(zr, i), p.z)) continue;
-        mine++;
-        uint64_t key;
-        if (!packed_weld_key(p, key)) { atomicOr(&status[ST_WELD_RANGE], 1u); continue; }
-        uint32_t s = hash_home(key, hsize);
-        bool placed = false;
-        for (uint32_t probe = 0; probe < 512u && probe < hsize; probe++) {
-            const uint64_t prev = atomicCAS((unsigned long long *) &hkeys[s], (unsigned long long) KEY_EMPTY, (unsigned long long) key);
-            if (prev == KEY_EMPTY || prev == key) { atomicMin(&hmin[s], i); placed = true; break; }
-            s = hash_next(s, hsize);
-        }
-        if (!placed) atomicOr(&status[ST_OVERFLOW], 64u);
-    }
-    const uint32_t ws = wave_sum(mine);
-    if (lane_id() == 0 && ws) atomicAdd(&s_n, ws);
-    __syncthreads();
-    if (threadIdx.x == 0 && s_n) atomicAdd(nband, s_n);
-}
-
-__global__ __launch_bounds__(256) void k_zs_band_resolve(const Vertex *__restrict__ v, uint32_t V, const ZsRanks *__restrict__ zrp, const uint64_t *__restrict__ hkeys,
-                                                          const uint32_t *__restrict__ hmin, uint32_t hsize, const uint32_t *__restrict__ segof,
-                                                          uint32_t *__restrict__ redirect, uint32_t *__restrict__ newcnt) {
-    const ZsRanks &zr = *zrp;
-    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < V; i += gridDim.x * blockDim.x) {
-        const Point p = v[i].position;
-        if (!zs_in_band(zr, zs_rank_of(zr, i), p.z)) continue;
-        uint64_t key;
-        if (!packed_weld_key(p, key)) continue;
-        uint32_t s = hash_home(key, hsize);
-        for (uint32_t probe = 0; probe < 512u && probe < hsize; probe++) {
-            const uint64_t k = hkeys[s];
-            if (k == KEY_EMPTY) break;
-            if (k == key) {
-                const uint32_t a = hmin[s];
-                if (a != i) {                                            // (a < i: the copy of a lower rank -- a rank's own keys are distinct)
-                    const uint32_t sa = segof[a], si = segof[i];
-                    // single-GPU order of the two first occurrences: by column, then by rank
-                    const bool a_first = (sa % NCOL) < (si % NCOL) || ((sa % NCOL) == (si % NCOL) && sa < si);
-                    const uint32_t win = a_first ? a : i, lose = a_first ? i : a;
-                    redirect[lose] = win;
-                    atomicSub(&newcnt[a_first ? si : sa], 1u);
-                }
-                break;
-            }
-            s = hash_next(s, hsize);
-        }
-    }
-}
-
-// kept vertices to their merged places; map[i] = merged number
-__global__ __launch_bounds__(256) void k_zs_vertex_out(const Vertex *__restrict__ v, uint32_t V, const ZsRanks *__restrict__ zrp, const uint32_t *__restrict__ redirect,
-                                                        const uint32_t *__restrict__ kept_before, const uint32_t *__restrict__ segof,
-                                                        const uint32_t *__restrict__ vstart, const uint32_t *__restrict__ vplan,
-                                                        Vertex *__restrict__ out, uint32_t cap, uint32_t *__restrict__ map) {
-    const ZsRanks &zr = *zrp;
-    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < V; i += gridDim.x * blockDim.x) {
-        if (redirect[i] != U32_NONE) continue;
-        const uint32_t seg = segof[i], first = zr.vbase[seg / NCOL] + vstart[seg];
-        const uint32_t g = vplan[2u * seg + 1u] + (kept_before[i] - kept_before[first]);
-        map[i] = g;
-        if (g < cap) out[g] = v[i];
-    }
-}
-
-// a dropped copy takes its partner's number (the partner is kept: its number is final).  Its own pass over the vertices: folded into the
-// index rewrite it would cost every one of the 3T index lookups a second gather (measured: +40 us at 2048^3, +0.2 ms at 4096^3)
-__global__ __launch_bounds__(256) void k_zs_loser_map(uint32_t V, const uint32_t *__restrict__ redirect, uint32_t *__restrict__ map) {
-    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < V; i += gridDim.x * blockDim.x) {
-        const uint32_t w = redirect[i];
-        if (w != U32_NONE) map[i] = map[w];
-    }
-}
-
-// the index buffers, segment by segment (gridDim.y workgroups share one), into the merged triangle order with merged vertex numbers
-__global__ __launch_bounds__(256) void k_zs_index_out(const uint32_t *__restrict__ idx_all, const uint32_t *__restrict__ counts, uint32_t cstride,
-                                                       const uint32_t *__restrict__ tplan, const ZsRanks *__restrict__ zrp, const uint32_t *__restrict__ map,
-                                                       uint32_t *__restrict__ out, uint32_t cap_tris) {
-    const ZsRanks &zr = *zrp;
-    const uint32_t nseg = zr.nranks * NCOL;
-    for (uint32_t seg = blockIdx.x; seg < nseg; seg += gridDim.x) {
-        const uint32_t r = seg / NCOL, n = counts[r * cstride + seg % NCOL];
-        if (n == 0) continue;
-        const uint32_t dst = tplan[2u * seg + 1u];
-        if (dst + n > cap_tris) continue;                              // flagged by k_merge_plan
-        const uint32_t ne = 3u * n, per = (ne + gridDim.y - 1u) / gridDim.y, e0 = blockIdx.y * per, e1 = e0 + per < ne ? e0 + per : ne;
-        const uint32_t *__restrict__ s = idx_all + 3ull * (zr.tbase[r] + tplan[2u * seg]);
-        uint32_t *__restrict__ d = out + 3ull * dst;
-        const uint32_t vb = zr.vbase[r];
-        for (uint32_t e = e0 + threadIdx.x; e < e1; e += 256) d[e] = map[vb + s[e]];
-    }
-}
-
-// ------------------------------------------------------------------------------------------
 // Dense mode: the same voxel list as the hierarchical refine, derived from
 // the dense (N+1)^3 sample lattice.
 //   P2a k_sign_bits      one bit per sample (sd <= 0): a pure streaming read, 4 B x (N+1)^3 -> HBM-bound
@@ -3062,11 +2758,11 @@ hipError_t launch_classify(hipStream_t st, int grid, int scene, const SceneParam
 hipError_t launch_tile_dedupe(hipStream_t st, int grid, const Point *vox, const uint32_t *n_ptr, Point vs, const uint8_t *cubeidx,
                               const uint32_t *tilecnt, uint32_t *trioff, uint32_t *tri_e, Vertex *uverts, uint4 *tdesc,
                               uint32_t ucap, uint32_t tcap, uint32_t *ntri_out, uint32_t *ntiles_out, uint32_t *status, uint64_t *dbg,
-                              bool prescan) {
+                              bool prescan, uint32_t *colcnt) {
     if (prescan)
         hipLaunchKernelGGL(k_scan_tiles, dim3(1), dim3(1024), 0, st, const_cast<uint32_t *>(tilecnt), n_ptr, 256u, ntri_out, tcap, status);
     hipLaunchKernelGGL(k_tile_dedupe, dim3(grid), dim3(256), 0, st, vox, n_ptr, vs, cubeidx, tilecnt, trioff, tri_e, uverts, tdesc,
-                       ucap, tcap, ntri_out, ntiles_out, status, dbg, prescan ? 1u : 0u);
+                       ucap, tcap, ntri_out, ntiles_out, status, dbg, prescan ? 1u : 0u, colcnt);
     return hipGetLastError();
 }
 
@@ -3347,54 +3043,6 @@ hipError_t launch_dist_finalize(hipStream_t st, int grid, const Vertex *v, uint3
 hipError_t launch_merge_plan(hipStream_t st, const uint32_t *d_counts, uint32_t cstride, int nranks, uint32_t *d_plan, uint32_t cap,
                              uint32_t *total_out, uint32_t *status) {
     hipLaunchKernelGGL(k_merge_plan, dim3(1), dim3(1024), 0, st, d_counts, cstride, (uint32_t) nranks, d_plan, cap, total_out, status);
-    return hipGetLastError();
-}
-
-// a rank's own first-seen vertex counts per column (carried to the root in the all-gather: the work stays where it is parallel)
-// workgroups that share one (rank, column) segment: enough for one element per thread in the occupied segments (about a third of the
-// columns hold surface), so that a segment's dependent loads are ONE round trip deep in small meshes; large meshes are bandwidth-bound anyway
-static uint32_t zs_seg_split(uint32_t tris, uint32_t nseg) {
-    const uint64_t per_seg = (9ull * tris + nseg - 1) / nseg;               // 3 indices per triangle, ~3x the average in the occupied segments
-    const uint64_t by_work = std::max<uint64_t>(1, (per_seg + 255) / 256), by_grid = std::max<uint64_t>(2, 16384 / nseg);   // (dispatching mostly
-    return (uint32_t) std::min<uint64_t>(16, std::min(by_work, by_grid));                                                      //  empty workgroups costs too)
-}
-
-hipError_t launch_zs_local_vcnt(hipStream_t st, const uint32_t *idx, uint32_t tris, const uint32_t *colcnt, const ZsRanks *d_zr1, uint32_t *tplan1, uint32_t *segmax,
-                                uint32_t *vstart, uint32_t *vcnt, uint32_t *scratch_total, uint32_t *status) {
-    hipLaunchKernelGGL(k_merge_plan, dim3(1), dim3(1024), 0, st, colcnt, 1024u, 1u, tplan1, 0xFFFFFFFFu, scratch_total, status);
-    (void) hipMemsetAsync(segmax, 0, 4096, st);
-    hipLaunchKernelGGL(k_zs_segmax, dim3(1024, zs_seg_split(tris, 1024u)), dim3(256), 0, st, idx, colcnt, 1024u, (const uint32_t *) tplan1, d_zr1, segmax);
-    hipLaunchKernelGGL(k_zs_vplan, dim3(1), dim3(1024), 0, st, (const uint32_t *) segmax, d_zr1, vstart, vcnt, status);
-    return hipGetLastError();
-}
-
-// z-slab indexed merge, first half: the segments' first-seen vertex ranges, every vertex's segment, the face-band pairs
-hipError_t launch_zs_front(hipStream_t st, int grid, const Vertex *v_all, const uint32_t *counts, uint32_t cstride, const uint32_t *vcounts,
-                           const ZsRanks &zr, const ZsRanks *d_zr, uint32_t *vstart, uint32_t *newcnt, uint32_t *segof,
-                           uint32_t *redirect, uint64_t *hkeys, uint32_t *hmin, uint32_t hsize, uint32_t *nband, uint32_t *status) {
-    const uint32_t V = zr.vbase[zr.nranks];
-    const int nseg = (int) (zr.nranks * 1024u);
-    (void) counts;
-    hipLaunchKernelGGL(k_zs_vstart, dim3(zr.nranks), dim3(1024), 0, st, vcounts, cstride, d_zr, vstart, newcnt, nband, status);
-    hipLaunchKernelGGL(k_zs_segfill, dim3(nseg), dim3(256), 0, st, (const uint32_t *) vstart, (const uint32_t *) newcnt, d_zr, segof, redirect);
-    if (zr.nranks > 1 && V) {
-        hipLaunchKernelGGL(k_zs_band_insert, dim3(grid), dim3(256), 0, st, v_all, V, d_zr, hkeys, hmin, hsize, nband, status);
-        hipLaunchKernelGGL(k_zs_band_resolve, dim3(grid), dim3(256), 0, st, v_all, V, d_zr, (const uint64_t *) hkeys, (const uint32_t *) hmin, hsize,
-                           (const uint32_t *) segof, redirect, newcnt);
-    }
-    return hipGetLastError();
-}
-
-// second half: merged vertices and indices (kept_before = the ordered numbering of the kept vertices, vplan = k_merge_plan of newcnt)
-hipError_t launch_zs_back(hipStream_t st, int grid, const Vertex *v_all, const uint32_t *idx_all, const uint32_t *counts, uint32_t cstride,
-                          const uint32_t *tplan, const ZsRanks &zr, const ZsRanks *d_zr, const uint32_t *redirect, const uint32_t *kept_before, const uint32_t *segof,
-                          const uint32_t *vstart, const uint32_t *vplan, Vertex *v_out, uint32_t cap_verts, uint32_t *map, uint32_t *i_out, uint32_t cap_tris) {
-    const uint32_t V = zr.vbase[zr.nranks];
-    if (V) {
-        hipLaunchKernelGGL(k_zs_vertex_out, dim3(grid), dim3(256), 0, st, v_all, V, d_zr, redirect, kept_before, segof, vstart, vplan, v_out, cap_verts, map);
-        if (zr.nranks > 1) hipLaunchKernelGGL(k_zs_loser_map, dim3(grid), dim3(256), 0, st, V, redirect, map);
-    }
-    hipLaunchKernelGGL(k_zs_index_out, dim3(zr.nranks * 1024u, zs_seg_split(zr.tbase[zr.nranks], zr.nranks * 1024u)), dim3(256), 0, st, idx_all, counts, cstride, tplan, d_zr, (const uint32_t *) map, i_out, cap_tris);
     return hipGetLastError();
 }
 

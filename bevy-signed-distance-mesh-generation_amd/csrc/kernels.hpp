@@ -58,7 +58,7 @@ hipError_t launch_classify(hipStream_t st, int grid, int scene, const SceneParam
 hipError_t launch_tile_dedupe(hipStream_t st, int grid, const Point *vox, const uint32_t *n_ptr, Point vs, const uint8_t *cubeidx,
                               const uint32_t *tilecnt, uint32_t *trioff, uint32_t *tri_e, Vertex *uverts, uint4 *tdesc,
                               uint32_t ucap, uint32_t tcap, uint32_t *ntri_out, uint32_t *ntiles_out, uint32_t *status, uint64_t *dbg = nullptr,
-                              bool prescan = false);
+                              bool prescan = false, uint32_t *colcnt = nullptr /* += triangles per level-0 column (pre-zeroed; z-slab gather) */);
 hipError_t launch_tile_prefix(hipStream_t st, const uint4 *tdesc, const uint32_t *ntiles_ptr, uint32_t *tpre, uint32_t *nu_out,
                               uint32_t *coarse);
 hipError_t launch_project(hipStream_t st, int grid, int scene, const SceneParams *sp, Vertex *uverts, const uint4 *tdesc,
@@ -112,25 +112,35 @@ hipError_t launch_column_counts(hipStream_t st, int grid, const Point *vox, cons
                                 uint32_t *colcnt);
 hipError_t launch_tile_tricount(hipStream_t st, int grid, const uint8_t *cubeidx, const uint32_t *n_ptr, uint32_t *tilecnt);
 // multi-GPU distributed weld (x-slabs)
-// z-slab indexed gather: the ranks' welded buffers concatenated in rank order (csrc/kernels.hip, "INDEXED gather")
+// ---- z-slab indexed gather (csrc/zslab.hip) -------------------------------------------------------------------------------
+// The ranks' welded slab buffers lie in SLOTS of the root's gather buffers: vertex i of rank r at vbase[r] + i, triangle t at
+// tbase[r] + t; vbase[r + 1] - vbase[r] is the slot's CAPACITY (a slot is as large as the message the root receives into it: the
+// exact count on the synchronous path, the planned size on the planned one), the actual counts are in the gathered rows.
 struct ZsRanks {
     uint32_t nranks;
-    uint32_t vbase[33], tbase[33];      // first vertex / triangle of rank r in the concatenated buffers; [nranks] = totals
+    uint32_t vbase[33], tbase[33];      // first vertex / triangle of rank r's slot; [nranks] = the slots' total
     float zlo[32], zhi[32];             // the slabs' z extents
     float zbot, ztop, band;             // the domain's z extent (a face on it is no slab face), half-width of the face bands
 };
-hipError_t launch_merge_plan(hipStream_t st, const uint32_t *d_counts, uint32_t cstride, int nranks, uint32_t *d_plan, uint32_t cap,
-                             uint32_t *total_out, uint32_t *status);
-// this rank's share of the indexed merge: vertices FIRST SEEN per level-0 column of its own welded slab (vcnt[1024]), from its index buffer
-hipError_t launch_zs_local_vcnt(hipStream_t st, const uint32_t *idx, uint32_t tris, const uint32_t *colcnt, const ZsRanks *d_zr1 /* one rank: {0, V}, {0, T} */,
-                                uint32_t *tplan1 /* [2048] */, uint32_t *segmax /* [1024] */, uint32_t *vstart /* [1024] */, uint32_t *vcnt /* [1024] */,
-                                uint32_t *scratch_total, uint32_t *status);
-hipError_t launch_zs_front(hipStream_t st, int grid, const Vertex *v_all, const uint32_t *counts, uint32_t cstride, const uint32_t *vcounts,
-                           const ZsRanks &zr /* host copy */, const ZsRanks *d_zr /* the same in device memory */, uint32_t *vstart, uint32_t *newcnt, uint32_t *segof,
-                           uint32_t *redirect, uint64_t *hkeys, uint32_t *hmin, uint32_t hsize, uint32_t *nband, uint32_t *status);
-hipError_t launch_zs_back(hipStream_t st, int grid, const Vertex *v_all, const uint32_t *idx_all, const uint32_t *counts, uint32_t cstride,
-                          const uint32_t *tplan, const ZsRanks &zr, const ZsRanks *d_zr, const uint32_t *redirect, const uint32_t *kept_before, const uint32_t *segof,
-                          const uint32_t *vstart, const uint32_t *vplan, Vertex *v_out, uint32_t cap_verts, uint32_t *map, uint32_t *i_out, uint32_t cap_tris);
+// words of a gathered row's record (row = 1024 column triangle counts | 1024 column first-seen vertex counts | record)
+enum ZsRec : uint32_t { ZR_STATUS = 0, ZR_TRIS = 1, ZR_CAP_V = 2, ZR_CAP_T = 3, ZR_VERTS = 4, ZR_FORM = 5, ZR_INJECT = 6, ZR_SIG = 7 };
+// words of the merge's own control block (device) and of what a step publishes to pinned host memory: [ZC_WORDS | R records of 8 words]
+enum ZsCtl : uint32_t { ZC_TRIS = 0, ZC_VERTS = 1, ZC_NBAND = 2, ZC_BANDFLAGS = 3 /* 1: weld range, 64: band hash full */, ZC_PLANFLAGS = 4 /* 1: rows invalid or over a slot's capacity, 2: merged triangles over capacity, 4: merged vertices over capacity */,
+                     ZC_SEQ = 5, ZC_RANKBAD = 8 /* + r: the vertex counts of rank r's row do not add up */, ZC_WORDS = 40 };
+// local phase, every rank: the slab's first-seen vertex counts per column from its own index buffer (row[1024 ..)), then the row's record;
+// `next_row`: the row of the next step's buffer, whose count areas are cleared here (the column counts are accumulated by k_tile_dedupe)
+hipError_t launch_zs_local(hipStream_t st, const uint32_t *idx, uint32_t tris_hint, uint32_t tri_cap, uint32_t *row, uint32_t *next_row,
+                           const uint32_t *ctr_tris, const uint32_t *ctr_verts, const uint32_t *status, uint32_t host_status, uint32_t cap_v,
+                           uint32_t cap_t, uint32_t inject, uint32_t sig);
+// root: the merge.  counts = the gathered rows (cstride words each); zr = the slot table (host copy for the grid sizes, d_zr the same in device
+// memory); the tables tplan / vplan [2 nseg], vstart / newcnt [nseg], per slot vertex segof / redirect / map; hash (hsize slots: 8-byte keys,
+// then 4-byte minima) only with more than one rank; zctl = ZC_WORDS words; pub (pinned host, optional) receives zctl and the records
+hipError_t launch_zs_merge(hipStream_t st, int grid, const Vertex *v_all, const uint32_t *idx_all, const uint32_t *counts, uint32_t cstride,
+                           const ZsRanks &zr, const ZsRanks *d_zr, uint32_t *tplan, uint32_t *vplan, uint32_t *vstart, uint32_t *newcnt,
+                           uint32_t *segof, uint32_t *redirect, uint32_t *map, uint64_t *hkeys, uint32_t hsize, Vertex *v_out, uint32_t cap_verts,
+                           uint32_t *i_out, uint32_t cap_tris, uint32_t *zctl, uint32_t seq, uint32_t *pub);
+// peers: the records (and a zeroed control block) to pinned host memory
+hipError_t launch_zs_publish(hipStream_t st, const uint32_t *counts, uint32_t cstride, uint32_t nranks, const uint32_t *zctl, uint32_t seq, uint32_t *pub);
 hipError_t launch_band_select(hipStream_t st, int grid, const Vertex *v, uint32_t V, float up_thr, float lo_thr, bool has_up, bool has_lo,
                               uint32_t *up_ids, uint64_t *up_keys, uint32_t *lo_ids, uint32_t *ctr, uint32_t *dup_of, uint32_t *status);
 hipError_t launch_dist_match(hipStream_t st, int grid, const uint64_t *prev_keys, uint32_t n_prev, uint64_t *hkeys, uint32_t *hpos, uint32_t hsize,

@@ -1,0 +1,430 @@
+// zslab.hip -- multi-GPU, z-slabs, INDEXED gather (the north star's "RCCL gather of per-slab vertex/index buffers").
+//
+// The reference is single-device (src/cuda/mod.rs:52); this is the build's own extension.  Every rank meshes AND welds its own
+// level-0 z-slab; the root receives the slabs' vertex and index buffers (24 B per vertex + 12 B per triangle, against 72 B per
+// triangle for raw lists) and restores the single-GPU mesh from them WITHOUT welding anything again -- no hash claim per corner,
+// only streaming passes over the gathered buffers:
+//
+//   * a rank's welded vertices are numbered in its own first-seen order (src/cuda/mod.rs:276-296), so the number of distinct
+//     vertices in its first n triangles is 1 + the largest index among them: the largest index per column segment, prefix-maximised
+//     over the columns, gives the number of local vertices FIRST SEEN in each level-0 column -- computed by every rank for its own
+//     slab (k_zs_segmax, k_zs_rowfinish) and carried to the root in the all-gather beside the column triangle counts;
+//   * in the single-GPU order (x outer, y, z inner: src/cuda/mod.rs:105-122) a level-0 column holds rank 0's triangles, then rank
+//     1's, ...: so the single-GPU first-seen vertex order is, column by column and rank by rank, each (rank, column) segment's
+//     first-seen vertices in their local order -- vertex buffers merge by segments exactly like the triangle lists;
+//   * the only vertices two slabs can share lie within `band` of a slab face: those go through one small hash (key -> smallest
+//     slot vertex id) and look themselves up; of a pair the copy whose first-seen segment comes first in the (column, rank) order
+//     is the single-GPU representative, the other one is dropped from its segment's count and redirected;
+//   * kept vertices are numbered segment by segment (a block scan inside the segment: no global scan) and written to their merged
+//     places, the dropped ones inherit their partner's number, and the index buffers are rewritten segment by segment.
+//
+// Inputs lie in SLOTS (kernels.hpp, ZsRanks): slot capacities come from the host (exact counts on the synchronous path, planned
+// sizes on the planned one, where the host does not know the counts when it enqueues the kernels); the ACTUAL counts are read from
+// the gathered rows on the device.  Every kernel first checks the rows against the slots (zs_rows_ok) and does nothing if a rank
+// reported a failure or a count exceeds its slot: the host sees the same records and repeats the step synchronously.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include <algorithm>
+
+#include "kernels.hpp"
+#include "prims.hpp"
+
+namespace sdm {
+
+static constexpr uint32_t NCOL = MESH_GENERATION_INIT_FACTOR * MESH_GENERATION_INIT_FACTOR;     // 1024 level-0 columns
+static constexpr uint32_t ZS_GAP = 0xfffffffeu;        // redirect[] of a slot entry behind the rank's last vertex
+static_assert(SHARD_REC == 2 * NCOL, "a row is 1024 triangle counts, 1024 vertex counts, the record");
+
+__device__ __forceinline__ uint32_t row_rec(const uint32_t *__restrict__ counts, uint32_t cstride, uint32_t r, uint32_t w) {
+    return counts[(size_t) r * cstride + SHARD_REC + w];
+}
+
+// every rank healthy and inside its slot?  (uniform over the grid: every workgroup evaluates the same words)  All threads must call.
+__device__ __forceinline__ bool zs_rows_ok(const uint32_t *__restrict__ counts, uint32_t cstride, const ZsRanks &zr) {
+    bool bad = false;
+    if (threadIdx.x < zr.nranks) {
+        const uint32_t r = threadIdx.x;
+        bad = row_rec(counts, cstride, r, ZR_STATUS) != 0u || row_rec(counts, cstride, r, ZR_FORM) != 1u ||
+              row_rec(counts, cstride, r, ZR_VERTS) > zr.vbase[r + 1u] - zr.vbase[r] || row_rec(counts, cstride, r, ZR_TRIS) > zr.tbase[r + 1u] - zr.tbase[r];
+    }
+    return __syncthreads_or(bad ? 1 : 0) == 0;
+}
+
+// src_start[r][c] = sum_{c' < c} counts[r][c'];  dst_start[r][c] = sum_{c' < c} sum_r' counts[r'][c'] + sum_{r' < r} counts[r'][c]
+// -> plan[(r * NCOL + c) * 2 + {0, 1}]; returns the grand total.  One 1024-thread workgroup, thread = column.
+__device__ __forceinline__ uint32_t zs_plan_body(const uint32_t *__restrict__ counts, uint32_t cstride, uint32_t nranks, uint32_t *__restrict__ plan,
+                                                 uint32_t *__restrict__ lds) {
+    const uint32_t c = threadIdx.x;
+    uint32_t col_total = 0;
+    for (uint32_t r = 0; r < nranks; r++) col_total += counts[(size_t) r * cstride + c];
+    uint32_t total;
+    const uint32_t col_base = block_excl_scan(col_total, total, lds);
+    uint32_t within = 0;
+    for (uint32_t r = 0; r < nranks; r++) {
+        const uint32_t n = counts[(size_t) r * cstride + c];
+        uint32_t rank_total;
+        const uint32_t src = block_excl_scan(n, rank_total, lds);
+        plan[(r * NCOL + c) * 2u] = src;
+        plan[(r * NCOL + c) * 2u + 1u] = col_base + within;
+        within += n;
+    }
+    return total;
+}
+
+// ------------------------------------------------------------------------------------------
+// local phase (every rank)
+// ------------------------------------------------------------------------------------------
+// largest local vertex index + 1 of every column segment of this rank's index buffer -> row[NCOL + c] (pre-zeroed; gridDim.y
+// workgroups share a segment: segments are very uneven, a column holds anything from nothing to tens of thousands of triangles).
+// Each workgroup sums the column counts in front of its column itself (<= 1024 words): no plan launch in front.
+__global__ __launch_bounds__(256) void k_zs_segmax(const uint32_t *__restrict__ idx, uint32_t tri_cap, uint32_t *__restrict__ row) {
+    __shared__ uint32_t s_red[4];
+    const uint32_t c = blockIdx.x, tid = threadIdx.x;
+    const uint32_t n = row[c];
+    if (n == 0) return;
+    uint32_t part = 0;
+    for (uint32_t i = tid; i < c; i += 256) part += row[i];
+    part = wave_sum(part);
+    if (lane_id() == 0) s_red[tid >> 6] = part;
+    __syncthreads();
+    const uint32_t src = s_red[0] + s_red[1] + s_red[2] + s_red[3];
+    if (src + n > tri_cap) return;                                     // (counts of a chain that overflowed: the record says so)
+    const uint32_t ne = 3u * n, per = (ne + gridDim.y - 1u) / gridDim.y, e0 = blockIdx.y * per, e1 = e0 + per < ne ? e0 + per : ne;
+    const uint32_t *__restrict__ s = idx + 3ull * src;
+    uint32_t m = 0;
+    for (uint32_t e = e0 + tid; e < e1; e += 256) { const uint32_t v = s[e] + 1u; m = v > m ? v : m; }
+    for (int o = 32; o > 0; o >>= 1) { const uint32_t t = (uint32_t) __shfl_xor((int) m, o, 64); m = t > m ? t : m; }
+    if (lane_id() == 0 && m) atomicMax(&row[NCOL + c], m);
+}
+
+// One workgroup: row[NCOL + c] (segment maxima) -> first-seen vertex counts per column (prefix maximum, then differences), the
+// checks that make the row trustworthy, the row's record, and the clear of the NEXT step's row (k_tile_dedupe accumulates the
+// column counts of the next chain into it; the buffers alternate).
+__global__ __launch_bounds__(1024) void k_zs_rowfinish(uint32_t *__restrict__ row, uint32_t *__restrict__ next_row, const uint32_t *__restrict__ ctr_tris,
+                                                        const uint32_t *__restrict__ ctr_verts, const uint32_t *__restrict__ status, uint32_t host_status,
+                                                        uint32_t cap_v, uint32_t cap_t, uint32_t inject, uint32_t sig) {
+    __shared__ uint32_t s[NCOL];
+    __shared__ uint32_t lds[17];
+    const uint32_t c = threadIdx.x;
+    const bool failed = host_status != 0u;                             // the host already knows this rank's local phase failed: an empty row
+    const uint32_t T = failed ? 0u : *ctr_tris, V = failed ? 0u : *ctr_verts;
+    const uint32_t tc = failed ? 0u : row[c];
+    s[c] = failed ? 0u : row[NCOL + c];
+    __syncthreads();
+    for (uint32_t o = 1; o < NCOL; o <<= 1) {                        // inclusive prefix maximum (Hillis-Steele: 10 steps)
+        const uint32_t a = s[c], b = c >= o ? s[c - o] : 0u;
+        __syncthreads();
+        s[c] = a > b ? a : b;
+        __syncthreads();
+    }
+    const uint32_t incl = s[c], excl = c ? s[c - 1u] : 0u;
+    uint32_t tsum;
+    (void) block_excl_scan(tc, tsum, lds);
+    if (failed) row[c] = 0u;
+    row[NCOL + c] = incl - excl;
+    if (next_row) { next_row[c] = 0u; next_row[NCOL + c] = 0u; }
+    if (c == NCOL - 1u) {
+        uint32_t st = host_status;
+        if (!failed) {
+            // what makes the local chain's result unusable: a capacity of the plan exceeded, a field the lattice path cannot take, a
+            // vertex outside the packed key range, an invariant -- and a row that does not describe the buffers
+            const uint32_t dev = (status[ST_OVERFLOW] ? 1u : 0u) | (status[ST_NOT_LATTICE] ? 2u : 0u) | (status[ST_WELD_RANGE] ? 4u : 0u) |
+                                 (status[ST_INTERNAL] ? 8u : 0u) | (status[ST_TILE_OVERFLOW] ? 16u : 0u) | (status[ST_NONFINITE] ? 32u : 0u) |
+                                 (tsum != T ? 64u : 0u) | (incl != V ? 128u : 0u);
+            if (dev) st = 0x80000000u | dev;
+        }
+        uint32_t *rec = row + SHARD_REC;
+        rec[ZR_STATUS] = st; rec[ZR_TRIS] = T; rec[ZR_CAP_V] = cap_v; rec[ZR_CAP_T] = cap_t;
+        rec[ZR_VERTS] = V; rec[ZR_FORM] = 1u; rec[ZR_INJECT] = inject; rec[ZR_SIG] = sig;
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// the merge (root)
+// ------------------------------------------------------------------------------------------
+__device__ __forceinline__ uint32_t zs_rank_of(const ZsRanks &zr, uint32_t i) {
+    uint32_t r = 0;
+    while (r + 1u < zr.nranks && i >= zr.vbase[r + 1u]) r++;
+    return r;
+}
+
+// One launch in front of everything else.  Workgroup (r, g) of the first nranks * 64: the exclusive prefix of rank r's first-seen
+// vertex counts (one block scan of the row), then its sixteen columns: vstart / newcnt of the segments, every vertex of theirs
+// learns its segment and starts as "kept" (the vertices of sixteen consecutive columns are one contiguous range of the slot).  The last
+// group of a rank checks the row's sum and marks the slot's unused tail.  The extra workgroup plans the triangle segments
+// (and, with one rank, the vertex segments: nothing can be dropped) and resets the merge's counters.  With more than one rank the
+// whole grid also clears the band hash.
+__global__ __launch_bounds__(1024) void k_zs_front(const uint32_t *__restrict__ counts, uint32_t cstride, const ZsRanks *__restrict__ zrp,
+                                                    uint32_t *__restrict__ tplan, uint32_t *__restrict__ vplan, uint32_t *__restrict__ vstart,
+                                                    uint32_t *__restrict__ newcnt, uint32_t *__restrict__ segof, uint32_t *__restrict__ redirect,
+                                                    uint32_t *__restrict__ hclear, uint32_t hwords, uint32_t cap_verts, uint32_t cap_tris,
+                                                    uint32_t *__restrict__ zctl) {
+    const ZsRanks &zr = *zrp;
+    __shared__ uint32_t lds[17];
+    __shared__ uint32_t s_b[17];
+    const uint32_t tid = threadIdx.x, R = zr.nranks, groups = R * 64u;
+    const bool ok = zs_rows_ok(counts, cstride, zr);
+    if (blockIdx.x == groups) {
+        uint32_t flags = ok ? 0u : 1u, T = 0, V = 0;
+        if (ok) {
+            T = zs_plan_body(counts, cstride, R, tplan, lds);
+            if (T > cap_tris) flags |= 2u;
+            if (R == 1u) {
+                V = zs_plan_body(counts + NCOL, cstride, 1u, vplan, lds);
+                if (V > cap_verts) flags |= 4u;
+            }
+        }
+        if (tid == 0) { zctl[ZC_TRIS] = T; zctl[ZC_VERTS] = V; zctl[ZC_NBAND] = 0u; zctl[ZC_BANDFLAGS] = 0u; zctl[ZC_PLANFLAGS] = flags; }
+        return;
+    }
+    if (!ok) return;
+    for (uint32_t i = blockIdx.x * 1024u + tid; i < hwords; i += groups * 1024u) hclear[i] = 0xffffffffu;      // (all-ones = empty key = no vertex yet)
+    const uint32_t r = blockIdx.x >> 6, c0 = (blockIdx.x & 63u) * 16u;
+    const uint32_t vc = counts[(size_t) r * cstride + NCOL + tid];
+    uint32_t total;
+    const uint32_t ex = block_excl_scan(vc, total, lds);
+    if (tid >= c0 && tid < c0 + 16u) { vstart[r * NCOL + tid] = ex; newcnt[r * NCOL + tid] = vc; s_b[tid - c0] = ex; }
+    if (tid == c0 + 16u) s_b[16] = ex;
+    if (c0 + 16u == NCOL && tid == 0) s_b[16] = total;
+    __syncthreads();
+    const uint32_t Vr = row_rec(counts, cstride, r, ZR_VERTS), vb = zr.vbase[r];
+    const uint32_t a = s_b[0], b = s_b[16] < Vr ? s_b[16] : Vr;
+    for (uint32_t i = a + tid; i < b; i += 1024u) {
+        uint32_t k = 0;
+#pragma unroll
+        for (uint32_t j = 1; j < 16u; j++) k += s_b[j] <= i ? 1u : 0u;
+        segof[vb + i] = r * NCOL + c0 + k;
+        redirect[vb + i] = U32_NONE;
+    }
+    if (c0 + 16u == NCOL) {
+        if (tid == 0) zctl[ZC_RANKBAD + r] = total != Vr ? 1u : 0u;       // the counts do not add up to the rank's vertices
+        const uint32_t cap = zr.vbase[r + 1u] - vb;
+        for (uint32_t i = Vr + tid; i < cap; i += 1024u) redirect[vb + i] = ZS_GAP;
+    }
+}
+
+__device__ __forceinline__ bool zs_in_band(const ZsRanks &zr, uint32_t r, float z) {
+    return (zr.zhi[r] < zr.ztop && z >= zr.zhi[r] - zr.band) || (zr.zlo[r] > zr.zbot && z <= zr.zlo[r] + zr.band);
+}
+
+__global__ __launch_bounds__(256) void k_zs_band_insert(const Vertex *__restrict__ v, const uint32_t *__restrict__ counts, uint32_t cstride,
+                                                         const ZsRanks *__restrict__ zrp, const uint32_t *__restrict__ redirect, uint64_t *__restrict__ hkeys,
+                                                         uint32_t *__restrict__ hmin, uint32_t hsize, uint32_t *__restrict__ zctl) {
+    // (the band is counted per workgroup at the END of its grid-stride loop: one counter add per wave that holds a band vertex --
+    // nearly every wave does, every column crosses the slab faces -- would queue tens of thousands of atomics on one word.  The table
+    // has room for twice the keys it was planned for; a probe sequence that gets long anyway means the plan was too small.)
+    const ZsRanks &zr = *zrp;
+    __shared__ uint32_t s_n;
+    if (!zs_rows_ok(counts, cstride, zr)) return;
+    if (threadIdx.x == 0) s_n = 0;
+    __syncthreads();
+    const uint32_t V = zr.vbase[zr.nranks];
+    uint32_t mine = 0;
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < V; i += gridDim.x * blockDim.x) {
+        if (redirect[i] == ZS_GAP) continue;
+        const Point p = v[i].position;
+        if (!zs_in_band(zr, zs_rank_of(zr, i), p.z)) continue;
+        mine++;
+        uint64_t key;
+        if (!packed_weld_key(p, key)) { atomicOr(&zctl[ZC_BANDFLAGS], 1u); continue; }
+        uint32_t s = hash_home(key, hsize);
+        bool placed = false;
+        for (uint32_t probe = 0; probe < 512u && probe < hsize; probe++) {
+            const uint64_t prev = atomicCAS((unsigned long long *) &hkeys[s], (unsigned long long) KEY_EMPTY, (unsigned long long) key);
+            if (prev == KEY_EMPTY || prev == key) { atomicMin(&hmin[s], i); placed = true; break; }
+            s = hash_next(s, hsize);
+        }
+        if (!placed) atomicOr(&zctl[ZC_BANDFLAGS], 64u);
+    }
+    const uint32_t ws = wave_sum(mine);
+    if (lane_id() == 0 && ws) atomicAdd(&s_n, ws);
+    __syncthreads();
+    if (threadIdx.x == 0 && s_n) atomicAdd(&zctl[ZC_NBAND], s_n);
+}
+
+__global__ __launch_bounds__(256) void k_zs_band_resolve(const Vertex *__restrict__ v, const uint32_t *__restrict__ counts, uint32_t cstride,
+                                                          const ZsRanks *__restrict__ zrp, const uint64_t *__restrict__ hkeys,
+                                                          const uint32_t *__restrict__ hmin, uint32_t hsize, const uint32_t *__restrict__ segof,
+                                                          uint32_t *__restrict__ redirect, uint32_t *__restrict__ newcnt) {
+    const ZsRanks &zr = *zrp;
+    if (!zs_rows_ok(counts, cstride, zr)) return;
+    const uint32_t V = zr.vbase[zr.nranks];
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < V; i += gridDim.x * blockDim.x) {
+        if (redirect[i] == ZS_GAP) continue;          // (a slot entry behind the rank's vertices; only `lose` entries are rewritten below, never to ZS_GAP)
+        const Point p = v[i].position;
+        if (!zs_in_band(zr, zs_rank_of(zr, i), p.z)) continue;
+        uint64_t key;
+        if (!packed_weld_key(p, key)) continue;
+        uint32_t s = hash_home(key, hsize);
+        for (uint32_t probe = 0; probe < 512u && probe < hsize; probe++) {
+            const uint64_t k = hkeys[s];
+            if (k == KEY_EMPTY) break;
+            if (k == key) {
+                const uint32_t a = hmin[s];
+                if (a != i) {                                            // (a < i: the copy of a lower rank -- a rank's own keys are distinct)
+                    const uint32_t sa = segof[a], si = segof[i];
+                    // single-GPU order of the two first occurrences: by column, then by rank
+                    const bool a_first = (sa % NCOL) < (si % NCOL) || ((sa % NCOL) == (si % NCOL) && sa < si);
+                    const uint32_t win = a_first ? a : i, lose = a_first ? i : a;
+                    redirect[lose] = win;
+                    atomicSub(&newcnt[a_first ? si : sa], 1u);
+                }
+                break;
+            }
+            s = hash_next(s, hsize);
+        }
+    }
+}
+
+// more than one rank: the vertex segments' merged places, from the counts the band pairs have decremented (one workgroup)
+__global__ __launch_bounds__(1024) void k_zs_vplan(const uint32_t *__restrict__ counts, uint32_t cstride, const ZsRanks *__restrict__ zrp,
+                                                    const uint32_t *__restrict__ newcnt, uint32_t *__restrict__ vplan, uint32_t cap_verts,
+                                                    uint32_t *__restrict__ zctl) {
+    const ZsRanks &zr = *zrp;
+    __shared__ uint32_t lds[17];
+    if (!zs_rows_ok(counts, cstride, zr)) return;
+    const uint32_t V = zs_plan_body(newcnt, NCOL, zr.nranks, vplan, lds);
+    if (threadIdx.x == 0) {
+        zctl[ZC_VERTS] = V;
+        if (V > cap_verts) atomicOr(&zctl[ZC_PLANFLAGS], 4u);
+    }
+}
+
+// kept vertices to their merged places; map[i] = merged number.  One workgroup per (rank, column) segment, four consecutive
+// vertices per thread and pass; the place inside the segment is a block scan over the kept flags (only band vertices are ever dropped).
+__global__ __launch_bounds__(256) void k_zs_vertex_out(const Vertex *__restrict__ v, const uint32_t *__restrict__ counts, uint32_t cstride,
+                                                        const ZsRanks *__restrict__ zrp, const uint32_t *__restrict__ redirect,
+                                                        const uint32_t *__restrict__ vstart, const uint32_t *__restrict__ vplan,
+                                                        Vertex *__restrict__ out, uint32_t cap, uint32_t *__restrict__ map) {
+    const ZsRanks &zr = *zrp;
+    __shared__ uint32_t lds[17];
+    if (!zs_rows_ok(counts, cstride, zr)) return;
+    const uint32_t tid = threadIdx.x;
+    for (uint32_t seg = blockIdx.x; seg < zr.nranks * NCOL; seg += gridDim.x) {
+        const uint32_t r = seg / NCOL;
+        uint32_t n0 = counts[(size_t) r * cstride + NCOL + seg % NCOL];
+        if (n0 == 0) continue;
+        const uint32_t vs0 = vstart[seg], Vr = row_rec(counts, cstride, r, ZR_VERTS);
+        if (vs0 >= Vr) continue;
+        if (n0 > Vr - vs0) n0 = Vr - vs0;                                   // (only if the row's counts do not add up: flagged by k_zs_front)
+        const uint32_t first = zr.vbase[r] + vs0, dst = vplan[2u * seg + 1u];
+        uint32_t run = 0;
+        for (uint32_t base = 0; base < n0; base += 1024u) {
+            const uint32_t k0 = base + 4u * tid;
+            uint32_t keep = 0;
+#pragma unroll
+            for (uint32_t j = 0; j < 4u; j++)
+                if (k0 + j < n0 && redirect[first + k0 + j] == U32_NONE) keep |= 1u << j;
+            uint32_t total;
+            uint32_t pos = dst + run + block_excl_scan((uint32_t) __popc(keep), total, lds);
+#pragma unroll
+            for (uint32_t j = 0; j < 4u; j++)
+                if (keep & (1u << j)) {
+                    map[first + k0 + j] = pos;
+                    if (pos < cap) out[pos] = v[first + k0 + j];
+                    pos++;
+                }
+            run += total;
+        }
+    }
+}
+
+// a dropped copy takes its partner's number (the partner is kept: its number is final).  Its own pass over the vertices: folded into the
+// index rewrite it would cost every one of the 3T index lookups a second gather (measured: +40 us at 2048^3, +0.2 ms at 4096^3)
+__global__ __launch_bounds__(256) void k_zs_loser_map(const uint32_t *__restrict__ counts, uint32_t cstride, const ZsRanks *__restrict__ zrp,
+                                                       const uint32_t *__restrict__ redirect, uint32_t *__restrict__ map) {
+    const ZsRanks &zr = *zrp;
+    if (!zs_rows_ok(counts, cstride, zr)) return;
+    const uint32_t V = zr.vbase[zr.nranks];
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < V; i += gridDim.x * blockDim.x) {
+        const uint32_t w = redirect[i];
+        if (w != U32_NONE && w != ZS_GAP) map[i] = map[w];
+    }
+}
+
+__device__ __forceinline__ void zs_publish_body(const uint32_t *__restrict__ counts, uint32_t cstride, uint32_t nranks, const uint32_t *__restrict__ zctl,
+                                                uint32_t seq, uint32_t *__restrict__ pub) {
+    const uint32_t tid = threadIdx.x;
+    if (tid < ZC_WORDS) pub[tid] = tid == ZC_SEQ ? seq : (zctl ? zctl[tid] : 0u);
+    if (tid < nranks * 8u) pub[ZC_WORDS + tid] = counts[(size_t) (tid >> 3) * cstride + SHARD_REC + (tid & 7u)];
+}
+
+// the index buffers, segment by segment (gridDim.y workgroups share one), into the merged triangle order with merged vertex numbers.
+// Workgroup (0, 0) also publishes the step's control block and the ranks' records to pinned host memory: every word of them was
+// final before this kernel started (no read-back copy behind the chain).
+__global__ __launch_bounds__(256) void k_zs_index_out(const uint32_t *__restrict__ idx_all, const uint32_t *__restrict__ counts, uint32_t cstride,
+                                                       const uint32_t *__restrict__ tplan, const ZsRanks *__restrict__ zrp, const uint32_t *__restrict__ map,
+                                                       uint32_t *__restrict__ out, uint32_t cap_tris, const uint32_t *__restrict__ zctl, uint32_t seq,
+                                                       uint32_t *__restrict__ pub) {
+    const ZsRanks &zr = *zrp;
+    if (pub && blockIdx.x == 0 && blockIdx.y == 0) zs_publish_body(counts, cstride, zr.nranks, zctl, seq, pub);
+    if (!zs_rows_ok(counts, cstride, zr)) return;
+    const uint32_t nseg = zr.nranks * NCOL;
+    for (uint32_t seg = blockIdx.x; seg < nseg; seg += gridDim.x) {
+        const uint32_t r = seg / NCOL, n = counts[(size_t) r * cstride + seg % NCOL];
+        if (n == 0) continue;
+        const uint32_t src = tplan[2u * seg], dst = tplan[2u * seg + 1u];
+        if (dst + n > cap_tris || src + n > row_rec(counts, cstride, r, ZR_TRIS)) continue;      // flagged by k_zs_front / the row's own check
+        const uint32_t ne = 3u * n, per = (ne + gridDim.y - 1u) / gridDim.y, e0 = blockIdx.y * per, e1 = e0 + per < ne ? e0 + per : ne;
+        const uint32_t *__restrict__ s = idx_all + 3ull * (zr.tbase[r] + src);
+        uint32_t *__restrict__ d = out + 3ull * dst;
+        const uint32_t vb = zr.vbase[r];
+        for (uint32_t e = e0 + threadIdx.x; e < e1; e += 256) d[e] = map[vb + s[e]];
+    }
+}
+
+__global__ __launch_bounds__(256) void k_zs_publish(const uint32_t *__restrict__ counts, uint32_t cstride, uint32_t nranks, const uint32_t *__restrict__ zctl,
+                                                     uint32_t seq, uint32_t *__restrict__ pub) {
+    zs_publish_body(counts, cstride, nranks, zctl, seq, pub);
+}
+
+// ------------------------------------------------------------------------------------------
+// launchers
+// ------------------------------------------------------------------------------------------
+// workgroups that share one (rank, column) segment: enough for one element per thread in the occupied segments (about a third of the
+// columns hold surface), so that a segment's dependent loads are ONE round trip deep in small meshes; large meshes are bandwidth-bound anyway
+static uint32_t zs_seg_split(uint32_t tris, uint32_t nseg) {
+    const uint64_t per_seg = (9ull * tris + nseg - 1) / nseg;               // 3 indices per triangle, ~3x the average in the occupied segments
+    const uint64_t by_work = std::max<uint64_t>(1, (per_seg + 255) / 256), by_grid = std::max<uint64_t>(2, 16384 / nseg);   // (dispatching mostly
+    return (uint32_t) std::min<uint64_t>(16, std::min(by_work, by_grid));                                                      //  empty workgroups costs too)
+}
+
+hipError_t launch_zs_local(hipStream_t st, const uint32_t *idx, uint32_t tris_hint, uint32_t tri_cap, uint32_t *row, uint32_t *next_row,
+                           const uint32_t *ctr_tris, const uint32_t *ctr_verts, const uint32_t *status, uint32_t host_status, uint32_t cap_v,
+                           uint32_t cap_t, uint32_t inject, uint32_t sig) {
+    if (!host_status)
+        hipLaunchKernelGGL(k_zs_segmax, dim3(NCOL, zs_seg_split(tris_hint, NCOL)), dim3(256), 0, st, idx, tri_cap, row);
+    hipLaunchKernelGGL(k_zs_rowfinish, dim3(1), dim3(1024), 0, st, row, next_row, ctr_tris, ctr_verts, status, host_status, cap_v, cap_t, inject, sig);
+    return hipGetLastError();
+}
+
+hipError_t launch_zs_merge(hipStream_t st, int grid, const Vertex *v_all, const uint32_t *idx_all, const uint32_t *counts, uint32_t cstride,
+                           const ZsRanks &zr, const ZsRanks *d_zr, uint32_t *tplan, uint32_t *vplan, uint32_t *vstart, uint32_t *newcnt,
+                           uint32_t *segof, uint32_t *redirect, uint32_t *map, uint64_t *hkeys, uint32_t hsize, Vertex *v_out, uint32_t cap_verts,
+                           uint32_t *i_out, uint32_t cap_tris, uint32_t *zctl, uint32_t seq, uint32_t *pub) {
+    const uint32_t R = zr.nranks, nseg = R * NCOL;
+    const bool band = R > 1;
+    hipLaunchKernelGGL(k_zs_front, dim3(R * 64u + 1u), dim3(1024), 0, st, counts, cstride, d_zr, tplan, vplan, vstart, newcnt, segof, redirect,
+                       band ? (uint32_t *) hkeys : nullptr, band ? 3u * hsize : 0u, cap_verts, cap_tris, zctl);
+    if (band) {
+        uint32_t *hmin = (uint32_t *) (hkeys + hsize);
+        hipLaunchKernelGGL(k_zs_band_insert, dim3(grid), dim3(256), 0, st, v_all, counts, cstride, d_zr, (const uint32_t *) redirect, hkeys, hmin, hsize, zctl);
+        hipLaunchKernelGGL(k_zs_band_resolve, dim3(grid), dim3(256), 0, st, v_all, counts, cstride, d_zr, (const uint64_t *) hkeys, (const uint32_t *) hmin,
+                           hsize, (const uint32_t *) segof, redirect, newcnt);
+        hipLaunchKernelGGL(k_zs_vplan, dim3(1), dim3(1024), 0, st, counts, cstride, d_zr, (const uint32_t *) newcnt, vplan, cap_verts, zctl);
+    }
+    hipLaunchKernelGGL(k_zs_vertex_out, dim3(nseg), dim3(256), 0, st, v_all, counts, cstride, d_zr, (const uint32_t *) redirect, (const uint32_t *) vstart,
+                       (const uint32_t *) vplan, v_out, cap_verts, map);
+    if (band) hipLaunchKernelGGL(k_zs_loser_map, dim3(grid), dim3(256), 0, st, counts, cstride, d_zr, (const uint32_t *) redirect, map);
+    hipLaunchKernelGGL(k_zs_index_out, dim3(nseg, zs_seg_split(zr.tbase[R], nseg)), dim3(256), 0, st, idx_all, counts, cstride, (const uint32_t *) tplan, d_zr,
+                       (const uint32_t *) map, i_out, cap_tris, (const uint32_t *) zctl, seq, pub);
+    return hipGetLastError();
+}
+
+hipError_t launch_zs_publish(hipStream_t st, const uint32_t *counts, uint32_t cstride, uint32_t nranks, const uint32_t *zctl, uint32_t seq, uint32_t *pub) {
+    hipLaunchKernelGGL(k_zs_publish, dim3(1), dim3(256), 0, st, counts, cstride, nranks, zctl, seq, pub);
+    return hipGetLastError();
+}
+
+}  // namespace sdm

@@ -371,6 +371,10 @@ class CudaHandler:
         self._chk(self._lib.sdmesh_sharded_regen(self._h, int(levels), int(root), ctypes.byref(info)))
         return info
 
+    def sharded_route(self):
+        """Route of the last indexed sharded step on this handle: 1 planned, 2 synchronous, 3 planned then repeated synchronously."""
+        return int(self._lib.sdmesh_sharded_route(self._h))
+
     def distributed_regen(self, levels):
         """ONE mesh over all ranks of the handle's communicator with the distributed weld (x-slabs): returns (RegenInfo of
         this rank's part, global index of its first kept vertex); download_mesh() then gives the part with global indices."""

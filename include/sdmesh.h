@@ -151,6 +151,7 @@ int sdmesh_use_own_stream(sdmesh_handle *h);
  *                       kernel writes them to the handle's pinned host block itself)
  *   "profile" = 1       time every stage of the planned chain with HIP events (sdmesh_profile_stages)
  *   "shard_indexed" = 0 sdmesh_sharded_regen in its raw form (unwelded slabs, triangle lists to the root, weld there); default 1: indexed form
+ *   "shard_planned" = 0 every indexed sdmesh_sharded_regen step on the synchronous route (default 1: planned steps in steady state)
  *   "weld_wide" = 1     always weld with the unbounded key form (default 0: packed 3 x 21-bit keys, and the wide form
  *                       automatically from the first vertex that does not fit them) */
 int sdmesh_set_option(sdmesh_handle *h, const char *name, int value);
@@ -267,15 +268,30 @@ int sdmesh_comm_ranks(sdmesh_handle *h, int *ranks_seen);
  * failed, so when any rank fails (its regen, an allocation, a count mismatch) every rank returns from this call with an
  * error -- the failing one with its own code, the others with SDMESH_ERR_PEER -- and none is left waiting in a collective.
  * The root's receive buffers grow behind a second one-word agreement, entered only when its published capacity is too
- * small (never in steady state).  Only an SDMESH_ERR_RCCL / SDMESH_ERR_HIP from a collective itself is not agreed upon. */
+ * small (never in steady state).  Only an SDMESH_ERR_RCCL / SDMESH_ERR_HIP from a collective itself is not agreed upon.
+ *
+ * Two routes (indexed form).  The first call -- and any call whose levels, root, scene, slab table or sizes no longer fit -- is
+ * SYNCHRONOUS: the message sizes are read back from the all-gather (three host synchronisations per step).  It ends by committing a
+ * plan: a slot size per rank (the rank's counts + 1/8 + 2048), the same on every rank because all derive it from the same gathered
+ * records.  Later calls are PLANNED: the slab's chain, its count kernels, the all-gather, plan-sized messages into plan-sized slots
+ * and the merge are enqueued blind and the call synchronises ONCE, at its end; the real counts ride in the gathered records, the
+ * kernels read them on the device, every rank verifies them afterwards.  A planned step that did not fit (or in which a rank
+ * reported a failure) is repeated synchronously by EVERY rank -- they all see the same records -- inside the same call.  Option
+ * "shard_planned" = 0 keeps every step synchronous.  Options that change what a rank does in this call ("shard_indexed",
+ * "shard_planned", the scene, the slab table) are part of the collective contract: set them on every rank alike. */
 int sdmesh_sharded_regen(sdmesh_handle *h, int levels, int root, sdmesh_regen_info *info);
+/* Which route the handle's last indexed sdmesh_sharded_regen / sdmesh_sharded_regen_rehearsal took: 1 planned, 2 synchronous,
+ * 3 planned and then repeated synchronously, 0 none yet. */
+int sdmesh_sharded_route(const sdmesh_handle *h);
 
 /* The indexed form of sdmesh_sharded_regen (its default; option "shard_indexed" = 0 selects the raw-list form described above) for
  * `nranks` handles of ONE process on ONE device, with device-to-device copies in place of the RCCL messages: handle r meshes and
- * welds level-0 z-slab r; the root handle concatenates the slabs' vertex / index buffers and merges them (csrc/kernels.hip,
- * "INDEXED gather": no second weld, streaming passes only) into the single-GPU mesh, bit for bit, which becomes the root handle's
- * mesh (sdmesh_device_mesh / sdmesh_download_mesh).  Every kernel and phase of the collective form runs; tests and single-GPU
- * measurements of the root's share use it.  All handles need the same slab bounds (sdmesh_set_slab_bounds / sdmesh_balance_slabs). */
+ * welds level-0 z-slab r; the root handle collects the slabs' vertex / index buffers in slots and merges them (csrc/zslab.hip:
+ * no second weld, streaming passes only) into the single-GPU mesh, bit for bit, which becomes the root handle's
+ * mesh (sdmesh_device_mesh / sdmesh_download_mesh).  Every kernel of the collective form runs, on both routes: the first call takes
+ * the synchronous one and commits the plan, a repeat with the same arguments the planned one (slots with head-room, counts read on
+ * the device, plan-sized copies).  Tests and single-GPU measurements of the root's share use it.  All handles need the same slab
+ * bounds (sdmesh_set_slab_bounds / sdmesh_balance_slabs). */
 int sdmesh_sharded_regen_rehearsal(sdmesh_handle **handles, int nranks, int levels, int root, sdmesh_regen_info *info);
 
 /* Dense mode: the same regen through the dense (N+1)^3 lattice -- P1 sample, P2a sign bits, P2b
