@@ -1209,6 +1209,11 @@ int sdmesh_set_option(sdmesh_handle *h, const char *name, int value) {
     }
     if (!strcmp(name, "inject_fail")) { h->inject_fail = value; return SDMESH_OK; }
     if (!strcmp(name, "shard_indexed")) { h->shard_indexed = value != 0; h->zsp.valid = false; return SDMESH_OK; }
+    if (!strcmp(name, "colcnt_debug")) {      // diagnostic: plain regens accumulate column counts into a scratch row (the cost of that hook alone)
+        if (value) { if (ensure(h, h->zs_ctl, 4ull * ZC_WORDS + 8192) != SDMESH_OK) return SDMESH_ERR_HIP; h->colcnt = (uint32_t *) h->zs_ctl.p + ZC_WORDS; }
+        else h->colcnt = nullptr;
+        return SDMESH_OK;
+    }
     if (!strcmp(name, "shard_slack")) { h->shard_slack = value != 0; h->zsp.valid = false; return SDMESH_OK; }
     if (!strcmp(name, "shard_planned")) { h->shard_planned = value != 0; h->zsp.valid = false; return SDMESH_OK; }   // (like every option of a collective call: the same on all ranks)
     if (!strcmp(name, "project_prio")) { h->project_prio = value != 0; drop_graph(h); return SDMESH_OK; }
@@ -2039,13 +2044,13 @@ int zs_root_ensure(sdmesh_handle *h, int R, uint64_t vslots, uint64_t tslots) {
     (void) R;
     SDCHK(ensure_grow(h, h->zs_verts, sizeof(Vertex) * v));
     SDCHK(ensure_grow(h, h->zs_idx, sizeof(IndexTriangle) * t));
-    SDCHK(ensure_grow(h, h->zs_pervert, 4ull * 3 * v));            // per slot vertex: segof | redirect | map
+    SDCHK(ensure_grow(h, h->zs_pervert, 4ull * 3 * v + 4ull * (v / 256 + 2)));    // per slot vertex: segof | redirect | map; then the drop counts per 256 of them
     SDCHK(ensure_grow(h, h->zs_vout, sizeof(Vertex) * v));
     SDCHK(ensure_grow(h, h->zs_iout, sizeof(IndexTriangle) * t));
     return SDMESH_OK;
 }
 uint32_t zs_root_capacity_v(const sdmesh_handle *h) {               // what this rank could take as a root without allocating
-    const size_t a = cap_items(h->zs_verts, sizeof(Vertex)), b = cap_items(h->zs_pervert, 12), c = cap_items(h->zs_vout, sizeof(Vertex));
+    const size_t a = cap_items(h->zs_verts, sizeof(Vertex)), b = h->zs_pervert.cap > 64 ? (h->zs_pervert.cap - 8) * 256 / (12 * 256 + 4) : 0, c = cap_items(h->zs_vout, sizeof(Vertex));
     return (uint32_t) std::min(a, std::min(b, c));
 }
 uint32_t zs_root_capacity_t(const sdmesh_handle *h) {
@@ -2060,6 +2065,7 @@ void zs_slot_table(const sdmesh_handle *h, int R, const uint32_t *cap_v, const u
     for (int r = 0; r < R; r++) {
         zr.vbase[r] = vb; zr.tbase[r] = tb;
         vb += cap_v[r]; tb += cap_t[r];
+        zr.tblk[r + 1] = zr.tblk[r] + (cap_t[r] + 255u) / 256u;
         uint32_t lo = F * (uint32_t) r / (uint32_t) R, hi = F * (uint32_t) (r + 1) / (uint32_t) R;
         if (h->slab_nparts == R && h->slab_mode == SDMESH_PART_ZSLAB) { lo = h->slab_bounds[r]; hi = h->slab_bounds[r + 1]; }
         zr.zlo[r] = -MESH_GENERATION_BB_SIZE / 2.0f + MESH_GENERATION_BB_SIZE * (float) lo / (float) F;
@@ -2090,9 +2096,9 @@ int zs_merge_enqueue(sdmesh_handle *h, const ZsRanks &zr, const uint32_t *d_coun
     }
     uint32_t *tplan = (uint32_t *) h->zs_tables.p, *vplan = tplan + 2 * nseg, *vstart = vplan + 2 * nseg, *newcnt = vstart + nseg;
     const uint32_t vcap = std::max<uint32_t>(V, 64u);
-    uint32_t *segof = (uint32_t *) h->zs_pervert.p, *redirect = segof + vcap, *map = redirect + vcap;
+    uint32_t *segof = (uint32_t *) h->zs_pervert.p, *redirect = segof + vcap, *map = redirect + vcap, *blockdrop = map + vcap;
     HIPCHK(launch_zs_merge(st, h->grid, (const Vertex *) h->zs_verts.p, (const uint32_t *) h->zs_idx.p, d_counts, SHARD_ROW, zr, (const ZsRanks *) h->zs_ranks.p,
-                           tplan, vplan, vstart, newcnt, segof, redirect, map, (uint64_t *) h->zs_hkeys.p, hsize, (Vertex *) h->zs_vout.p,
+                           tplan, vplan, vstart, newcnt, segof, redirect, map, blockdrop, (uint64_t *) h->zs_hkeys.p, hsize, (Vertex *) h->zs_vout.p,
                            (uint32_t) std::min<size_t>(h->zs_vout.cap / sizeof(Vertex), 0xFFFFFFFFu), (uint32_t *) h->zs_iout.p,
                            (uint32_t) std::min<size_t>(h->zs_iout.cap / sizeof(IndexTriangle), 0xFFFFFFFFu), (uint32_t *) h->zs_ctl.p, seq, h->h_zs_pub));
     (void) T;
@@ -2112,7 +2118,7 @@ int zs_merge_finish(sdmesh_handle *h, const ZsRanks &zr, const uint32_t *d_count
             HIPCHK(hipStreamSynchronize(h->stream));
             continue;
         }
-        if (pub[ZC_PLANFLAGS]) return fail(h, SDMESH_ERR_INTERNAL, "indexed merge: plan flags 0x%x (rows invalid or an output buffer too small)", pub[ZC_PLANFLAGS]);
+        if (pub[ZC_PLANFLAGS] | pub[ZC_VFLAGS]) return fail(h, SDMESH_ERR_INTERNAL, "indexed merge: plan flags 0x%x (rows invalid or an output buffer too small)", pub[ZC_PLANFLAGS] | pub[ZC_VFLAGS]);
         for (uint32_t r = 0; r < zr.nranks; r++)
             if (pub[ZC_RANKBAD + r]) return fail(h, SDMESH_ERR_INTERNAL, "indexed merge: the first-seen vertex counts of rank %u do not add up to its vertices", r);
         h->res_v = (Vertex *) h->zs_vout.p;                                  // the merged mesh is the handle's mesh now
@@ -2274,7 +2280,7 @@ int zs_planned_local(sdmesh_handle *h, int levels, int me, int R, const sdmesh_h
     if (lrc == SDMESH_OK && ended && (h->last_direct || !h->welded || h->wide_active)) lrc = fail(h, SDMESH_ERR_INTERNAL, "a slab left the packed-key lattice path");
     if (lrc != SDMESH_OK && h->pend_active) { sdmesh_regen_info tmp; (void) regen_impl(h, 0, 0, 0, 1, &tmp, 2); }
     const uint32_t *idx = slot_i ? (const uint32_t *) slot_i : (const uint32_t *) h->indices.p;
-    HIPCHK(launch_zs_local(st, idx, std::max<uint32_t>(h->plan_tris, 1u), slot_i ? pl.cap_t[me] : cap_items(h->indices, sizeof(IndexTriangle)), d_row, d_next,
+    HIPCHK(launch_zs_local(st, idx, pl.cap_t[me], slot_i ? pl.cap_t[me] : cap_items(h->indices, sizeof(IndexTriangle)), d_row, d_next,
                            h->d_ctr + CTR_NTRI, h->d_ctr + CTR_NVERT, h->d_status, (uint32_t) lrc, zs_root_capacity_v(h), zs_root_capacity_t(h), (uint32_t) inject, pl.sig));
     return lrc;
 }

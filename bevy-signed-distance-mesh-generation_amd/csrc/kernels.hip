@@ -832,7 +832,8 @@ __global__ __launch_bounds__(256) void k_tile_dedupe(const Point *__restrict__ v
                                                       uint32_t *__restrict__ ntiles_out, uint32_t *__restrict__ status,
                                                       uint64_t *__restrict__ dbg /* optional: 8 s_memtime stamps per tile (tools/tile_phases.py) */,
                                                       uint32_t prescanned /* tilecnt = exclusive prefix, *ntri_out = total (k_scan_tiles in front) */,
-                                                      uint32_t *__restrict__ colcnt /* optional (multi-GPU z-slabs): += triangles per level-0 (x0, y0) column; pre-zeroed */) {
+                                                      uint32_t *__restrict__ colstart /* optional (multi-GPU z-slabs): [c] = 1 + first triangle of level-0 (x0, y0) column c, for the columns that hold voxels; pre-zeroed */,
+                                                      uint32_t colshift /* log2(voxels per level-0 cell edge) */) {
 #define SDM_STAMP(k) do { if (dbg && tid == 0) dbg[8ull * tile + (k)] = __builtin_amdgcn_s_memtime(); } while (0)
     __shared__ uint64_t s_keys[T_HASH];
     __shared__ uint64_t s_aux[2 * TILE];                    // insert phase: per-voxel lattice coordinates + triangle row;
@@ -841,6 +842,7 @@ __global__ __launch_bounds__(256) void k_tile_dedupe(const Point *__restrict__ v
     __shared__ uint16_t s_tri[T_TRI * 3];
     __shared__ uint16_t s_vlo[TILE];
     __shared__ uint8_t s_tvox[T_TRI];
+    __shared__ uint16_t s_col[TILE];
     __shared__ uint32_t s_scan[17];
     __shared__ uint32_t s_bad, s_full;
     static_assert(sizeof(uint64_t) * 2 * TILE == sizeof(uint16_t) * T_HASH, "s_aux is reused for the local ids");
@@ -859,6 +861,7 @@ __global__ __launch_bounds__(256) void k_tile_dedupe(const Point *__restrict__ v
         const uint32_t v = tile * TILE + tid;
         const uint32_t ci = v < n ? cubeidx[v] : 0u;
         const Point b = vox[v < n ? v : (n - 1)];
+        const float bpx = (colstart && tid == 0 && tile > 0) ? vox[v - 1u].x : 0.0f, bpy = (colstart && tid == 0 && tile > 0) ? vox[v - 1u].y : 0.0f;
         uint32_t part = 0;
         if (!prescanned) for (uint32_t i = tid; i < tile; i += 256) part += tilecnt[i];
         const uint32_t ntri = v < n ? (uint32_t) MC_TRI_COUNT[ci] : 0u;
@@ -873,26 +876,29 @@ __global__ __launch_bounds__(256) void k_tile_dedupe(const Point *__restrict__ v
             const bool okx = lattice_coord(b.x, vs.x, mx), oky = lattice_coord(b.y, vs.y, my), okz = lattice_coord(b.z, vs.z, mz);
             lat_ok = okx && oky && okz;
         }
-        if (colcnt) {
-            // triangles per level-0 column (the z-slab gather's order restoration): a column is a contiguous range of the
-            // list, so a wave's voxels nearly always share one -> one atomic per wave; the few waves on a boundary add per lane
-            const float cell = MESH_GENERATION_BB_SIZE / (float) MESH_GENERATION_INIT_FACTOR;
-            const uint32_t F = MESH_GENERATION_INIT_FACTOR;
-            uint32_t cx = (uint32_t) floorf((b.x + 2.5f) / cell), cy = (uint32_t) floorf((b.y + 2.5f) / cell);
-            cx = cx < F ? cx : F - 1; cy = cy < F ? cy : F - 1;
-            const uint32_t col = cx * F + cy, col0 = (uint32_t) __builtin_amdgcn_readfirstlane((int) col);
-            if (__ballot(ntri != 0u && col != col0) == 0ull) {
-                const uint32_t ws = wave_sum(ntri);
-                if (lane_id() == 0 && ws) atomicAdd(&colcnt[col0], ws);
-            } else if (ntri) {
-                atomicAdd(&colcnt[col], ntri);
-            }
+        // (multi-GPU z-slabs) a level-0 column is a contiguous range of the list: the voxel whose column differs from its
+        // predecessor's publishes where the column's triangles start -- a plain store with one writer per column.  (Atomic adds of the
+        // triangle counts from here cost the kernel 10 us at 512^3: ~14 k device-scope atomics.)  Column from the lattice coordinates:
+        // 2^colshift voxels per level-0 cell edge.
+        uint32_t col = 0xffffu;
+        if (colstart && v < n) {
+            int cx = mx, cy = my;
+            if (!ntri) { (void) lattice_coord(b.x, vs.x, cx); (void) lattice_coord(b.y, vs.y, cy); }
+            col = (((uint32_t) cx >> colshift) & 31u) * MESH_GENERATION_INIT_FACTOR + (((uint32_t) cy >> colshift) & 31u);
+            s_col[tid] = (uint16_t) col;
         }
         SDM_STAMP(1);
         uint32_t ttri;
         const uint32_t lo = block_excl_scan(ntri, ttri, s_scan);
         SDM_STAMP(2);
         if (v < n) trioff[v] = tbase + lo;
+        if (colstart && v < n) {          // (s_col: the scan above has synchronised)
+            uint32_t prev = 0xffffu;
+            if (tid) prev = s_col[tid - 1u];
+            else if (tile) { int px = 0, py = 0; (void) lattice_coord(bpx, vs.x, px); (void) lattice_coord(bpy, vs.y, py);
+                             prev = (((uint32_t) px >> colshift) & 31u) * MESH_GENERATION_INIT_FACTOR + (((uint32_t) py >> colshift) & 31u); }
+            if (col != prev) colstart[col] = tbase + lo + 1u;
+        }
         if (tile == ntiles - 1 && tid == 0 && !prescanned) {
             uint32_t tot = tbase + ttri;
             if (tot > tcap) { atomicOr(&status[ST_OVERFLOW], 1u); tot = tcap; }
@@ -2758,11 +2764,17 @@ hipError_t launch_classify(hipStream_t st, int grid, int scene, const SceneParam
 hipError_t launch_tile_dedupe(hipStream_t st, int grid, const Point *vox, const uint32_t *n_ptr, Point vs, const uint8_t *cubeidx,
                               const uint32_t *tilecnt, uint32_t *trioff, uint32_t *tri_e, Vertex *uverts, uint4 *tdesc,
                               uint32_t ucap, uint32_t tcap, uint32_t *ntri_out, uint32_t *ntiles_out, uint32_t *status, uint64_t *dbg,
-                              bool prescan, uint32_t *colcnt) {
+                              bool prescan, uint32_t *colstart) {
+    // voxels per level-0 cell edge = (5 / 32) / vs.x, a power of two for every field the lattice path takes
+    uint32_t colshift = 0;
+    {
+        const float ratio = (MESH_GENERATION_BB_SIZE / (float) MESH_GENERATION_INIT_FACTOR) / vs.x;
+        while ((float) (1u << (colshift + 1u)) <= ratio && colshift < 20u) colshift++;
+    }
     if (prescan)
         hipLaunchKernelGGL(k_scan_tiles, dim3(1), dim3(1024), 0, st, const_cast<uint32_t *>(tilecnt), n_ptr, 256u, ntri_out, tcap, status);
     hipLaunchKernelGGL(k_tile_dedupe, dim3(grid), dim3(256), 0, st, vox, n_ptr, vs, cubeidx, tilecnt, trioff, tri_e, uverts, tdesc,
-                       ucap, tcap, ntri_out, ntiles_out, status, dbg, prescan ? 1u : 0u, colcnt);
+                       ucap, tcap, ntri_out, ntiles_out, status, dbg, prescan ? 1u : 0u, colstart, colshift);
     return hipGetLastError();
 }
 

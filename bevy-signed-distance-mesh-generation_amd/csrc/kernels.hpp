@@ -119,14 +119,15 @@ hipError_t launch_tile_tricount(hipStream_t st, int grid, const uint8_t *cubeidx
 struct ZsRanks {
     uint32_t nranks;
     uint32_t vbase[33], tbase[33];      // first vertex / triangle of rank r's slot; [nranks] = the slots' total
+    uint32_t tblk[33];                  // first 256-triangle block of rank r's slot in k_zs_index_out's grid; [nranks] = blocks in all
     float zlo[32], zhi[32];             // the slabs' z extents
     float zbot, ztop, band;             // the domain's z extent (a face on it is no slab face), half-width of the face bands
 };
 // words of a gathered row's record (row = 1024 column triangle counts | 1024 column first-seen vertex counts | record)
 enum ZsRec : uint32_t { ZR_STATUS = 0, ZR_TRIS = 1, ZR_CAP_V = 2, ZR_CAP_T = 3, ZR_VERTS = 4, ZR_FORM = 5, ZR_INJECT = 6, ZR_SIG = 7 };
 // words of the merge's own control block (device) and of what a step publishes to pinned host memory: [ZC_WORDS | R records of 8 words]
-enum ZsCtl : uint32_t { ZC_TRIS = 0, ZC_VERTS = 1, ZC_NBAND = 2, ZC_BANDFLAGS = 3 /* 1: weld range, 64: band hash full */, ZC_PLANFLAGS = 4 /* 1: rows invalid or over a slot's capacity, 2: merged triangles over capacity, 4: merged vertices over capacity */,
-                     ZC_SEQ = 5, ZC_RANKBAD = 8 /* + r: the vertex counts of rank r's row do not add up */, ZC_WORDS = 40 };
+enum ZsCtl : uint32_t { ZC_TRIS = 0, ZC_VERTS = 1, ZC_NBAND = 2, ZC_BANDFLAGS = 3 /* 1: weld range, 64: band hash full */, ZC_PLANFLAGS = 4 /* 1: rows invalid or over a slot's capacity, 2: merged triangles over capacity */,
+                     ZC_SEQ = 5, ZC_VFLAGS = 6 /* 4: merged vertices over capacity */, ZC_RANKBAD = 8 /* + r: the vertex counts of rank r's row do not add up */, ZC_WORDS = 40 };
 // local phase, every rank: the slab's first-seen vertex counts per column from its own index buffer (row[1024 ..)), then the row's record;
 // `next_row`: the row of the next step's buffer, whose count areas are cleared here (the column counts are accumulated by k_tile_dedupe)
 hipError_t launch_zs_local(hipStream_t st, const uint32_t *idx, uint32_t tris_hint, uint32_t tri_cap, uint32_t *row, uint32_t *next_row,
@@ -137,8 +138,8 @@ hipError_t launch_zs_local(hipStream_t st, const uint32_t *idx, uint32_t tris_hi
 // then 4-byte minima) only with more than one rank; zctl = ZC_WORDS words; pub (pinned host, optional) receives zctl and the records
 hipError_t launch_zs_merge(hipStream_t st, int grid, const Vertex *v_all, const uint32_t *idx_all, const uint32_t *counts, uint32_t cstride,
                            const ZsRanks &zr, const ZsRanks *d_zr, uint32_t *tplan, uint32_t *vplan, uint32_t *vstart, uint32_t *newcnt,
-                           uint32_t *segof, uint32_t *redirect, uint32_t *map, uint64_t *hkeys, uint32_t hsize, Vertex *v_out, uint32_t cap_verts,
-                           uint32_t *i_out, uint32_t cap_tris, uint32_t *zctl, uint32_t seq, uint32_t *pub);
+                           uint32_t *segof, uint32_t *redirect, uint32_t *map, uint32_t *blockdrop /* per 256 slot vertices */, uint64_t *hkeys, uint32_t hsize,
+                           Vertex *v_out, uint32_t cap_verts, uint32_t *i_out, uint32_t cap_tris, uint32_t *zctl, uint32_t seq, uint32_t *pub);
 // peers: the records (and a zeroed control block) to pinned host memory
 hipError_t launch_zs_publish(hipStream_t st, const uint32_t *counts, uint32_t cstride, uint32_t nranks, const uint32_t *zctl, uint32_t seq, uint32_t *pub);
 hipError_t launch_band_select(hipStream_t st, int grid, const Vertex *v, uint32_t V, float up_thr, float lo_thr, bool has_up, bool has_lo,

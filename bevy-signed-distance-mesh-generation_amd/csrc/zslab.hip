@@ -34,6 +34,8 @@ namespace sdm {
 
 static constexpr uint32_t NCOL = MESH_GENERATION_INIT_FACTOR * MESH_GENERATION_INIT_FACTOR;     // 1024 level-0 columns
 static constexpr uint32_t ZS_GAP = 0xfffffffeu;        // redirect[] of a slot entry behind the rank's last vertex
+static constexpr uint32_t ZS_VBLK = 256;               // slot vertices per workgroup of k_zs_vertex_out = per entry of blockdrop[]
+static constexpr uint32_t ZS_TBLK = 256;               // slot triangles per workgroup of k_zs_index_out (zr.tblk counts these)
 static_assert(SHARD_REC == 2 * NCOL, "a row is 1024 triangle counts, 1024 vertex counts, the record");
 
 __device__ __forceinline__ uint32_t row_rec(const uint32_t *__restrict__ counts, uint32_t cstride, uint32_t r, uint32_t w) {
@@ -75,53 +77,122 @@ __device__ __forceinline__ uint32_t zs_plan_body(const uint32_t *__restrict__ co
 // ------------------------------------------------------------------------------------------
 // local phase (every rank)
 // ------------------------------------------------------------------------------------------
-// largest local vertex index + 1 of every column segment of this rank's index buffer -> row[NCOL + c] (pre-zeroed; gridDim.y
-// workgroups share a segment: segments are very uneven, a column holds anything from nothing to tens of thousands of triangles).
-// Each workgroup sums the column counts in front of its column itself (<= 1024 words): no plan launch in front.
-__global__ __launch_bounds__(256) void k_zs_segmax(const uint32_t *__restrict__ idx, uint32_t tri_cap, uint32_t *__restrict__ row) {
-    __shared__ uint32_t s_red[4];
-    const uint32_t c = blockIdx.x, tid = threadIdx.x;
-    const uint32_t n = row[c];
-    if (n == 0) return;
-    uint32_t part = 0;
-    for (uint32_t i = tid; i < c; i += 256) part += row[i];
-    part = wave_sum(part);
-    if (lane_id() == 0) s_red[tid >> 6] = part;
-    __syncthreads();
-    const uint32_t src = s_red[0] + s_red[1] + s_red[2] + s_red[3];
-    if (src + n > tri_cap) return;                                     // (counts of a chain that overflowed: the record says so)
-    const uint32_t ne = 3u * n, per = (ne + gridDim.y - 1u) / gridDim.y, e0 = blockIdx.y * per, e1 = e0 + per < ne ? e0 + per : ne;
-    const uint32_t *__restrict__ s = idx + 3ull * src;
-    uint32_t m = 0;
-    for (uint32_t e = e0 + tid; e < e1; e += 256) { const uint32_t v = s[e] + 1u; m = v > m ? v : m; }
-    for (int o = 32; o > 0; o >>= 1) { const uint32_t t = (uint32_t) __shfl_xor((int) m, o, 64); m = t > m ? t : m; }
-    if (lane_id() == 0 && m) atomicMax(&row[NCOL + c], m);
+// the largest c in [0, NCOL) with s_start[c] <= t (s_start non-decreasing, s_start[0] == 0): the column whose segment holds item t
+__device__ __forceinline__ uint32_t zs_col_of(const uint32_t *__restrict__ s_start, uint32_t t) {
+    uint32_t lo = 0, hi = NCOL;
+    while (hi - lo > 1u) {
+        const uint32_t mid = (lo + hi) >> 1;
+        if (s_start[mid] <= t) lo = mid; else hi = mid;
+    }
+    return lo;
 }
 
-// One workgroup: row[NCOL + c] (segment maxima) -> first-seen vertex counts per column (prefix maximum, then differences), the
-// checks that make the row trustworthy, the row's record, and the clear of the NEXT step's row (k_tile_dedupe accumulates the
-// column counts of the next chain into it; the buffers alternate).
+// Column starts from what k_tile_dedupe published: enc[c] = 1 + first triangle of column c for the columns that hold voxels, 0 for the
+// others.  An empty column starts where the next one does (so that zs_col_of never answers with it): s_start[c] = the suffix minimum of
+// the published starts, T behind the last -> s_start[0 .. NCOL].  256 threads, four consecutive columns each; all must call; lds >= 4 words.
+__device__ __forceinline__ void zs_starts_from_published(const uint32_t *__restrict__ enc, uint32_t T, uint32_t *__restrict__ s_start, uint32_t *__restrict__ lds) {
+    const uint32_t tid = threadIdx.x, lane = lane_id(), wave = tid >> 6;
+    uint32_t m[4];
+#pragma unroll
+    for (uint32_t k = 0; k < 4u; k++) { const uint32_t e = enc[4u * tid + k]; m[k] = e ? e - 1u : U32_NONE; }
+#pragma unroll
+    for (int k = 2; k >= 0; k--) m[k] = m[k] < m[k + 1] ? m[k] : m[k + 1];          // suffix minimum inside the thread's four
+    uint32_t x = m[0];
+#pragma unroll
+    for (uint32_t o = 1; o < 64u; o <<= 1) {                                          // inclusive suffix minimum over the wave's lanes
+        const uint32_t y = (uint32_t) __shfl_down((int) x, o, 64);
+        if (lane + o < 64u) x = y < x ? y : x;
+    }
+    uint32_t after = (uint32_t) __shfl_down((int) x, 1u, 64);                         // the lanes behind this one
+    if (lane == 63u) after = U32_NONE;
+    if (lane == 0) lds[wave] = x;
+    __syncthreads();
+    for (uint32_t w = wave + 1u; w < 4u; w++) after = lds[w] < after ? lds[w] : after;
+    after = T < after ? T : after;
+#pragma unroll
+    for (uint32_t k = 0; k < 4u; k++) s_start[4u * tid + k] = m[k] < after ? m[k] : after;
+    if (tid == 0) s_start[NCOL] = T;
+    __syncthreads();
+}
+
+// largest local vertex index + 1 of every column segment of this rank's index buffer -> row[NCOL + c] (pre-zeroed).  Flat over the
+// triangles, one per thread: every workgroup derives the segments' starts from the published column starts itself (no plan launch
+// in front), a triangle finds its column by bisection in LDS, the maxima are reduced per wave and per workgroup in LDS: one global
+// atomicMax per (workgroup, column) pair -- a wave's, and nearly always a workgroup's, triangles share a column.
+__global__ __launch_bounds__(256) void k_zs_segmax(const uint32_t *__restrict__ idx, const uint32_t *__restrict__ ctr_tris, uint32_t tri_cap,
+                                                    uint32_t *__restrict__ row) {
+    __shared__ uint32_t s_start[NCOL + 1];
+    __shared__ uint32_t s_m[NCOL];
+    __shared__ uint32_t lds[17];
+    uint32_t T = *ctr_tris;
+    if (T > tri_cap) T = tri_cap;                                        // (a chain that overflowed: the record says so)
+    if (blockIdx.x * 256u >= T) return;
+    const uint32_t tid = threadIdx.x, t = blockIdx.x * 256u + tid;
+    const bool in = t < T;
+    uint32_t m = 0;
+    if (in) {                                                            // (the loads first: the table below costs a few barriers)
+        const uint32_t a = idx[3ull * t], b = idx[3ull * t + 1u], d = idx[3ull * t + 2u];
+        m = (a > b ? (a > d ? a : d) : (b > d ? b : d)) + 1u;
+    }
+#pragma unroll
+    for (uint32_t k = 0; k < 4u; k++) s_m[tid + 256u * k] = 0u;
+    zs_starts_from_published(row, T, s_start, lds);
+    const uint32_t c = in ? zs_col_of(s_start, t) : 0u;
+    const uint64_t has = __ballot(in);
+    if (has) {
+        const uint32_t cf = (uint32_t) __builtin_amdgcn_readlane((int) c, (int) __builtin_ctzll(has));
+        if (__ballot(in && c != cf) == 0ull) {
+            for (int o = 32; o > 0; o >>= 1) { const uint32_t x = (uint32_t) __shfl_xor((int) m, o, 64); m = x > m ? x : m; }
+            if (lane_id() == 0) atomicMax(&s_m[cf], m);
+        } else if (in) {
+            atomicMax(&s_m[c], m);
+        }
+    }
+    __syncthreads();
+    // (the workgroup's columns are the contiguous range between its first and its last triangle's)
+    const uint32_t c_lo = zs_col_of(s_start, blockIdx.x * 256u), t_hi = blockIdx.x * 256u + 255u < T ? blockIdx.x * 256u + 255u : T - 1u;
+    const uint32_t c_hi = zs_col_of(s_start, t_hi);
+    for (uint32_t cc = c_lo + tid; cc <= c_hi; cc += 256u) { const uint32_t mm = s_m[cc]; if (mm) atomicMax(&row[NCOL + cc], mm); }
+}
+
+// One workgroup: row[c] (published column starts) -> column triangle counts; row[NCOL + c] (segment maxima) -> first-seen vertex counts per
+// column (prefix maximum, then differences); the checks that make the row trustworthy; the row's record; and the clear of the NEXT step's
+// row (the next chain publishes into it; the buffers alternate).
 __global__ __launch_bounds__(1024) void k_zs_rowfinish(uint32_t *__restrict__ row, uint32_t *__restrict__ next_row, const uint32_t *__restrict__ ctr_tris,
                                                         const uint32_t *__restrict__ ctr_verts, const uint32_t *__restrict__ status, uint32_t host_status,
                                                         uint32_t cap_v, uint32_t cap_t, uint32_t inject, uint32_t sig) {
-    __shared__ uint32_t s[NCOL];
+    __shared__ uint32_t s[NCOL + 1];
     __shared__ uint32_t lds[17];
     const uint32_t c = threadIdx.x;
     const bool failed = host_status != 0u;                             // the host already knows this rank's local phase failed: an empty row
     const uint32_t T = failed ? 0u : *ctr_tris, V = failed ? 0u : *ctr_verts;
-    const uint32_t tc = failed ? 0u : row[c];
+    // column starts: suffix minimum of the published ones, T behind the last
+    const uint32_t enc = failed ? 0u : row[c];
+    s[c] = enc ? enc - 1u : U32_NONE;
+    if (c == 0) s[NCOL] = T;
+    __syncthreads();
+    for (uint32_t o = 1; o < NCOL; o <<= 1) {                        // inclusive suffix minimum (Hillis-Steele: 10 steps)
+        const uint32_t a = s[c], b = c + o < NCOL ? s[c + o] : T;
+        __syncthreads();
+        s[c] = a < b ? a : b;
+        __syncthreads();
+    }
+    const uint32_t start = s[c] < T ? s[c] : T, next = c + 1u < NCOL ? (s[c + 1u] < T ? s[c + 1u] : T) : T;
+    const uint32_t tc = next >= start ? next - start : 0u;
+    const uint32_t disorder = __syncthreads_or((next < start || (c == 0 && start != 0u && T != 0u)) ? 1 : 0);      // (starts that do not ascend from 0)
+    uint32_t tsum;
+    (void) block_excl_scan(tc, tsum, lds);
+    // first-seen vertices per column: prefix maximum of the segment maxima, then differences
     s[c] = failed ? 0u : row[NCOL + c];
     __syncthreads();
-    for (uint32_t o = 1; o < NCOL; o <<= 1) {                        // inclusive prefix maximum (Hillis-Steele: 10 steps)
+    for (uint32_t o = 1; o < NCOL; o <<= 1) {                        // inclusive prefix maximum
         const uint32_t a = s[c], b = c >= o ? s[c - o] : 0u;
         __syncthreads();
         s[c] = a > b ? a : b;
         __syncthreads();
     }
     const uint32_t incl = s[c], excl = c ? s[c - 1u] : 0u;
-    uint32_t tsum;
-    (void) block_excl_scan(tc, tsum, lds);
-    if (failed) row[c] = 0u;
+    row[c] = tc;
     row[NCOL + c] = incl - excl;
     if (next_row) { next_row[c] = 0u; next_row[NCOL + c] = 0u; }
     if (c == NCOL - 1u) {
@@ -131,7 +202,7 @@ __global__ __launch_bounds__(1024) void k_zs_rowfinish(uint32_t *__restrict__ ro
             // vertex outside the packed key range, an invariant -- and a row that does not describe the buffers
             const uint32_t dev = (status[ST_OVERFLOW] ? 1u : 0u) | (status[ST_NOT_LATTICE] ? 2u : 0u) | (status[ST_WELD_RANGE] ? 4u : 0u) |
                                  (status[ST_INTERNAL] ? 8u : 0u) | (status[ST_TILE_OVERFLOW] ? 16u : 0u) | (status[ST_NONFINITE] ? 32u : 0u) |
-                                 (tsum != T ? 64u : 0u) | (incl != V ? 128u : 0u);
+                                 ((tsum != T || disorder) ? 64u : 0u) | (incl != V ? 128u : 0u);
             if (dev) st = 0x80000000u | dev;
         }
         uint32_t *rec = row + SHARD_REC;
@@ -152,34 +223,41 @@ __device__ __forceinline__ uint32_t zs_rank_of(const ZsRanks &zr, uint32_t i) {
 // One launch in front of everything else.  Workgroup (r, g) of the first nranks * 64: the exclusive prefix of rank r's first-seen
 // vertex counts (one block scan of the row), then its sixteen columns: vstart / newcnt of the segments, every vertex of theirs
 // learns its segment and starts as "kept" (the vertices of sixteen consecutive columns are one contiguous range of the slot).  The last
-// group of a rank checks the row's sum and marks the slot's unused tail.  The extra workgroup plans the triangle segments
-// (and, with one rank, the vertex segments: nothing can be dropped) and resets the merge's counters.  With more than one rank the
-// whole grid also clears the band hash.
+// group of a rank checks the row's sum and marks the slot's unused tail.  Two extra workgroups plan the triangle segments
+// (resetting the merge's counters) and, with one rank, the vertex segments (nothing can be dropped).  With more than one rank the
+// whole grid also clears the band hash and the per-block drop counts.
 __global__ __launch_bounds__(1024) void k_zs_front(const uint32_t *__restrict__ counts, uint32_t cstride, const ZsRanks *__restrict__ zrp,
                                                     uint32_t *__restrict__ tplan, uint32_t *__restrict__ vplan, uint32_t *__restrict__ vstart,
                                                     uint32_t *__restrict__ newcnt, uint32_t *__restrict__ segof, uint32_t *__restrict__ redirect,
-                                                    uint32_t *__restrict__ hclear, uint32_t hwords, uint32_t cap_verts, uint32_t cap_tris,
-                                                    uint32_t *__restrict__ zctl) {
+                                                    uint32_t *__restrict__ hclear, uint32_t hwords, uint32_t *__restrict__ blockdrop, uint32_t cap_verts,
+                                                    uint32_t cap_tris, uint32_t *__restrict__ zctl) {
     const ZsRanks &zr = *zrp;
     __shared__ uint32_t lds[17];
     __shared__ uint32_t s_b[17];
     const uint32_t tid = threadIdx.x, R = zr.nranks, groups = R * 64u;
     const bool ok = zs_rows_ok(counts, cstride, zr);
-    if (blockIdx.x == groups) {
-        uint32_t flags = ok ? 0u : 1u, T = 0, V = 0;
+    if (blockIdx.x == groups) {                  // the triangle segments' plan, the merge's counters
+        uint32_t flags = ok ? 0u : 1u, T = 0;
         if (ok) {
             T = zs_plan_body(counts, cstride, R, tplan, lds);
             if (T > cap_tris) flags |= 2u;
-            if (R == 1u) {
-                V = zs_plan_body(counts + NCOL, cstride, 1u, vplan, lds);
-                if (V > cap_verts) flags |= 4u;
-            }
         }
-        if (tid == 0) { zctl[ZC_TRIS] = T; zctl[ZC_VERTS] = V; zctl[ZC_NBAND] = 0u; zctl[ZC_BANDFLAGS] = 0u; zctl[ZC_PLANFLAGS] = flags; }
+        if (tid == 0) { zctl[ZC_TRIS] = T; zctl[ZC_NBAND] = 0u; zctl[ZC_BANDFLAGS] = 0u; zctl[ZC_PLANFLAGS] = flags; if (R > 1u || !ok) zctl[ZC_VERTS] = 0u; }
+        return;
+    }
+    if (blockIdx.x == groups + 1u) {             // one rank: nothing can be dropped, the vertex segments' plan is final now
+        if (ok && R == 1u) {
+            const uint32_t V = zs_plan_body(counts + NCOL, cstride, 1u, vplan, lds);
+            if (tid == 0) { zctl[ZC_VERTS] = V; zctl[ZC_VFLAGS] = V > cap_verts ? 4u : 0u; }
+        } else if (tid == 0) {
+            zctl[ZC_VFLAGS] = 0u;
+        }
         return;
     }
     if (!ok) return;
     for (uint32_t i = blockIdx.x * 1024u + tid; i < hwords; i += groups * 1024u) hclear[i] = 0xffffffffu;      // (all-ones = empty key = no vertex yet)
+    if (blockdrop)
+        for (uint32_t i = blockIdx.x * 1024u + tid; i < zr.vbase[R] / ZS_VBLK + 1u; i += groups * 1024u) blockdrop[i] = 0u;
     const uint32_t r = blockIdx.x >> 6, c0 = (blockIdx.x & 63u) * 16u;
     const uint32_t vc = counts[(size_t) r * cstride + NCOL + tid];
     uint32_t total;
@@ -246,7 +324,7 @@ __global__ __launch_bounds__(256) void k_zs_band_insert(const Vertex *__restrict
 __global__ __launch_bounds__(256) void k_zs_band_resolve(const Vertex *__restrict__ v, const uint32_t *__restrict__ counts, uint32_t cstride,
                                                           const ZsRanks *__restrict__ zrp, const uint64_t *__restrict__ hkeys,
                                                           const uint32_t *__restrict__ hmin, uint32_t hsize, const uint32_t *__restrict__ segof,
-                                                          uint32_t *__restrict__ redirect, uint32_t *__restrict__ newcnt) {
+                                                          uint32_t *__restrict__ redirect, uint32_t *__restrict__ newcnt, uint32_t *__restrict__ blockdrop) {
     const ZsRanks &zr = *zrp;
     if (!zs_rows_ok(counts, cstride, zr)) return;
     const uint32_t V = zr.vbase[zr.nranks];
@@ -269,6 +347,7 @@ __global__ __launch_bounds__(256) void k_zs_band_resolve(const Vertex *__restric
                     const uint32_t win = a_first ? a : i, lose = a_first ? i : a;
                     redirect[lose] = win;
                     atomicSub(&newcnt[a_first ? si : sa], 1u);
+                    atomicAdd(&blockdrop[lose / ZS_VBLK], 1u);       // (k_zs_vertex_out numbers the kept vertices of a segment from these)
                 }
                 break;
             }
@@ -287,46 +366,66 @@ __global__ __launch_bounds__(1024) void k_zs_vplan(const uint32_t *__restrict__ 
     const uint32_t V = zs_plan_body(newcnt, NCOL, zr.nranks, vplan, lds);
     if (threadIdx.x == 0) {
         zctl[ZC_VERTS] = V;
-        if (V > cap_verts) atomicOr(&zctl[ZC_PLANFLAGS], 4u);
+        zctl[ZC_VFLAGS] = V > cap_verts ? 4u : 0u;
     }
 }
 
-// kept vertices to their merged places; map[i] = merged number.  One workgroup per (rank, column) segment, four consecutive
-// vertices per thread and pass; the place inside the segment is a block scan over the kept flags (only band vertices are ever dropped).
+// kept vertices to their merged places; map[i] = merged number.  Flat over the slot space, one entry per thread, every load that does not
+// depend on another one issued in front.  A kept vertex's place = its segment's merged start + its rank among the segment's kept vertices
+// = (i - first) - (dropped copies in [first, i)).  Only band vertices are ever dropped, and only with several ranks: the drops in front of i
+// are counted inside the workgroup's own ZS_VBLK entries by a block scan; a segment that began in an earlier block (only the block's
+// first segment can) adds the drops between its first vertex and the block -- the tail of the first vertex's block, read here, and
+// the whole blocks in between from blockdrop[] (k_zs_band_resolve).  No global scan.
 __global__ __launch_bounds__(256) void k_zs_vertex_out(const Vertex *__restrict__ v, const uint32_t *__restrict__ counts, uint32_t cstride,
-                                                        const ZsRanks *__restrict__ zrp, const uint32_t *__restrict__ redirect,
-                                                        const uint32_t *__restrict__ vstart, const uint32_t *__restrict__ vplan,
+                                                        const ZsRanks *__restrict__ zrp, const uint32_t *__restrict__ redirect, const uint32_t *__restrict__ segof,
+                                                        const uint32_t *__restrict__ vstart, const uint32_t *__restrict__ vplan, const uint32_t *__restrict__ blockdrop,
                                                         Vertex *__restrict__ out, uint32_t cap, uint32_t *__restrict__ map) {
     const ZsRanks &zr = *zrp;
     __shared__ uint32_t lds[17];
+    __shared__ uint32_t s_e[ZS_VBLK];
+    __shared__ uint32_t s_x;
+    const uint32_t tid = threadIdx.x, V = zr.vbase[zr.nranks], b0 = blockIdx.x * ZS_VBLK, i = b0 + tid;
+    if (b0 >= V) return;
+    // (speculative loads: entries behind V or in a slot's tail read allocated memory, their values are not used)
+    const uint32_t red = i < V ? redirect[i] : ZS_GAP;
+    const uint32_t seg_i = i < V ? segof[i] : 0u;
+    Vertex vert;
+    if (i < V) vert = v[i];
     if (!zs_rows_ok(counts, cstride, zr)) return;
-    const uint32_t tid = threadIdx.x;
-    for (uint32_t seg = blockIdx.x; seg < zr.nranks * NCOL; seg += gridDim.x) {
-        const uint32_t r = seg / NCOL;
-        uint32_t n0 = counts[(size_t) r * cstride + NCOL + seg % NCOL];
-        if (n0 == 0) continue;
-        const uint32_t vs0 = vstart[seg], Vr = row_rec(counts, cstride, r, ZR_VERTS);
-        if (vs0 >= Vr) continue;
-        if (n0 > Vr - vs0) n0 = Vr - vs0;                                   // (only if the row's counts do not add up: flagged by k_zs_front)
-        const uint32_t first = zr.vbase[r] + vs0, dst = vplan[2u * seg + 1u];
-        uint32_t run = 0;
-        for (uint32_t base = 0; base < n0; base += 1024u) {
-            const uint32_t k0 = base + 4u * tid;
-            uint32_t keep = 0;
-#pragma unroll
-            for (uint32_t j = 0; j < 4u; j++)
-                if (k0 + j < n0 && redirect[first + k0 + j] == U32_NONE) keep |= 1u << j;
-            uint32_t total;
-            uint32_t pos = dst + run + block_excl_scan((uint32_t) __popc(keep), total, lds);
-#pragma unroll
-            for (uint32_t j = 0; j < 4u; j++)
-                if (keep & (1u << j)) {
-                    map[first + k0 + j] = pos;
-                    if (pos < cap) out[pos] = v[first + k0 + j];
-                    pos++;
-                }
-            run += total;
+    const bool drops = zr.nranks > 1u;
+    const bool kept = red == U32_NONE;
+    uint32_t first = 0, dstart = 0;
+    if (kept) { first = zr.vbase[seg_i / NCOL] + vstart[seg_i]; dstart = vplan[2u * seg_i + 1u]; }
+    uint32_t before = 0;
+    if (drops) {
+        const uint32_t d = (red != U32_NONE && red != ZS_GAP) ? 1u : 0u;
+        uint32_t total;
+        s_e[tid] = block_excl_scan(d, total, lds);
+        // drops of the block's first segment in front of the block
+        uint32_t x = 0;
+        const uint32_t r0 = (uint32_t) __builtin_amdgcn_readfirstlane((int) red), s0 = (uint32_t) __builtin_amdgcn_readfirstlane((int) seg_i);
+        uint32_t first0 = b0;
+        if (tid < 64u) {
+            // (wave 0 holds the block's first entry in its first lane)
+            if (r0 != ZS_GAP) first0 = zr.vbase[s0 / NCOL] + vstart[s0];
         }
+        if (tid == 0) s_x = first0;
+        __syncthreads();
+        first0 = s_x;
+        __syncthreads();
+        if (first0 < b0) {
+            const uint32_t fb = first0 / ZS_VBLK, fend = (fb + 1u) * ZS_VBLK;          // (fend <= b0)
+            for (uint32_t j = first0 + tid; j < fend; j += 256u) { const uint32_t q = redirect[j]; x += (q != U32_NONE && q != ZS_GAP) ? 1u : 0u; }
+            for (uint32_t bb = fb + 1u + tid; bb < blockIdx.x; bb += 256u) x += blockdrop[bb];
+        }
+        uint32_t xt;
+        (void) block_excl_scan(x, xt, lds);
+        if (kept) before = first >= b0 ? s_e[tid] - s_e[first - b0] : s_e[tid] + xt;
+    }
+    if (kept) {
+        const uint32_t g = dstart + (i - first) - before;
+        map[i] = g;
+        if (g < cap) out[g] = vert;
     }
 }
 
@@ -350,28 +449,36 @@ __device__ __forceinline__ void zs_publish_body(const uint32_t *__restrict__ cou
     if (tid < nranks * 8u) pub[ZC_WORDS + tid] = counts[(size_t) (tid >> 3) * cstride + SHARD_REC + (tid & 7u)];
 }
 
-// the index buffers, segment by segment (gridDim.y workgroups share one), into the merged triangle order with merged vertex numbers.
-// Workgroup (0, 0) also publishes the step's control block and the ranks' records to pinned host memory: every word of them was
-// final before this kernel started (no read-back copy behind the chain).
+// the index buffers into the merged triangle order with merged vertex numbers.  Flat over the triangle slots: workgroup = ZS_TBLK slot
+// triangles of one rank (blocks per rank from the slot capacities: zr.tblk), one triangle per thread; it finds its column segment by
+// bisection over the rank's segment starts in LDS (tplan's source offsets).  Workgroup 0 also publishes the step's control block and
+// the ranks' records to pinned host memory: every word of them was final before this kernel started (no read-back copy behind the chain).
 __global__ __launch_bounds__(256) void k_zs_index_out(const uint32_t *__restrict__ idx_all, const uint32_t *__restrict__ counts, uint32_t cstride,
                                                        const uint32_t *__restrict__ tplan, const ZsRanks *__restrict__ zrp, const uint32_t *__restrict__ map,
                                                        uint32_t *__restrict__ out, uint32_t cap_tris, const uint32_t *__restrict__ zctl, uint32_t seq,
                                                        uint32_t *__restrict__ pub) {
     const ZsRanks &zr = *zrp;
-    if (pub && blockIdx.x == 0 && blockIdx.y == 0) zs_publish_body(counts, cstride, zr.nranks, zctl, seq, pub);
-    if (!zs_rows_ok(counts, cstride, zr)) return;
-    const uint32_t nseg = zr.nranks * NCOL;
-    for (uint32_t seg = blockIdx.x; seg < nseg; seg += gridDim.x) {
-        const uint32_t r = seg / NCOL, n = counts[(size_t) r * cstride + seg % NCOL];
-        if (n == 0) continue;
-        const uint32_t src = tplan[2u * seg], dst = tplan[2u * seg + 1u];
-        if (dst + n > cap_tris || src + n > row_rec(counts, cstride, r, ZR_TRIS)) continue;      // flagged by k_zs_front / the row's own check
-        const uint32_t ne = 3u * n, per = (ne + gridDim.y - 1u) / gridDim.y, e0 = blockIdx.y * per, e1 = e0 + per < ne ? e0 + per : ne;
-        const uint32_t *__restrict__ s = idx_all + 3ull * (zr.tbase[r] + src);
-        uint32_t *__restrict__ d = out + 3ull * dst;
-        const uint32_t vb = zr.vbase[r];
-        for (uint32_t e = e0 + threadIdx.x; e < e1; e += 256) d[e] = map[vb + s[e]];
-    }
+    __shared__ uint32_t s_start[NCOL + 1];
+    if (pub && blockIdx.x == 0) zs_publish_body(counts, cstride, zr.nranks, zctl, seq, pub);
+    uint32_t r = 0;
+    while (r + 1u < zr.nranks && blockIdx.x >= zr.tblk[r + 1u]) r++;
+    const uint32_t Tr = row_rec(counts, cstride, r, ZR_TRIS), t = (blockIdx.x - zr.tblk[r]) * ZS_TBLK + threadIdx.x;
+    const bool in = t < Tr && t < zr.tbase[r + 1u] - zr.tbase[r];
+    const uint32_t *__restrict__ s = idx_all + 3ull * zr.tbase[r];
+    const uint32_t vb = zr.vbase[r];
+    uint32_t a = 0, b = 0, d = 0;
+    if (in) { a = s[3ull * t]; b = s[3ull * t + 1u]; d = s[3ull * t + 2u]; }            // (in front of the table and the checks)
+#pragma unroll
+    for (uint32_t k = 0; k < 4u; k++) s_start[threadIdx.x + 256u * k] = tplan[2u * (r * NCOL + threadIdx.x + 256u * k)];
+    if (!zs_rows_ok(counts, cstride, zr)) return;                       // (synchronises: s_start is complete)
+    if (!in) return;
+    const uint32_t Vr = row_rec(counts, cstride, r, ZR_VERTS);
+    if (a >= Vr || b >= Vr || d >= Vr) return;                          // (not an index of this rank: never of a checked row)
+    const uint32_t ma = map[vb + a], mb = map[vb + b], md = map[vb + d];
+    const uint32_t c = zs_col_of(s_start, t), seg = r * NCOL + c;
+    const uint32_t dst = tplan[2u * seg + 1u] + (t - s_start[c]);
+    if (dst >= cap_tris) return;                                        // flagged by k_zs_front
+    out[3ull * dst] = ma; out[3ull * dst + 1u] = mb; out[3ull * dst + 2u] = md;
 }
 
 __global__ __launch_bounds__(256) void k_zs_publish(const uint32_t *__restrict__ counts, uint32_t cstride, uint32_t nranks, const uint32_t *__restrict__ zctl,
@@ -382,42 +489,35 @@ __global__ __launch_bounds__(256) void k_zs_publish(const uint32_t *__restrict__
 // ------------------------------------------------------------------------------------------
 // launchers
 // ------------------------------------------------------------------------------------------
-// workgroups that share one (rank, column) segment: enough for one element per thread in the occupied segments (about a third of the
-// columns hold surface), so that a segment's dependent loads are ONE round trip deep in small meshes; large meshes are bandwidth-bound anyway
-static uint32_t zs_seg_split(uint32_t tris, uint32_t nseg) {
-    const uint64_t per_seg = (9ull * tris + nseg - 1) / nseg;               // 3 indices per triangle, ~3x the average in the occupied segments
-    const uint64_t by_work = std::max<uint64_t>(1, (per_seg + 255) / 256), by_grid = std::max<uint64_t>(2, 16384 / nseg);   // (dispatching mostly
-    return (uint32_t) std::min<uint64_t>(16, std::min(by_work, by_grid));                                                      //  empty workgroups costs too)
-}
-
 hipError_t launch_zs_local(hipStream_t st, const uint32_t *idx, uint32_t tris_hint, uint32_t tri_cap, uint32_t *row, uint32_t *next_row,
                            const uint32_t *ctr_tris, const uint32_t *ctr_verts, const uint32_t *status, uint32_t host_status, uint32_t cap_v,
                            uint32_t cap_t, uint32_t inject, uint32_t sig) {
+    // (tris_hint: what the grid is sized for -- the exact count on the synchronous route, the slot's capacity on the planned one)
     if (!host_status)
-        hipLaunchKernelGGL(k_zs_segmax, dim3(NCOL, zs_seg_split(tris_hint, NCOL)), dim3(256), 0, st, idx, tri_cap, row);
+        hipLaunchKernelGGL(k_zs_segmax, dim3(std::max<uint32_t>(1u, (std::min(tris_hint, tri_cap) + 255u) / 256u)), dim3(256), 0, st, idx, ctr_tris, tri_cap, row);
     hipLaunchKernelGGL(k_zs_rowfinish, dim3(1), dim3(1024), 0, st, row, next_row, ctr_tris, ctr_verts, status, host_status, cap_v, cap_t, inject, sig);
     return hipGetLastError();
 }
 
 hipError_t launch_zs_merge(hipStream_t st, int grid, const Vertex *v_all, const uint32_t *idx_all, const uint32_t *counts, uint32_t cstride,
                            const ZsRanks &zr, const ZsRanks *d_zr, uint32_t *tplan, uint32_t *vplan, uint32_t *vstart, uint32_t *newcnt,
-                           uint32_t *segof, uint32_t *redirect, uint32_t *map, uint64_t *hkeys, uint32_t hsize, Vertex *v_out, uint32_t cap_verts,
-                           uint32_t *i_out, uint32_t cap_tris, uint32_t *zctl, uint32_t seq, uint32_t *pub) {
-    const uint32_t R = zr.nranks, nseg = R * NCOL;
+                           uint32_t *segof, uint32_t *redirect, uint32_t *map, uint32_t *blockdrop, uint64_t *hkeys, uint32_t hsize, Vertex *v_out,
+                           uint32_t cap_verts, uint32_t *i_out, uint32_t cap_tris, uint32_t *zctl, uint32_t seq, uint32_t *pub) {
+    const uint32_t R = zr.nranks;
     const bool band = R > 1;
-    hipLaunchKernelGGL(k_zs_front, dim3(R * 64u + 1u), dim3(1024), 0, st, counts, cstride, d_zr, tplan, vplan, vstart, newcnt, segof, redirect,
-                       band ? (uint32_t *) hkeys : nullptr, band ? 3u * hsize : 0u, cap_verts, cap_tris, zctl);
+    hipLaunchKernelGGL(k_zs_front, dim3(R * 64u + 2u), dim3(1024), 0, st, counts, cstride, d_zr, tplan, vplan, vstart, newcnt, segof, redirect,
+                       band ? (uint32_t *) hkeys : nullptr, band ? 3u * hsize : 0u, band ? blockdrop : nullptr, cap_verts, cap_tris, zctl);
     if (band) {
         uint32_t *hmin = (uint32_t *) (hkeys + hsize);
         hipLaunchKernelGGL(k_zs_band_insert, dim3(grid), dim3(256), 0, st, v_all, counts, cstride, d_zr, (const uint32_t *) redirect, hkeys, hmin, hsize, zctl);
         hipLaunchKernelGGL(k_zs_band_resolve, dim3(grid), dim3(256), 0, st, v_all, counts, cstride, d_zr, (const uint64_t *) hkeys, (const uint32_t *) hmin,
-                           hsize, (const uint32_t *) segof, redirect, newcnt);
+                           hsize, (const uint32_t *) segof, redirect, newcnt, blockdrop);
         hipLaunchKernelGGL(k_zs_vplan, dim3(1), dim3(1024), 0, st, counts, cstride, d_zr, (const uint32_t *) newcnt, vplan, cap_verts, zctl);
     }
-    hipLaunchKernelGGL(k_zs_vertex_out, dim3(nseg), dim3(256), 0, st, v_all, counts, cstride, d_zr, (const uint32_t *) redirect, (const uint32_t *) vstart,
-                       (const uint32_t *) vplan, v_out, cap_verts, map);
+    hipLaunchKernelGGL(k_zs_vertex_out, dim3((zr.vbase[R] + ZS_VBLK - 1u) / ZS_VBLK + 1u), dim3(256), 0, st, v_all, counts, cstride, d_zr, (const uint32_t *) redirect,
+                       (const uint32_t *) segof, (const uint32_t *) vstart, (const uint32_t *) vplan, (const uint32_t *) blockdrop, v_out, cap_verts, map);
     if (band) hipLaunchKernelGGL(k_zs_loser_map, dim3(grid), dim3(256), 0, st, counts, cstride, d_zr, (const uint32_t *) redirect, map);
-    hipLaunchKernelGGL(k_zs_index_out, dim3(nseg, zs_seg_split(zr.tbase[R], nseg)), dim3(256), 0, st, idx_all, counts, cstride, (const uint32_t *) tplan, d_zr,
+    hipLaunchKernelGGL(k_zs_index_out, dim3(std::max<uint32_t>(1u, zr.tblk[R])), dim3(256), 0, st, idx_all, counts, cstride, (const uint32_t *) tplan, d_zr,
                        (const uint32_t *) map, i_out, cap_tris, (const uint32_t *) zctl, seq, pub);
     return hipGetLastError();
 }
