@@ -192,7 +192,7 @@ struct sdmesh_handle {
     DevBuf shard_mine, shard_counts, shard_recv, shard_lists, shard_plan, shard_merged;
     // z-slab INDEXED gather (root): the ranks' welded buffers concatenated, the merge's tables, its outputs (swapped into vertices / indices)
     // z-slab INDEXED gather: the ranks' welded buffers in SLOTS of zs_verts / zs_idx (root), the merge's tables, its outputs
-    DevBuf zs_verts, zs_idx, zs_tables, zs_pervert, zs_hkeys, zs_vout, zs_iout, zs_ranks, zs_ctl, shard_counts2;
+    DevBuf zs_verts, zs_idx, zs_tables, zs_pervert, zs_hkeys, zs_vout, zs_iout, zs_ranks, zs_ctl, shard_counts2, zs_colscratch;
     ZsRanks *h_zs = nullptr;       // pinned staging copy of the merge's slot table
     ZsRanks zs_uploaded{};         // what zs_ranks holds (uploaded again only when the table changes: never in steady state)
     bool zs_uploaded_valid = false;
@@ -214,7 +214,8 @@ struct sdmesh_handle {
     uint32_t zs_seq = 0;           // step number, published with the step's results (a stale host copy is told apart)
     uint32_t zs_last_route = 0;    // 1 = the last indexed step ran planned, 2 = synchronous, 3 = planned, then repeated synchronously
     // hooks of a sharded local phase into the ordinary chain
-    uint32_t *colcnt = nullptr;    // != nullptr: k_tile_dedupe adds the triangles per level-0 column into this (pre-zeroed) row
+    uint32_t *colcnt = nullptr;    // != nullptr: the chain publishes where every level-0 column starts into this (pre-zeroed) row: [c] in triangles
+                                   // (k_tile_dedupe), [1024 + c] in welded vertices (k_tile_rank, k_tile_finish; scratch: zs_colscratch)
     Vertex *out_v = nullptr;       // != nullptr: the weld writes the mesh here (the root's slot of the gather buffers) instead of h->vertices / h->indices
     uint32_t *out_i = nullptr;
     uint32_t out_vcap = 0;
@@ -397,7 +398,7 @@ int mesh_front(sdmesh_handle *h, const Point *d_vox, const uint32_t *n_ptr, Poin
     HIPCHK(launch_tile_dedupe(st, h->tgrid, d_vox, n_ptr, vs, (const uint8_t *) h->cubeidx.p, (const uint32_t *) tilecnt,
                               (uint32_t *) h->trioff.p, (uint32_t *) h->tri_e.p, (Vertex *) h->uverts.p, (uint4 *) h->tdesc.p,
                               h->ucap, h->tcap, h->d_ctr + CTR_NTRI, h->d_ctr + CTR_NTILES, h->d_status, d_tile_dbg,
-                              tiles(h->cap_vox) > PRESCAN_TILES, h->colcnt));
+                              tiles(h->cap_vox) > PRESCAN_TILES, h->colcnt, h->colcnt ? (uint32_t *) h->zs_colscratch.p : nullptr));
     SDCHK(prof_mark(h, "tile_dedupe"));
     // few tiles: the projection's workgroups prefix the tile counts themselves (no k_tile_prefix launch)
     const bool local_pre = h->local_prefix && tiles(h->cap_vox) <= SDM_LOCAL_TILES;
@@ -496,7 +497,8 @@ int mesh_weld(sdmesh_handle *h, const Vertex *uverts, uint32_t max_tiles, bool p
                            h->out_v ? h->out_v : (Vertex *) h->vertices.p, h->out_v ? h->out_vcap : (uint32_t) (h->vertices.cap / sizeof(Vertex)), h->d_ctr + CTR_NVERT,
                            h->out_v ? h->out_i : (uint32_t *) h->indices.p, h->d_status, flip_scene, h->d_sp, part,
                            publish ? h->d_ctr : nullptr, publish ? h->h_pinned : nullptr, CTR_WORDS + ST_WORDS, CTR_WORDS + ST_OVERFLOW, CTR_NVERT,
-                           flip_scene >= 0 ? h->tf_threads : 256));
+                           flip_scene >= 0 ? h->tf_threads : 256, h->colcnt, h->colcnt ? (const uint32_t *) h->zs_colscratch.p : nullptr,
+                           h->colcnt ? (uint32_t *) h->zs_colscratch.p + 1024 : nullptr, h->colcnt ? h->colcnt + 1024 : nullptr));
         if (part == 1) SDCHK(prof_mark(h, flip_scene >= 0 ? "tile_first_flip" : "tile_first"));
     }
     SDCHK(prof_mark(h, h->profile ? "weld_rank_scan_finish" : "weld"));
@@ -1106,7 +1108,7 @@ void sdmesh_destroy(sdmesh_handle *h) {
                       &h->first_ord_buf, &h->uverts, &h->tri_e, &h->vslot, &h->tdesc, &h->tfirst, &h->tfpre, &h->tpre, &h->flip, &h->wvidx, &h->torder, &h->wrep_buf, &h->wfm_buf,
                       &h->vertices, &h->indices, &h->raw, &h->compact, &h->staging, &h->dense_samples, &h->dense_bits,
                       &h->cellcnt, &h->dist_upids, &h->dist_upkeys, &h->dist_loids, &h->dist_prevkeys, &h->dist_hkeys, &h->dist_hpos, &h->dist_dupof,
-                      &h->dist_newidx, &h->dist_tilecnt, &h->dist_counts, &h->dist_upg, &h->dist_prevg, &h->dist_verts, &h->dist_nups, &h->col_list1, &h->col_mask2, &h->col_mask3, &h->colinfo, &h->prof_rounds, &h->proj_diag, &h->shard_mine, &h->shard_counts, &h->shard_recv, &h->shard_lists, &h->shard_plan, &h->shard_merged, &h->zs_verts, &h->zs_idx, &h->zs_tables, &h->zs_pervert, &h->zs_hkeys, &h->zs_vout, &h->zs_iout, &h->zs_ranks, &h->zs_ctl, &h->shard_counts2};
+                      &h->dist_newidx, &h->dist_tilecnt, &h->dist_counts, &h->dist_upg, &h->dist_prevg, &h->dist_verts, &h->dist_nups, &h->col_list1, &h->col_mask2, &h->col_mask3, &h->colinfo, &h->prof_rounds, &h->proj_diag, &h->shard_mine, &h->shard_counts, &h->shard_recv, &h->shard_lists, &h->shard_plan, &h->shard_merged, &h->zs_verts, &h->zs_idx, &h->zs_tables, &h->zs_pervert, &h->zs_hkeys, &h->zs_vout, &h->zs_iout, &h->zs_ranks, &h->zs_ctl, &h->shard_counts2, &h->zs_colscratch};
     (void) sdmesh_comm_destroy(h);
     if (h->h_counts) (void) hipHostFree(h->h_counts);
     if (h->h_lists) (void) hipHostFree(h->h_lists);
@@ -1210,7 +1212,7 @@ int sdmesh_set_option(sdmesh_handle *h, const char *name, int value) {
     if (!strcmp(name, "inject_fail")) { h->inject_fail = value; return SDMESH_OK; }
     if (!strcmp(name, "shard_indexed")) { h->shard_indexed = value != 0; h->zsp.valid = false; return SDMESH_OK; }
     if (!strcmp(name, "colcnt_debug")) {      // diagnostic: plain regens accumulate column counts into a scratch row (the cost of that hook alone)
-        if (value) { if (ensure(h, h->zs_ctl, 4ull * ZC_WORDS + 8192) != SDMESH_OK) return SDMESH_ERR_HIP; h->colcnt = (uint32_t *) h->zs_ctl.p + ZC_WORDS; }
+        if (value) { if (ensure(h, h->zs_ctl, 4ull * ZC_WORDS + 8192) != SDMESH_OK || ensure(h, h->zs_colscratch, 8192) != SDMESH_OK) return SDMESH_ERR_HIP; h->colcnt = (uint32_t *) h->zs_ctl.p + ZC_WORDS; }
         else h->colcnt = nullptr;
         return SDMESH_OK;
     }
@@ -2029,7 +2031,8 @@ int zs_scratch(sdmesh_handle *h, int R) {
     SDCHK(ensure(h, h->shard_counts, 4ull * (size_t) R * SHARD_ROW));
     SDCHK(ensure(h, h->shard_counts2, 4ull * (size_t) R * SHARD_ROW));
     if (fresh) h->zsp.valid = false;               // (only ever on a handle's first sharded call or after the communicator grew: the same call on every rank)
-    SDCHK(ensure(h, h->zs_ctl, 4ull * ZC_WORDS));
+    SDCHK(ensure(h, h->zs_ctl, 4ull * ZC_WORDS + 8192));
+    SDCHK(ensure(h, h->zs_colscratch, 8192));
     SDCHK(ensure(h, h->zs_ranks, sizeof(ZsRanks)));
     SDCHK(ensure(h, h->zs_tables, 4ull * 6 * (size_t) R * 1024));   // tplan [2 nseg] | vplan [2 nseg] | vstart [nseg] | newcnt [nseg]
     SDCHK(ensure_shard_host(h, R));
@@ -2158,6 +2161,7 @@ int zs_exchange(sdmesh_handle *h, const std::vector<ZsMsg> &msgs) {
 
 // this rank's slab, meshed AND welded with the ordinary synchronous regen; the column triangle counts land in `row` (pre-zeroed) on the way
 int zs_local_sync(sdmesh_handle *h, int levels, int part, int nparts, uint32_t *row, sdmesh_regen_info *slab) {
+    SDCHK(ensure(h, h->zs_colscratch, 8192));
     const int saved_skip = h->skip_weld;
     h->skip_weld = 0;
     h->colcnt = row;
@@ -2184,8 +2188,8 @@ int zs_step_sync(sdmesh_handle *h, int levels, int root, int inject, sdmesh_rege
     const int lrc = inject == 1 ? fail(h, SDMESH_ERR_INTERNAL, "injected failure (option inject_fail)") : zs_local_sync(h, levels, me, R, d_row, &slab);
     const uint32_t t_mine = lrc == SDMESH_OK ? h->n_tris : 0u, v_mine = lrc == SDMESH_OK ? h->n_verts : 0u;
     // 2. the row's vertex counts and record, then the all-gather -- ALWAYS entered
-    HIPCHK(launch_zs_local(st, (const uint32_t *) h->indices.p, t_mine, cap_items(h->indices, sizeof(IndexTriangle)), d_row, nullptr, h->d_ctr + CTR_NTRI,
-                           h->d_ctr + CTR_NVERT, h->d_status, (uint32_t) lrc, zs_root_capacity_v(h), zs_root_capacity_t(h), (uint32_t) inject, 0u));
+    HIPCHK(launch_zs_local(st, d_row, nullptr, h->d_ctr + CTR_NTRI, h->d_ctr + CTR_NVERT, h->d_status, (uint32_t) lrc, zs_root_capacity_v(h), zs_root_capacity_t(h),
+                           (uint32_t) inject, 0u));
     NCCLCHK(g_rccl.AllGather(d_row, d_counts, SHARD_ROW, ncclUint32, h->comm, st));                     // in place
     HIPCHK(hipMemcpyAsync(h->h_counts, d_counts, 4ull * (size_t) R * SHARD_ROW, hipMemcpyDeviceToHost, st));
     HIPCHK(hipStreamSynchronize(st));
@@ -2267,6 +2271,7 @@ int zs_planned_local(sdmesh_handle *h, int levels, int me, int R, const sdmesh_h
         SDCHK(ensure(h, h->vertices, sizeof(Vertex) * (size_t) pl.cap_v[me]));
         SDCHK(ensure(h, h->indices, sizeof(IndexTriangle) * (size_t) pl.cap_t[me]));
     }
+    SDCHK(ensure(h, h->zs_colscratch, 8192));
     const int saved_skip = h->skip_weld;
     h->skip_weld = 0;
     h->colcnt = d_row;
@@ -2279,9 +2284,8 @@ int zs_planned_local(sdmesh_handle *h, int levels, int me, int R, const sdmesh_h
     h->skip_weld = saved_skip;
     if (lrc == SDMESH_OK && ended && (h->last_direct || !h->welded || h->wide_active)) lrc = fail(h, SDMESH_ERR_INTERNAL, "a slab left the packed-key lattice path");
     if (lrc != SDMESH_OK && h->pend_active) { sdmesh_regen_info tmp; (void) regen_impl(h, 0, 0, 0, 1, &tmp, 2); }
-    const uint32_t *idx = slot_i ? (const uint32_t *) slot_i : (const uint32_t *) h->indices.p;
-    HIPCHK(launch_zs_local(st, idx, pl.cap_t[me], slot_i ? pl.cap_t[me] : cap_items(h->indices, sizeof(IndexTriangle)), d_row, d_next,
-                           h->d_ctr + CTR_NTRI, h->d_ctr + CTR_NVERT, h->d_status, (uint32_t) lrc, zs_root_capacity_v(h), zs_root_capacity_t(h), (uint32_t) inject, pl.sig));
+    HIPCHK(launch_zs_local(st, d_row, d_next, h->d_ctr + CTR_NTRI, h->d_ctr + CTR_NVERT, h->d_status, (uint32_t) lrc, zs_root_capacity_v(h), zs_root_capacity_t(h),
+                           (uint32_t) inject, pl.sig));
     return lrc;
 }
 
@@ -2570,8 +2574,7 @@ extern "C" int sdmesh_sharded_regen_rehearsal(sdmesh_handle **hs, int nranks, in
         uint32_t *row = d_counts + (size_t) r * SHARD_ROW;
         const int rc = inject == 1 ? fail(h, SDMESH_ERR_INTERNAL, "injected failure (option inject_fail)") : zs_local_sync(h, levels, r, R, row, &slab);
         if (rc != SDMESH_OK) { if (h != H) (void) fail(H, rc, "slab %d: %s", r, h->err); return rc; }
-        HIPCHK(launch_zs_local(h->stream, (const uint32_t *) h->indices.p, h->n_tris, cap_items(h->indices, sizeof(IndexTriangle)), row, nullptr, h->d_ctr + CTR_NTRI,
-                               h->d_ctr + CTR_NVERT, h->d_status, 0u, 0u, 0u, 0u, 0u));
+        HIPCHK(launch_zs_local(h->stream, row, nullptr, h->d_ctr + CTR_NTRI, h->d_ctr + CTR_NVERT, h->d_status, 0u, 0u, 0u, 0u, 0u));
         HIPCHK(hipStreamSynchronize(h->stream));
         Tr[r] = h->n_tris; Vr[r] = h->n_verts;
         cap_v[r] = zs_padded(H, Vr[r]); cap_t[r] = zs_padded(H, Tr[r]);

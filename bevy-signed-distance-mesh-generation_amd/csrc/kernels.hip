@@ -833,6 +833,7 @@ __global__ __launch_bounds__(256) void k_tile_dedupe(const Point *__restrict__ v
                                                       uint64_t *__restrict__ dbg /* optional: 8 s_memtime stamps per tile (tools/tile_phases.py) */,
                                                       uint32_t prescanned /* tilecnt = exclusive prefix, *ntri_out = total (k_scan_tiles in front) */,
                                                       uint32_t *__restrict__ colstart /* optional (multi-GPU z-slabs): [c] = 1 + first triangle of level-0 (x0, y0) column c, for the columns that hold voxels; pre-zeroed */,
+                                                      uint32_t *__restrict__ coltile /* with colstart: [c] = the tile that holds the column's first voxel */,
                                                       uint32_t colshift /* log2(voxels per level-0 cell edge) */) {
 #define SDM_STAMP(k) do { if (dbg && tid == 0) dbg[8ull * tile + (k)] = __builtin_amdgcn_s_memtime(); } while (0)
     __shared__ uint64_t s_keys[T_HASH];
@@ -897,7 +898,7 @@ __global__ __launch_bounds__(256) void k_tile_dedupe(const Point *__restrict__ v
             if (tid) prev = s_col[tid - 1u];
             else if (tile) { int px = 0, py = 0; (void) lattice_coord(bpx, vs.x, px); (void) lattice_coord(bpy, vs.y, py);
                              prev = (((uint32_t) px >> colshift) & 31u) * MESH_GENERATION_INIT_FACTOR + (((uint32_t) py >> colshift) & 31u); }
-            if (col != prev) colstart[col] = tbase + lo + 1u;
+            if (col != prev) { colstart[col] = tbase + lo + 1u; coltile[col] = tile; }
         }
         if (tile == ntiles - 1 && tid == 0 && !prescanned) {
             uint32_t tot = tbase + ttri;
@@ -1630,7 +1631,8 @@ __global__ __launch_bounds__(256) void k_tile_rank(const uint4 *__restrict__ tde
                                                     const uint32_t *__restrict__ first_ord, const uint2 *__restrict__ wfm,
                                                     const uint32_t *__restrict__ vslot,
                                                     uint32_t *__restrict__ wv, uint32_t *__restrict__ torder,
-                                                    uint32_t *__restrict__ tfirst) {
+                                                    uint32_t *__restrict__ tfirst, const uint32_t *__restrict__ colstart,
+                                                    const uint32_t *__restrict__ coltile, uint32_t *__restrict__ colvloc) {
     __shared__ uint32_t s_bits[3 * T_TRI / 32];      // 120 words: one bit per local ordinal
     __shared__ uint32_t s_pre[3 * T_TRI / 32];
     __shared__ uint32_t s_scan[17];
@@ -1669,6 +1671,19 @@ __global__ __launch_bounds__(256) void k_tile_rank(const uint4 *__restrict__ tde
         if (tid < 3 * T_TRI / 32) s_pre[tid] = ex;
         __syncthreads();
         if (tid == 0) tfirst[tile] = total;
+        if (colstart) {
+            // (multi-GPU z-slabs) the columns whose first voxel lies in this tile: how many of the tile's first-seen vertices come before
+            // the column's first triangle -- with the tiles' prefix (k_tile_finish) that is where the column's vertices start in the
+            // welded order, because welded vertices are numbered in first-seen order (src/cuda/mod.rs:276-296)
+#pragma unroll
+            for (uint32_t k = 0; k < 4; k++) {
+                const uint32_t c = tid + 256u * k, cs = colstart[c];
+                if (cs && coltile[c] == tile) {
+                    const uint32_t x = 3u * (cs - 1u - d.z);
+                    colvloc[c] = x >= 3u * d.w ? total : s_pre[x >> 5] + __popc(s_bits[x >> 5] & ((1u << (x & 31u)) - 1u));
+                }
+            }
+        }
 #pragma unroll
         for (uint32_t k = 0; k < 2; k++) {
             if (lo_of[k] != U32_NONE) {
@@ -1725,7 +1740,9 @@ __global__ __launch_bounds__(256) void k_tile_finish(const Vertex *__restrict__ 
                                                       uint32_t *__restrict__ indices, uint32_t *__restrict__ status,
                                                       uint32_t *__restrict__ nverts_out,
                                                       const uint32_t *__restrict__ pub_src, uint32_t *__restrict__ pub_dst, uint32_t pub_words,
-                                                      uint32_t pub_ovf, uint32_t pub_nvert) {
+                                                      uint32_t pub_ovf, uint32_t pub_nvert, const uint32_t *__restrict__ colstart,
+                                                      const uint32_t *__restrict__ coltile, const uint32_t *__restrict__ colvloc,
+                                                      uint32_t *__restrict__ colvstart /* [c] = 1 + first welded vertex first seen in column c, for the columns colstart names */) {
     __shared__ uint32_t s_pre[LOCAL_TILES + 1], s_scan[17];
     const uint32_t ntiles = *ntiles_ptr, tid = threadIdx.x;
     const bool local = tfpre == nullptr;
@@ -1753,6 +1770,15 @@ __global__ __launch_bounds__(256) void k_tile_finish(const Vertex *__restrict__ 
         if (tid == pub_nvert) v = total;
         if (tid == pub_ovf && total > vcap) v |= 16u;
         pub_dst[tid] = v;
+    }
+    if (colstart && blockIdx.x == 0) {
+#pragma unroll
+        for (uint32_t k = 0; k < 4; k++) {
+            const uint32_t c = tid + 256u * k, cs = colstart[c];
+            uint32_t vs = 0;
+            if (cs) { const uint32_t ct = coltile[c]; vs = (ct < ntiles ? (local ? s_pre[ct] : tfpre[ct]) : total) + colvloc[c] + 1u; }
+            colvstart[c] = vs;
+        }
     }
     for (uint32_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
         const uint4 d = tdesc[tile];
@@ -2764,7 +2790,7 @@ hipError_t launch_classify(hipStream_t st, int grid, int scene, const SceneParam
 hipError_t launch_tile_dedupe(hipStream_t st, int grid, const Point *vox, const uint32_t *n_ptr, Point vs, const uint8_t *cubeidx,
                               const uint32_t *tilecnt, uint32_t *trioff, uint32_t *tri_e, Vertex *uverts, uint4 *tdesc,
                               uint32_t ucap, uint32_t tcap, uint32_t *ntri_out, uint32_t *ntiles_out, uint32_t *status, uint64_t *dbg,
-                              bool prescan, uint32_t *colstart) {
+                              bool prescan, uint32_t *colstart, uint32_t *coltile) {
     // voxels per level-0 cell edge = (5 / 32) / vs.x, a power of two for every field the lattice path takes
     uint32_t colshift = 0;
     {
@@ -2774,7 +2800,7 @@ hipError_t launch_tile_dedupe(hipStream_t st, int grid, const Point *vox, const 
     if (prescan)
         hipLaunchKernelGGL(k_scan_tiles, dim3(1), dim3(1024), 0, st, const_cast<uint32_t *>(tilecnt), n_ptr, 256u, ntri_out, tcap, status);
     hipLaunchKernelGGL(k_tile_dedupe, dim3(grid), dim3(256), 0, st, vox, n_ptr, vs, cubeidx, tilecnt, trioff, tri_e, uverts, tdesc,
-                       ucap, tcap, ntri_out, ntiles_out, status, dbg, prescan ? 1u : 0u, colstart, colshift);
+                       ucap, tcap, ntri_out, ntiles_out, status, dbg, prescan ? 1u : 0u, colstart, coltile, colshift);
     return hipGetLastError();
 }
 
@@ -2854,7 +2880,8 @@ hipError_t launch_weld(hipStream_t st, int grid, const Vertex *uverts, const uin
                        uint32_t *vslot, uint32_t *wv, uint32_t *torder, uint32_t *tfirst, uint32_t *tfpre,
                        Vertex *vertices, uint32_t vcap, uint32_t *nverts_out, uint32_t *indices, uint32_t *status,
                        int flip_scene, const SceneParams *sp, int part, const uint32_t *pub_src, uint32_t *pub_dst, uint32_t pub_words,
-                       uint32_t pub_ovf, uint32_t pub_nvert, int tf_threads) {
+                       uint32_t pub_ovf, uint32_t pub_nvert, int tf_threads, const uint32_t *colstart, const uint32_t *coltile, uint32_t *colvloc,
+                       uint32_t *colvstart) {
     if (tf_threads != 128 && tf_threads != 256 && tf_threads != 512 && tf_threads != 768 && tf_threads != 1024) tf_threads = 256;
     // part: 0 = the whole weld, 1 = k_tile_first only, 2 = everything behind it (so that a stage marker fits between)
     const bool stop_after_first = part == 1;
@@ -2874,11 +2901,12 @@ hipError_t launch_weld(hipStream_t st, int grid, const Vertex *uverts, const uin
     if (stop_after_first) return hipGetLastError();
 rest:
     hipLaunchKernelGGL(k_tile_rank, dim3(grid), dim3(256), 0, st, tdesc, ntiles_ptr, first_ord, wfm, vslot, wv, torder,
-                       tfirst);
+                       tfirst, colstart, coltile, colvloc);
     // tfpre == nullptr: few enough tiles for k_tile_finish to prefix the first-seen counts itself
     if (tfpre) hipLaunchKernelGGL(k_scan_u32, dim3(1), dim3(1024), 0, st, tfirst, ntiles_ptr, tfpre, nverts_out);
     hipLaunchKernelGGL(k_tile_finish, dim3(grid), dim3(256), 0, st, uverts, tdesc, ntiles_ptr, tfpre, tfirst, torder, tri_e, vslot,
-                       wv, vertices, vcap, indices, status, nverts_out, pub_src, pub_dst, pub_words, pub_ovf, pub_nvert);
+                       wv, vertices, vcap, indices, status, nverts_out, pub_src, pub_dst, pub_words, pub_ovf, pub_nvert, colstart, coltile,
+                       (const uint32_t *) colvloc, colvstart);
     return hipGetLastError();
 }
 

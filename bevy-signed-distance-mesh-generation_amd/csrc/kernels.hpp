@@ -58,7 +58,9 @@ hipError_t launch_classify(hipStream_t st, int grid, int scene, const SceneParam
 hipError_t launch_tile_dedupe(hipStream_t st, int grid, const Point *vox, const uint32_t *n_ptr, Point vs, const uint8_t *cubeidx,
                               const uint32_t *tilecnt, uint32_t *trioff, uint32_t *tri_e, Vertex *uverts, uint4 *tdesc,
                               uint32_t ucap, uint32_t tcap, uint32_t *ntri_out, uint32_t *ntiles_out, uint32_t *status, uint64_t *dbg = nullptr,
-                              bool prescan = false, uint32_t *colcnt = nullptr /* += triangles per level-0 column (pre-zeroed; z-slab gather) */);
+                              bool prescan = false,
+                              uint32_t *colstart = nullptr /* z-slab gather: [c] = 1 + first triangle of level-0 column c where the column holds voxels (pre-zeroed) */,
+                              uint32_t *coltile = nullptr /* with colstart: the tile of the column's first voxel */);
 hipError_t launch_tile_prefix(hipStream_t st, const uint4 *tdesc, const uint32_t *ntiles_ptr, uint32_t *tpre, uint32_t *nu_out,
                               uint32_t *coarse);
 hipError_t launch_project(hipStream_t st, int grid, int scene, const SceneParams *sp, Vertex *uverts, const uint4 *tdesc,
@@ -88,7 +90,9 @@ hipError_t launch_weld(hipStream_t st, int grid, const Vertex *uverts, const uin
                        Vertex *vertices, uint32_t vcap, uint32_t *nverts_out, uint32_t *indices, uint32_t *status,
                        int flip_scene = -1 /* >= 0: the orientation test runs inside k_tile_first */, const SceneParams *sp = nullptr,
                        int part = 0, const uint32_t *pub_src = nullptr /* control block -> host copy by k_tile_finish */, uint32_t *pub_dst = nullptr,
-                       uint32_t pub_words = 0, uint32_t pub_ovf = 0, uint32_t pub_nvert = 0, int tf_threads = 256 /* workgroup size of k_tile_first */);
+                       uint32_t pub_words = 0, uint32_t pub_ovf = 0, uint32_t pub_nvert = 0, int tf_threads = 256 /* workgroup size of k_tile_first */,
+                       const uint32_t *colstart = nullptr, const uint32_t *coltile = nullptr /* as launch_tile_dedupe left them */, uint32_t *colvloc = nullptr /* [1024] scratch */,
+                       uint32_t *colvstart = nullptr /* out: [c] = 1 + first welded vertex first seen in column c (0 where colstart is) */);
 hipError_t launch_expand_compact(hipStream_t st, int grid, const Vertex *uverts, const uint32_t *tri_e, const uint8_t *flip,
                                  const uint32_t *ntri_ptr, Triangle *out, uint32_t cap);
 hipError_t launch_expand_raw(hipStream_t st, int grid, const Vertex *uverts, const uint32_t *tri_e, const uint8_t *flip,
@@ -128,11 +132,10 @@ enum ZsRec : uint32_t { ZR_STATUS = 0, ZR_TRIS = 1, ZR_CAP_V = 2, ZR_CAP_T = 3, 
 // words of the merge's own control block (device) and of what a step publishes to pinned host memory: [ZC_WORDS | R records of 8 words]
 enum ZsCtl : uint32_t { ZC_TRIS = 0, ZC_VERTS = 1, ZC_NBAND = 2, ZC_BANDFLAGS = 3 /* 1: weld range, 64: band hash full */, ZC_PLANFLAGS = 4 /* 1: rows invalid or over a slot's capacity, 2: merged triangles over capacity */,
                      ZC_SEQ = 5, ZC_VFLAGS = 6 /* 4: merged vertices over capacity */, ZC_RANKBAD = 8 /* + r: the vertex counts of rank r's row do not add up */, ZC_WORDS = 40 };
-// local phase, every rank: the slab's first-seen vertex counts per column from its own index buffer (row[1024 ..)), then the row's record;
-// `next_row`: the row of the next step's buffer, whose count areas are cleared here (the column counts are accumulated by k_tile_dedupe)
-hipError_t launch_zs_local(hipStream_t st, const uint32_t *idx, uint32_t tris_hint, uint32_t tri_cap, uint32_t *row, uint32_t *next_row,
-                           const uint32_t *ctr_tris, const uint32_t *ctr_verts, const uint32_t *status, uint32_t host_status, uint32_t cap_v,
-                           uint32_t cap_t, uint32_t inject, uint32_t sig);
+// local phase, every rank: the row the chain published (column starts in triangles and in welded vertices: k_tile_dedupe, k_tile_finish)
+// becomes counts, checked, with its record; `next_row`: the row of the next step's buffer, cleared here (the next chain publishes into it)
+hipError_t launch_zs_local(hipStream_t st, uint32_t *row, uint32_t *next_row, const uint32_t *ctr_tris, const uint32_t *ctr_verts, const uint32_t *status,
+                           uint32_t host_status, uint32_t cap_v, uint32_t cap_t, uint32_t inject, uint32_t sig);
 // root: the merge.  counts = the gathered rows (cstride words each); zr = the slot table (host copy for the grid sizes, d_zr the same in device
 // memory); the tables tplan / vplan [2 nseg], vstart / newcnt [nseg], per slot vertex segof / redirect / map; hash (hsize slots: 8-byte keys,
 // then 4-byte minima) only with more than one rank; zctl = ZC_WORDS words; pub (pinned host, optional) receives zctl and the records

@@ -7,8 +7,9 @@
 //
 //   * a rank's welded vertices are numbered in its own first-seen order (src/cuda/mod.rs:276-296), so the number of distinct
 //     vertices in its first n triangles is 1 + the largest index among them: the largest index per column segment, prefix-maximised
-//     over the columns, gives the number of local vertices FIRST SEEN in each level-0 column -- computed by every rank for its own
-//     slab (k_zs_segmax, k_zs_rowfinish) and carried to the root in the all-gather beside the column triangle counts;
+//     over the columns, gives the number of local vertices FIRST SEEN in each level-0 column -- equivalently, the vertices first seen
+//     in a column are a contiguous range of the rank's vertex buffer, whose start the rank's own weld publishes on the way (k_tile_rank,
+//     k_tile_finish in kernels.hip; decoded by k_zs_rowfinish) and which rides to the root in the all-gather beside the column triangle counts;
 //   * in the single-GPU order (x outer, y, z inner: src/cuda/mod.rs:105-122) a level-0 column holds rank 0's triangles, then rank
 //     1's, ...: so the single-GPU first-seen vertex order is, column by column and rank by rank, each (rank, column) segment's
 //     first-seen vertices in their local order -- vertex buffers merge by segments exactly like the triangle lists;
@@ -24,6 +25,7 @@
 // reported a failure or a count exceeds its slot: the host sees the same records and repeats the step synchronously.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdlib.h>
 
 #include <algorithm>
 
@@ -87,77 +89,29 @@ __device__ __forceinline__ uint32_t zs_col_of(const uint32_t *__restrict__ s_sta
     return lo;
 }
 
-// Column starts from what k_tile_dedupe published: enc[c] = 1 + first triangle of column c for the columns that hold voxels, 0 for the
-// others.  An empty column starts where the next one does (so that zs_col_of never answers with it): s_start[c] = the suffix minimum of
-// the published starts, T behind the last -> s_start[0 .. NCOL].  256 threads, four consecutive columns each; all must call; lds >= 4 words.
-__device__ __forceinline__ void zs_starts_from_published(const uint32_t *__restrict__ enc, uint32_t T, uint32_t *__restrict__ s_start, uint32_t *__restrict__ lds) {
-    const uint32_t tid = threadIdx.x, lane = lane_id(), wave = tid >> 6;
-    uint32_t m[4];
-#pragma unroll
-    for (uint32_t k = 0; k < 4u; k++) { const uint32_t e = enc[4u * tid + k]; m[k] = e ? e - 1u : U32_NONE; }
-#pragma unroll
-    for (int k = 2; k >= 0; k--) m[k] = m[k] < m[k + 1] ? m[k] : m[k + 1];          // suffix minimum inside the thread's four
-    uint32_t x = m[0];
-#pragma unroll
-    for (uint32_t o = 1; o < 64u; o <<= 1) {                                          // inclusive suffix minimum over the wave's lanes
-        const uint32_t y = (uint32_t) __shfl_down((int) x, o, 64);
-        if (lane + o < 64u) x = y < x ? y : x;
+// published starts -> counts: enc[c] = 1 + the first item (triangle / welded vertex) of column c for the columns that hold voxels, 0 for
+// the others; an empty column starts where the next one does (suffix minimum), `end` behind the last.  One 1024-thread workgroup, thread =
+// column; s: NCOL + 1 words.  Returns the column's count; `bad` is raised for starts that do not ascend from 0.
+__device__ __forceinline__ uint32_t zs_decode_starts(uint32_t enc, uint32_t end, uint32_t *__restrict__ s, bool &bad) {
+    const uint32_t c = threadIdx.x;
+    __syncthreads();
+    s[c] = enc ? enc - 1u : U32_NONE;
+    __syncthreads();
+    for (uint32_t o = 1; o < NCOL; o <<= 1) {                        // inclusive suffix minimum (Hillis-Steele: 10 steps)
+        const uint32_t a = s[c], b = c + o < NCOL ? s[c + o] : U32_NONE;
+        __syncthreads();
+        s[c] = a < b ? a : b;
+        __syncthreads();
     }
-    uint32_t after = (uint32_t) __shfl_down((int) x, 1u, 64);                         // the lanes behind this one
-    if (lane == 63u) after = U32_NONE;
-    if (lane == 0) lds[wave] = x;
-    __syncthreads();
-    for (uint32_t w = wave + 1u; w < 4u; w++) after = lds[w] < after ? lds[w] : after;
-    after = T < after ? T : after;
-#pragma unroll
-    for (uint32_t k = 0; k < 4u; k++) s_start[4u * tid + k] = m[k] < after ? m[k] : after;
-    if (tid == 0) s_start[NCOL] = T;
-    __syncthreads();
+    const uint32_t start = s[c] < end ? s[c] : end, next = c + 1u < NCOL ? (s[c + 1u] < end ? s[c + 1u] : end) : end;
+    bad = next < start || (c == 0 && start != 0u && end != 0u) || (s[c] != U32_NONE && s[c] > end);
+    return next >= start ? next - start : 0u;
 }
 
-// largest local vertex index + 1 of every column segment of this rank's index buffer -> row[NCOL + c] (pre-zeroed).  Flat over the
-// triangles, one per thread: every workgroup derives the segments' starts from the published column starts itself (no plan launch
-// in front), a triangle finds its column by bisection in LDS, the maxima are reduced per wave and per workgroup in LDS: one global
-// atomicMax per (workgroup, column) pair -- a wave's, and nearly always a workgroup's, triangles share a column.
-__global__ __launch_bounds__(256) void k_zs_segmax(const uint32_t *__restrict__ idx, const uint32_t *__restrict__ ctr_tris, uint32_t tri_cap,
-                                                    uint32_t *__restrict__ row) {
-    __shared__ uint32_t s_start[NCOL + 1];
-    __shared__ uint32_t s_m[NCOL];
-    __shared__ uint32_t lds[17];
-    uint32_t T = *ctr_tris;
-    if (T > tri_cap) T = tri_cap;                                        // (a chain that overflowed: the record says so)
-    if (blockIdx.x * 256u >= T) return;
-    const uint32_t tid = threadIdx.x, t = blockIdx.x * 256u + tid;
-    const bool in = t < T;
-    uint32_t m = 0;
-    if (in) {                                                            // (the loads first: the table below costs a few barriers)
-        const uint32_t a = idx[3ull * t], b = idx[3ull * t + 1u], d = idx[3ull * t + 2u];
-        m = (a > b ? (a > d ? a : d) : (b > d ? b : d)) + 1u;
-    }
-#pragma unroll
-    for (uint32_t k = 0; k < 4u; k++) s_m[tid + 256u * k] = 0u;
-    zs_starts_from_published(row, T, s_start, lds);
-    const uint32_t c = in ? zs_col_of(s_start, t) : 0u;
-    const uint64_t has = __ballot(in);
-    if (has) {
-        const uint32_t cf = (uint32_t) __builtin_amdgcn_readlane((int) c, (int) __builtin_ctzll(has));
-        if (__ballot(in && c != cf) == 0ull) {
-            for (int o = 32; o > 0; o >>= 1) { const uint32_t x = (uint32_t) __shfl_xor((int) m, o, 64); m = x > m ? x : m; }
-            if (lane_id() == 0) atomicMax(&s_m[cf], m);
-        } else if (in) {
-            atomicMax(&s_m[c], m);
-        }
-    }
-    __syncthreads();
-    // (the workgroup's columns are the contiguous range between its first and its last triangle's)
-    const uint32_t c_lo = zs_col_of(s_start, blockIdx.x * 256u), t_hi = blockIdx.x * 256u + 255u < T ? blockIdx.x * 256u + 255u : T - 1u;
-    const uint32_t c_hi = zs_col_of(s_start, t_hi);
-    for (uint32_t cc = c_lo + tid; cc <= c_hi; cc += 256u) { const uint32_t mm = s_m[cc]; if (mm) atomicMax(&row[NCOL + cc], mm); }
-}
-
-// One workgroup: row[c] (published column starts) -> column triangle counts; row[NCOL + c] (segment maxima) -> first-seen vertex counts per
-// column (prefix maximum, then differences); the checks that make the row trustworthy; the row's record; and the clear of the NEXT step's
-// row (the next chain publishes into it; the buffers alternate).
+// One workgroup: the row the chain published -- row[c] = column starts in triangles (k_tile_dedupe), row[NCOL + c] = column starts in
+// welded vertices (k_tile_finish; welded vertices are numbered in first-seen order, so the vertices first seen in a column are a
+// contiguous range) -- becomes the row the merge reads: triangle counts and first-seen vertex counts per column; the checks that make
+// it trustworthy; its record; and the clear of the NEXT step's row (the next chain publishes into it; the buffers alternate).
 __global__ __launch_bounds__(1024) void k_zs_rowfinish(uint32_t *__restrict__ row, uint32_t *__restrict__ next_row, const uint32_t *__restrict__ ctr_tris,
                                                         const uint32_t *__restrict__ ctr_verts, const uint32_t *__restrict__ status, uint32_t host_status,
                                                         uint32_t cap_v, uint32_t cap_t, uint32_t inject, uint32_t sig) {
@@ -166,34 +120,16 @@ __global__ __launch_bounds__(1024) void k_zs_rowfinish(uint32_t *__restrict__ ro
     const uint32_t c = threadIdx.x;
     const bool failed = host_status != 0u;                             // the host already knows this rank's local phase failed: an empty row
     const uint32_t T = failed ? 0u : *ctr_tris, V = failed ? 0u : *ctr_verts;
-    // column starts: suffix minimum of the published ones, T behind the last
-    const uint32_t enc = failed ? 0u : row[c];
-    s[c] = enc ? enc - 1u : U32_NONE;
-    if (c == 0) s[NCOL] = T;
-    __syncthreads();
-    for (uint32_t o = 1; o < NCOL; o <<= 1) {                        // inclusive suffix minimum (Hillis-Steele: 10 steps)
-        const uint32_t a = s[c], b = c + o < NCOL ? s[c + o] : T;
-        __syncthreads();
-        s[c] = a < b ? a : b;
-        __syncthreads();
-    }
-    const uint32_t start = s[c] < T ? s[c] : T, next = c + 1u < NCOL ? (s[c + 1u] < T ? s[c + 1u] : T) : T;
-    const uint32_t tc = next >= start ? next - start : 0u;
-    const uint32_t disorder = __syncthreads_or((next < start || (c == 0 && start != 0u && T != 0u)) ? 1 : 0);      // (starts that do not ascend from 0)
-    uint32_t tsum;
+    const uint32_t enc_t = failed ? 0u : row[c], enc_v = failed ? 0u : row[NCOL + c];
+    bool bad_t, bad_v;
+    const uint32_t tc = zs_decode_starts(enc_t, T, s, bad_t);
+    const uint32_t vc = zs_decode_starts(enc_v, V, s, bad_v);
+    const uint32_t disorder = __syncthreads_or((bad_t || bad_v || ((enc_t != 0u) != (enc_v != 0u))) ? 1 : 0);
+    uint32_t tsum, vsum;
     (void) block_excl_scan(tc, tsum, lds);
-    // first-seen vertices per column: prefix maximum of the segment maxima, then differences
-    s[c] = failed ? 0u : row[NCOL + c];
-    __syncthreads();
-    for (uint32_t o = 1; o < NCOL; o <<= 1) {                        // inclusive prefix maximum
-        const uint32_t a = s[c], b = c >= o ? s[c - o] : 0u;
-        __syncthreads();
-        s[c] = a > b ? a : b;
-        __syncthreads();
-    }
-    const uint32_t incl = s[c], excl = c ? s[c - 1u] : 0u;
+    (void) block_excl_scan(vc, vsum, lds);
     row[c] = tc;
-    row[NCOL + c] = incl - excl;
+    row[NCOL + c] = vc;
     if (next_row) { next_row[c] = 0u; next_row[NCOL + c] = 0u; }
     if (c == NCOL - 1u) {
         uint32_t st = host_status;
@@ -202,7 +138,7 @@ __global__ __launch_bounds__(1024) void k_zs_rowfinish(uint32_t *__restrict__ ro
             // vertex outside the packed key range, an invariant -- and a row that does not describe the buffers
             const uint32_t dev = (status[ST_OVERFLOW] ? 1u : 0u) | (status[ST_NOT_LATTICE] ? 2u : 0u) | (status[ST_WELD_RANGE] ? 4u : 0u) |
                                  (status[ST_INTERNAL] ? 8u : 0u) | (status[ST_TILE_OVERFLOW] ? 16u : 0u) | (status[ST_NONFINITE] ? 32u : 0u) |
-                                 ((tsum != T || disorder) ? 64u : 0u) | (incl != V ? 128u : 0u);
+                                 ((tsum != T || disorder) ? 64u : 0u) | (vsum != V ? 128u : 0u);
             if (dev) st = 0x80000000u | dev;
         }
         uint32_t *rec = row + SHARD_REC;
@@ -379,19 +315,23 @@ __global__ __launch_bounds__(1024) void k_zs_vplan(const uint32_t *__restrict__ 
 __global__ __launch_bounds__(256) void k_zs_vertex_out(const Vertex *__restrict__ v, const uint32_t *__restrict__ counts, uint32_t cstride,
                                                         const ZsRanks *__restrict__ zrp, const uint32_t *__restrict__ redirect, const uint32_t *__restrict__ segof,
                                                         const uint32_t *__restrict__ vstart, const uint32_t *__restrict__ vplan, const uint32_t *__restrict__ blockdrop,
-                                                        Vertex *__restrict__ out, uint32_t cap, uint32_t *__restrict__ map) {
+                                                        Vertex *__restrict__ out, uint32_t cap, uint32_t *__restrict__ map, uint32_t dbg) {
     const ZsRanks &zr = *zrp;
     __shared__ uint32_t lds[17];
     __shared__ uint32_t s_e[ZS_VBLK];
     __shared__ uint32_t s_x;
     const uint32_t tid = threadIdx.x, V = zr.vbase[zr.nranks], b0 = blockIdx.x * ZS_VBLK, i = b0 + tid;
     if (b0 >= V) return;
-    // (speculative loads: entries behind V or in a slot's tail read allocated memory, their values are not used)
+    // (speculative loads: entries behind V or in a slot's tail read allocated memory, their values are not used.)  The block's vertices
+    // as six coalesced dword loads per thread: a 24-byte vertex per lane would touch every line six times.
     const uint32_t red = i < V ? redirect[i] : ZS_GAP;
     const uint32_t seg_i = i < V ? segof[i] : 0u;
-    Vertex vert;
-    if (i < V) vert = v[i];
-    if (!zs_rows_ok(counts, cstride, zr)) return;
+    const uint32_t nd = (V - b0 < ZS_VBLK ? V - b0 : ZS_VBLK) * 6u;
+    const uint32_t *__restrict__ v32 = reinterpret_cast<const uint32_t *>(v) + 6ull * b0;
+    uint32_t w[6];
+#pragma unroll
+    for (uint32_t j = 0; j < 6u; j++) w[j] = (tid + 256u * j < nd && !(dbg & 1u)) ? v32[tid + 256u * j] : 0u;
+    if (!(dbg & 8u) && !zs_rows_ok(counts, cstride, zr)) return;
     const bool drops = zr.nranks > 1u;
     const bool kept = red == U32_NONE;
     uint32_t first = 0, dstart = 0;
@@ -422,10 +362,20 @@ __global__ __launch_bounds__(256) void k_zs_vertex_out(const Vertex *__restrict_
         (void) block_excl_scan(x, xt, lds);
         if (kept) before = first >= b0 ? s_e[tid] - s_e[first - b0] : s_e[tid] + xt;
     }
+    uint32_t g = U32_NONE;
     if (kept) {
-        const uint32_t g = dstart + (i - first) - before;
-        map[i] = g;
-        if (g < cap) out[g] = vert;
+        g = dstart + (i - first) - before;
+        if (!(dbg & 4u)) map[i] = g;
+        if (g >= cap) g = U32_NONE;                                       // flagged by the plan
+    }
+    __syncthreads();
+    s_e[tid] = g;                                                         // (s_e: its last readers are behind the barrier above)
+    __syncthreads();
+    uint32_t *__restrict__ out32 = reinterpret_cast<uint32_t *>(out);
+#pragma unroll
+    for (uint32_t j = 0; j < 6u; j++) {
+        const uint32_t k = tid + 256u * j;
+        if (k < nd && !(dbg & 2u)) { const uint32_t gg = s_e[k / 6u]; if (gg != U32_NONE) out32[6ull * gg + k % 6u] = w[j]; }
     }
 }
 
@@ -459,26 +409,41 @@ __global__ __launch_bounds__(256) void k_zs_index_out(const uint32_t *__restrict
                                                        uint32_t *__restrict__ pub) {
     const ZsRanks &zr = *zrp;
     __shared__ uint32_t s_start[NCOL + 1];
+    __shared__ uint32_t s_dst[ZS_TBLK];
     if (pub && blockIdx.x == 0) zs_publish_body(counts, cstride, zr.nranks, zctl, seq, pub);
     uint32_t r = 0;
     while (r + 1u < zr.nranks && blockIdx.x >= zr.tblk[r + 1u]) r++;
-    const uint32_t Tr = row_rec(counts, cstride, r, ZR_TRIS), t = (blockIdx.x - zr.tblk[r]) * ZS_TBLK + threadIdx.x;
-    const bool in = t < Tr && t < zr.tbase[r + 1u] - zr.tbase[r];
-    const uint32_t *__restrict__ s = idx_all + 3ull * zr.tbase[r];
-    const uint32_t vb = zr.vbase[r];
-    uint32_t a = 0, b = 0, d = 0;
-    if (in) { a = s[3ull * t]; b = s[3ull * t + 1u]; d = s[3ull * t + 2u]; }            // (in front of the table and the checks)
+    const uint32_t tid = threadIdx.x, t0 = (blockIdx.x - zr.tblk[r]) * ZS_TBLK, t = t0 + tid;
+    const uint32_t slot = zr.tbase[r + 1u] - zr.tbase[r];
+    if (t0 >= slot) return;
+    // the block's 768 indices as three coalesced dword loads per thread (speculative: in front of the table and the checks)
+    const uint32_t ne_cap = (slot - t0 < ZS_TBLK ? slot - t0 : ZS_TBLK) * 3u;
+    const uint32_t *__restrict__ s = idx_all + 3ull * (zr.tbase[r] + t0);
+    uint32_t e[3];
 #pragma unroll
-    for (uint32_t k = 0; k < 4u; k++) s_start[threadIdx.x + 256u * k] = tplan[2u * (r * NCOL + threadIdx.x + 256u * k)];
+    for (uint32_t j = 0; j < 3u; j++) e[j] = tid + 256u * j < ne_cap ? s[tid + 256u * j] : 0u;
+#pragma unroll
+    for (uint32_t k = 0; k < 4u; k++) s_start[tid + 256u * k] = tplan[2u * (r * NCOL + tid + 256u * k)];
     if (!zs_rows_ok(counts, cstride, zr)) return;                       // (synchronises: s_start is complete)
-    if (!in) return;
-    const uint32_t Vr = row_rec(counts, cstride, r, ZR_VERTS);
-    if (a >= Vr || b >= Vr || d >= Vr) return;                          // (not an index of this rank: never of a checked row)
-    const uint32_t ma = map[vb + a], mb = map[vb + b], md = map[vb + d];
-    const uint32_t c = zs_col_of(s_start, t), seg = r * NCOL + c;
-    const uint32_t dst = tplan[2u * seg + 1u] + (t - s_start[c]);
-    if (dst >= cap_tris) return;                                        // flagged by k_zs_front
-    out[3ull * dst] = ma; out[3ull * dst + 1u] = mb; out[3ull * dst + 2u] = md;
+    const uint32_t Tr = row_rec(counts, cstride, r, ZR_TRIS), Vr = row_rec(counts, cstride, r, ZR_VERTS), vb = zr.vbase[r];
+    if (t0 >= Tr) return;
+    uint32_t dst = U32_NONE;
+    if (t < Tr) {
+        const uint32_t c = zs_col_of(s_start, t);
+        dst = tplan[2u * (r * NCOL + c) + 1u] + (t - s_start[c]);
+        if (dst >= cap_tris) dst = U32_NONE;                            // flagged by k_zs_front
+    }
+    s_dst[tid] = dst;
+    const uint32_t ne = (Tr - t0 < ZS_TBLK ? Tr - t0 : ZS_TBLK) * 3u;
+    uint32_t m[3];
+#pragma unroll
+    for (uint32_t j = 0; j < 3u; j++) m[j] = (tid + 256u * j < ne && e[j] < Vr) ? map[vb + e[j]] : 0u;
+    __syncthreads();
+#pragma unroll
+    for (uint32_t j = 0; j < 3u; j++) {
+        const uint32_t k = tid + 256u * j;
+        if (k < ne) { const uint32_t dd = s_dst[k / 3u]; if (dd != U32_NONE) out[3ull * dd + k % 3u] = m[j]; }
+    }
 }
 
 __global__ __launch_bounds__(256) void k_zs_publish(const uint32_t *__restrict__ counts, uint32_t cstride, uint32_t nranks, const uint32_t *__restrict__ zctl,
@@ -489,12 +454,8 @@ __global__ __launch_bounds__(256) void k_zs_publish(const uint32_t *__restrict__
 // ------------------------------------------------------------------------------------------
 // launchers
 // ------------------------------------------------------------------------------------------
-hipError_t launch_zs_local(hipStream_t st, const uint32_t *idx, uint32_t tris_hint, uint32_t tri_cap, uint32_t *row, uint32_t *next_row,
-                           const uint32_t *ctr_tris, const uint32_t *ctr_verts, const uint32_t *status, uint32_t host_status, uint32_t cap_v,
-                           uint32_t cap_t, uint32_t inject, uint32_t sig) {
-    // (tris_hint: what the grid is sized for -- the exact count on the synchronous route, the slot's capacity on the planned one)
-    if (!host_status)
-        hipLaunchKernelGGL(k_zs_segmax, dim3(std::max<uint32_t>(1u, (std::min(tris_hint, tri_cap) + 255u) / 256u)), dim3(256), 0, st, idx, ctr_tris, tri_cap, row);
+hipError_t launch_zs_local(hipStream_t st, uint32_t *row, uint32_t *next_row, const uint32_t *ctr_tris, const uint32_t *ctr_verts, const uint32_t *status,
+                           uint32_t host_status, uint32_t cap_v, uint32_t cap_t, uint32_t inject, uint32_t sig) {
     hipLaunchKernelGGL(k_zs_rowfinish, dim3(1), dim3(1024), 0, st, row, next_row, ctr_tris, ctr_verts, status, host_status, cap_v, cap_t, inject, sig);
     return hipGetLastError();
 }
@@ -515,7 +476,8 @@ hipError_t launch_zs_merge(hipStream_t st, int grid, const Vertex *v_all, const 
         hipLaunchKernelGGL(k_zs_vplan, dim3(1), dim3(1024), 0, st, counts, cstride, d_zr, (const uint32_t *) newcnt, vplan, cap_verts, zctl);
     }
     hipLaunchKernelGGL(k_zs_vertex_out, dim3((zr.vbase[R] + ZS_VBLK - 1u) / ZS_VBLK + 1u), dim3(256), 0, st, v_all, counts, cstride, d_zr, (const uint32_t *) redirect,
-                       (const uint32_t *) segof, (const uint32_t *) vstart, (const uint32_t *) vplan, (const uint32_t *) blockdrop, v_out, cap_verts, map);
+                       (const uint32_t *) segof, (const uint32_t *) vstart, (const uint32_t *) vplan, (const uint32_t *) blockdrop, v_out, cap_verts, map,
+                       (uint32_t) (getenv("SDM_ZSDBG") ? atoi(getenv("SDM_ZSDBG")) : 0));
     if (band) hipLaunchKernelGGL(k_zs_loser_map, dim3(grid), dim3(256), 0, st, counts, cstride, d_zr, (const uint32_t *) redirect, map);
     hipLaunchKernelGGL(k_zs_index_out, dim3(std::max<uint32_t>(1u, zr.tblk[R])), dim3(256), 0, st, idx_all, counts, cstride, (const uint32_t *) tplan, d_zr,
                        (const uint32_t *) map, i_out, cap_tris, (const uint32_t *) zctl, seq, pub);
