@@ -192,7 +192,7 @@ struct sdmesh_handle {
     DevBuf shard_mine, shard_counts, shard_recv, shard_lists, shard_plan, shard_merged;
     // z-slab INDEXED gather (root): the ranks' welded buffers concatenated, the merge's tables, its outputs (swapped into vertices / indices)
     // z-slab INDEXED gather: the ranks' welded buffers in SLOTS of zs_verts / zs_idx (root), the merge's tables, its outputs
-    DevBuf zs_verts, zs_idx, zs_tables, zs_pervert, zs_hkeys, zs_vout, zs_iout, zs_ranks, zs_ctl, shard_counts2, zs_colscratch;
+    DevBuf zs_verts, zs_idx, zs_tables, zs_pervert, zs_hkeys, zs_vout, zs_iout, zs_ranks, zs_ctl, shard_counts2, zs_colscratch, zs_hints;
     ZsRanks *h_zs = nullptr;       // pinned staging copy of the merge's slot table
     ZsRanks zs_uploaded{};         // what zs_ranks holds (uploaded again only when the table changes: never in steady state)
     bool zs_uploaded_valid = false;
@@ -1108,7 +1108,7 @@ void sdmesh_destroy(sdmesh_handle *h) {
                       &h->first_ord_buf, &h->uverts, &h->tri_e, &h->vslot, &h->tdesc, &h->tfirst, &h->tfpre, &h->tpre, &h->flip, &h->wvidx, &h->torder, &h->wrep_buf, &h->wfm_buf,
                       &h->vertices, &h->indices, &h->raw, &h->compact, &h->staging, &h->dense_samples, &h->dense_bits,
                       &h->cellcnt, &h->dist_upids, &h->dist_upkeys, &h->dist_loids, &h->dist_prevkeys, &h->dist_hkeys, &h->dist_hpos, &h->dist_dupof,
-                      &h->dist_newidx, &h->dist_tilecnt, &h->dist_counts, &h->dist_upg, &h->dist_prevg, &h->dist_verts, &h->dist_nups, &h->col_list1, &h->col_mask2, &h->col_mask3, &h->colinfo, &h->prof_rounds, &h->proj_diag, &h->shard_mine, &h->shard_counts, &h->shard_recv, &h->shard_lists, &h->shard_plan, &h->shard_merged, &h->zs_verts, &h->zs_idx, &h->zs_tables, &h->zs_pervert, &h->zs_hkeys, &h->zs_vout, &h->zs_iout, &h->zs_ranks, &h->zs_ctl, &h->shard_counts2, &h->zs_colscratch};
+                      &h->dist_newidx, &h->dist_tilecnt, &h->dist_counts, &h->dist_upg, &h->dist_prevg, &h->dist_verts, &h->dist_nups, &h->col_list1, &h->col_mask2, &h->col_mask3, &h->colinfo, &h->prof_rounds, &h->proj_diag, &h->shard_mine, &h->shard_counts, &h->shard_recv, &h->shard_lists, &h->shard_plan, &h->shard_merged, &h->zs_verts, &h->zs_idx, &h->zs_tables, &h->zs_pervert, &h->zs_hkeys, &h->zs_vout, &h->zs_iout, &h->zs_ranks, &h->zs_ctl, &h->shard_counts2, &h->zs_colscratch, &h->zs_hints};
     (void) sdmesh_comm_destroy(h);
     if (h->h_counts) (void) hipHostFree(h->h_counts);
     if (h->h_lists) (void) hipHostFree(h->h_lists);
@@ -2044,10 +2044,10 @@ int zs_scratch(sdmesh_handle *h, int R) {
 // everything the root's merge touches, for slots of vslots vertices / tslots triangles in all
 int zs_root_ensure(sdmesh_handle *h, int R, uint64_t vslots, uint64_t tslots) {
     const size_t v = (size_t) std::max<uint64_t>(vslots, 64), t = (size_t) std::max<uint64_t>(tslots, 64);
-    (void) R;
     SDCHK(ensure_grow(h, h->zs_verts, sizeof(Vertex) * v));
     SDCHK(ensure_grow(h, h->zs_idx, sizeof(IndexTriangle) * t));
     SDCHK(ensure_grow(h, h->zs_pervert, 4ull * 3 * v + 4ull * (v / 256 + 2)));    // per slot vertex: segof | redirect | map; then the drop counts per 256 of them
+    SDCHK(ensure_grow(h, h->zs_hints, 4ull * (t / 256 + (size_t) R + 2)));     // one word per 256 slot triangles (every rank's slot rounds up)
     SDCHK(ensure_grow(h, h->zs_vout, sizeof(Vertex) * v));
     SDCHK(ensure_grow(h, h->zs_iout, sizeof(IndexTriangle) * t));
     return SDMESH_OK;
@@ -2057,7 +2057,8 @@ uint32_t zs_root_capacity_v(const sdmesh_handle *h) {               // what this
     return (uint32_t) std::min(a, std::min(b, c));
 }
 uint32_t zs_root_capacity_t(const sdmesh_handle *h) {
-    return std::min(cap_items(h->zs_idx, sizeof(IndexTriangle)), cap_items(h->zs_iout, sizeof(IndexTriangle)));
+    const uint32_t by_hints = h->zs_hints.cap > 4ull * 40 ? (uint32_t) std::min<size_t>((h->zs_hints.cap / 4 - 36) * 256, 0xFFFFFFFFu) : 0u;
+    return std::min(by_hints, std::min(cap_items(h->zs_idx, sizeof(IndexTriangle)), cap_items(h->zs_iout, sizeof(IndexTriangle))));
 }
 
 void zs_slot_table(const sdmesh_handle *h, int R, const uint32_t *cap_v, const uint32_t *cap_t, int levels, ZsRanks &zr) {
@@ -2101,7 +2102,7 @@ int zs_merge_enqueue(sdmesh_handle *h, const ZsRanks &zr, const uint32_t *d_coun
     const uint32_t vcap = std::max<uint32_t>(V, 64u);
     uint32_t *segof = (uint32_t *) h->zs_pervert.p, *redirect = segof + vcap, *map = redirect + vcap, *blockdrop = map + vcap;
     HIPCHK(launch_zs_merge(st, h->grid, (const Vertex *) h->zs_verts.p, (const uint32_t *) h->zs_idx.p, d_counts, SHARD_ROW, zr, (const ZsRanks *) h->zs_ranks.p,
-                           tplan, vplan, vstart, newcnt, segof, redirect, map, blockdrop, (uint64_t *) h->zs_hkeys.p, hsize, (Vertex *) h->zs_vout.p,
+                           tplan, vplan, vstart, newcnt, segof, redirect, map, blockdrop, (uint32_t *) h->zs_hints.p, (uint64_t *) h->zs_hkeys.p, hsize, (Vertex *) h->zs_vout.p,
                            (uint32_t) std::min<size_t>(h->zs_vout.cap / sizeof(Vertex), 0xFFFFFFFFu), (uint32_t *) h->zs_iout.p,
                            (uint32_t) std::min<size_t>(h->zs_iout.cap / sizeof(IndexTriangle), 0xFFFFFFFFu), (uint32_t *) h->zs_ctl.p, seq, h->h_zs_pub));
     (void) T;

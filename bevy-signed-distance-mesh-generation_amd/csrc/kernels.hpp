@@ -141,7 +141,8 @@ hipError_t launch_zs_local(hipStream_t st, uint32_t *row, uint32_t *next_row, co
 // then 4-byte minima) only with more than one rank; zctl = ZC_WORDS words; pub (pinned host, optional) receives zctl and the records
 hipError_t launch_zs_merge(hipStream_t st, int grid, const Vertex *v_all, const uint32_t *idx_all, const uint32_t *counts, uint32_t cstride,
                            const ZsRanks &zr, const ZsRanks *d_zr, uint32_t *tplan, uint32_t *vplan, uint32_t *vstart, uint32_t *newcnt,
-                           uint32_t *segof, uint32_t *redirect, uint32_t *map, uint32_t *blockdrop /* per 256 slot vertices */, uint64_t *hkeys, uint32_t hsize,
+                           uint32_t *segof, uint32_t *redirect, uint32_t *map, uint32_t *blockdrop /* per 256 slot vertices */, uint32_t *thint /* per 256 slot triangles */,
+                           uint64_t *hkeys, uint32_t hsize,
                            Vertex *v_out, uint32_t cap_verts, uint32_t *i_out, uint32_t cap_tris, uint32_t *zctl, uint32_t seq, uint32_t *pub);
 // peers: the records (and a zeroed control block) to pinned host memory
 hipError_t launch_zs_publish(hipStream_t st, const uint32_t *counts, uint32_t cstride, uint32_t nranks, const uint32_t *zctl, uint32_t seq, uint32_t *pub);

@@ -25,7 +25,6 @@
 // reported a failure or a count exceeds its slot: the host sees the same records and repeats the step synchronously.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
-#include <stdlib.h>
 
 #include <algorithm>
 
@@ -38,6 +37,7 @@ static constexpr uint32_t NCOL = MESH_GENERATION_INIT_FACTOR * MESH_GENERATION_I
 static constexpr uint32_t ZS_GAP = 0xfffffffeu;        // redirect[] of a slot entry behind the rank's last vertex
 static constexpr uint32_t ZS_VBLK = 256;               // slot vertices per workgroup of k_zs_vertex_out = per entry of blockdrop[]
 static constexpr uint32_t ZS_TBLK = 256;               // slot triangles per workgroup of k_zs_index_out (zr.tblk counts these)
+static constexpr uint32_t ZS_FCOLS = 4;                // columns per workgroup of k_zs_front's per-vertex pass
 static_assert(SHARD_REC == 2 * NCOL, "a row is 1024 triangle counts, 1024 vertex counts, the record");
 
 __device__ __forceinline__ uint32_t row_rec(const uint32_t *__restrict__ counts, uint32_t cstride, uint32_t r, uint32_t w) {
@@ -72,6 +72,32 @@ __device__ __forceinline__ uint32_t zs_plan_body(const uint32_t *__restrict__ co
         plan[(r * NCOL + c) * 2u] = src;
         plan[(r * NCOL + c) * 2u + 1u] = col_base + within;
         within += n;
+    }
+    return total;
+}
+
+// the triangle plan with the block hints of k_zs_index_out: thint[zr.tblk[r] + j] = the column that holds triangle j * ZS_TBLK of rank r
+// (so a workgroup of that kernel stages only the few segment starts its 256 triangles can fall into, not the rank's 1024)
+__device__ __forceinline__ uint32_t zs_col_of(const uint32_t *__restrict__ s_start, uint32_t t);
+__device__ __forceinline__ uint32_t zs_tplan_with_hints(const uint32_t *__restrict__ counts, uint32_t cstride, const ZsRanks &zr, uint32_t *__restrict__ plan,
+                                                        uint32_t *__restrict__ thint, uint32_t *__restrict__ s_src /* NCOL + 1 */, uint32_t *__restrict__ lds) {
+    const uint32_t c = threadIdx.x, nranks = zr.nranks;
+    uint32_t col_total = 0;
+    for (uint32_t r = 0; r < nranks; r++) col_total += counts[(size_t) r * cstride + c];
+    uint32_t total;
+    const uint32_t col_base = block_excl_scan(col_total, total, lds);
+    uint32_t within = 0;
+    for (uint32_t r = 0; r < nranks; r++) {
+        const uint32_t n = counts[(size_t) r * cstride + c];
+        uint32_t rank_total;
+        const uint32_t src = block_excl_scan(n, rank_total, lds);
+        plan[(r * NCOL + c) * 2u] = src;
+        plan[(r * NCOL + c) * 2u + 1u] = col_base + within;
+        within += n;
+        __syncthreads();
+        s_src[c] = src;
+        __syncthreads();
+        for (uint32_t j = c; j < zr.tblk[r + 1u] - zr.tblk[r]; j += 1024u) thint[zr.tblk[r] + j] = zs_col_of(s_src, j * ZS_TBLK);
     }
     return total;
 }
@@ -156,26 +182,27 @@ __device__ __forceinline__ uint32_t zs_rank_of(const ZsRanks &zr, uint32_t i) {
     return r;
 }
 
-// One launch in front of everything else.  Workgroup (r, g) of the first nranks * 64: the exclusive prefix of rank r's first-seen
-// vertex counts (one block scan of the row), then its sixteen columns: vstart / newcnt of the segments, every vertex of theirs
-// learns its segment and starts as "kept" (the vertices of sixteen consecutive columns are one contiguous range of the slot).  The last
+// One launch in front of everything else.  Workgroup (r, g) of the first nranks * 256: the exclusive prefix of rank r's first-seen
+// vertex counts (one block scan of the row), then its four columns: vstart / newcnt of the segments, every vertex of theirs
+// learns its segment and starts as "kept" (the vertices of consecutive columns are one contiguous range of the slot).  The last
 // group of a rank checks the row's sum and marks the slot's unused tail.  Two extra workgroups plan the triangle segments
 // (resetting the merge's counters) and, with one rank, the vertex segments (nothing can be dropped).  With more than one rank the
 // whole grid also clears the band hash and the per-block drop counts.
 __global__ __launch_bounds__(1024) void k_zs_front(const uint32_t *__restrict__ counts, uint32_t cstride, const ZsRanks *__restrict__ zrp,
                                                     uint32_t *__restrict__ tplan, uint32_t *__restrict__ vplan, uint32_t *__restrict__ vstart,
                                                     uint32_t *__restrict__ newcnt, uint32_t *__restrict__ segof, uint32_t *__restrict__ redirect,
-                                                    uint32_t *__restrict__ hclear, uint32_t hwords, uint32_t *__restrict__ blockdrop, uint32_t cap_verts,
-                                                    uint32_t cap_tris, uint32_t *__restrict__ zctl) {
+                                                    uint32_t *__restrict__ hclear, uint32_t hwords, uint32_t *__restrict__ blockdrop, uint32_t *__restrict__ thint,
+                                                    uint32_t cap_verts, uint32_t cap_tris, uint32_t *__restrict__ zctl) {
     const ZsRanks &zr = *zrp;
     __shared__ uint32_t lds[17];
-    __shared__ uint32_t s_b[17];
-    const uint32_t tid = threadIdx.x, R = zr.nranks, groups = R * 64u;
+    __shared__ uint32_t s_b[ZS_FCOLS + 1];
+    __shared__ uint32_t s_src[NCOL + 1];
+    const uint32_t tid = threadIdx.x, R = zr.nranks, groups = R * (NCOL / ZS_FCOLS);
     const bool ok = zs_rows_ok(counts, cstride, zr);
-    if (blockIdx.x == groups) {                  // the triangle segments' plan, the merge's counters
+    if (blockIdx.x == groups) {                  // the triangle segments' plan (with k_zs_index_out's block hints), the merge's counters
         uint32_t flags = ok ? 0u : 1u, T = 0;
         if (ok) {
-            T = zs_plan_body(counts, cstride, R, tplan, lds);
+            T = zs_tplan_with_hints(counts, cstride, zr, tplan, thint, s_src, lds);
             if (T > cap_tris) flags |= 2u;
         }
         if (tid == 0) { zctl[ZC_TRIS] = T; zctl[ZC_NBAND] = 0u; zctl[ZC_BANDFLAGS] = 0u; zctl[ZC_PLANFLAGS] = flags; if (R > 1u || !ok) zctl[ZC_VERTS] = 0u; }
@@ -194,24 +221,24 @@ __global__ __launch_bounds__(1024) void k_zs_front(const uint32_t *__restrict__ 
     for (uint32_t i = blockIdx.x * 1024u + tid; i < hwords; i += groups * 1024u) hclear[i] = 0xffffffffu;      // (all-ones = empty key = no vertex yet)
     if (blockdrop)
         for (uint32_t i = blockIdx.x * 1024u + tid; i < zr.vbase[R] / ZS_VBLK + 1u; i += groups * 1024u) blockdrop[i] = 0u;
-    const uint32_t r = blockIdx.x >> 6, c0 = (blockIdx.x & 63u) * 16u;
+    const uint32_t r = blockIdx.x / (NCOL / ZS_FCOLS), c0 = (blockIdx.x % (NCOL / ZS_FCOLS)) * ZS_FCOLS;
     const uint32_t vc = counts[(size_t) r * cstride + NCOL + tid];
     uint32_t total;
     const uint32_t ex = block_excl_scan(vc, total, lds);
-    if (tid >= c0 && tid < c0 + 16u) { vstart[r * NCOL + tid] = ex; newcnt[r * NCOL + tid] = vc; s_b[tid - c0] = ex; }
-    if (tid == c0 + 16u) s_b[16] = ex;
-    if (c0 + 16u == NCOL && tid == 0) s_b[16] = total;
+    if (tid >= c0 && tid < c0 + ZS_FCOLS) { vstart[r * NCOL + tid] = ex; newcnt[r * NCOL + tid] = vc; s_b[tid - c0] = ex; }
+    if (tid == c0 + ZS_FCOLS) s_b[ZS_FCOLS] = ex;
+    if (c0 + ZS_FCOLS == NCOL && tid == 0) s_b[ZS_FCOLS] = total;
     __syncthreads();
     const uint32_t Vr = row_rec(counts, cstride, r, ZR_VERTS), vb = zr.vbase[r];
-    const uint32_t a = s_b[0], b = s_b[16] < Vr ? s_b[16] : Vr;
+    const uint32_t a = s_b[0], b = s_b[ZS_FCOLS] < Vr ? s_b[ZS_FCOLS] : Vr;
     for (uint32_t i = a + tid; i < b; i += 1024u) {
         uint32_t k = 0;
 #pragma unroll
-        for (uint32_t j = 1; j < 16u; j++) k += s_b[j] <= i ? 1u : 0u;
+        for (uint32_t j = 1; j < ZS_FCOLS; j++) k += s_b[j] <= i ? 1u : 0u;
         segof[vb + i] = r * NCOL + c0 + k;
         redirect[vb + i] = U32_NONE;
     }
-    if (c0 + 16u == NCOL) {
+    if (c0 + ZS_FCOLS == NCOL) {
         if (tid == 0) zctl[ZC_RANKBAD + r] = total != Vr ? 1u : 0u;       // the counts do not add up to the rank's vertices
         const uint32_t cap = zr.vbase[r + 1u] - vb;
         for (uint32_t i = Vr + tid; i < cap; i += 1024u) redirect[vb + i] = ZS_GAP;
@@ -401,12 +428,12 @@ __device__ __forceinline__ void zs_publish_body(const uint32_t *__restrict__ cou
 
 // the index buffers into the merged triangle order with merged vertex numbers.  Flat over the triangle slots: workgroup = ZS_TBLK slot
 // triangles of one rank (blocks per rank from the slot capacities: zr.tblk), one triangle per thread; it finds its column segment by
-// bisection over the rank's segment starts in LDS (tplan's source offsets).  Workgroup 0 also publishes the step's control block and
+// bisection over the few segment starts the block can fall into (tplan's source offsets between the block's hint and the next one's).  Workgroup 0 also publishes the step's control block and
 // the ranks' records to pinned host memory: every word of them was final before this kernel started (no read-back copy behind the chain).
 __global__ __launch_bounds__(256) void k_zs_index_out(const uint32_t *__restrict__ idx_all, const uint32_t *__restrict__ counts, uint32_t cstride,
-                                                       const uint32_t *__restrict__ tplan, const ZsRanks *__restrict__ zrp, const uint32_t *__restrict__ map,
-                                                       uint32_t *__restrict__ out, uint32_t cap_tris, const uint32_t *__restrict__ zctl, uint32_t seq,
-                                                       uint32_t *__restrict__ pub) {
+                                                       const uint32_t *__restrict__ tplan, const uint32_t *__restrict__ thint, const ZsRanks *__restrict__ zrp,
+                                                       const uint32_t *__restrict__ map, uint32_t *__restrict__ out, uint32_t cap_tris,
+                                                       const uint32_t *__restrict__ zctl, uint32_t seq, uint32_t *__restrict__ pub) {
     const ZsRanks &zr = *zrp;
     __shared__ uint32_t s_start[NCOL + 1];
     __shared__ uint32_t s_dst[ZS_TBLK];
@@ -416,28 +443,33 @@ __global__ __launch_bounds__(256) void k_zs_index_out(const uint32_t *__restrict
     const uint32_t tid = threadIdx.x, t0 = (blockIdx.x - zr.tblk[r]) * ZS_TBLK, t = t0 + tid;
     const uint32_t slot = zr.tbase[r + 1u] - zr.tbase[r];
     if (t0 >= slot) return;
-    // the block's 768 indices as three coalesced dword loads per thread (speculative: in front of the table and the checks)
+    // the block's 768 indices as three coalesced dword loads per thread (speculative: in front of the hints and the checks)
     const uint32_t ne_cap = (slot - t0 < ZS_TBLK ? slot - t0 : ZS_TBLK) * 3u;
     const uint32_t *__restrict__ s = idx_all + 3ull * (zr.tbase[r] + t0);
     uint32_t e[3];
 #pragma unroll
     for (uint32_t j = 0; j < 3u; j++) e[j] = tid + 256u * j < ne_cap ? s[tid + 256u * j] : 0u;
-#pragma unroll
-    for (uint32_t k = 0; k < 4u; k++) s_start[tid + 256u * k] = tplan[2u * (r * NCOL + tid + 256u * k)];
-    if (!zs_rows_ok(counts, cstride, zr)) return;                       // (synchronises: s_start is complete)
+    // the columns this block's triangles can fall into: from its own first triangle's to the next block's (k_zs_front's hints)
+    uint32_t c_lo = thint[blockIdx.x], c_hi = blockIdx.x + 1u < zr.tblk[r + 1u] ? thint[blockIdx.x + 1u] : NCOL - 1u;
+    if (!zs_rows_ok(counts, cstride, zr)) return;
+    if (c_lo >= NCOL || c_hi >= NCOL || c_hi < c_lo) { c_lo = 0; c_hi = NCOL - 1u; }          // (never of a checked row)
+    const uint32_t w = c_hi - c_lo + 1u;
+    for (uint32_t k = tid; k < w; k += 256u) s_start[k] = tplan[2u * (r * NCOL + c_lo + k)];
     const uint32_t Tr = row_rec(counts, cstride, r, ZR_TRIS), Vr = row_rec(counts, cstride, r, ZR_VERTS), vb = zr.vbase[r];
     if (t0 >= Tr) return;
-    uint32_t dst = U32_NONE;
-    if (t < Tr) {
-        const uint32_t c = zs_col_of(s_start, t);
-        dst = tplan[2u * (r * NCOL + c) + 1u] + (t - s_start[c]);
-        if (dst >= cap_tris) dst = U32_NONE;                            // flagged by k_zs_front
-    }
-    s_dst[tid] = dst;
     const uint32_t ne = (Tr - t0 < ZS_TBLK ? Tr - t0 : ZS_TBLK) * 3u;
     uint32_t m[3];
 #pragma unroll
     for (uint32_t j = 0; j < 3u; j++) m[j] = (tid + 256u * j < ne && e[j] < Vr) ? map[vb + e[j]] : 0u;
+    __syncthreads();
+    uint32_t dst = U32_NONE;
+    if (t < Tr) {
+        uint32_t lo = 0, hi = w;                                        // the largest k with s_start[k] <= t
+        while (hi - lo > 1u) { const uint32_t mid = (lo + hi) >> 1; if (s_start[mid] <= t) lo = mid; else hi = mid; }
+        dst = tplan[2u * (r * NCOL + c_lo + lo) + 1u] + (t - s_start[lo]);
+        if (dst >= cap_tris) dst = U32_NONE;                            // flagged by k_zs_front
+    }
+    s_dst[tid] = dst;
     __syncthreads();
 #pragma unroll
     for (uint32_t j = 0; j < 3u; j++) {
@@ -462,12 +494,12 @@ hipError_t launch_zs_local(hipStream_t st, uint32_t *row, uint32_t *next_row, co
 
 hipError_t launch_zs_merge(hipStream_t st, int grid, const Vertex *v_all, const uint32_t *idx_all, const uint32_t *counts, uint32_t cstride,
                            const ZsRanks &zr, const ZsRanks *d_zr, uint32_t *tplan, uint32_t *vplan, uint32_t *vstart, uint32_t *newcnt,
-                           uint32_t *segof, uint32_t *redirect, uint32_t *map, uint32_t *blockdrop, uint64_t *hkeys, uint32_t hsize, Vertex *v_out,
-                           uint32_t cap_verts, uint32_t *i_out, uint32_t cap_tris, uint32_t *zctl, uint32_t seq, uint32_t *pub) {
+                           uint32_t *segof, uint32_t *redirect, uint32_t *map, uint32_t *blockdrop, uint32_t *thint, uint64_t *hkeys, uint32_t hsize,
+                           Vertex *v_out, uint32_t cap_verts, uint32_t *i_out, uint32_t cap_tris, uint32_t *zctl, uint32_t seq, uint32_t *pub) {
     const uint32_t R = zr.nranks;
     const bool band = R > 1;
-    hipLaunchKernelGGL(k_zs_front, dim3(R * 64u + 2u), dim3(1024), 0, st, counts, cstride, d_zr, tplan, vplan, vstart, newcnt, segof, redirect,
-                       band ? (uint32_t *) hkeys : nullptr, band ? 3u * hsize : 0u, band ? blockdrop : nullptr, cap_verts, cap_tris, zctl);
+    hipLaunchKernelGGL(k_zs_front, dim3(R * (NCOL / ZS_FCOLS) + 2u), dim3(1024), 0, st, counts, cstride, d_zr, tplan, vplan, vstart, newcnt, segof, redirect,
+                       band ? (uint32_t *) hkeys : nullptr, band ? 3u * hsize : 0u, band ? blockdrop : nullptr, thint, cap_verts, cap_tris, zctl);
     if (band) {
         uint32_t *hmin = (uint32_t *) (hkeys + hsize);
         hipLaunchKernelGGL(k_zs_band_insert, dim3(grid), dim3(256), 0, st, v_all, counts, cstride, d_zr, (const uint32_t *) redirect, hkeys, hmin, hsize, zctl);
@@ -476,10 +508,9 @@ hipError_t launch_zs_merge(hipStream_t st, int grid, const Vertex *v_all, const 
         hipLaunchKernelGGL(k_zs_vplan, dim3(1), dim3(1024), 0, st, counts, cstride, d_zr, (const uint32_t *) newcnt, vplan, cap_verts, zctl);
     }
     hipLaunchKernelGGL(k_zs_vertex_out, dim3((zr.vbase[R] + ZS_VBLK - 1u) / ZS_VBLK + 1u), dim3(256), 0, st, v_all, counts, cstride, d_zr, (const uint32_t *) redirect,
-                       (const uint32_t *) segof, (const uint32_t *) vstart, (const uint32_t *) vplan, (const uint32_t *) blockdrop, v_out, cap_verts, map,
-                       (uint32_t) (getenv("SDM_ZSDBG") ? atoi(getenv("SDM_ZSDBG")) : 0));
+                       (const uint32_t *) segof, (const uint32_t *) vstart, (const uint32_t *) vplan, (const uint32_t *) blockdrop, v_out, cap_verts, map, 0u);
     if (band) hipLaunchKernelGGL(k_zs_loser_map, dim3(grid), dim3(256), 0, st, counts, cstride, d_zr, (const uint32_t *) redirect, map);
-    hipLaunchKernelGGL(k_zs_index_out, dim3(std::max<uint32_t>(1u, zr.tblk[R])), dim3(256), 0, st, idx_all, counts, cstride, (const uint32_t *) tplan, d_zr,
+    hipLaunchKernelGGL(k_zs_index_out, dim3(std::max<uint32_t>(1u, zr.tblk[R])), dim3(256), 0, st, idx_all, counts, cstride, (const uint32_t *) tplan, (const uint32_t *) thint, d_zr,
                        (const uint32_t *) map, i_out, cap_tris, (const uint32_t *) zctl, seq, pub);
     return hipGetLastError();
 }
