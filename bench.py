@@ -407,7 +407,7 @@ def roofline_legs(h, out, n_grid, scene, params, consts):
     try:
         for sc in dict.fromkeys(("sphere", scene)):
             h.set_scene(sc, [0.25] if sc == "anim" else None)
-            rows = {str(n_grid): row(sc, n_grid, 50, burst=True), str(n_grid // 2): row(sc, n_grid // 2, 200), str(2 * n_grid): row(sc, 2 * n_grid, 20)}
+            rows = {str(n_grid): row(sc, n_grid, 50, burst=True), str(n_grid // 2): row(sc, n_grid // 2, 600), str(2 * n_grid): row(sc, 2 * n_grid, 20)}
             by_grid[sc] = dict(sorted(rows.items(), key=lambda kv: int(kv[0])))
             roofs[sc] = dict({"bound": "hbm", "kernel": f"k_sample_dense<{sc}>", "peak": HBM_PEAK_GBPS, "traffic": traffic.get(sc), "window": window},
                              **rows[str(n_grid)])

@@ -2607,6 +2607,59 @@ extern "C" int sdmesh_sharded_regen_rehearsal(sdmesh_handle **hs, int nranks, in
     return SDMESH_OK;
 }
 
+// The two halves of the indexed z-slab step as separate calls, for a caller that brings its own transport (the gloo-staged rehearsal
+// with several processes on one GPU, partition.ShardedMesher): exactly the kernels of sdmesh_sharded_regen's synchronous route.
+static_assert(SHARD_ROW == SDMESH_ZSLAB_ROW_WORDS, "sdmesh.h names the row size");
+extern "C" int sdmesh_zslab_local(sdmesh_handle *h, int levels, int part, int nparts, uint32_t *d_row, sdmesh_regen_info *info) {
+    if (!h || !d_row) return SDMESH_ERR_INVALID;
+    HIPCHK(hipSetDevice(h->device));
+    HIPCHK(hipMemsetAsync(d_row, 0, 4ull * SHARD_ROW, h->stream));
+    sdmesh_regen_info slab;
+    memset(&slab, 0, sizeof slab);
+    SDCHK(zs_local_sync(h, levels, part, nparts, d_row, &slab));
+    HIPCHK(launch_zs_local(h->stream, d_row, nullptr, h->d_ctr + CTR_NTRI, h->d_ctr + CTR_NVERT, h->d_status, 0u, 0u, 0u, 0u, 0u));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    if (info) *info = slab;
+    return SDMESH_OK;
+}
+
+extern "C" int sdmesh_zslab_merge(sdmesh_handle *h, int nranks, int levels, const uint32_t *d_rows, const struct Vertex *const *d_verts,
+                                  const struct IndexTriangle *const *d_tris, sdmesh_regen_info *info) {
+    if (!h || !d_rows || !d_verts || !d_tris || nranks < 1 || nranks > 32 || levels < 0 || levels > SDMESH_MAX_LEVELS) return SDMESH_ERR_INVALID;
+    const int R = nranks;
+    HIPCHK(hipSetDevice(h->device));
+    SDCHK(zs_scratch(h, R));
+    h->zsp.valid = false;
+    h->mesh_valid = false;
+    uint32_t *d_counts = zs_counts(h, 0);
+    HIPCHK(hipMemcpyAsync(d_counts, d_rows, 4ull * (size_t) R * SHARD_ROW, hipMemcpyDeviceToDevice, h->stream));
+    HIPCHK(hipMemcpyAsync(h->h_counts, d_counts, 4ull * (size_t) R * SHARD_ROW, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    uint32_t Tr[32] = {0}, Vr[32] = {0};
+    uint64_t vtot = 0, ttot = 0;
+    for (int r = 0; r < R; r++) {
+        const uint32_t *rec = h->h_counts + (size_t) r * SHARD_ROW + SHARD_REC;
+        if (rec[ZR_STATUS] || rec[ZR_FORM] != 1u) return fail(h, SDMESH_ERR_INVALID, "row %d is not a healthy row of the indexed form (status 0x%x)", r, rec[ZR_STATUS]);
+        Tr[r] = rec[ZR_TRIS]; Vr[r] = rec[ZR_VERTS];
+        if ((Vr[r] && !d_verts[r]) || (Tr[r] && !d_tris[r])) return SDMESH_ERR_INVALID;
+        vtot += Vr[r]; ttot += Tr[r];
+    }
+    if (vtot > 0x0FFFFFFFull || ttot > 0x0FFFFFFFull) return fail(h, SDMESH_ERR_INVALID, "too many vertices / triangles for one mesh");
+    SDCHK(zs_root_ensure(h, R, vtot, ttot));
+    ZsRanks zr;
+    zs_slot_table(h, R, Vr, Tr, levels, zr);              // (slots of exactly the slabs' sizes)
+    for (int r = 0; r < R; r++) {
+        if (Vr[r]) HIPCHK(hipMemcpyAsync((Vertex *) h->zs_verts.p + zr.vbase[r], d_verts[r], sizeof(Vertex) * (size_t) Vr[r], hipMemcpyDeviceToDevice, h->stream));
+        if (Tr[r]) HIPCHK(hipMemcpyAsync((IndexTriangle *) h->zs_idx.p + zr.tbase[r], d_tris[r], sizeof(IndexTriangle) * (size_t) Tr[r], hipMemcpyDeviceToDevice, h->stream));
+    }
+    const uint32_t seq = ++h->zs_seq;
+    SDCHK(zs_merge_enqueue(h, zr, d_counts, false, seq));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    Point vs;
+    vs.x = vs.y = vs.z = (MESH_GENERATION_BB_SIZE / (float) MESH_GENERATION_INIT_FACTOR) / (float) (1u << levels);
+    return zs_merge_finish(h, zr, d_counts, seq, levels, vs, info);
+}
+
 // ================================================================================================
 // Multi-GPU: ONE mesh, x-slabs, DISTRIBUTED weld (the mesh stays distributed)
 // ================================================================================================

@@ -371,6 +371,23 @@ class CudaHandler:
         self._chk(self._lib.sdmesh_sharded_regen(self._h, int(levels), int(root), ctypes.byref(info)))
         return info
 
+    ZSLAB_ROW_WORDS = 2056
+
+    def zslab_local(self, levels, part, nparts, row_dev_ptr):
+        """This rank's half of the indexed z-slab step with a caller-provided transport: slab regen + weld, row -> device buffer."""
+        info = RegenInfo()
+        self._chk(self._lib.sdmesh_zslab_local(self._h, int(levels), int(part), int(nparts), ctypes.c_void_p(row_dev_ptr), ctypes.byref(info)))
+        return info
+
+    def zslab_merge(self, levels, rows_dev_ptr, vert_ptrs, tri_ptrs):
+        """The root's half: rows of all ranks + their vertex / index buffers (device pointers on this GPU) -> the single-GPU mesh."""
+        n = len(vert_ptrs)
+        va = (ctypes.c_void_p * n)(*[ctypes.c_void_p(p) for p in vert_ptrs])
+        ta = (ctypes.c_void_p * n)(*[ctypes.c_void_p(p) for p in tri_ptrs])
+        info = RegenInfo()
+        self._chk(self._lib.sdmesh_zslab_merge(self._h, n, int(levels), ctypes.c_void_p(rows_dev_ptr), va, ta, ctypes.byref(info)))
+        return info
+
     def sharded_route(self):
         """Route of the last indexed sharded step on this handle: 1 planned, 2 synchronous, 3 planned then repeated synchronously."""
         return int(self._lib.sdmesh_sharded_route(self._h))

@@ -138,21 +138,23 @@ class ShardedMesher:
 
     With RCCL available to the job (process group backend "nccl", or a single rank) the whole step is ONE library call,
     `sdmesh_sharded_regen`, by default in its INDEXED form: z-slab regen AND weld per rank, ncclAllGather of the 1024 per-column
-    triangle counts (+ sizes and a status word), grouped ncclSend / ncclRecv of the slabs' vertex and index buffers to the root
-    (24 B per vertex + 12 B per triangle, each peer on its own xGMI link), and on the root the merge of those buffers by
-    (column, rank) segments -- no second weld (csrc/kernels.hip, "INDEXED gather").  Option "shard_indexed" = 0 selects the
-    raw form (unwelded slabs, 72 B per triangle, order-restoring merge kernel + first-seen weld of every corner on the root).
-    The communicator is the library's own (`sdmesh_comm_init`); torch.distributed only carries the 128-byte unique id to the ranks.
+    triangle counts and first-seen vertex counts (+ sizes and a status word), grouped ncclSend / ncclRecv of the slabs' vertex and
+    index buffers to the root (24 B per vertex + 12 B per triangle, each peer on its own xGMI link), and on the root the merge of
+    those buffers by (column, rank) segments -- no second weld (csrc/zslab.hip); in steady state the step is enqueued blind from a
+    collective plan and synchronises once.  Option "shard_indexed" = 0 selects the raw form (unwelded slabs, 72 B per triangle,
+    order-restoring merge kernel + first-seen weld of every corner on the root).  The communicator is the library's own
+    (`sdmesh_comm_init`); torch.distributed only carries the 128-byte unique id to the ranks.
 
-    Under "gloo" (the rehearsals that put several ranks on one GPU, where RCCL refuses duplicate devices) only the
-    TRANSPORT differs, and the raw form is the one rehearsed: counts and triangle lists are staged through host memory by
-    torch.distributed, everything else -- slab regen, column counts, `sdmesh_merge_by_column`, `sdmesh_weld_device_triangles` --
-    is the same C ABI.  (The indexed form is rehearsed in one process by `sdmesh_sharded_regen_rehearsal`.)"""
+    Under "gloo" (the rehearsals that put several ranks on one GPU, where RCCL refuses duplicate devices) only the TRANSPORT
+    differs: rows and buffers are staged through host memory by torch.distributed, everything else is the same C ABI and the same
+    kernels -- indexed form: `sdmesh_zslab_local` per rank, `sdmesh_zslab_merge` on the root; raw form (`indexed=False`): slab regen
+    without weld, column counts, `sdmesh_merge_by_column`, `sdmesh_weld_device_triangles`."""
 
-    def __init__(self, pkg, handler, levels, rank, world, device, transport=None, balance=True):
+    def __init__(self, pkg, handler, levels, rank, world, device, transport=None, balance=True, indexed=True):
         import torch.distributed as dist
         self.pkg, self.h, self.levels, self.rank, self.world, self.dev = pkg, handler, levels, rank, world, device
         self.dist = dist
+        self.indexed = indexed
         # slabs of equal surface content instead of equal thickness (every rank derives the same table from the scene)
         self.bounds = handler.balance_slabs(pkg.PART_ZSLAB, world, min(levels, 3)) if (balance and world > 1) else None
         if transport is None:
@@ -170,6 +172,7 @@ class ShardedMesher:
             self.cc = torch.zeros(NCOLS, dtype=torch.int32, device=device)
             self.allc = torch.zeros((world, NCOLS), dtype=torch.int32, device=device)
             self.merged = None
+            self.row = torch.zeros(handler.ZSLAB_ROW_WORDS, dtype=torch.int32, device=device)
 
     def close(self):
         if self.transport == "rccl" and self.h.comm is not None:
@@ -180,9 +183,40 @@ class ShardedMesher:
         if self.transport == "rccl":
             info = self.h.sharded_regen(self.levels, 0)
             return info if self.rank == 0 else None
-        return self._step_staged()
+        return self._step_staged_indexed() if self.indexed else self._step_staged()
 
-    # -- gloo rehearsal: same kernels, host-staged transport ---------------------------------------------------------
+    # -- gloo rehearsal, indexed form: the product's kernels on every rank and on the root, host-staged transport -------------------
+    def _step_staged_indexed(self):
+        h, dist, R = self.h, self.dist, self.world
+        h.zslab_local(self.levels, self.rank, R, self.row.data_ptr())
+        verts, tris = h.device_mesh_tensors(self.dev)                 # this rank's welded slab (views of the handle's buffers)
+        rows = [torch.zeros(h.ZSLAB_ROW_WORDS, dtype=torch.int32) for _ in range(R)]
+        if R > 1:
+            dist.all_gather(rows, self.row.cpu())
+        else:
+            rows = [self.row.cpu()]
+        if self.rank != 0:
+            if verts.shape[0]:
+                dist.send(verts.cpu(), dst=0)
+            if tris.shape[0]:
+                dist.send(tris.cpu(), dst=0)
+            return None
+        allrows = torch.stack(rows).to(self.dev)
+        vs, ts = [verts], [tris]
+        for r in range(1, R):
+            nt, nv = int(rows[r][2048 + 1]), int(rows[r][2048 + 4])          # the record: triangles, vertices (kernels.hpp ZsRec)
+            bv, bt = torch.empty((nv, 6), dtype=torch.float32), torch.empty((nt, 3), dtype=torch.int32)
+            if nv:
+                dist.recv(bv, src=r)
+            if nt:
+                dist.recv(bt, src=r)
+            vs.append(bv.to(self.dev)); ts.append(bt.to(self.dev))
+        torch.cuda.current_stream().synchronize()                         # the staged copies above ran on torch's stream
+        info = h.zslab_merge(self.levels, allrows.data_ptr(), [v.data_ptr() if v.numel() else 0 for v in vs],
+                             [t.data_ptr() if t.numel() else 0 for t in ts])
+        return info
+
+    # -- gloo rehearsal, raw form: same kernels, host-staged transport ------------------------------------------------------------------
     def _step_staged(self):
         h, dist = self.h, self.dist
         h.set_option("skip_weld", 1)

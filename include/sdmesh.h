@@ -294,6 +294,17 @@ int sdmesh_sharded_route(const sdmesh_handle *h);
  * bounds (sdmesh_set_slab_bounds / sdmesh_balance_slabs). */
 int sdmesh_sharded_regen_rehearsal(sdmesh_handle **handles, int nranks, int levels, int root, sdmesh_regen_info *info);
 
+/* The two halves of the indexed z-slab step for a caller that moves the bytes itself (the several-process rehearsal over gloo with all
+ * ranks on one GPU, where RCCL refuses duplicate devices): exactly the kernels of sdmesh_sharded_regen's synchronous route.
+ * sdmesh_zslab_local: this rank meshes and welds level-0 z-slab `part` of `nparts`; d_row (device, SDMESH_ZSLAB_ROW_WORDS u32) receives its
+ * row: 1024 column triangle counts, 1024 column first-seen vertex counts, the record.  The slab's mesh is the handle's mesh
+ * (sdmesh_device_mesh).  sdmesh_zslab_merge (root): d_rows = the nranks rows in rank order, d_verts[r] / d_tris[r] = rank r's vertex /
+ * index buffer on THIS device; the merged single-GPU mesh becomes the handle's mesh.  Slab bounds must agree (sdmesh_set_slab_bounds). */
+#define SDMESH_ZSLAB_ROW_WORDS 2056
+int sdmesh_zslab_local(sdmesh_handle *h, int levels, int part, int nparts, uint32_t *d_row, sdmesh_regen_info *info);
+int sdmesh_zslab_merge(sdmesh_handle *h, int nranks, int levels, const uint32_t *d_rows, const struct Vertex *const *d_verts,
+                       const struct IndexTriangle *const *d_tris, sdmesh_regen_info *info);
+
 /* Dense mode: the same regen through the dense (N+1)^3 lattice -- P1 sample, P2a sign bits, P2b
  * LDS-tiled classify with the hierarchical ancestor criterion (A2'), then the usual mesh stage.  O(N^3) work; it
  * exists as the cross-check that "dense == hierarchical" and to measure the two HBM passes, not as the fast path. */
