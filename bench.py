@@ -366,6 +366,74 @@ def reference_abi_leg(pkg, local_rank, scene, params, levels):
             "voxels_meshed": n_last, "triangle_slots_written_MB": round(5 * n_last * 72 / 1e6, 1), "per_level": rows}
 
 
+def host_api_leg(pkg, local_rank, scene, params, levels_list=(3, 4), reps=12):
+    """The reference's OWN call pattern through the C ABI, PCIe-inclusive (never `value`): host `Vec<Point>` in and out at every call, as
+    the renderer drives CudaHandler (src/renderer/mod.rs:168-171, src/cuda/mod.rs:105-122, 124-202, 204-346): create_cuda_voxel_field,
+    k x refine_voxel_field (upload n points, download the kept children), voxel_field_to_mesh (upload, chain, counts) and the mesh
+    download (vertices + indices to pageable host memory).  Median wall ms per call over `reps` runs, ctypes overhead included."""
+    import ctypes
+    from bevy_signed_distance_mesh_generation_amd import handler as H
+    A = pkg._abi
+    h = pkg.CudaHandler(local_rank, scene, params)
+    lib, hh = h._lib, h._h
+    out = {"what": "the reference's host-buffer API through the C ABI, PCIe-inclusive: create_cuda_voxel_field, k x refine_voxel_field (host points in, "
+                   "kept children out), voxel_field_to_mesh (host points in, counts out) + sdmesh_download_mesh (24 B per vertex + 12 B per triangle "
+                   "to pageable host memory); median wall ms per call; beside it the device-resident regen of the same size.  Not the metric."}
+    for k in levels_list:
+        rows = {"create_voxel_field": [], "refine": [[] for _ in range(k)], "voxel_field_to_mesh": [], "download_mesh": [], "total": []}
+        nv, nt = ctypes.c_size_t(0), ctypes.c_size_t(0)
+        sizes = []
+        for rep in range(reps + 2):
+            t_start = time.perf_counter()
+            vox = np.empty((A.MESH_GENERATION_INIT_FACTOR ** 3, 3), np.float32)
+            size = np.empty(3, np.float32)
+            t0 = time.perf_counter()
+            lib.sdmesh_create_voxel_field(vox.ctypes.data, size.ctypes.data)
+            tc = time.perf_counter() - t0
+            tr = []
+            n = vox.shape[0]
+            sz = H._pt(size)
+            for lv in range(k):
+                outb = np.zeros((8 * n, 3), np.float32); outb.fill(0.0)      # (touched, like the reference's zero-initialised Vec: src/cuda/mod.rs:179-183)
+                n_out, size_out = ctypes.c_size_t(0), A.Point()
+                t0 = time.perf_counter()
+                rc = lib.sdmesh_refine_voxel_field(hh, vox.ctypes.data, n, sz, outb.ctypes.data, 8 * n, ctypes.byref(n_out), ctypes.byref(size_out))
+                tr.append(time.perf_counter() - t0)
+                if rc != 0:
+                    raise RuntimeError("sdmesh_refine_voxel_field failed")
+                vox, n, sz = outb, n_out.value, size_out
+            t0 = time.perf_counter()
+            rc = lib.sdmesh_voxel_field_to_mesh(hh, vox.ctypes.data, n, sz, None, 0, ctypes.byref(nv), None, 0, ctypes.byref(nt))
+            tm = time.perf_counter() - t0
+            if rc != 0:
+                raise RuntimeError("sdmesh_voxel_field_to_mesh failed")
+            verts, idx = np.empty((nv.value, 2, 3), np.float32), np.empty((nt.value, 3), np.uint32)
+            verts.fill(0.0); idx.fill(0)                                 # (touched pages: the copy is timed, not the first-touch faults)
+            t0 = time.perf_counter()
+            lib.sdmesh_download_mesh(hh, verts.ctypes.data, idx.ctypes.data)
+            td = time.perf_counter() - t0
+            if rep >= 2:
+                rows["create_voxel_field"].append(tc); rows["voxel_field_to_mesh"].append(tm); rows["download_mesh"].append(td)
+                for lv in range(k):
+                    rows["refine"][lv].append(tr[lv])
+                rows["total"].append(time.perf_counter() - t_start)
+            sizes = [n, nv.value, nt.value]
+        med = lambda v: round(float(np.median(v)) * 1e3, 4)     # noqa: E731
+        h.regen(k)
+        t0 = time.perf_counter()
+        for _ in range(50):
+            h.regen(k)
+        dres = (time.perf_counter() - t0) / 50 * 1e3
+        out[f"{32 << k}^3"] = {"create_voxel_field_ms": med(rows["create_voxel_field"]), "refine_voxel_field_ms": [med(v) for v in rows["refine"]],
+                               "voxel_field_to_mesh_ms": med(rows["voxel_field_to_mesh"]), "download_mesh_ms": med(rows["download_mesh"]),
+                               "mesh_plus_download_ms": round(med(rows["voxel_field_to_mesh"]) + med(rows["download_mesh"]), 4),
+                               "whole_sequence_ms": med(rows["total"]), "voxels": sizes[0], "vertices": sizes[1], "triangles": sizes[2],
+                               "bytes_up_last_call": 12 * sizes[0], "bytes_down_mesh": 24 * sizes[1] + 12 * sizes[2],
+                               "device_resident_regen_ms": round(dres, 4)}
+    h.close()
+    return out
+
+
 def steady_ms(h, which, n, ptr, reps, warm_ms=40.0, windows=3):
     """HIP-event time per launch of one kernel in steady state: at least `warm_ms` of THAT kernel first (the chip's clock and power
     management settle over ~25 ms under a new load; a fixed number of warm-up launches is 3 ms at 256^3 and 120 ms at 1024^3), then
@@ -790,6 +858,7 @@ def main():
             ra["native_chain_device_ms"] = out["device_ms_per_step"]
             ra["native_speedup_over_reference_shaped_kernels"] = round(ra["kernels_total_ms"] / out["device_ms_per_step"], 1)
         out["reference_abi_kernels"] = ra
+    out["host_api"] = host_api_leg(pkg, local_rank, args.scene, params)
     roofline_legs(h, out, n_grid, args.scene, params, consts)
     out["roofline_step"] = roofline_step_leg(pkg, local_rank, args.scene, params, args.levels, consts, info)
     if not args.no_cpu_baseline:

@@ -158,6 +158,8 @@ struct sdmesh_handle {
                                    // runs even the waves out but every wave then pays the straggler rounds: measured slower, 48.7 -> 57 us)
     int inject_fail = 0;           // option "inject_fail" (tests of the multi-GPU agreement): 1 = this rank's local phase of the next one-mesh
                                    // call fails, 2 = its buffer growth after the first agreement fails; cleared by the call
+    int download_streams = 1;      // option "download_streams" = 2: sdmesh_download_mesh copies the vertex and the index buffer on two streams (measured slower:
+                                   // 12.7 MB to touched pageable memory 0.287 ms on one stream = 44 GB/s, the link's rate; 0.31-0.35 ms on two)
     int timing = 0;                // option "timing": 1 = an event pair around the planned chain fills info->device_ms; off by default:
                                    // the two marker packets cost ~9 us of wall time per regen (0.155 -> 0.146 ms at 512^3)
     // mesh stage
@@ -1015,7 +1017,9 @@ int regen_impl(sdmesh_handle *h, int levels, int mode, int part, int nparts, sdm
 // shared front half of the host-buffer mesh calls: upload, lattice path, fall back to direct
 // when the field is not a lattice field (or when forced).  On return either (uverts, tri_e) are
 // valid (direct == false) or h->raw holds the 5n raw slots (direct == true).
-int host_mesh_front(sdmesh_handle *h, const Point *voxels, uint32_t n, Point vs, bool &direct) {
+int host_mesh_front(sdmesh_handle *h, const Point *voxels, uint32_t n, Point vs, bool &direct, bool with_weld = false) {
+    // with_weld: the weld is enqueued behind the front half and both are waited for together (one host synchronisation per attempt; the weld
+    // of a front half that turns out to need another route is wasted work, which only a non-lattice field or a first call pays)
     hipStream_t st = h->stream;
     SDCHK(ensure(h, h->vox[0], sizeof(Point) * (size_t) n));
     h->cur = 0;
@@ -1028,7 +1032,16 @@ int host_mesh_front(sdmesh_handle *h, const Point *voxels, uint32_t n, Point vs,
     if (!direct) {
         SDCHK(layout_mesh(h, n, 0));
         for (int attempt = 0; attempt < 2; attempt++) {
-            SDCHK(mesh_front(h, (const Point *) h->vox[0].p, h->d_ctr + CTR_LEVEL0, vs, true));
+            if (with_weld) {
+                // size hints as the planned chain has them (grid sizes and kernel forms only: any count is handled): a refined field holds
+                // about 1.2 pre-weld vertices and 2 triangles per voxel; with them the claims run in the projection kernel and the orientation
+                // test inside k_tile_first, as on the device-resident path
+                h->lane_hint = n + n / 4u; h->tri_hint = 2u * n;
+            }
+            const int frc = mesh_front(h, (const Point *) h->vox[0].p, h->d_ctr + CTR_LEVEL0, vs, true, false, false, nullptr, with_weld);
+            h->lane_hint = 0; h->tri_hint = 0;
+            SDCHK(frc);
+            if (with_weld) SDCHK(mesh_weld(h, (const Vertex *) h->uverts.p, tiles(h->cap_vox)));
             SDCHK(read_back(h));
             const uint32_t *s = h->h_pinned + CTR_WORDS;
             if (s[ST_NOT_LATTICE] || s[ST_TILE_OVERFLOW] || s[ST_NONFINITE]) { direct = true; break; }
@@ -1222,6 +1235,7 @@ int sdmesh_set_option(sdmesh_handle *h, const char *name, int value) {
     if (!strcmp(name, "project_grid")) { h->project_grid = value < 0 ? 0 : (value > 65535 ? 65535 : value); drop_graph(h); return SDMESH_OK; }
     if (!strcmp(name, "project_batch")) { h->project_batch = value < 0 ? 0 : (value > 6 ? 6 : value); drop_graph(h); return SDMESH_OK; }
     if (!strcmp(name, "timing")) { h->timing = value != 0; return SDMESH_OK; }
+    if (!strcmp(name, "download_streams")) { h->download_streams = value == 1 ? 1 : 2; return SDMESH_OK; }
     if (!strcmp(name, "local_prefix")) { h->local_prefix = value != 0; drop_graph(h); return SDMESH_OK; }
     if (!strcmp(name, "publish_ctl")) { h->publish_ctl = value != 0; drop_graph(h); return SDMESH_OK; }
     if (!strcmp(name, "fuse_flip")) { h->fuse_flip = value < 0 ? 0 : (value > 2 ? 2 : value); drop_graph(h); return SDMESH_OK; }
@@ -1364,10 +1378,8 @@ int sdmesh_voxel_field_to_mesh(sdmesh_handle *h, const struct Point *voxels, siz
     bool direct = false;
     if (h->weld_wide) h->wide_active = true;
     for (int pass = 0; pass < 2; pass++) {
-        SDCHK(host_mesh_front(h, voxels, (uint32_t) n, voxel_size, direct));
-        if (direct) SDCHK(weld_raw_device(h, (const Triangle *) h->raw.p, 5u * (uint32_t) n));
-        else SDCHK(mesh_weld(h, (const Vertex *) h->uverts.p, tiles(h->cap_vox)));
-        SDCHK(read_back(h));
+        SDCHK(host_mesh_front(h, voxels, (uint32_t) n, voxel_size, direct, true));
+        if (direct) { SDCHK(weld_raw_device(h, (const Triangle *) h->raw.p, 5u * (uint32_t) n)); SDCHK(read_back(h)); }
         if (!h->h_pinned[CTR_WORDS + ST_WELD_RANGE] || h->wide_active) break;
         h->wide_active = true;               // a vertex outside the packed key range: weld again with [i64; 3]-equivalent keys
     }
@@ -1517,6 +1529,17 @@ int sdmesh_column_triangle_counts(sdmesh_handle *h, uint32_t *d_counts) {
 int sdmesh_download_mesh(sdmesh_handle *h, struct Vertex *verts, struct IndexTriangle *tris) {
     if (!h) return SDMESH_ERR_INVALID;
     if (!h->mesh_valid) return fail(h, SDMESH_ERR_INVALID, "no mesh on the device");
+    // (option "download_streams" = 2: the two buffers on two streams.  Measured slower than one after the other: one copy already runs at the link's rate)
+    const bool both = verts && h->n_verts && tris && h->n_tris && h->side && h->stream != nullptr && h->download_streams == 2;
+    if (both) {
+        HIPCHK(hipEventRecord(h->ev_fork, h->stream));
+        HIPCHK(hipStreamWaitEvent(h->side, h->ev_fork, 0));
+        HIPCHK(hipMemcpyAsync(tris, h->res_i ? (const void *) h->res_i : h->indices.p, sizeof(IndexTriangle) * (size_t) h->n_tris, hipMemcpyDeviceToHost, h->side));
+        HIPCHK(hipMemcpyAsync(verts, h->res_v ? (const void *) h->res_v : h->vertices.p, sizeof(Vertex) * (size_t) h->n_verts, hipMemcpyDeviceToHost, h->stream));
+        HIPCHK(hipStreamSynchronize(h->side));
+        HIPCHK(hipStreamSynchronize(h->stream));
+        return SDMESH_OK;
+    }
     if (verts && h->n_verts)
         HIPCHK(hipMemcpyAsync(verts, h->res_v ? (const void *) h->res_v : h->vertices.p, sizeof(Vertex) * (size_t) h->n_verts, hipMemcpyDeviceToHost, h->stream));
     if (tris && h->n_tris)
