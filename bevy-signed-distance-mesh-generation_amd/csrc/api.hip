@@ -12,6 +12,7 @@
 #include <math.h>
 #include <stdarg.h>
 #include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include <algorithm>
@@ -1108,6 +1109,29 @@ int sdmesh_create(int device, sdmesh_handle **out) {
     memset(h->h_pinned, 0, (CTR_WORDS + ST_WORDS) * 4);
     if ((e = hipMalloc((void **) &h->d_sp, sizeof(SceneParams))) != hipSuccess) return bail(e, "hipMalloc");
     if ((e = hipHostMalloc((void **) &h->h_sp, sizeof(SceneParams), hipHostMallocDefault)) != hipSuccess) return bail(e, "hipHostMalloc");
+#if !defined(SDM_FAST_MATH)
+    // The strict build's bit-exactness rests on a property of the silicon (one Markstein step on v_rsq_f32 / v_rcp_f32 rounds correctly:
+    // csrc/sdf.hpp), proven by enumeration on the tested gfx950 parts.  Prove it on THIS device too, once per process and device (about a
+    // second; SDMESH_SKIP_SELFCHECK=1 skips it): a part on which it does not hold must not silently produce other bits.
+    {
+        static bool checked[64] = {false};
+        const char *skip = getenv("SDMESH_SKIP_SELFCHECK");
+        if (device < 64 && !checked[device] && !(skip && skip[0] == '1')) {
+            uint64_t bad[SDMESH_SELFCHECKS] = {0};
+            const int rc = sdmesh_selfcheck_arithmetic(h, bad, SDMESH_SELFCHECKS);
+            uint64_t sum = 0;
+            for (int i = 0; i < SDMESH_SELFCHECKS; i++) sum += bad[i];
+            if (rc != SDMESH_OK || sum != 0) {
+                fprintf(stderr, "sdmesh_create: the lean exact arithmetic is NOT exact on device %d (mismatches %llu %llu %llu %llu %llu, rc %d): this build's "
+                                "results would differ from IEEE-754; refusing\n", device, (unsigned long long) bad[0], (unsigned long long) bad[1],
+                        (unsigned long long) bad[2], (unsigned long long) bad[3], (unsigned long long) bad[4], rc);
+                sdmesh_destroy(h);
+                return SDMESH_ERR_INTERNAL;
+            }
+            checked[device] = true;
+        }
+    }
+#endif
     *out = h;
     return SDMESH_OK;
 }
@@ -1562,7 +1586,10 @@ static hipError_t launch_p1(sdmesh_handle *h, float *d_out, uint32_t N, uint32_t
     const int grid = h->dense_grid > 0 ? h->dense_grid : 8 * h->grid;
     // measured (round-1 sweep): the write-bound sphere wants whole 16-B aligned cache lines per store (flat
     // quads, 5.5 TB/s vs 3.9 with dword-aligned row stores); the VALU-bound scenes want the leaner row kernel
-    const bool rows = h->dense_rows == 2 ? (h->scene != SDMESH_SCENE_SPHERE) : (h->dense_rows != 0);
+    bool rows = h->dense_rows == 2 ? (h->scene != SDMESH_SCENE_SPHERE) : (h->dense_rows != 0);
+    // the flat kernels store 16-byte quads: a slab written into its place of a shared volume starts at x_begin (N + 1)^2 samples, which is
+    // only dword-aligned when N + 1 is odd -> the row kernel there (4-byte aligned vector stores)
+    if ((reinterpret_cast<uintptr_t>(d_out) & 15u) != 0) rows = true;
     if (!rows && h->dense_q1 && N >= 1u) return launch_sample_dense_q1(h->stream, h->scene, h->d_sp, d_out, N, h->dense_nt != 0, x0, x1);
     return rows ? launch_sample_dense_rows(h->stream, h->dense_grid, h->scene, h->d_sp, d_out, N, h->dense_nt != 0, x0, x1, h->dense_aligned != 0, h->dense_nt == 2)
                          : launch_sample_dense(h->stream, grid, h->scene, h->d_sp, d_out, N, h->dense_nt != 0, h->dense_contig != 0, x0, x1);
@@ -2179,7 +2206,7 @@ int zs_exchange(sdmesh_handle *h, const std::vector<ZsMsg> &msgs) {
     }
     const ncclResult_t end = g_rccl.GroupEnd();
     if (first == ncclSuccess) first = end;
-    if (first != ncclSuccess) return fail(h, SDMESH_ERR_RCCL, "z-slab gather: an RCCL message failed: %s", g_rccl.GetErrorString(first));
+    if (first != ncclSuccess) return fail(h, SDMESH_ERR_RCCL, "an RCCL message of the one-mesh exchange failed: %s", g_rccl.GetErrorString(first));
     return SDMESH_OK;
 }
 
@@ -2446,7 +2473,7 @@ int sdmesh_sharded_regen(sdmesh_handle *h, int levels, int root, sdmesh_regen_in
     HIPCHK(launch_pack_record(st, d_row + SHARD_REC, nullptr, nullptr, (uint32_t) lrc, n_mine, cap_items(h->shard_recv, sizeof(Triangle)),
                               cap_items(h->shard_merged, sizeof(Triangle))));
     // (k_pack_record writes {v0, v1 | status, v2, v3}: word 0 = status, word 1 = triangles here)
-    HIPCHK(launch_pack_record(st, d_row + SHARD_REC + 4, nullptr, nullptr, 0u, 0u, 0u, 0u));                    // {vertices: none, raw form}
+    HIPCHK(launch_pack_record(st, d_row + SHARD_REC + 4, nullptr, nullptr, 0u, 0u, (uint32_t) inject, 0u));     // {vertices: none, raw form, inject}
     NCCLCHK(g_rccl.AllGather(d_row, d_counts, SHARD_ROW, ncclUint32, h->comm, st));                     // in place
     HIPCHK(hipMemcpyAsync(h->h_counts, d_counts, 4ull * (size_t) R * SHARD_ROW, hipMemcpyDeviceToHost, st));
     HIPCHK(hipStreamSynchronize(st));
@@ -2466,17 +2493,19 @@ int sdmesh_sharded_regen(sdmesh_handle *h, int levels, int root, sdmesh_regen_in
     if (total > 0x0FFFFFFFull) return fail(h, SDMESH_ERR_INVALID, "too many triangles for one weld");
     // 4. the root's receive / merge buffers; grown behind a second agreement only if its published capacity is too small
     const uint32_t *root_row = h->h_counts + (size_t) root * SHARD_ROW;
-    if (foreign > root_row[SHARD_REC + 2] || total > root_row[SHARD_REC + 3] || inject == 2) {
+    bool any_inject2 = false;                              // (an injected growth failure on ANY rank: every rank takes the same branch)
+    for (int r = 0; r < R; r++) any_inject2 = any_inject2 || h->h_counts[(size_t) r * SHARD_ROW + SHARD_REC + ZR_INJECT] == 2u;
+    if (foreign > root_row[SHARD_REC + 2] || total > root_row[SHARD_REC + 3] || any_inject2) {
         int grc = SDMESH_OK;
-        if (me == root) {
-            grc = inject == 2 ? fail(h, SDMESH_ERR_HIP, "injected allocation failure (option inject_fail)")
-                                      : ensure_grow(h, h->shard_recv, sizeof(Triangle) * (size_t) std::max<uint64_t>(foreign, 1));
+        if (inject == 2) grc = fail(h, SDMESH_ERR_HIP, "injected allocation failure (option inject_fail)");
+        else if (me == root) {
+            grc = ensure_grow(h, h->shard_recv, sizeof(Triangle) * (size_t) std::max<uint64_t>(foreign, 1));
             if (grc == SDMESH_OK) grc = ensure_grow(h, h->shard_merged, sizeof(Triangle) * (size_t) std::max<uint64_t>(total, 1));
         }
         uint32_t worst = 0;
         SDCHK(agree_flag(h, grc == SDMESH_OK ? 0u : 1u, &worst));
         if (grc != SDMESH_OK) return grc;
-        if (worst) return fail(h, SDMESH_ERR_PEER, "the root (rank %d) could not grow its receive buffers; every rank returns an error", root);
+        if (worst) return fail(h, SDMESH_ERR_PEER, "a rank (the root is rank %d) could not grow its buffers; every rank returns an error", root);
     }
     if (me != root) {
         // 5a. peers: the slab's triangles go straight to the root (each peer on its own xGMI link)
@@ -2492,11 +2521,11 @@ int sdmesh_sharded_regen(sdmesh_handle *h, int levels, int root, sdmesh_regen_in
         h->h_lists[r] = (Triangle *) h->shard_recv.p + off;
         off += tr[r];
     }
-    if (foreign) {
-        NCCLCHK(g_rccl.GroupStart());
+    {
+        std::vector<ZsMsg> msgs;                               // (grouped; the group is closed on every path)
         for (int r = 0; r < R; r++)
-            if (r != root && tr[r]) NCCLCHK(g_rccl.Recv(h->h_lists[r], (size_t) tr[r] * 18, ncclFloat32, r, h->comm, st));
-        NCCLCHK(g_rccl.GroupEnd());
+            if (r != root && tr[r]) msgs.push_back({h->h_lists[r], (size_t) tr[r] * 18, ncclFloat32, r, false});
+        SDCHK(zs_exchange(h, msgs));
     }
     // 6. order-restoring merge (HIP kernel), then the first-seen weld of the merged list = the single-GPU mesh.  (From here
     //    on nobody waits for the root any more: a failure is the root's alone.)
@@ -2735,7 +2764,7 @@ uint32_t dist_prev_capacity(const sdmesh_handle *h) {
 }
 
 int dist_grow_prev(sdmesh_handle *h, uint32_t n_prev) {
-    if (h->inject_fail == 2) { h->inject_fail = 0; return fail(h, SDMESH_ERR_HIP, "injected allocation failure (option inject_fail)"); }
+    if (h->inject_fail == 2) { h->inject_fail = 0; return fail(h, SDMESH_ERR_HIP, "injected allocation failure (option inject_fail)"); }   // (set on this rank)
     const uint32_t n = std::max<uint32_t>(n_prev, 1);
     SDCHK(ensure_grow(h, h->dist_prevkeys, 8ull * n));
     SDCHK(ensure_grow(h, h->dist_prevg, 4ull * n));
@@ -2809,8 +2838,9 @@ int sdmesh_distributed_regen(sdmesh_handle *h, int levels, sdmesh_regen_info *in
     // 1. band sizes of every rank (the one extra host synchronisation of a distributed step: message lengths must be host
     //    values), each with the rank's status and what it can take from its lower neighbour without growing -- ALWAYS entered
     uint32_t *d_nups = (uint32_t *) h->dist_nups.p, *d_counts = (uint32_t *) h->dist_counts.p;
+    const int inject = h->inject_fail;                         // (2 = "my buffer growth fails": every rank must learn it, or only this one enters the agreement below)
     HIPCHK(launch_pack_record(st, d_nups + (size_t) me * DIST_REC, lrc == SDMESH_OK ? h->d_ctr + CTR_DIST_NUP : nullptr, nullptr, 0u, (uint32_t) lrc,
-                              dist_prev_capacity(h), 0u));
+                              dist_prev_capacity(h), (uint32_t) inject));
     NCCLCHK(g_rccl.AllGather(d_nups + (size_t) me * DIST_REC, d_nups, DIST_REC, ncclUint32, h->comm, st));        // in place
     uint32_t *rec = h->h_counts;
     HIPCHK(hipMemcpyAsync(rec, d_nups, 4ull * (size_t) R * DIST_REC, hipMemcpyDeviceToHost, st));
@@ -2823,18 +2853,19 @@ int sdmesh_distributed_regen(sdmesh_handle *h, int levels, sdmesh_regen_info *in
     bool any_grow = false;
     for (int r = 1; r < R; r++) any_grow = any_grow || nups[r - 1] > rec[(size_t) r * DIST_REC + 2];
     for (int r = 0; r < R; r++) any_grow = any_grow || rec[(size_t) r * DIST_REC + 2] == 0u;          // (a first call: nothing allocated yet)
-    if (any_grow || h->inject_fail == 2) {
+    for (int r = 0; r < R; r++) any_grow = any_grow || rec[(size_t) r * DIST_REC + 3] == 2u;          // (an injected growth failure on ANY rank: the same decision everywhere)
+    if (any_grow) {
         const int grc = dist_grow_prev(h, n_prev);
         uint32_t worst = 0;
         SDCHK(agree_flag(h, grc == SDMESH_OK ? 0u : 1u, &worst));
         if (grc != SDMESH_OK) return grc;
         if (worst) return fail(h, SDMESH_ERR_PEER, "a rank could not grow its band buffers; every rank returns an error");
     }
-    if (n_up || n_prev) {
-        NCCLCHK(g_rccl.GroupStart());
-        if (n_up) NCCLCHK(g_rccl.Send(h->dist_upkeys.p, n_up, ncclUint64, me + 1, h->comm, st));
-        if (n_prev) NCCLCHK(g_rccl.Recv(h->dist_prevkeys.p, n_prev, ncclUint64, me - 1, h->comm, st));
-        NCCLCHK(g_rccl.GroupEnd());
+    {
+        std::vector<ZsMsg> msgs;                               // (grouped; the group is closed on every path)
+        if (n_up) msgs.push_back({h->dist_upkeys.p, n_up, ncclUint64, me + 1, true});
+        if (n_prev) msgs.push_back({h->dist_prevkeys.p, n_prev, ncclUint64, me - 1, false});
+        SDCHK(zs_exchange(h, msgs));
     }
     // (nothing below allocates: a failure from here on is a HIP / RCCL error, after which the communicator is gone anyway)
     SDCHK(dist_phase_match(h, n_prev));
@@ -2843,11 +2874,11 @@ int sdmesh_distributed_regen(sdmesh_handle *h, int levels, sdmesh_regen_info *in
     HIPCHK(launch_pack_record(st, d_counts + (size_t) me * DIST_REC, h->d_ctr + CTR_DIST_NKEEP, h->d_status, 0u, 0u, 0u, 0u));
     NCCLCHK(g_rccl.AllGather(d_counts + (size_t) me * DIST_REC, d_counts, DIST_REC, ncclUint32, h->comm, st));
     SDCHK(dist_phase_pack(h, me, n_up));
-    if (n_up || n_prev) {
-        NCCLCHK(g_rccl.GroupStart());
-        if (n_up) NCCLCHK(g_rccl.Send(h->dist_upg.p, n_up, ncclUint32, me + 1, h->comm, st));
-        if (n_prev) NCCLCHK(g_rccl.Recv(h->dist_prevg.p, n_prev, ncclUint32, me - 1, h->comm, st));
-        NCCLCHK(g_rccl.GroupEnd());
+    {
+        std::vector<ZsMsg> msgs;
+        if (n_up) msgs.push_back({h->dist_upg.p, n_up, ncclUint32, me + 1, true});
+        if (n_prev) msgs.push_back({h->dist_prevg.p, n_prev, ncclUint32, me - 1, false});
+        SDCHK(zs_exchange(h, msgs));
     }
     SDCHK(dist_phase_final(h, me));
     HIPCHK(hipMemcpyAsync(rec, d_counts, 4ull * (size_t) R * DIST_REC, hipMemcpyDeviceToHost, st));

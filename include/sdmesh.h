@@ -79,7 +79,9 @@ typedef struct sdmesh_regen_info {
 /* ---- lifetime ----------------------------------------------------------------------------- */
 
 /* CudaHandler::new (src/cuda/mod.rs:49-103): picks the device, loads the kernels, creates the
- * grow-only device buffers (DynamicCudaSlice, :10-23). */
+ * grow-only device buffers (DynamicCudaSlice, :10-23).  The first handle a process makes on a device also runs
+ * sdmesh_selfcheck_arithmetic there (strict build; about a second; SDMESH_SKIP_SELFCHECK=1 in the environment skips it) and the call
+ * fails with SDMESH_ERR_INTERNAL on a part whose v_rsq_f32 / v_rcp_f32 do not make the lean square root / reciprocal exact. */
 int sdmesh_create(int device, sdmesh_handle **out);
 void sdmesh_destroy(sdmesh_handle *h);
 const char *sdmesh_last_error(const sdmesh_handle *h);
