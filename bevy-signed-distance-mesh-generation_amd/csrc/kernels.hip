@@ -2882,7 +2882,7 @@ hipError_t launch_weld(hipStream_t st, int grid, const Vertex *uverts, const uin
                        int flip_scene, const SceneParams *sp, int part, const uint32_t *pub_src, uint32_t *pub_dst, uint32_t pub_words,
                        uint32_t pub_ovf, uint32_t pub_nvert, int tf_threads, const uint32_t *colstart, const uint32_t *coltile, uint32_t *colvloc,
                        uint32_t *colvstart) {
-    if (tf_threads != 128 && tf_threads != 256 && tf_threads != 512 && tf_threads != 768 && tf_threads != 1024) tf_threads = 256;
+    if (tf_threads < 128 || tf_threads > 1024 || tf_threads % 64) tf_threads = 256;
     // part: 0 = the whole weld, 1 = k_tile_first only, 2 = everything behind it (so that a stage marker fits between)
     const bool stop_after_first = part == 1;
     if (part == 2) goto rest;
