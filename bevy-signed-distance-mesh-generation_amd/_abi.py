@@ -25,7 +25,7 @@ MESH_GENERATION_BB_SIZE = 5.0
 MAX_LEVELS = 15
 
 SCENES = {"sdobj": 0, "sphere": 1, "csg3": 2, "anim": 3}
-OPS = {"sphere": 1, "box": 2, "box_skeleton": 3, "capsule": 4, "torus_y": 5}
+OPS = {"sphere": 1, "box": 2, "box_skeleton": 3, "capsule": 4, "torus_y": 5, "ray": 6, "simple_box": 7, "simple_bounding_box": 8, "wrap": 9}
 COMBINES = {"set": 0, "min": 1, "max": 2, "smooth_min": 3, "subtract": 4}
 INSTR = np.dtype([("op", "<u4"), ("combine", "<u4"), ("k", "<f4"), ("a", "<f4", (7,))])
 assert INSTR.itemsize == 40
@@ -115,6 +115,8 @@ SYMBOLS = {
     "sdmesh_comm_init": (_i, [_vp, _vp, _i, _i]),
     "sdmesh_comm_destroy": (_i, [_vp]),
     "sdmesh_comm_ranks": (_i, [_vp, ctypes.POINTER(_i)]),
+    "sdmesh_set_program_motion": (_i, [_vp, _vp, _i]),
+    "sdmesh_set_program_time": (_i, [_vp, ctypes.c_float]),
     "sdmesh_sharded_regen": (_i, [_vp, _i, _i, ctypes.POINTER(RegenInfo)]),
     "sdmesh_sharded_route": (_i, [_vp]),
     "sdmesh_zslab_local": (_i, [_vp, _i, _i, _i, _vp, ctypes.POINTER(RegenInfo)]),

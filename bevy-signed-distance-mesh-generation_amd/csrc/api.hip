@@ -78,6 +78,9 @@ struct sdmesh_handle {
     SceneParams sp{};
     SceneParams *d_sp = nullptr;   // device copy of sp (kernels read the scene uniform through this pointer)
     SceneParams *h_sp = nullptr;   // pinned staging for it
+    SdfInstr prog_base[SDM_MAX_INSTR] = {};        // the program as set; sp.prog = prog_base + prog_time * prog_motion (sdmesh_set_program_time)
+    float prog_motion[SDM_MAX_INSTR][7] = {};
+    float prog_time = 0.0f;
     bool sp_dirty = true;
     int grid = 1024;           // workgroups per grid-stride launch of the item-parallel kernels (4 per CU)
     int tgrid = 4096;          // workgroups of the per-tile kernels.  With 4 per CU a 512^3 field (1037 tiles on 1024
@@ -1186,16 +1189,51 @@ int sdmesh_set_program(sdmesh_handle *h, const sdmesh_instr *instrs, int n) {
     if (n < 1 || n > SDM_MAX_INSTR) return fail(h, SDMESH_ERR_INVALID, "a program has 1..%d instructions", SDM_MAX_INSTR);
     static_assert(sizeof(sdmesh_instr) == sizeof(SdfInstr), "sdmesh_instr layout");
     for (int i = 0; i < n; i++) {
-        if (instrs[i].op < OP_SPHERE || instrs[i].op > OP_TORUS_Y || instrs[i].combine > CB_SUBTRACT)
+        if (instrs[i].op < OP_SPHERE || instrs[i].op > OP_LAST || instrs[i].combine > CB_SUBTRACT)
             return fail(h, SDMESH_ERR_INVALID, "instruction %d: unknown op/combine", i);
     }
-    if (instrs[0].combine != CB_SET) return fail(h, SDMESH_ERR_INVALID, "the first instruction must use SDMESH_CB_SET");
+    int first = 0;
+    while (first < n && instrs[first].op == OP_WRAP) first++;              // (wraps only move the point)
+    if (first == n || instrs[first].combine != CB_SET) return fail(h, SDMESH_ERR_INVALID, "the first primitive must use SDMESH_CB_SET");
     h->scene = SCENE_PROGRAM;
     memset(&h->sp, 0, sizeof h->sp);
     h->sp.ninstr = (uint32_t) n;
     memcpy(h->sp.prog, instrs, sizeof(SdfInstr) * (size_t) n);
+    memcpy(h->prog_base, instrs, sizeof(SdfInstr) * (size_t) n);
+    memset(h->prog_motion, 0, sizeof h->prog_motion);
+    h->prog_time = 0.0f;
     h->sp_dirty = true;
     h->plan_valid = false;
+    return SDMESH_OK;
+}
+
+namespace {
+// a[i][j] + time * da[i][j] in f32, the multiplication rounded before the addition (the oracle's Python helper does the same)
+void apply_program_time(sdmesh_handle *h) {
+    for (uint32_t i = 0; i < h->sp.ninstr; i++)
+        for (int j = 0; j < 7; j++) {
+            volatile float prod = h->prog_time * h->prog_motion[i][j];
+            h->sp.prog[i].a[j] = h->prog_base[i].a[j] + prod;
+        }
+    h->sp_dirty = true;
+}
+}  // namespace
+
+int sdmesh_set_program_motion(sdmesh_handle *h, const float *motion, int n) {
+    if (!h) return SDMESH_ERR_INVALID;
+    if (h->scene != SCENE_PROGRAM) return fail(h, SDMESH_ERR_INVALID, "no program is set (sdmesh_set_program)");
+    if (motion && n != (int) h->sp.ninstr) return fail(h, SDMESH_ERR_INVALID, "the motion table needs one row of 7 rates per instruction (%u)", h->sp.ninstr);
+    memset(h->prog_motion, 0, sizeof h->prog_motion);
+    if (motion) memcpy(h->prog_motion, motion, sizeof(float) * 7 * (size_t) n);
+    apply_program_time(h);
+    return SDMESH_OK;
+}
+
+int sdmesh_set_program_time(sdmesh_handle *h, float time) {
+    if (!h) return SDMESH_ERR_INVALID;
+    if (h->scene != SCENE_PROGRAM) return fail(h, SDMESH_ERR_INVALID, "no program is set (sdmesh_set_program)");
+    h->prog_time = time;
+    apply_program_time(h);
     return SDMESH_OK;
 }
 

@@ -43,8 +43,12 @@ namespace sdm {
 enum Scene : int { SCENE_SDOBJ = 0, SCENE_SPHERE = 1, SCENE_CSG3 = 2, SCENE_ANIM = 3, SCENE_PROGRAM = 4, SCENE_COUNT = 5 };
 
 // Runtime SDF program: a linear CSG chain  acc = combine_i(acc, primitive_i(p)).
-// Primitives are the reference's (cuda/includes/signed_distance.cu:61-113) plus a torus; layout == sdmesh_instr.
-enum SdfOp : uint32_t { OP_SPHERE = 1, OP_BOX = 2, OP_BOX_SKELETON = 3, OP_CAPSULE = 4, OP_TORUS_Y = 5 };
+// Primitives are the reference's (cuda/includes/signed_distance.cu:61-131: sd_ray in both forms, sd_line, sd_box, sd_box_skeleton,
+// sd_simple_box, sd_simple_bounding_box) plus a sphere with a radius and a torus; OP_WRAP is the reference's domain repetition
+// (signed_distance.cu:9-18) applied to the point every later instruction sees.  Layout == sdmesh_instr.  (sd_mandelbulb, :29-52, is
+// acos / atan2 / pow / sin / cos / log: not reproducible bit for bit between a CPU libm and the device, and the reference never calls it.)
+enum SdfOp : uint32_t { OP_SPHERE = 1, OP_BOX = 2, OP_BOX_SKELETON = 3, OP_CAPSULE = 4, OP_TORUS_Y = 5, OP_RAY = 6, OP_SIMPLE_BOX = 7,
+                        OP_SIMPLE_BOUNDING_BOX = 8, OP_WRAP = 9, OP_LAST = 9 };
 enum SdfCombine : uint32_t { CB_SET = 0, CB_MIN = 1, CB_MAX = 2, CB_SMOOTH_MIN = 3, CB_SUBTRACT = 4 };
 #define SDM_MAX_INSTR 16
 
@@ -296,6 +300,11 @@ SDM_HD float sd_box_skeleton_g(f3 p, f3 bp, f3 bs, float lw) {      // signed_di
     return sd;
 }
 
+SDM_HD float wrap1(float x, float lower, float higher) {            // signed_distance.cu:9-11; glm::mod(x, y) = x - y * floor(x / y)
+    const float xx = x - lower, y = higher - lower;
+    return lower + (xx - y * floorf(xx / y));
+}
+
 SDM_HD float sdf_program(f3 p, const SceneParams &sp) {
     float acc = 3.40282347E+38f;
     const uint32_t n = sp.ninstr < SDM_MAX_INSTR ? sp.ninstr : SDM_MAX_INSTR;
@@ -303,6 +312,10 @@ SDM_HD float sdf_program(f3 p, const SceneParams &sp) {
         const SdfInstr &in = sp.prog[i];
         const f3 c = mk(in.a[0], in.a[1], in.a[2]);
         float d;
+        if (in.op == OP_WRAP) {                                     // signed_distance.cu:13-18: the point of every later instruction
+            p = mk(wrap1(p.x, in.a[0], in.a[3]), wrap1(p.y, in.a[1], in.a[4]), wrap1(p.z, in.a[2], in.a[5]));
+            continue;
+        }
         switch (in.op) {
         case OP_SPHERE: { f3 e = sub3(p, c); d = sqrt_rn(dot3(e, e)) - in.a[3]; } break;
         case OP_BOX: d = sd_box(p, c, mk(in.a[3], in.a[4], in.a[5])); break;
@@ -313,6 +326,21 @@ SDM_HD float sdf_program(f3 p, const SceneParams &sp) {
             float qx = sqrt_rn(e.x * e.x + e.z * e.z) - in.a[3];
             d = sqrt_rn(qx * qx + e.y * e.y) - in.a[4];
         } break;
+        case OP_RAY: {                                              // signed_distance.cu:61-63 (unbounded; a[6] = radius, 0 for the bare distance)
+            const f3 bd = mk(in.a[3], in.a[4], in.a[5]);
+            const f3 q = add3(c, scale3(bd, dot3(sub3(p, c), bd)));
+            const f3 e = sub3(p, q);                                // distance(a, b) = length(b - a)
+            d = sqrt_rn(dot3(e, e)) - in.a[6];
+        } break;
+        case OP_SIMPLE_BOX: {                                       // signed_distance.cu:115-118: the interior term of sd_box alone
+            const f3 e = sub3(p, c);
+            const f3 q = mk(fabsf(e.x) - in.a[3] / 2.0f, fabsf(e.y) - in.a[4] / 2.0f, fabsf(e.z) - in.a[5] / 2.0f);
+            const f3 m = mk(gmin(q.x, 0.0f), gmin(q.y, 0.0f), gmin(q.z, 0.0f));
+            d = gmax(gmax(m.x, m.y), m.z);
+        } break;
+        case OP_SIMPLE_BOUNDING_BOX:                                // signed_distance.cu:120-131: a[0..2] = bb_min, a[3..5] = bb_max
+            d = gmax(gmax(in.a[0] - p.x, gmax(in.a[1] - p.y, in.a[2] - p.z)), gmax(p.x - in.a[3], gmax(p.y - in.a[4], p.z - in.a[5])));
+            break;
         default: d = 3.40282347E+38f; break;
         }
         switch (in.combine) {

@@ -146,6 +146,17 @@ class CudaHandler:
         self.scene = "program"
         self._chk(self._lib.sdmesh_set_program(self._h, arr.ctypes.data, len(arr)))
 
+    def set_program_motion(self, motion):
+        """Per-instruction rates [n, 7]: the kernels see args + time * rates (evaluated on the host in f32).  None clears them."""
+        if motion is None:
+            self._chk(self._lib.sdmesh_set_program_motion(self._h, None, 0))
+            return
+        m = np.ascontiguousarray(motion, np.float32).reshape(-1, 7)
+        self._chk(self._lib.sdmesh_set_program_motion(self._h, m.ctypes.data, m.shape[0]))
+
+    def set_program_time(self, t):
+        self._chk(self._lib.sdmesh_set_program_time(self._h, float(np.float32(t))))
+
     def set_animation_time(self, t):
         """sphere centre (0, 0.5*sin t, 0); sin is evaluated on the host."""
         self.set_scene("anim", [np.float32(0.5) * np.float32(math.sin(t))])

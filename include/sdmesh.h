@@ -98,7 +98,11 @@ int sdmesh_set_scene(sdmesh_handle *h, int scene, const float *params, int npara
  *   combine: SET, MIN (union), MAX (intersection), SMOOTH_MIN with radius k (signed_distance.cu:20-23), SUBTRACT
  * The reference scene is {BOX_SKELETON (0,0,0) (3,1,.5) .1 SET; SPHERE (0,0,0) 1 SMOOTH_MIN k=.5} and gives results
  * bit-identical to SDMESH_SCENE_SDOBJ. */
-enum { SDMESH_OP_SPHERE = 1, SDMESH_OP_BOX = 2, SDMESH_OP_BOX_SKELETON = 3, SDMESH_OP_CAPSULE = 4, SDMESH_OP_TORUS_Y = 5 };
+enum { SDMESH_OP_SPHERE = 1, SDMESH_OP_BOX = 2, SDMESH_OP_BOX_SKELETON = 3, SDMESH_OP_CAPSULE = 4, SDMESH_OP_TORUS_Y = 5,
+       SDMESH_OP_RAY = 6 /* a[0..2] origin, a[3..5] direction, a[6] radius: sd_ray(p, bl, bd) - r, the unbounded ray (signed_distance.cu:61-63) */,
+       SDMESH_OP_SIMPLE_BOX = 7 /* a[0..2] centre, a[3..5] size: sd_simple_box (:115-118) */,
+       SDMESH_OP_SIMPLE_BOUNDING_BOX = 8 /* a[0..2] bb_min, a[3..5] bb_max: sd_simple_bounding_box (:120-131) */,
+       SDMESH_OP_WRAP = 9 /* a[0..2] lower, a[3..5] higher: every LATER instruction sees wrap(p, lower, higher) (:9-18); combine / k unused */ };
 enum { SDMESH_CB_SET = 0, SDMESH_CB_MIN = 1, SDMESH_CB_MAX = 2, SDMESH_CB_SMOOTH_MIN = 3, SDMESH_CB_SUBTRACT = 4 };
 #define SDMESH_MAX_INSTR 16
 typedef struct sdmesh_instr {
@@ -108,6 +112,12 @@ typedef struct sdmesh_instr {
     float a[7];
 } sdmesh_instr;
 int sdmesh_set_program(sdmesh_handle *h, const sdmesh_instr *instrs, int n);
+/* Time-varying programs ("time-varying CSG", BASELINE configs[4] as a program): per instruction seven rates da[i][0..7); the arguments the
+ * kernels see are a[i][j] + time * da[i][j], evaluated on the host in f32 (one multiplication, one addition, no contraction) whenever the
+ * time changes -- the device interpreter is unchanged and a frame costs one 700-byte uniform upload.  motion == NULL clears the rates.
+ * sdmesh_set_program resets rates and time.  Sizes may change with the time: the capacity plan follows as for any scene change. */
+int sdmesh_set_program_motion(sdmesh_handle *h, const float *motion /* n x 7 */, int n);
+int sdmesh_set_program_time(sdmesh_handle *h, float time);
 
 /* Run on a caller-owned hipStream_t, taken exactly as HIP reads it: NULL is the legacy default stream (which is what
  * torch.cuda.current_stream().cuda_stream is for torch's default stream).  hipGraph replay needs a capturable stream, so

@@ -17,7 +17,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 _LIB = None
 
 SCENES = {"sdobj": 0, "sphere": 1, "csg3": 2, "anim": 3, "program": 4}
-OPS = {"sphere": 1, "box": 2, "box_skeleton": 3, "capsule": 4, "torus_y": 5}
+OPS = {"sphere": 1, "box": 2, "box_skeleton": 3, "capsule": 4, "torus_y": 5, "ray": 6, "simple_box": 7, "simple_bounding_box": 8, "wrap": 9}
 COMBINES = {"set": 0, "min": 1, "max": 2, "smooth_min": 3, "subtract": 4}
 INSTR = np.dtype([("op", "<u4"), ("combine", "<u4"), ("k", "<f4"), ("a", "<f4", (7,))])
 
@@ -95,6 +95,22 @@ def set_program(program):
         arr[i]["a"][: a.size] = a
     lib().orc_set_program(arr.ctypes.data, len(arr))
     return arr
+
+
+def program_at_time(program, motion, t):
+    """The program the kernels see at time t: args + t * rates in f32, the product rounded before the sum (sdmesh_set_program_time)."""
+    t = np.float32(t)
+    out = []
+    for ins, rates in zip(program, motion):
+        a = np.asarray(ins[1], np.float32)
+        r = np.zeros(7, np.float32)
+        rr = np.asarray(rates, np.float32).ravel()
+        r[: rr.size] = rr
+        full = np.zeros(7, np.float32)
+        full[: a.size] = a
+        eff = (full + (t * r).astype(np.float32)).astype(np.float32)
+        out.append((ins[0], eff.tolist()) + tuple(ins[2:]))
+    return out
 
 
 def set_threads(n):

@@ -68,7 +68,8 @@ enum { SCENE_SDOBJ = 0, SCENE_SPHERE = 1, SCENE_CSG3 = 2, SCENE_ANIM = 3, SCENE_
 
 /* 4 PROGRAM: build-defined runtime SDF program, a linear CSG chain of the reference's
  * primitives: acc = combine_i(acc, primitive_i(p)).  Same instruction layout as include/sdmesh.h sdmesh_instr. */
-enum { OP_SPHERE = 1, OP_BOX = 2, OP_BOX_SKELETON = 3, OP_CAPSULE = 4, OP_TORUS_Y = 5 };
+enum { OP_SPHERE = 1, OP_BOX = 2, OP_BOX_SKELETON = 3, OP_CAPSULE = 4, OP_TORUS_Y = 5, OP_RAY = 6, OP_SIMPLE_BOX = 7, OP_SIMPLE_BOUNDING_BOX = 8,
+       OP_WRAP = 9 };
 enum { CB_SET = 0, CB_MIN = 1, CB_MAX = 2, CB_SMOOTH_MIN = 3, CB_SUBTRACT = 4 };
 typedef struct { uint32_t op, combine; float k; float a[7]; } OrcInstr;
 static OrcInstr g_prog[16];
@@ -102,6 +103,30 @@ static inline v3 cross3(v3 x, v3 y) {
 static inline float vget(v3 a, int i) { return i == 0 ? a.x : (i == 1 ? a.y : a.z); }
 static inline void vaddi(v3 *a, int i, float s) {
     if (i == 0) a->x += s; else if (i == 1) a->y += s; else a->z += s;
+}
+
+/* signed_distance.cu:9-11; glm::mod(x, y) = x - y * floor(x / y) */
+static float wrap1(float x, float lower, float higher) {
+    float xx = x - lower, y = higher - lower;
+    return lower + (xx - y * floorf(xx / y));
+}
+
+/* signed_distance.cu:61-63 */
+static float sd_ray_unbounded(v3 p, v3 bl, v3 bd) {
+    return distance3(vadd(bl, vscale(bd, dot3(vsub(p, bl), bd))), p);
+}
+
+/* signed_distance.cu:115-118 */
+static float sd_simple_box(v3 p, v3 bp, v3 bs) {
+    v3 e = vsub(p, bp);
+    v3 q = V(gabs(e.x) - bs.x / 2.0f, gabs(e.y) - bs.y / 2.0f, gabs(e.z) - bs.z / 2.0f);
+    v3 m = V(gmin(q.x, 0.0f), gmin(q.y, 0.0f), gmin(q.z, 0.0f));
+    return gmax(gmax(m.x, m.y), m.z);
+}
+
+/* signed_distance.cu:120-131 */
+static float sd_simple_bounding_box(v3 p, v3 bb_min, v3 bb_max) {
+    return gmax(gmax(bb_min.x - p.x, gmax(bb_min.y - p.y, bb_min.z - p.z)), gmax(p.x - bb_max.x, gmax(p.y - bb_max.y, p.z - bb_max.z)));
 }
 
 /* signed_distance.cu:20-23 */
@@ -180,12 +205,19 @@ static float sdf_eval(int scene, const float *params, v3 p) {
             const OrcInstr *in = &g_prog[i];
             v3 c = V(in->a[0], in->a[1], in->a[2]);
             float d;
+            if (in->op == OP_WRAP) {      /* signed_distance.cu:13-18: wraps the point every later instruction sees */
+                p = V(wrap1(p.x, in->a[0], in->a[3]), wrap1(p.y, in->a[1], in->a[4]), wrap1(p.z, in->a[2], in->a[5]));
+                continue;
+            }
             switch (in->op) {
             case OP_SPHERE: d = length3(vsub(p, c)) - in->a[3]; break;
             case OP_BOX: d = sd_box(p, c, V(in->a[3], in->a[4], in->a[5])); break;
             case OP_BOX_SKELETON: d = sd_box_skeleton(p, c, V(in->a[3], in->a[4], in->a[5]), in->a[6]); break;
             case OP_CAPSULE: d = sd_line(p, c, V(in->a[3], in->a[4], in->a[5])) - in->a[6]; break;
             case OP_TORUS_Y: d = sd_torus_y(vsub(p, c), in->a[3], in->a[4]); break;
+            case OP_RAY: d = sd_ray_unbounded(p, c, V(in->a[3], in->a[4], in->a[5])) - in->a[6]; break;
+            case OP_SIMPLE_BOX: d = sd_simple_box(p, c, V(in->a[3], in->a[4], in->a[5])); break;
+            case OP_SIMPLE_BOUNDING_BOX: d = sd_simple_bounding_box(p, c, V(in->a[3], in->a[4], in->a[5])); break;
             default: d = (float) 3.40282347E+38; break;
             }
             switch (in->combine) {

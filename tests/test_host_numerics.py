@@ -24,6 +24,44 @@ PROGRAMS = {
 }
 
 
+PROGRAMS.update({
+    # round 4: the rest of the reference's primitive list (signed_distance.cu:9-18, 61-63, 115-131): the unbounded ray (a cylinder with a
+    # radius), sd_simple_bounding_box, sd_simple_box as the clipping term it is in the reference, and the domain repetition
+    "newops": [("ray", [0.2, 0, -0.1, 0, 1, 0, 0.5], "set"), ("simple_bounding_box", [-1.2, -0.4, -0.9, 1.2, 0.4, 0.9], "min"),
+               ("sphere", [0, 0, 0, 1.1], "smooth_min", 0.3), ("simple_box", [0, 0, 0, 6, 6, 6], "max")],
+    "wrapped": [("wrap", [-1.25, -1.25, -1.25, 1.25, 1.25, 1.25], "set"), ("sphere", [0, 0, 0, 0.8], "set"),
+                ("box", [0, 0, 0, 1.0, 1.0, 1.0], "smooth_min", 0.2)],
+})
+
+
+def random_program2(seed):
+    """Like random_program, over the round-4 ops as well (ray, simple_bounding_box, an optional leading wrap)."""
+    rng = np.random.default_rng(5000 + seed)
+    u = lambda lo, hi: float(np.float32(rng.uniform(lo, hi)))      # noqa: E731
+    prog = []
+    if rng.integers(0, 2):
+        w = u(1.0, 2.5)
+        prog.append(("wrap", [-w, -w, -w, w, w, w], "set"))
+    for i in range(int(rng.integers(2, 5))):
+        op = ["sphere", "ray", "simple_bounding_box", "capsule", "box"][int(rng.integers(0, 5))]
+        c = [u(-1.0, 1.0), u(-1.0, 1.0), u(-1.0, 1.0)]
+        if op == "sphere":
+            a = c + [u(0.4, 1.2)]
+        elif op == "ray":
+            d = np.asarray([u(-1, 1), u(-1, 1), u(-1, 1)], np.float32)
+            d = (d / np.float32(np.sqrt(np.float32((d * d).sum())))).astype(np.float32)
+            a = c + [float(x) for x in d] + [u(0.15, 0.5)]
+        elif op == "simple_bounding_box":
+            a = [c[0] - u(0.3, 1.0), c[1] - u(0.3, 1.0), c[2] - u(0.3, 1.0), c[0] + u(0.3, 1.0), c[1] + u(0.3, 1.0), c[2] + u(0.3, 1.0)]
+        elif op == "capsule":
+            a = c + [u(-1.5, 1.5), u(-1.5, 1.5), u(-1.5, 1.5), u(0.1, 0.5)]
+        else:
+            a = c + [u(0.5, 2.0), u(0.5, 2.0), u(0.5, 2.0)]
+        cb = "set" if i == 0 else ["min", "smooth_min", "subtract"][int(rng.integers(0, 3))]
+        prog.append((op, a, cb, u(0.1, 0.5)) if cb == "smooth_min" else (op, a, cb))
+    return prog
+
+
 def random_program(seed):
     """Seeded random CSG chain (2..6 instructions, every primitive and combine reachable) for the fuzz tests."""
     rng = np.random.default_rng(seed)
@@ -75,7 +113,7 @@ def _points(seed, n):
     return np.concatenate([uni, grid, lat, near]).astype(np.float32)
 
 
-def _host(L, scene, pts, params):
+def _host(L, scene, pts, params, project=True):
     n = len(pts)
     p = np.zeros(4, np.float32)
     if params:
@@ -83,7 +121,7 @@ def _host(L, scene, pts, params):
     sd = np.empty(n, np.float32); nrm = np.empty((n, 3), np.float32)
     proj = np.empty((n, 3), np.float32); flip = np.empty(n // 3, np.int32)
     assert L.sdm_host_eval(SCENES[scene], p.ctypes.data, pts.ctypes.data, n, sd.ctypes.data, nrm.ctypes.data,
-                           proj.ctypes.data, flip.ctypes.data) == 0
+                           proj.ctypes.data if project else None, flip.ctypes.data if project else None) == 0
     return sd, nrm, proj, flip
 
 
@@ -100,7 +138,7 @@ def test_sdf_normal_projection_bit_exact(oracle, hostnum, scene, params):
     assert np.array_equal(flip, ref["flip"])
 
 
-@pytest.mark.parametrize("name", ["sdobj", "csg3", "mix"])
+@pytest.mark.parametrize("name", ["sdobj", "csg3", "mix", "newops", "wrapped"])
 def test_sdf_programs_bit_exact(oracle, hostnum, name):
     """Runtime SDF programs: product interpreter == oracle interpreter, and the two programs that restate AOT scenes
     reproduce those scenes exactly (the generic 12-bar loop equals the restructured one-sqrt sd_obj)."""
@@ -141,6 +179,31 @@ def test_random_programs_bit_exact_on_host(oracle, hostnum, seed):
     for a, b in ((nrm, ref["nrm"]), (proj, ref["proj"])):
         assert ((a.view(np.uint32) == b.view(np.uint32)) | (np.isnan(a) & np.isnan(b))).all()
     assert np.array_equal(flip, ref["flip"])
+
+
+@pytest.mark.parametrize("seed", [0, 1, 2, 3, 4, 5])
+def test_random_programs_with_the_round4_ops_bit_exact_on_host(oracle, hostnum, seed):
+    """Fuzz over the ops added in round 4 (ray, simple_bounding_box, wrap): product interpreter == oracle interpreter, values and
+    stencil normals (no projection: wrapped domains hold points a Newton iteration can circle for its full 10 000 rounds)."""
+    prog = random_program2(seed)
+    arr = oracle.set_program(prog)
+    hostnum.sdm_host_set_program(arr.ctypes.data, len(arr))
+    pts = _points(2000 + seed, 3000)
+    ref = oracle.eval_points("program", pts, None, normals=True, project=False, flips=False)
+    sd, nrm, _, _ = _host(hostnum, "program", pts, None, project=False)
+    assert np.array_equal(sd.view(np.uint32), ref["sd"].view(np.uint32)), prog
+    assert ((nrm.view(np.uint32) == ref["nrm"].view(np.uint32)) | (np.isnan(nrm) & np.isnan(ref["nrm"]))).all(), prog
+
+
+def test_program_time_is_applied_in_f32(oracle):
+    """oracle.program_at_time: args + t * rates, the product rounded to f32 before the sum (what sdmesh_set_program_time computes on the host)."""
+    prog = [("sphere", [0.1, 0.2, 0.3, 1.0], "set"), ("capsule", [0, 0, 0, 1, 1, 1, 0.2], "min")]
+    motion = [[0, 0.3, 0, 0.01], [0.5, 0, 0, 0, 0, 0, 0.001]]
+    out = oracle.program_at_time(prog, motion, 0.7)
+    t = np.float32(0.7)
+    assert out[0][1][1] == float(np.float32(np.float32(0.2) + np.float32(t * np.float32(0.3))))
+    assert out[1][1][6] == float(np.float32(np.float32(0.2) + np.float32(t * np.float32(0.001))))
+    assert out[0][2] == "set" and out[1][2] == "min" and len(out[0][1]) == 7
 
 
 def test_cube_frame_rewrite_bit_exact_on_host(oracle, hostnum):
