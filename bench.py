@@ -813,6 +813,25 @@ def main():
                               "mtris_per_s": round(atris / da / 1e6, 1)}
         anim["frames_per_s"] = anim["hipgraph"]["frames_per_s"]
         ha.close()
+        # the same animation as a runtime SDF PROGRAM in time (row N3: the reference scene's two instructions, the sphere's centre moved by
+        # sdmesh_set_program_time; interpreted in every kernel, so slower than the compiled scene) -- same meshes, frame for frame (tests)
+        hp = pkg.CudaHandler(local_rank, "sdobj")
+        hp.set_program([("box_skeleton", [0, 0, 0, 3, 1, 0.5, 0.1], "set"), ("sphere", [0, 0, 0, 1], "smooth_min", 0.5)])
+        hp.set_program_motion([[0] * 7, [0, 1.0, 0, 0, 0, 0, 0]])
+        for cy in (0.5, -0.5, 0.0):
+            hp.set_program_time(cy); hp.regen(args.levels)
+        import math
+        for f in range(10):
+            hp.set_program_time(0.5 * math.sin(f / 60.0)); hp.regen(args.levels)
+        torch.cuda.synchronize()
+        ta = time.perf_counter()
+        for f in range(60):
+            hp.set_program_time(0.5 * math.sin(f / 60.0))
+            hp.regen(args.levels)
+        torch.cuda.synchronize()
+        da = time.perf_counter() - ta
+        anim["as_program"] = {"frames_per_s": round(60 / da, 1), "ms_per_frame": round(da / 60 * 1e3, 4), "frames": 60}
+        hp.close()
         # the same 120 frames with three frames in flight (one handle each, sdmesh_regen_begin / _end): frame f + 1 and f + 2 are
         # meshed while frame f is waited for -- throughput of a renderer that double-buffers its meshes; an extra, not `frames_per_s`
         depth = 3

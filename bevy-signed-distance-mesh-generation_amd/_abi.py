@@ -122,6 +122,7 @@ SYMBOLS = {
     "sdmesh_zslab_local": (_i, [_vp, _i, _i, _i, _vp, ctypes.POINTER(RegenInfo)]),
     "sdmesh_zslab_merge": (_i, [_vp, _i, _i, _vp, _vp, _vp, ctypes.POINTER(RegenInfo)]),
     "sdmesh_distributed_regen": (_i, [_vp, _i, ctypes.POINTER(RegenInfo), ctypes.POINTER(_u32)]),
+    "sdmesh_distributed_route": (_i, [_vp]),
     "sdmesh_distributed_regen_rehearsal": (_i, [_vp, _i, _i, _vp, _vp]),
     "sdmesh_sharded_regen_rehearsal": (_i, [_vp, _i, _i, _i, ctypes.POINTER(RegenInfo)]),
     "sdmesh_download_mesh": (_i, [_vp, _vp, _vp]),

@@ -216,6 +216,14 @@ struct sdmesh_handle {
         uint32_t slab_sig = 0, sig = 0;
         uint32_t cap_v[32] = {0}, cap_t[32] = {0};      // slot = message size of rank r, in vertices / triangles
     } zsp;
+    struct DistPlan {              // the x-slab distributed weld's plan, collective like ZsPlan: the message size of every rank's upper band
+        bool valid = false;
+        int levels = -1, R = 0, scene = -1;
+        uint32_t slab_sig = 0, sig = 0;
+        uint32_t cap_up[32] = {0};
+    } dsp;
+    uint32_t dist_last_route = 0;  // like zs_last_route
+    uint32_t *h_dist_pub = nullptr;    // pinned: [seq .. | the two record tables] of a planned distributed step
     int zs_cur = 0;                // which of the two count buffers (shard_counts / shard_counts2) the next step uses
     uint32_t zs_seq = 0;           // step number, published with the step's results (a stale host copy is told apart)
     uint32_t zs_last_route = 0;    // 1 = the last indexed step ran planned, 2 = synchronous, 3 = planned, then repeated synchronously
@@ -1156,6 +1164,7 @@ void sdmesh_destroy(sdmesh_handle *h) {
     if (h->h_lists) (void) hipHostFree(h->h_lists);
     if (h->h_zs) (void) hipHostFree(h->h_zs);
     if (h->h_zs_pub) (void) hipHostFree(h->h_zs_pub);
+    if (h->h_dist_pub) (void) hipHostFree(h->h_dist_pub);
     for (DevBuf *b : bufs) release(*b);
     if (h->h_pinned) (void) hipHostFree(h->h_pinned);
     if (h->d_sp) (void) hipFree(h->d_sp);
@@ -1293,8 +1302,8 @@ int sdmesh_set_option(sdmesh_handle *h, const char *name, int value) {
         else h->colcnt = nullptr;
         return SDMESH_OK;
     }
-    if (!strcmp(name, "shard_slack")) { h->shard_slack = value != 0; h->zsp.valid = false; return SDMESH_OK; }
-    if (!strcmp(name, "shard_planned")) { h->shard_planned = value != 0; h->zsp.valid = false; return SDMESH_OK; }   // (like every option of a collective call: the same on all ranks)
+    if (!strcmp(name, "shard_slack")) { h->shard_slack = value != 0; h->zsp.valid = false; h->dsp.valid = false; return SDMESH_OK; }
+    if (!strcmp(name, "shard_planned")) { h->shard_planned = value != 0; h->zsp.valid = false; h->dsp.valid = false; return SDMESH_OK; }   // (like every option of a collective call: the same on all ranks)
     if (!strcmp(name, "project_prio")) { h->project_prio = value != 0; drop_graph(h); return SDMESH_OK; }
     if (!strcmp(name, "project_grid")) { h->project_grid = value < 0 ? 0 : (value > 65535 ? 65535 : value); drop_graph(h); return SDMESH_OK; }
     if (!strcmp(name, "project_batch")) { h->project_batch = value < 0 ? 0 : (value > 6 ? 6 : value); drop_graph(h); return SDMESH_OK; }
@@ -2757,29 +2766,48 @@ extern "C" int sdmesh_zslab_merge(sdmesh_handle *h, int nranks, int levels, cons
 // ================================================================================================
 namespace {
 
-// phase 1: this rank's slab, meshed AND welded locally; then the face bands (enqueued, not waited for)
-int dist_scratch(sdmesh_handle *h) {                       // the records of the two exchanges: DIST_REC words per rank, <= 32 ranks
+// Two routes through the same kernels, as in the z-slab gather (see there): SYNCHRONOUS (message lengths read back from the first all-gather;
+// three host synchronisations; commits the plan) and PLANNED (the slab's chain, the band kernels, both all-gathers and plan-sized
+// neighbour messages enqueued blind from a collective plan; one host synchronisation at the end; a step whose band sizes did not fit is
+// repeated synchronously by every rank, because every rank sees the same records).
+uint32_t dist_padded(const sdmesh_handle *h, uint32_t n) { return h->shard_slack ? n + n / 8u + 2048u : n + 1u; }
+
+uint32_t dist_slab_sig(const sdmesh_handle *h, int R) {
+    uint32_t s = 2166136261u;
+    const bool own = h->slab_nparts == R && h->slab_mode == SDMESH_PART_XSLAB;
+    for (int i = 0; own && i <= R; i++) s = (s ^ h->slab_bounds[i]) * 16777619u;
+    return s ^ (own ? 0x9e3779b9u : 0u);
+}
+
+int dist_scratch(sdmesh_handle *h) {                       // the records of the two exchanges: DIST_REC words per rank, <= 32 ranks; their pinned landing zone
     SDCHK(ensure(h, h->dist_counts, 4ull * 32 * DIST_REC));
     SDCHK(ensure(h, h->dist_nups, 4ull * 32 * DIST_REC));
+    if (!h->h_dist_pub) HIPCHK(hipHostMalloc((void **) &h->h_dist_pub, 4ull * (8 + 2 * 32 * DIST_REC), hipHostMallocDefault));
     return SDMESH_OK;
 }
 
-int dist_phase_local(sdmesh_handle *h, int levels, int R, int me, sdmesh_regen_info *slab) {
-    if (h->inject_fail == 1) { h->inject_fail = 0; return fail(h, SDMESH_ERR_INTERNAL, "injected failure (option inject_fail)"); }
-    SDCHK(regen_impl(h, levels, SDMESH_PART_XSLAB, me, R, slab));
-    if (!h->welded || h->last_direct) return fail(h, SDMESH_ERR_INTERNAL, "the distributed weld needs the locally welded lattice path");
-    hipStream_t st = h->stream;
-    const uint32_t V = h->n_verts, T = h->n_tris;
-    h->dist_V = V; h->dist_T = T;
-    const size_t vcap = std::max<uint32_t>(V, 64);
+// band / numbering buffers for up to vcap vertices of this rank (a rank's own band is at most its vertices)
+int dist_ensure_local(sdmesh_handle *h, size_t vcap) {
+    vcap = std::max<size_t>(vcap, 64);
     SDCHK(ensure_grow(h, h->dist_upids, 4 * vcap));
     SDCHK(ensure_grow(h, h->dist_upkeys, 8 * vcap));
     SDCHK(ensure_grow(h, h->dist_loids, 4 * vcap));
     SDCHK(ensure_grow(h, h->dist_dupof, 4 * vcap));
     SDCHK(ensure_grow(h, h->dist_newidx, 4 * vcap));
-    SDCHK(ensure_grow(h, h->dist_tilecnt, 4ull * (tiles((uint32_t) vcap) + 16)));
+    SDCHK(ensure_grow(h, h->dist_tilecnt, 4ull * (tiles((uint32_t) std::min<size_t>(vcap, 0xFFFFFF00u)) + 16)));
     SDCHK(ensure_grow(h, h->dist_upg, 4 * vcap));
-    SDCHK(ensure(h, h->dist_verts, std::max<size_t>(h->vertices.cap, sizeof(Vertex) * vcap)));   // swapped with h->vertices below: same capacity
+    SDCHK(ensure(h, h->dist_verts, sizeof(Vertex) * vcap));
+    return SDMESH_OK;
+}
+uint32_t dist_local_capacity(const sdmesh_handle *h) {         // vertices the buffers above hold
+    const size_t c = std::min(std::min(std::min(h->dist_upids.cap / 4, h->dist_upkeys.cap / 8), std::min(h->dist_loids.cap / 4, h->dist_dupof.cap / 4)),
+                              std::min(std::min(h->dist_newidx.cap / 4, h->dist_upg.cap / 4), std::min(h->dist_verts.cap / sizeof(Vertex), h->vertices.cap / sizeof(Vertex))));
+    return (uint32_t) std::min<size_t>(c, 0xFFFFFFFFu);
+}
+
+// the face bands of this rank's welded slab (enqueued behind whatever produced h->vertices; V is read on the device)
+int dist_bands(sdmesh_handle *h, int levels, int R, int me, bool keep_status) {
+    hipStream_t st = h->stream;
     const uint32_t F = MESH_GENERATION_INIT_FACTOR;
     uint32_t lo = F * (uint32_t) me / (uint32_t) R, hi = F * (uint32_t) (me + 1) / (uint32_t) R;
     if (h->slab_nparts == R && h->slab_mode == SDMESH_PART_XSLAB) { lo = h->slab_bounds[me]; hi = h->slab_bounds[me + 1]; }
@@ -2788,11 +2816,21 @@ int dist_phase_local(sdmesh_handle *h, int levels, int R, int me, sdmesh_regen_i
     const float x_lo = -MESH_GENERATION_BB_SIZE / 2.0f + MESH_GENERATION_BB_SIZE * (float) lo / (float) F;
     const float x_hi = -MESH_GENERATION_BB_SIZE / 2.0f + MESH_GENERATION_BB_SIZE * (float) hi / (float) F;
     HIPCHK(hipMemsetAsync(h->d_ctr + CTR_DIST_NUP, 0, 4 * sizeof(uint32_t), st));
-    SDCHK(zero_status(h));
-    HIPCHK(launch_band_select(st, h->grid, (const Vertex *) h->vertices.p, V, x_hi - band, x_lo + band, me + 1 < R, me > 0,
+    if (!keep_status) SDCHK(zero_status(h));               // (planned route: the chain's own flags must reach the record)
+    HIPCHK(launch_band_select(st, h->grid, (const Vertex *) h->vertices.p, h->d_ctr + CTR_NVERT, dist_local_capacity(h), x_hi - band, x_lo + band, me + 1 < R, me > 0,
                               (uint32_t *) h->dist_upids.p, (uint64_t *) h->dist_upkeys.p, (uint32_t *) h->dist_loids.p,
                               h->d_ctr + CTR_DIST_NUP, (uint32_t *) h->dist_dupof.p, h->d_status));
     return SDMESH_OK;
+}
+
+// synchronous route, phase 1: this rank's slab, meshed AND welded locally with its own read-back; then the face bands (enqueued, not waited for)
+int dist_phase_local(sdmesh_handle *h, int levels, int R, int me, sdmesh_regen_info *slab) {
+    if (h->inject_fail == 1) { h->inject_fail = 0; return fail(h, SDMESH_ERR_INTERNAL, "injected failure (option inject_fail)"); }
+    SDCHK(regen_impl(h, levels, SDMESH_PART_XSLAB, me, R, slab));
+    if (!h->welded || h->last_direct) return fail(h, SDMESH_ERR_INTERNAL, "the distributed weld needs the locally welded lattice path");
+    h->dist_V = h->n_verts; h->dist_T = h->n_tris;
+    SDCHK(dist_ensure_local(h, h->vertices.cap / sizeof(Vertex)));
+    return dist_bands(h, levels, R, me, false);
 }
 
 // what this rank can take from its lower neighbour without growing anything: band vertices
@@ -2813,35 +2851,36 @@ int dist_grow_prev(sdmesh_handle *h, uint32_t n_prev) {
     return SDMESH_OK;
 }
 
-// phase 2: match my lower band against the lower neighbour's upper-band keys (already in dist_prevkeys), number what I keep
-int dist_phase_match(sdmesh_handle *h, uint32_t n_prev) {
+// phase 2: match my lower band against the lower neighbour's upper-band keys (already in dist_prevkeys; their count at *n_prev_ptr, at most
+// cap_prev), number what I keep
+int dist_phase_match(sdmesh_handle *h, const uint32_t *n_prev_ptr, uint32_t cap_prev) {
     hipStream_t st = h->stream;
-    if (n_prev) {
-        const uint32_t hsize = 2u * n_prev + 64u;                // (dist_grow_prev made room)
+    if (cap_prev) {
+        const uint32_t hsize = 2u * cap_prev + 64u;              // (dist_grow_prev made room)
         HIPCHK(hipMemsetAsync(h->dist_hkeys.p, 0xFF, 8ull * hsize, st));
-        HIPCHK(launch_dist_match(st, h->grid, (const uint64_t *) h->dist_prevkeys.p, n_prev, (uint64_t *) h->dist_hkeys.p, (uint32_t *) h->dist_hpos.p,
+        HIPCHK(launch_dist_match(st, h->grid, (const uint64_t *) h->dist_prevkeys.p, n_prev_ptr, cap_prev, (uint64_t *) h->dist_hkeys.p, (uint32_t *) h->dist_hpos.p,
                                  hsize, (const Vertex *) h->vertices.p, (const uint32_t *) h->dist_loids.p, h->d_ctr + CTR_DIST_NLO,
                                  (uint32_t *) h->dist_dupof.p, h->d_status));
     }
-    HIPCHK(launch_set_u32(st, h->d_ctr + CTR_DIST_V, h->dist_V));
-    HIPCHK(launch_dist_number(st, h->tgrid, (const uint32_t *) h->dist_dupof.p, h->dist_V, h->d_ctr + CTR_DIST_V, (uint32_t *) h->dist_tilecnt.p,
+    HIPCHK(launch_dist_number(st, h->tgrid, (const uint32_t *) h->dist_dupof.p, h->d_ctr + CTR_NVERT, dist_local_capacity(h), (uint32_t *) h->dist_tilecnt.p,
                               h->d_ctr + CTR_DIST_NKEEP, (uint32_t *) h->dist_newidx.p, h->d_status));
     return SDMESH_OK;
 }
 
-// phase 3: the global numbers of my upper band (dist_counts holds every rank's kept count)
-int dist_phase_pack(sdmesh_handle *h, int me, uint32_t n_up) {
-    if (n_up)
-        HIPCHK(launch_dist_pack_up(h->stream, h->grid, (const uint32_t *) h->dist_upids.p, n_up, (const uint32_t *) h->dist_newidx.p,
+// phase 3: the global numbers of my upper band (dist_counts holds every rank's kept count; the band's size at *n_up_ptr, at most cap_up)
+int dist_phase_pack(sdmesh_handle *h, int me, const uint32_t *n_up_ptr, uint32_t cap_up) {
+    if (cap_up)
+        HIPCHK(launch_dist_pack_up(h->stream, h->grid, (const uint32_t *) h->dist_upids.p, n_up_ptr, cap_up, (const uint32_t *) h->dist_newidx.p,
                                    (const uint32_t *) h->dist_counts.p, (uint32_t) me, (uint32_t *) h->dist_upg.p));
     return SDMESH_OK;
 }
 
 // phase 4: kept vertices compacted, indices global (dist_prevg holds the lower neighbour's numbers of its upper band)
-int dist_phase_final(sdmesh_handle *h, int me) {
-    HIPCHK(launch_dist_finalize(h->stream, h->grid, (const Vertex *) h->vertices.p, h->dist_V, h->dist_T, (const uint32_t *) h->dist_dupof.p,
-                                (const uint32_t *) h->dist_newidx.p, (const uint32_t *) h->dist_prevg.p, (const uint32_t *) h->dist_counts.p,
-                                (uint32_t) me, (uint32_t *) h->indices.p, (Vertex *) h->dist_verts.p));
+int dist_phase_final(sdmesh_handle *h, int me, uint32_t cap_prev) {
+    HIPCHK(launch_dist_finalize(h->stream, h->grid, (const Vertex *) h->vertices.p, h->d_ctr + CTR_NVERT, dist_local_capacity(h), h->d_ctr + CTR_NTRI,
+                                cap_items(h->indices, sizeof(IndexTriangle)), (const uint32_t *) h->dist_dupof.p, (const uint32_t *) h->dist_newidx.p,
+                                (const uint32_t *) h->dist_prevg.p, cap_prev, (const uint32_t *) h->dist_counts.p, (uint32_t) me, (uint32_t *) h->indices.p,
+                                (Vertex *) h->dist_verts.p));
     h->res_v = (Vertex *) h->dist_verts.p;                 // the compacted list is the handle's vertex buffer now (the indices were rewritten in place)
     h->res_i = nullptr;
     return SDMESH_OK;
@@ -2859,48 +2898,55 @@ int dist_finish_host(sdmesh_handle *h, int R, int me, const uint32_t *counts /* 
     return SDMESH_OK;
 }
 
-}  // namespace
+// the device status word of a rank's record -> this rank's return code
+int dist_record_error(sdmesh_handle *h, int r, int me, uint32_t st) {
+    if (!st) return SDMESH_OK;
+    if (st == 0x100u) return fail(h, r == me ? SDMESH_ERR_WELD_RANGE : SDMESH_ERR_PEER, "rank %d: the distributed weld needs vertices inside the packed key range", r);
+    return fail(h, r == me ? SDMESH_ERR_INTERNAL : SDMESH_ERR_PEER, "rank %d: device status 0x%x in the distributed weld", r, st);
+}
 
-extern "C" {
-
-int sdmesh_distributed_regen(sdmesh_handle *h, int levels, sdmesh_regen_info *info, uint32_t *first_vertex) {
-    if (!h) return SDMESH_ERR_INVALID;
-    if (!h->comm) return fail(h, SDMESH_ERR_INVALID, "no communicator (sdmesh_comm_init)");
+int dist_step_sync(sdmesh_handle *h, int levels, sdmesh_regen_info *info, uint32_t *first_vertex) {
     const int R = h->comm_nranks, me = h->comm_rank;
     hipStream_t st = h->stream;
-    SDCHK(dist_scratch(h));                                    // (before anything can fail on one rank only, see peer_failure)
-    SDCHK(ensure_shard_host(h, R));                            // pinned landing zone of the records (>= 32 x DIST_REC words)
+    h->dsp.valid = false;
     sdmesh_regen_info slab;
     memset(&slab, 0, sizeof slab);
+    const int inject = h->inject_fail;                         // (2 = "my buffer growth fails": every rank must learn it, or only this one enters the agreement below)
     const int lrc = dist_phase_local(h, levels, R, me, &slab);
     uint32_t counts[32] = {0};
     // (a one-rank communicator takes the same route: its collectives are degenerate, every phase still runs)
-    // 1. band sizes of every rank (the one extra host synchronisation of a distributed step: message lengths must be host
-    //    values), each with the rank's status and what it can take from its lower neighbour without growing -- ALWAYS entered
+    // 1. band sizes of every rank (message lengths must be host values here), each with the rank's status and what it can take from its
+    //    lower neighbour without growing -- ALWAYS entered
     uint32_t *d_nups = (uint32_t *) h->dist_nups.p, *d_counts = (uint32_t *) h->dist_counts.p;
-    const int inject = h->inject_fail;                         // (2 = "my buffer growth fails": every rank must learn it, or only this one enters the agreement below)
-    HIPCHK(launch_pack_record(st, d_nups + (size_t) me * DIST_REC, lrc == SDMESH_OK ? h->d_ctr + CTR_DIST_NUP : nullptr, nullptr, 0u, (uint32_t) lrc,
-                              dist_prev_capacity(h), (uint32_t) inject));
+    HIPCHK(launch_dist_record(st, d_nups + (size_t) me * DIST_REC, h->d_ctr + CTR_DIST_NUP, nullptr, (uint32_t) lrc, dist_prev_capacity(h), (uint32_t) inject, 0u));
     NCCLCHK(g_rccl.AllGather(d_nups + (size_t) me * DIST_REC, d_nups, DIST_REC, ncclUint32, h->comm, st));        // in place
     uint32_t *rec = h->h_counts;
     HIPCHK(hipMemcpyAsync(rec, d_nups, 4ull * (size_t) R * DIST_REC, hipMemcpyDeviceToHost, st));
     HIPCHK(hipStreamSynchronize(st));
     SDCHK(peer_failure(h, R, me, rec, DIST_REC, 1, lrc));
-    uint32_t nups[32];
-    for (int r = 0; r < R; r++) nups[r] = rec[(size_t) r * DIST_REC];
-    const uint32_t n_up = me + 1 < R ? nups[me] : 0u, n_prev = me > 0 ? nups[me - 1] : 0u;
-    // 2. room for the neighbour's band; grown behind a one-word agreement only if some rank's published capacity is too small
+    uint32_t nups[32] = {0}, cap_up[32] = {0};
+    for (int r = 0; r < R; r++) { nups[r] = r + 1 < R ? rec[(size_t) r * DIST_REC] : 0u; cap_up[r] = r + 1 < R ? dist_padded(h, nups[r]) : 0u; }
+    const uint32_t n_up = nups[me], n_prev = me > 0 ? nups[me - 1] : 0u;
+    // 2. room for the neighbour's band (plan-sized already: the next step may be a planned one); grown behind a one-word agreement only if some
+    //    rank's published capacity is too small
     bool any_grow = false;
-    for (int r = 1; r < R; r++) any_grow = any_grow || nups[r - 1] > rec[(size_t) r * DIST_REC + 2];
+    for (int r = 1; r < R; r++) any_grow = any_grow || cap_up[r - 1] > rec[(size_t) r * DIST_REC + 2];
     for (int r = 0; r < R; r++) any_grow = any_grow || rec[(size_t) r * DIST_REC + 2] == 0u;          // (a first call: nothing allocated yet)
     for (int r = 0; r < R; r++) any_grow = any_grow || rec[(size_t) r * DIST_REC + 3] == 2u;          // (an injected growth failure on ANY rank: the same decision everywhere)
     if (any_grow) {
-        const int grc = dist_grow_prev(h, n_prev);
+        const int grc = dist_grow_prev(h, me > 0 ? cap_up[me - 1] : 0u);
         uint32_t worst = 0;
         SDCHK(agree_flag(h, grc == SDMESH_OK ? 0u : 1u, &worst));
         if (grc != SDMESH_OK) return grc;
         if (worst) return fail(h, SDMESH_ERR_PEER, "a rank could not grow its band buffers; every rank returns an error");
     }
+    // 3. the plan of the next steps: the same on every rank
+    sdmesh_handle::DistPlan &pl = h->dsp;
+    pl.levels = levels; pl.R = R; pl.scene = h->scene; pl.slab_sig = dist_slab_sig(h, R);
+    uint32_t sig = 2166136261u;
+    for (int r = 0; r < R; r++) { pl.cap_up[r] = cap_up[r]; sig = (sig ^ cap_up[r]) * 16777619u; }
+    pl.sig = sig | 1u;
+    pl.valid = h->shard_planned != 0;
     {
         std::vector<ZsMsg> msgs;                               // (grouped; the group is closed on every path)
         if (n_up) msgs.push_back({h->dist_upkeys.p, n_up, ncclUint64, me + 1, true});
@@ -2908,30 +2954,117 @@ int sdmesh_distributed_regen(sdmesh_handle *h, int levels, sdmesh_regen_info *in
         SDCHK(zs_exchange(h, msgs));
     }
     // (nothing below allocates: a failure from here on is a HIP / RCCL error, after which the communicator is gone anyway)
-    SDCHK(dist_phase_match(h, n_prev));
-    // 3. kept counts of every rank (stay on the device for the kernels) + each rank's device status: a vertex outside the
+    SDCHK(dist_phase_match(h, me > 0 ? d_nups + (size_t) (me - 1) * DIST_REC : d_nups, n_prev));
+    // 4. kept counts of every rank (stay on the device for the kernels) + each rank's device status: a vertex outside the
     //    packed key range on ONE rank fails the call on ALL of them
-    HIPCHK(launch_pack_record(st, d_counts + (size_t) me * DIST_REC, h->d_ctr + CTR_DIST_NKEEP, h->d_status, 0u, 0u, 0u, 0u));
+    HIPCHK(launch_dist_record(st, d_counts + (size_t) me * DIST_REC, h->d_ctr + CTR_DIST_NKEEP, h->d_status, 0u, 0u, 0u, 0u));
     NCCLCHK(g_rccl.AllGather(d_counts + (size_t) me * DIST_REC, d_counts, DIST_REC, ncclUint32, h->comm, st));
-    SDCHK(dist_phase_pack(h, me, n_up));
+    SDCHK(dist_phase_pack(h, me, d_nups + (size_t) me * DIST_REC, n_up));
     {
         std::vector<ZsMsg> msgs;
         if (n_up) msgs.push_back({h->dist_upg.p, n_up, ncclUint32, me + 1, true});
         if (n_prev) msgs.push_back({h->dist_prevg.p, n_prev, ncclUint32, me - 1, false});
         SDCHK(zs_exchange(h, msgs));
     }
-    SDCHK(dist_phase_final(h, me));
+    SDCHK(dist_phase_final(h, me, n_prev));
     HIPCHK(hipMemcpyAsync(rec, d_counts, 4ull * (size_t) R * DIST_REC, hipMemcpyDeviceToHost, st));
     SDCHK(read_back(h));
     for (int r = 0; r < R; r++) {
         counts[r] = rec[(size_t) r * DIST_REC];
-        if (rec[(size_t) r * DIST_REC + 1] & 0x100u)
-            return fail(h, r == me ? SDMESH_ERR_WELD_RANGE : SDMESH_ERR_PEER, "rank %d: the distributed weld needs vertices inside the packed key range", r);
-        if (rec[(size_t) r * DIST_REC + 1])
-            return fail(h, r == me ? SDMESH_ERR_INTERNAL : SDMESH_ERR_PEER, "rank %d: device status 0x%x in the distributed weld", r, rec[(size_t) r * DIST_REC + 1]);
+        SDCHK(dist_record_error(h, r, me, rec[(size_t) r * DIST_REC + 1]));
     }
     return dist_finish_host(h, R, me, counts, info, slab, first_vertex);
 }
+
+int dist_step_planned(sdmesh_handle *h, int levels, sdmesh_regen_info *info, uint32_t *first_vertex) {
+    const int R = h->comm_nranks, me = h->comm_rank;
+    hipStream_t st = h->stream;
+    const sdmesh_handle::DistPlan &pl = h->dsp;
+    const int inject = h->inject_fail;
+    h->inject_fail = 0;
+    const uint32_t cap_up = pl.cap_up[me], cap_prev = me > 0 ? pl.cap_up[me - 1] : 0u;
+    // buffers first (nothing below may allocate once the chain is in flight)
+    if (dist_prev_capacity(h) < cap_prev || (cap_prev && dist_prev_capacity(h) == 0u)) SDCHK(dist_grow_prev(h, cap_prev));
+    // 1. the slab's chain from its capacity plan (a handle without one runs its regen synchronously here), then everything else, blind
+    int lrc = inject == 1 ? fail(h, SDMESH_ERR_INTERNAL, "injected failure (option inject_fail)") : regen_impl(h, levels, SDMESH_PART_XSLAB, me, R, nullptr, 1);
+    sdmesh_regen_info slab;
+    memset(&slab, 0, sizeof slab);
+    bool ended = false;
+    if (lrc == SDMESH_OK && !h->pend_async) { lrc = regen_impl(h, 0, 0, 0, 1, &slab, 2); ended = true; }
+    if (lrc == SDMESH_OK && ended && (h->last_direct || !h->welded || h->wide_active)) lrc = fail(h, SDMESH_ERR_INTERNAL, "a slab left the packed-key lattice path");
+    if (lrc != SDMESH_OK && h->pend_active) { sdmesh_regen_info tmp; (void) regen_impl(h, 0, 0, 0, 1, &tmp, 2); }
+    if (lrc == SDMESH_OK) lrc = dist_ensure_local(h, std::max<size_t>(h->vertices.cap / sizeof(Vertex), cap_up));     // (grow-only: allocates on the first planned step at most)
+    uint32_t *d_nups = (uint32_t *) h->dist_nups.p, *d_counts = (uint32_t *) h->dist_counts.p;
+    if (lrc == SDMESH_OK) lrc = dist_bands(h, levels, R, me, true);
+    if (lrc == SDMESH_ERR_HIP) return lrc;
+    const uint32_t seq = ++h->zs_seq;
+    HIPCHK(launch_dist_record(st, d_nups + (size_t) me * DIST_REC, h->d_ctr + CTR_DIST_NUP, h->d_status, (uint32_t) lrc, dist_prev_capacity(h), (uint32_t) inject, pl.sig));
+    NCCLCHK(g_rccl.AllGather(d_nups + (size_t) me * DIST_REC, d_nups, DIST_REC, ncclUint32, h->comm, st));        // in place
+    {
+        std::vector<ZsMsg> msgs;                               // plan-sized messages (the real counts are in the records)
+        if (me + 1 < R && cap_up) msgs.push_back({h->dist_upkeys.p, cap_up, ncclUint64, me + 1, true});
+        if (me > 0 && cap_prev) msgs.push_back({h->dist_prevkeys.p, cap_prev, ncclUint64, me - 1, false});
+        SDCHK(zs_exchange(h, msgs));
+    }
+    if (lrc == SDMESH_OK) {
+        SDCHK(dist_phase_match(h, me > 0 ? d_nups + (size_t) (me - 1) * DIST_REC : d_nups, cap_prev));
+    }
+    HIPCHK(launch_dist_record(st, d_counts + (size_t) me * DIST_REC, h->d_ctr + CTR_DIST_NKEEP, h->d_status, (uint32_t) lrc, 0u, 0u, pl.sig));
+    NCCLCHK(g_rccl.AllGather(d_counts + (size_t) me * DIST_REC, d_counts, DIST_REC, ncclUint32, h->comm, st));
+    if (lrc == SDMESH_OK) SDCHK(dist_phase_pack(h, me, d_nups + (size_t) me * DIST_REC, me + 1 < R ? cap_up : 0u));
+    {
+        std::vector<ZsMsg> msgs;
+        if (me + 1 < R && cap_up) msgs.push_back({h->dist_upg.p, cap_up, ncclUint32, me + 1, true});
+        if (me > 0 && cap_prev) msgs.push_back({h->dist_prevg.p, cap_prev, ncclUint32, me - 1, false});
+        SDCHK(zs_exchange(h, msgs));
+    }
+    if (lrc == SDMESH_OK) SDCHK(dist_phase_final(h, me, cap_prev));
+    HIPCHK(launch_dist_publish(st, d_nups, d_counts, (uint32_t) R, seq, h->h_dist_pub));
+    // the step's one host synchronisation
+    HIPCHK(hipStreamSynchronize(st));
+    int erc = SDMESH_OK;
+    if (h->pend_active) erc = regen_impl(h, 0, 0, 0, 1, &slab, 2);           // the chain's own verdict (its record said so already if it overflowed)
+    const uint32_t *pub = h->h_dist_pub;
+    if (pub[0] != seq) return fail(h, SDMESH_ERR_INTERNAL, "the planned distributed step did not publish its records (step %u, found %u)", seq, pub[0]);
+    const uint32_t *rn = pub + 8, *rc = pub + 8 + (size_t) R * DIST_REC;
+    bool redo = erc != SDMESH_OK || lrc != SDMESH_OK;
+    uint32_t counts[32] = {0};
+    for (int r = 0; r < R; r++) {
+        const uint32_t nup = r + 1 < R ? rn[(size_t) r * DIST_REC] : 0u;
+        redo = redo || rn[(size_t) r * DIST_REC + 1] != 0u || rc[(size_t) r * DIST_REC + 1] != 0u || nup > pl.cap_up[r] || rn[(size_t) r * DIST_REC + 3] != 0u ||
+               rn[(size_t) r * DIST_REC + 4] != pl.sig || rc[(size_t) r * DIST_REC + 4] != pl.sig;
+        counts[r] = rc[(size_t) r * DIST_REC];
+    }
+    if (redo) return ZS_REDO;
+    h->dist_V = h->n_verts; h->dist_T = h->n_tris;
+    return dist_finish_host(h, R, me, counts, info, slab, first_vertex);
+}
+
+}  // namespace
+
+extern "C" {
+
+int sdmesh_distributed_regen(sdmesh_handle *h, int levels, sdmesh_regen_info *info, uint32_t *first_vertex) {
+    if (!h) return SDMESH_ERR_INVALID;
+    if (!h->comm) return fail(h, SDMESH_ERR_INVALID, "no communicator (sdmesh_comm_init)");
+    const int R = h->comm_nranks;
+    SDCHK(dist_scratch(h));                                    // (before anything can fail on one rank only, see peer_failure)
+    SDCHK(ensure_shard_host(h, R));                            // pinned landing zone of the records (>= 32 x DIST_REC words)
+    const sdmesh_handle::DistPlan &pl = h->dsp;
+    if (h->shard_planned && pl.valid && pl.levels == levels && pl.R == R && pl.scene == h->scene && pl.slab_sig == dist_slab_sig(h, R)) {
+        const int inject = h->inject_fail;
+        const int rc = dist_step_planned(h, levels, info, first_vertex);
+        if (rc != ZS_REDO) { h->dist_last_route = 1; return rc; }
+        h->dist_last_route = 3;
+        h->inject_fail = inject;                               // (the repeat fails where the planned step was told to)
+        h->mesh_valid = false;
+        return dist_step_sync(h, levels, info, first_vertex);
+    }
+    h->dist_last_route = 2;
+    return dist_step_sync(h, levels, info, first_vertex);
+}
+
+int sdmesh_distributed_route(const sdmesh_handle *h) { return h ? (int) h->dist_last_route : 0; }
 
 // The same step for `nranks` handles of ONE process on one device, device-to-device copies standing in for the two
 // neighbour messages and host arithmetic for the two all-gathers: every kernel and every phase of the distributed weld
@@ -2958,12 +3091,16 @@ int sdmesh_distributed_regen_rehearsal(sdmesh_handle **hs, int nranks, int level
             if (r != worst_rank) (void) fail(hs[r], SDMESH_ERR_PEER, "rank %d failed in this collective call (status 0x%x); every rank returns an error", worst_rank, worst);
         return worst;
     }
+    uint32_t nrecs[32 * DIST_REC] = {0};                  // (the band-size records every handle would hold after the first all-gather)
+    for (int r = 0; r < R; r++) nrecs[(size_t) r * DIST_REC] = nups[r];
     for (int r = 0; r < R; r++) {
         sdmesh_handle *h = hs[r];
+        h->dsp.valid = false;
         const uint32_t n_prev = r > 0 ? nups[r - 1] : 0u;
         if (n_prev > dist_prev_capacity(h) || dist_prev_capacity(h) == 0u) SDCHK(dist_grow_prev(h, n_prev));
+        HIPCHK(hipMemcpyAsync(h->dist_nups.p, nrecs, 4ull * (size_t) R * DIST_REC, hipMemcpyHostToDevice, h->stream));
         if (n_prev) HIPCHK(hipMemcpyAsync(h->dist_prevkeys.p, hs[r - 1]->dist_upkeys.p, 8ull * n_prev, hipMemcpyDeviceToDevice, h->stream));
-        SDCHK(dist_phase_match(h, n_prev));
+        SDCHK(dist_phase_match(h, (const uint32_t *) h->dist_nups.p + (size_t) (r > 0 ? r - 1 : 0) * DIST_REC, n_prev));
         HIPCHK(hipMemcpyAsync(&counts[r], h->d_ctr + CTR_DIST_NKEEP, 4, hipMemcpyDeviceToHost, h->stream));
         HIPCHK(hipStreamSynchronize(h->stream));
     }
@@ -2972,14 +3109,14 @@ int sdmesh_distributed_regen_rehearsal(sdmesh_handle **hs, int nranks, int level
     for (int r = 0; r < R; r++) {
         sdmesh_handle *h = hs[r];
         HIPCHK(hipMemcpyAsync(h->dist_counts.p, recs, 4ull * (size_t) R * DIST_REC, hipMemcpyHostToDevice, h->stream));
-        SDCHK(dist_phase_pack(h, r, r + 1 < R ? nups[r] : 0u));
+        SDCHK(dist_phase_pack(h, r, (const uint32_t *) h->dist_nups.p + (size_t) r * DIST_REC, r + 1 < R ? nups[r] : 0u));
         HIPCHK(hipStreamSynchronize(h->stream));
     }
     for (int r = 0; r < R; r++) {
         sdmesh_handle *h = hs[r];
         const uint32_t n_prev = r > 0 ? nups[r - 1] : 0u;
         if (n_prev) HIPCHK(hipMemcpyAsync(h->dist_prevg.p, hs[r - 1]->dist_upg.p, 4ull * n_prev, hipMemcpyDeviceToDevice, h->stream));
-        SDCHK(dist_phase_final(h, r));
+        SDCHK(dist_phase_final(h, r, n_prev));
         SDCHK(read_back(h));
         if (h->h_pinned[CTR_WORDS + ST_WELD_RANGE]) return fail(h, SDMESH_ERR_WELD_RANGE, "the distributed weld needs vertices inside the packed key range");
         SDCHK(dist_finish_host(h, R, r, counts, infos ? &infos[r] : nullptr, slab[(size_t) r], first_vertex ? &first_vertex[r] : nullptr));

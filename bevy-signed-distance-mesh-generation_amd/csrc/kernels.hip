@@ -2021,12 +2021,15 @@ __global__ __launch_bounds__(256) void k_merge_copy(const Triangle *const *__res
 // Nothing proportional to the mesh crosses a link or is hashed again; the mesh stays distributed.
 // ------------------------------------------------------------------------------------------
 
-__global__ __launch_bounds__(256) void k_band_select(const Vertex *__restrict__ v, uint32_t V, float up_thr, float lo_thr, uint32_t has_up,
+// (counts come from device memory in every kernel of this group: the planned step enqueues them before the host knows any count;
+//  `cap` arguments bound what a count that overflowed its plan can make a kernel touch -- such a step is repeated anyway)
+__global__ __launch_bounds__(256) void k_band_select(const Vertex *__restrict__ v, const uint32_t *__restrict__ v_ptr, uint32_t vcap, float up_thr, float lo_thr, uint32_t has_up,
                                                       uint32_t has_lo, uint32_t *__restrict__ up_ids, uint64_t *__restrict__ up_keys,
                                                       uint32_t *__restrict__ lo_ids, uint32_t *__restrict__ ctr /* [0] n_up, [1] n_lo */,
                                                       uint32_t *__restrict__ dup_of, uint32_t *__restrict__ status) {
     const uint32_t lane = lane_id();
     const uint64_t lt = (1ull << lane) - 1ull;
+    const uint32_t V = *v_ptr < vcap ? *v_ptr : vcap;
     const uint32_t Vr = (V + 63u) & ~63u;                      // whole waves stay together for the ballots
     for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < Vr; i += gridDim.x * blockDim.x) {
         bool up = false, lo = false;
@@ -2061,8 +2064,9 @@ __global__ __launch_bounds__(256) void k_band_select(const Vertex *__restrict__ 
     }
 }
 
-__global__ __launch_bounds__(256) void k_dist_hash_build(const uint64_t *__restrict__ keys, uint32_t n, uint64_t *__restrict__ hkeys,
-                                                          uint32_t *__restrict__ hpos, uint32_t hsize) {
+__global__ __launch_bounds__(256) void k_dist_hash_build(const uint64_t *__restrict__ keys, const uint32_t *__restrict__ n_ptr, uint32_t ncap,
+                                                          uint64_t *__restrict__ hkeys, uint32_t *__restrict__ hpos, uint32_t hsize) {
+    const uint32_t n = *n_ptr < ncap ? *n_ptr : ncap;
     for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
         const uint64_t key = keys[i];
         uint32_t s = hash_home(key, hsize);
@@ -2094,8 +2098,10 @@ __global__ __launch_bounds__(256) void k_dist_hash_lookup(const Vertex *__restri
     }
 }
 
-__global__ __launch_bounds__(256) void k_dist_keep_count(const uint32_t *__restrict__ dup_of, uint32_t V, uint32_t *__restrict__ tilecnt) {
+__global__ __launch_bounds__(256) void k_dist_keep_count(const uint32_t *__restrict__ dup_of, const uint32_t *__restrict__ v_ptr, uint32_t vcap,
+                                                          uint32_t *__restrict__ tilecnt) {
     __shared__ uint32_t s_cnt;
+    const uint32_t V = *v_ptr < vcap ? *v_ptr : vcap;
     const uint32_t ntiles = (V + TILE - 1) / TILE;
     for (uint32_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
         if (threadIdx.x == 0) s_cnt = 0;
@@ -2109,9 +2115,10 @@ __global__ __launch_bounds__(256) void k_dist_keep_count(const uint32_t *__restr
     }
 }
 
-__global__ __launch_bounds__(256) void k_dist_newidx(const uint32_t *__restrict__ dup_of, uint32_t V, const uint32_t *__restrict__ tileoff,
-                                                      uint32_t *__restrict__ newidx) {
+__global__ __launch_bounds__(256) void k_dist_newidx(const uint32_t *__restrict__ dup_of, const uint32_t *__restrict__ v_ptr, uint32_t vcap,
+                                                      const uint32_t *__restrict__ tileoff, uint32_t *__restrict__ newidx) {
     __shared__ uint32_t lds[17];
+    const uint32_t V = *v_ptr < vcap ? *v_ptr : vcap;
     const uint32_t ntiles = (V + TILE - 1) / TILE;
     for (uint32_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
         const uint32_t i = tile * TILE + threadIdx.x;
@@ -2141,23 +2148,51 @@ __global__ void k_pack_record(uint32_t *__restrict__ dst, const uint32_t *__rest
     dst[3] = v3;
 }
 
-__global__ __launch_bounds__(256) void k_dist_pack_up(const uint32_t *__restrict__ up_ids, uint32_t n_up, const uint32_t *__restrict__ newidx,
-                                                       const uint32_t *__restrict__ counts, uint32_t me, uint32_t *__restrict__ up_g) {
+// One DIST_REC-word record of the distributed weld's two all-gathers: {count, status, capacity for the lower neighbour's band, inject, sig, 0, 0, 0};
+// status = the host's code for a local phase that already failed, else the device flags that make the chain's result unusable
+__global__ void k_dist_record(uint32_t *__restrict__ dst, const uint32_t *__restrict__ count, const uint32_t *__restrict__ status, uint32_t host_status,
+                              uint32_t cap_prev, uint32_t inject, uint32_t sig) {
+    uint32_t st = host_status;
+    if (!st && status) {
+        const uint32_t dev = (status[ST_OVERFLOW] ? 1u : 0u) | (status[ST_NOT_LATTICE] ? 2u : 0u) | (status[ST_INTERNAL] ? 8u : 0u) |
+                             (status[ST_TILE_OVERFLOW] ? 16u : 0u) | (status[ST_NONFINITE] ? 32u : 0u);
+        if (dev) st = 0x80000000u | dev;
+        else if (status[ST_WELD_RANGE]) st = 0x100u;                   // (its own code: the caller reports SDMESH_ERR_WELD_RANGE)
+    }
+    dst[0] = (count && !host_status) ? *count : 0u;
+    dst[1] = st; dst[2] = cap_prev; dst[3] = inject; dst[4] = sig; dst[5] = 0u; dst[6] = 0u; dst[7] = 0u;
+}
+
+// both record tables of a distributed step and its sequence number to pinned host memory: [seq | R records of the band sizes | R of the kept counts]
+__global__ void k_dist_publish(const uint32_t *__restrict__ nups, const uint32_t *__restrict__ counts, uint32_t nranks, uint32_t seq, uint32_t *__restrict__ pub) {
+    const uint32_t t = threadIdx.x;
+    if (t == 0) pub[0] = seq;
+    if (t < nranks * DIST_REC) { pub[8u + t] = nups[t]; pub[8u + nranks * DIST_REC + t] = counts[t]; }
+}
+
+__global__ __launch_bounds__(256) void k_dist_pack_up(const uint32_t *__restrict__ up_ids, const uint32_t *__restrict__ n_up_ptr, uint32_t ncap,
+                                                       const uint32_t *__restrict__ newidx, const uint32_t *__restrict__ counts, uint32_t me,
+                                                       uint32_t *__restrict__ up_g) {
     const uint32_t off = dist_offset(counts, me);
+    const uint32_t n_up = *n_up_ptr < ncap ? *n_up_ptr : ncap;
     for (uint32_t j = blockIdx.x * blockDim.x + threadIdx.x; j < n_up; j += gridDim.x * blockDim.x) up_g[j] = off + newidx[up_ids[j]];
 }
 
-__global__ __launch_bounds__(256) void k_dist_finalize(const Vertex *__restrict__ v, uint32_t V, uint32_t T, const uint32_t *__restrict__ dup_of,
-                                                        const uint32_t *__restrict__ newidx, const uint32_t *__restrict__ prev_g,
+__global__ __launch_bounds__(256) void k_dist_finalize(const Vertex *__restrict__ v, const uint32_t *__restrict__ v_ptr, uint32_t vcap,
+                                                        const uint32_t *__restrict__ t_ptr, uint32_t tcap, const uint32_t *__restrict__ dup_of,
+                                                        const uint32_t *__restrict__ newidx, const uint32_t *__restrict__ prev_g, uint32_t pcap,
                                                         const uint32_t *__restrict__ counts, uint32_t me, uint32_t *__restrict__ indices,
                                                         Vertex *__restrict__ out_v) {
     const uint32_t off = dist_offset(counts, me);
+    const uint32_t V = *v_ptr < vcap ? *v_ptr : vcap, T = *t_ptr < tcap ? *t_ptr : tcap;
     const uint32_t stride = gridDim.x * blockDim.x, t0 = blockIdx.x * blockDim.x + threadIdx.x;
     for (uint32_t i = t0; i < V; i += stride)
         if (dup_of[i] == U32_NONE) out_v[newidx[i]] = v[i];
     for (uint32_t c = t0; c < 3u * T; c += stride) {
-        const uint32_t vi = indices[c], d = dup_of[vi];
-        indices[c] = d == U32_NONE ? off + newidx[vi] : prev_g[d];
+        const uint32_t vi = indices[c];
+        if (vi >= V) continue;                                         // (never of a chain that kept to its plan)
+        const uint32_t d = dup_of[vi];
+        indices[c] = d == U32_NONE ? off + newidx[vi] : (d < pcap ? prev_g[d] : 0u);
     }
 }
 
@@ -3046,37 +3081,38 @@ hipError_t launch_merge_by_column(hipStream_t st, const Triangle *const *d_lists
 }
 
 
-hipError_t launch_band_select(hipStream_t st, int grid, const Vertex *v, uint32_t V, float up_thr, float lo_thr, bool has_up, bool has_lo,
+hipError_t launch_band_select(hipStream_t st, int grid, const Vertex *v, const uint32_t *v_ptr, uint32_t vcap, float up_thr, float lo_thr, bool has_up, bool has_lo,
                               uint32_t *up_ids, uint64_t *up_keys, uint32_t *lo_ids, uint32_t *ctr, uint32_t *dup_of, uint32_t *status) {
-    hipLaunchKernelGGL(k_band_select, dim3(grid), dim3(256), 0, st, v, V, up_thr, lo_thr, has_up ? 1u : 0u, has_lo ? 1u : 0u, up_ids, up_keys, lo_ids, ctr,
+    hipLaunchKernelGGL(k_band_select, dim3(grid), dim3(256), 0, st, v, v_ptr, vcap, up_thr, lo_thr, has_up ? 1u : 0u, has_lo ? 1u : 0u, up_ids, up_keys, lo_ids, ctr,
                        dup_of, status);
     return hipGetLastError();
 }
 
-hipError_t launch_dist_match(hipStream_t st, int grid, const uint64_t *prev_keys, uint32_t n_prev, uint64_t *hkeys, uint32_t *hpos, uint32_t hsize,
+hipError_t launch_dist_match(hipStream_t st, int grid, const uint64_t *prev_keys, const uint32_t *n_prev_ptr, uint32_t ncap, uint64_t *hkeys, uint32_t *hpos, uint32_t hsize,
                              const Vertex *v, const uint32_t *lo_ids, const uint32_t *n_lo_ptr, uint32_t *dup_of, uint32_t *status) {
-    hipLaunchKernelGGL(k_dist_hash_build, dim3(grid), dim3(256), 0, st, prev_keys, n_prev, hkeys, hpos, hsize);
+    hipLaunchKernelGGL(k_dist_hash_build, dim3(grid), dim3(256), 0, st, prev_keys, n_prev_ptr, ncap, hkeys, hpos, hsize);
     hipLaunchKernelGGL(k_dist_hash_lookup, dim3(grid), dim3(256), 0, st, v, lo_ids, n_lo_ptr, hkeys, hpos, hsize, dup_of, status);
     return hipGetLastError();
 }
 
-hipError_t launch_dist_number(hipStream_t st, int grid, const uint32_t *dup_of, uint32_t V, const uint32_t *v_ptr, uint32_t *tilecnt,
+hipError_t launch_dist_number(hipStream_t st, int grid, const uint32_t *dup_of, const uint32_t *v_ptr, uint32_t vcap, uint32_t *tilecnt,
                               uint32_t *n_keep_out, uint32_t *newidx, uint32_t *status) {
-    hipLaunchKernelGGL(k_dist_keep_count, dim3(grid), dim3(256), 0, st, dup_of, V, tilecnt);
+    hipLaunchKernelGGL(k_dist_keep_count, dim3(grid), dim3(256), 0, st, dup_of, v_ptr, vcap, tilecnt);
     hipLaunchKernelGGL(k_scan_tiles, dim3(1), dim3(1024), 0, st, tilecnt, v_ptr, 256u, n_keep_out, 0xFFFFFFFFu, status);
-    hipLaunchKernelGGL(k_dist_newidx, dim3(grid), dim3(256), 0, st, dup_of, V, (const uint32_t *) tilecnt, newidx);
+    hipLaunchKernelGGL(k_dist_newidx, dim3(grid), dim3(256), 0, st, dup_of, v_ptr, vcap, (const uint32_t *) tilecnt, newidx);
     return hipGetLastError();
 }
 
-hipError_t launch_dist_pack_up(hipStream_t st, int grid, const uint32_t *up_ids, uint32_t n_up, const uint32_t *newidx, const uint32_t *counts,
+hipError_t launch_dist_pack_up(hipStream_t st, int grid, const uint32_t *up_ids, const uint32_t *n_up_ptr, uint32_t ncap, const uint32_t *newidx, const uint32_t *counts,
                                uint32_t me, uint32_t *up_g) {
-    hipLaunchKernelGGL(k_dist_pack_up, dim3(grid), dim3(256), 0, st, up_ids, n_up, newidx, counts, me, up_g);
+    hipLaunchKernelGGL(k_dist_pack_up, dim3(grid), dim3(256), 0, st, up_ids, n_up_ptr, ncap, newidx, counts, me, up_g);
     return hipGetLastError();
 }
 
-hipError_t launch_dist_finalize(hipStream_t st, int grid, const Vertex *v, uint32_t V, uint32_t T, const uint32_t *dup_of, const uint32_t *newidx,
-                                const uint32_t *prev_g, const uint32_t *counts, uint32_t me, uint32_t *indices, Vertex *out_v) {
-    hipLaunchKernelGGL(k_dist_finalize, dim3(grid), dim3(256), 0, st, v, V, T, dup_of, newidx, prev_g, counts, me, indices, out_v);
+hipError_t launch_dist_finalize(hipStream_t st, int grid, const Vertex *v, const uint32_t *v_ptr, uint32_t vcap, const uint32_t *t_ptr, uint32_t tcap,
+                                const uint32_t *dup_of, const uint32_t *newidx, const uint32_t *prev_g, uint32_t pcap, const uint32_t *counts, uint32_t me,
+                                uint32_t *indices, Vertex *out_v) {
+    hipLaunchKernelGGL(k_dist_finalize, dim3(grid), dim3(256), 0, st, v, v_ptr, vcap, t_ptr, tcap, dup_of, newidx, prev_g, pcap, counts, me, indices, out_v);
     return hipGetLastError();
 }
 
@@ -3165,6 +3201,17 @@ hipError_t launch_selfcheck(hipStream_t st, int which, unsigned long long *bad) 
 hipError_t launch_pack_record(hipStream_t st, uint32_t *dst, const uint32_t *count, const uint32_t *status, uint32_t v0, uint32_t v1, uint32_t v2,
                               uint32_t v3) {
     hipLaunchKernelGGL(k_pack_record, dim3(1), dim3(1), 0, st, dst, count, status, v0, v1, v2, v3);
+    return hipGetLastError();
+}
+
+hipError_t launch_dist_record(hipStream_t st, uint32_t *dst, const uint32_t *count, const uint32_t *status, uint32_t host_status, uint32_t cap_prev,
+                              uint32_t inject, uint32_t sig) {
+    hipLaunchKernelGGL(k_dist_record, dim3(1), dim3(1), 0, st, dst, count, status, host_status, cap_prev, inject, sig);
+    return hipGetLastError();
+}
+
+hipError_t launch_dist_publish(hipStream_t st, const uint32_t *nups, const uint32_t *counts, uint32_t nranks, uint32_t seq, uint32_t *pub) {
+    hipLaunchKernelGGL(k_dist_publish, dim3(1), dim3(256), 0, st, nups, counts, nranks, seq, pub);
     return hipGetLastError();
 }
 

@@ -28,7 +28,7 @@ enum StatusWord : int {
 //                   triangles; indexed form: vertices / triangles), vertices, indexed form?, 0, 0}
 static constexpr uint32_t SHARD_ROW = 2048 + 8;
 static constexpr uint32_t SHARD_REC = 2048;        // first word of the record inside a row
-static constexpr uint32_t DIST_REC = 4;
+static constexpr uint32_t DIST_REC = 8;            // {count, status, capacity for the lower neighbour's band, inject, plan signature, 0, 0, 0}
 
 hipError_t launch_refine_mask(hipStream_t st, int grid, int scene, const SceneParams *sp, const Point *vox,
                               const uint32_t *n_ptr, Point cs, uint8_t *mask, uint32_t *tilecnt, int chunk = 32, uint32_t *signs = nullptr);
@@ -146,16 +146,21 @@ hipError_t launch_zs_merge(hipStream_t st, int grid, const Vertex *v_all, const 
                            Vertex *v_out, uint32_t cap_verts, uint32_t *i_out, uint32_t cap_tris, uint32_t *zctl, uint32_t seq, uint32_t *pub);
 // peers: the records (and a zeroed control block) to pinned host memory
 hipError_t launch_zs_publish(hipStream_t st, const uint32_t *counts, uint32_t cstride, uint32_t nranks, const uint32_t *zctl, uint32_t seq, uint32_t *pub);
-hipError_t launch_band_select(hipStream_t st, int grid, const Vertex *v, uint32_t V, float up_thr, float lo_thr, bool has_up, bool has_lo,
+// distributed weld (x-slabs): every count is read from device memory (`*_ptr`), bounded by the capacity beside it
+hipError_t launch_band_select(hipStream_t st, int grid, const Vertex *v, const uint32_t *v_ptr, uint32_t vcap, float up_thr, float lo_thr, bool has_up, bool has_lo,
                               uint32_t *up_ids, uint64_t *up_keys, uint32_t *lo_ids, uint32_t *ctr, uint32_t *dup_of, uint32_t *status);
-hipError_t launch_dist_match(hipStream_t st, int grid, const uint64_t *prev_keys, uint32_t n_prev, uint64_t *hkeys, uint32_t *hpos, uint32_t hsize,
+hipError_t launch_dist_match(hipStream_t st, int grid, const uint64_t *prev_keys, const uint32_t *n_prev_ptr, uint32_t ncap, uint64_t *hkeys, uint32_t *hpos, uint32_t hsize,
                              const Vertex *v, const uint32_t *lo_ids, const uint32_t *n_lo_ptr, uint32_t *dup_of, uint32_t *status);
-hipError_t launch_dist_number(hipStream_t st, int grid, const uint32_t *dup_of, uint32_t V, const uint32_t *v_ptr, uint32_t *tilecnt,
+hipError_t launch_dist_number(hipStream_t st, int grid, const uint32_t *dup_of, const uint32_t *v_ptr, uint32_t vcap, uint32_t *tilecnt,
                               uint32_t *n_keep_out, uint32_t *newidx, uint32_t *status);
-hipError_t launch_dist_pack_up(hipStream_t st, int grid, const uint32_t *up_ids, uint32_t n_up, const uint32_t *newidx, const uint32_t *counts,
+hipError_t launch_dist_pack_up(hipStream_t st, int grid, const uint32_t *up_ids, const uint32_t *n_up_ptr, uint32_t ncap, const uint32_t *newidx, const uint32_t *counts,
                                uint32_t me, uint32_t *up_g);
-hipError_t launch_dist_finalize(hipStream_t st, int grid, const Vertex *v, uint32_t V, uint32_t T, const uint32_t *dup_of, const uint32_t *newidx,
-                                const uint32_t *prev_g, const uint32_t *counts, uint32_t me, uint32_t *indices, Vertex *out_v);
+hipError_t launch_dist_finalize(hipStream_t st, int grid, const Vertex *v, const uint32_t *v_ptr, uint32_t vcap, const uint32_t *t_ptr, uint32_t tcap,
+                                const uint32_t *dup_of, const uint32_t *newidx, const uint32_t *prev_g, uint32_t pcap, const uint32_t *counts, uint32_t me,
+                                uint32_t *indices, Vertex *out_v);
+hipError_t launch_dist_record(hipStream_t st, uint32_t *dst, const uint32_t *count, const uint32_t *status, uint32_t host_status, uint32_t cap_prev,
+                              uint32_t inject, uint32_t sig);
+hipError_t launch_dist_publish(hipStream_t st, const uint32_t *nups, const uint32_t *counts, uint32_t nranks, uint32_t seq, uint32_t *pub /* 8 + 2 nranks DIST_REC words */);
 hipError_t launch_sign_bits(hipStream_t st, int grid, const float *samples, uint64_t total, uint32_t *bits);
 hipError_t launch_dense_classify(hipStream_t st, int grid, bool emit, const uint32_t *bits, uint32_t k, uint32_t *cellcnt,
                                  Point *vox, uint8_t *cubeidx, uint32_t cap);

@@ -403,6 +403,10 @@ class CudaHandler:
         """Route of the last indexed sharded step on this handle: 1 planned, 2 synchronous, 3 planned then repeated synchronously."""
         return int(self._lib.sdmesh_sharded_route(self._h))
 
+    def distributed_route(self):
+        """Route of the last sdmesh_distributed_regen on this handle: 1 planned, 2 synchronous, 3 planned then repeated synchronously."""
+        return int(self._lib.sdmesh_distributed_route(self._h))
+
     def distributed_regen(self, levels):
         """ONE mesh over all ranks of the handle's communicator with the distributed weld (x-slabs): returns (RegenInfo of
         this rank's part, global index of its first kept vertex); download_mesh() then gives the part with global indices."""

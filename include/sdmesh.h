@@ -381,6 +381,11 @@ int sdmesh_render_device(sdmesh_handle *h, const struct GlobalsBuffer *globals, 
  * sdmesh_sharded_regen (status words ride in the two all-gathers; a vertex outside the packed weld-key range on one rank
  * fails the call on all).  x-slabs must not be empty (sdmesh_set_slab_bounds rejects such a table). */
 int sdmesh_distributed_regen(sdmesh_handle *h, int levels, sdmesh_regen_info *info, uint32_t *first_vertex);
+/* Like sdmesh_sharded_regen, the call has two routes: synchronous (the band sizes are read back for the message lengths; commits the plan:
+ * a message size per rank, the band + 1/8 + 2048) and planned (chain, band kernels, both all-gathers and plan-sized neighbour messages
+ * enqueued blind, one host synchronisation; repeated synchronously by every rank if a band did not fit).  1 planned, 2 synchronous,
+ * 3 planned then repeated, 0 none yet. */
+int sdmesh_distributed_route(const sdmesh_handle *h);
 /* The same step for nranks handles of one process on one device (copies instead of messages): the rehearsal used where
  * only one GPU exists.  infos / first_vertex: arrays of nranks (optional). */
 int sdmesh_distributed_regen_rehearsal(sdmesh_handle **handles, int nranks, int levels, sdmesh_regen_info *infos, uint32_t *first_vertex);
