@@ -14,6 +14,12 @@ run regen_write --kernel-trace --pmc WRITE_SIZE --output-format csv -d $O/regen_
 run dense_write --kernel-trace --pmc WRITE_SIZE --output-format csv -d $O/dense_write -- $P $R/tools/dense_once.py || exit 1
 run dense_fetch --kernel-trace --pmc FETCH_SIZE --output-format csv -d $O/dense_fetch -- $P $R/tools/dense_once.py || exit 1
 run bench_trace --kernel-trace --stats --output-format csv -d $O/bench_trace -- $P $R/bench.py --steps 100 --warmup 10 --no-cpu-baseline --no-sizes --no-pipelined --no-anim --no-ref-abi || exit 1
+# the one-mesh steps on a one-rank RCCL communicator (what one GPU can run of the multi-GPU protocol): kernel traces + wall times
+for k in 4 5; do
+  run zslab_trace_$k --kernel-trace --stats --output-format csv -d $O/zslab_trace_$k -- $P $R/tools/prof_sharded.py zslab sdobj $k 40 || exit 1
+  run xslab_trace_$k --kernel-trace --stats --output-format csv -d $O/xslab_trace_$k -- $P $R/tools/prof_sharded.py xslab sdobj $k 40 || exit 1
+done
+( for f in plain zslab xslab; do for k in 3 4 5; do $P $R/tools/prof_sharded.py $f sdobj $k 200 2>/dev/null | grep ms_per_step; done; done ) > $O/one_mesh_one_rank.txt
 cd $R
 for u in valu_rate valu_issue; do      # (built in-tree by the builder; a fresh clone compiles them here)
   [ -x tools/ubench/$u ] || /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -w $([ $u = valu_rate ] && echo -ffp-contract=off) tools/ubench/$u.hip -o tools/ubench/$u

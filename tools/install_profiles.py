@@ -12,6 +12,13 @@ shutil.copy(one(f"{P}/dense_fetch/**/*_counter_collection.csv"), f"profiles/{tag
 open(f"profiles/{tag}_bench_under_rocprof.json", "w").write(
     "".join(l for l in open(f"{P}/bench_trace.stdout") if l.startswith("{")))
 shutil.copy(f"{P}/bench_plain.json", f"profiles/{tag}_bench_plain.json")
+for k in (4, 5):                                                    # round 4: the one-mesh steps on a one-rank communicator
+    for form in ("zslab", "xslab"):
+        g = glob.glob(f"{P}/{form}_trace_{k}/**/*_kernel_stats.csv", recursive=True)
+        if g:
+            shutil.copy(max(g, key=os.path.getmtime), f"profiles/{tag}_{form}_{32 << k}_one_rank_kernel_stats.csv")
+if os.path.exists(f"{P}/one_mesh_one_rank.txt"):
+    shutil.copy(f"{P}/one_mesh_one_rank.txt", f"profiles/{tag}_one_mesh_one_rank_wall.txt")
 for src, dst in (("streaming_window.csv", f"{tag}_bench_streaming_kernels_timed_window.csv"), ("valu_rate.jsonl", f"{tag}_ubench_valu_rate.jsonl"),
                  ("valu_issue.jsonl", f"{tag}_ubench_valu_issue.jsonl"),
                  ("project_timeline.json", f"{tag}_project1_wave_timeline.json"), ("tile_phases.txt", f"{tag}_tile_dedupe_phases.txt")):

@@ -21,4 +21,4 @@ t0 = time.perf_counter()
 for _ in range(reps):
     info = step()
 dt = (time.perf_counter() - t0) / reps
-print(form, scene, k, info.triangles, info.vertices, "ms_per_step", round(dt * 1e3, 4), "route", h.sharded_route() if form == "zslab" else None)
+print(form, scene, k, info.triangles, info.vertices, "ms_per_step", round(dt * 1e3, 4), "route", {"zslab": h.sharded_route, "xslab": h.distributed_route, "plain": lambda: None}[form]())
