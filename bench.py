@@ -419,11 +419,12 @@ def host_api_leg(pkg, local_rank, scene, params, levels_list=(3, 4), reps=12):
                 rows["total"].append(time.perf_counter() - t_start)
             sizes = [n, nv.value, nt.value]
         med = lambda v: round(float(np.median(v)) * 1e3, 4)     # noqa: E731
-        h.regen(k)
-        t0 = time.perf_counter()
-        for _ in range(50):
+        for _ in range(300):                                             # (the PCIe-bound calls above leave the GPU mostly idle: let the clocks come back)
             h.regen(k)
-        dres = (time.perf_counter() - t0) / 50 * 1e3
+        t0 = time.perf_counter()
+        for _ in range(100):
+            h.regen(k)
+        dres = (time.perf_counter() - t0) / 100 * 1e3
         out[f"{32 << k}^3"] = {"create_voxel_field_ms": med(rows["create_voxel_field"]), "refine_voxel_field_ms": [med(v) for v in rows["refine"]],
                                "voxel_field_to_mesh_ms": med(rows["voxel_field_to_mesh"]), "download_mesh_ms": med(rows["download_mesh"]),
                                "mesh_plus_download_ms": round(med(rows["voxel_field_to_mesh"]) + med(rows["download_mesh"]), 4),
@@ -758,7 +759,7 @@ def main():
 
     # --- several regens in flight (one handle each): most kernels of the chain are latency-bound, so they overlap
     if not args.no_pipelined:
-        depth = 3          # (measured, tools/pipeline_depth.py: 1 / 2 / 3 / 4 / 6 / 8 in flight = 0.129 / 0.083 / 0.070 / 0.085 / 0.087 / 0.088 ms per regen at 512^3)
+        depth = 3          # (measured in round 3, MEASUREMENTS.md: 1 / 2 / 3 / 4 / 6 / 8 in flight = 0.129 / 0.083 / 0.070 / 0.085 / 0.087 / 0.088 ms per regen at 512^3)
         hs = [pkg.CudaHandler(local_rank, args.scene, params) for _ in range(depth)]
         for hh in hs:
             hh.regen(args.levels); hh.set_option("graph", 1 if args.graph else 0); hh.regen(args.levels); hh.regen(args.levels)
