@@ -234,7 +234,8 @@ def one_mesh_legs(pkg, job, local_rank, scene, params, levels_list, base_levels,
                                f"{t1[lv]['triangles']} / {t1[lv]['vertices']}")
         xslab[f"{n}^3"] = {"ms_per_regen": round(ms, 4), "t_1rank_ms": round(t1[lv]["ms"], 4),
                            "speedup_vs_1rank": round(t1[lv]["ms"] / ms, 3), "mvoxels_per_s": round(n ** 3 / ms / 1e3, 1),
-                           "triangles": int(cnt[1]), "vertices": int(cnt[0]), "steps": k}
+                           "triangles": int(cnt[1]), "vertices": int(cnt[0]), "steps": k,
+                           "route": {1: "planned (one host synchronisation)", 2: "synchronous", 3: "planned, repeated synchronously"}.get(h.distributed_route())}
     h.close()
     return primary, {"n_gpus": world, "ranks_seen": ranks_seen, "slab_bounds": {"z": zbounds, "x": xbounds},
                      "zslab_indexed_gather": {"what": "sdmesh_sharded_regen (indexed form): level-0 z-slab per rank, meshed AND welded there; ncclAllGather of "

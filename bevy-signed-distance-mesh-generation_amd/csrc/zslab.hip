@@ -117,20 +117,27 @@ __device__ __forceinline__ uint32_t zs_col_of(const uint32_t *__restrict__ s_sta
 
 // published starts -> counts: enc[c] = 1 + the first item (triangle / welded vertex) of column c for the columns that hold voxels, 0 for
 // the others; an empty column starts where the next one does (suffix minimum), `end` behind the last.  One 1024-thread workgroup, thread =
-// column; s: NCOL + 1 words.  Returns the column's count; `bad` is raised for starts that do not ascend from 0.
+// column; s: >= 16 words of LDS.  Returns the column's count; `bad` is raised for starts that do not ascend from 0.
 __device__ __forceinline__ uint32_t zs_decode_starts(uint32_t enc, uint32_t end, uint32_t *__restrict__ s, bool &bad) {
-    const uint32_t c = threadIdx.x;
-    __syncthreads();
-    s[c] = enc ? enc - 1u : U32_NONE;
-    __syncthreads();
-    for (uint32_t o = 1; o < NCOL; o <<= 1) {                        // inclusive suffix minimum (Hillis-Steele: 10 steps)
-        const uint32_t a = s[c], b = c + o < NCOL ? s[c + o] : U32_NONE;
-        __syncthreads();
-        s[c] = a < b ? a : b;
-        __syncthreads();
+    const uint32_t c = threadIdx.x, lane = c & 63u, wave = c >> 6;
+    // inclusive suffix minimum over the 1024 columns: inside the wave by shuffles, across the 16 waves through LDS
+    uint32_t x = enc ? enc - 1u : U32_NONE;
+#pragma unroll
+    for (uint32_t o = 1; o < 64u; o <<= 1) {
+        const uint32_t y = (uint32_t) __shfl_down((int) x, o, 64);
+        if (lane + o < 64u) x = y < x ? y : x;
     }
-    const uint32_t start = s[c] < end ? s[c] : end, next = c + 1u < NCOL ? (s[c + 1u] < end ? s[c + 1u] : end) : end;
-    bad = next < start || (c == 0 && start != 0u && end != 0u) || (s[c] != U32_NONE && s[c] > end);
+    __syncthreads();                                                 // (s: the previous use is over)
+    if (lane == 0) s[wave] = x;
+    __syncthreads();
+    uint32_t after = U32_NONE;                                       // the waves behind this one
+    for (uint32_t w = wave + 1u; w < 16u; w++) after = s[w] < after ? s[w] : after;
+    x = after < x ? after : x;
+    // the next column's start: the next lane's value, or for the wave's last lane the minimum of the waves behind
+    uint32_t nx = (uint32_t) __shfl_down((int) x, 1u, 64);
+    if (lane == 63u) nx = after;
+    const uint32_t start = x < end ? x : end, next = c + 1u < NCOL ? (nx < end ? nx : end) : end;
+    bad = next < start || (c == 0 && start != 0u && end != 0u) || (x != U32_NONE && x > end);
     return next >= start ? next - start : 0u;
 }
 
