@@ -196,7 +196,6 @@ struct sdmesh_handle {
     ncclComm_t comm = nullptr;
     int comm_rank = 0, comm_nranks = 1;
     DevBuf shard_mine, shard_counts, shard_recv, shard_lists, shard_plan, shard_merged;
-    // z-slab INDEXED gather (root): the ranks' welded buffers concatenated, the merge's tables, its outputs (swapped into vertices / indices)
     // z-slab INDEXED gather: the ranks' welded buffers in SLOTS of zs_verts / zs_idx (root), the merge's tables, its outputs
     DevBuf zs_verts, zs_idx, zs_tables, zs_pervert, zs_hkeys, zs_vout, zs_iout, zs_ranks, zs_ctl, shard_counts2, zs_colscratch, zs_hints;
     ZsRanks *h_zs = nullptr;       // pinned staging copy of the merge's slot table

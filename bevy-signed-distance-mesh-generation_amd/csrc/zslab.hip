@@ -16,8 +16,10 @@
 //   * the only vertices two slabs can share lie within `band` of a slab face: those go through one small hash (key -> smallest
 //     slot vertex id) and look themselves up; of a pair the copy whose first-seen segment comes first in the (column, rank) order
 //     is the single-GPU representative, the other one is dropped from its segment's count and redirected;
-//   * kept vertices are numbered segment by segment (a block scan inside the segment: no global scan) and written to their merged
-//     places, the dropped ones inherit their partner's number, and the index buffers are rewritten segment by segment.
+//   * a kept vertex's merged place is its segment's merged start + its position in the segment - the dropped copies in front of it
+//     inside the segment (counted per 256-entry block: no global scan); the dropped ones inherit their partner's number; every
+//     triangle finds its segment by bisection over a few segment starts and is rewritten with the merged numbers.  All of it as flat,
+//     one-item-per-thread streaming kernels (k_zs_vertex_out, k_zs_loser_map, k_zs_index_out).
 //
 // Inputs lie in SLOTS (kernels.hpp, ZsRanks): slot capacities come from the host (exact counts on the synchronous path, planned
 // sizes on the planned one, where the host does not know the counts when it enqueues the kernels); the ACTUAL counts are read from

@@ -66,7 +66,7 @@ def merge_triangles(tri_lists, counts):
 
 
 def indexed_merge_reference(parts, counts, z_faces, band):
-    """CPU restatement (numpy) of the root's share of the INDEXED z-slab gather (zs_merge / k_zs_* in csrc), for the tests that
+    """CPU restatement (numpy) of the root's share of the INDEXED z-slab gather (k_zs_* in csrc/zslab.hip), for the tests that
     run without a GPU -- the product path calls `sdmesh_sharded_regen`, never this.
 
     parts: per rank (verts [V_r, 6] f32 = position | normal in the rank's own first-seen order, idx [T_r, 3] local indices in the
