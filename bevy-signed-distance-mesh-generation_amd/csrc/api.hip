@@ -204,6 +204,7 @@ struct sdmesh_handle {
     uint32_t *h_zs_pub = nullptr;  // pinned: what a step publishes (ZC_WORDS control words, then the ranks' records)
     int shard_indexed = 1;         // option "shard_indexed": sdmesh_sharded_regen gathers welded per-slab vertex / index buffers (0: raw triangle lists + root weld)
     int shard_planned = 1;         // option "shard_planned": 0 = every indexed step takes the synchronous route (three host synchronisations)
+    int zs_block = 0;              // option "zs_block": slot entries per workgroup of k_zs_vertex_out / k_zs_index_out (256, 1024; 0 = by the mesh's size)
     int shard_slack = 1;           // option "shard_slack": 0 = the plan's slots have no head-room (any growth makes the next planned step repeat: tests)
     uint32_t zs_band_plan = 0;     // face-band vertices of the last indexed merge (sizes the band hash of the next one)
     // The PLANNED indexed step (steady state: one host synchronisation).  The plan is COLLECTIVE state: every rank derives it from the
@@ -1301,6 +1302,7 @@ int sdmesh_set_option(sdmesh_handle *h, const char *name, int value) {
         else h->colcnt = nullptr;
         return SDMESH_OK;
     }
+    if (!strcmp(name, "zs_block")) { if (value != 0 && value != 256 && value != 1024) return fail(h, SDMESH_ERR_INVALID, "zs_block: 0, 256 or 1024"); h->zs_block = value; return SDMESH_OK; }
     if (!strcmp(name, "shard_slack")) { h->shard_slack = value != 0; h->zsp.valid = false; h->dsp.valid = false; return SDMESH_OK; }
     if (!strcmp(name, "shard_planned")) { h->shard_planned = value != 0; h->zsp.valid = false; h->dsp.valid = false; return SDMESH_OK; }   // (like every option of a collective call: the same on all ranks)
     if (!strcmp(name, "project_prio")) { h->project_prio = value != 0; drop_graph(h); return SDMESH_OK; }
@@ -2162,12 +2164,16 @@ uint32_t zs_root_capacity_t(const sdmesh_handle *h) {
 void zs_slot_table(const sdmesh_handle *h, int R, const uint32_t *cap_v, const uint32_t *cap_t, int levels, ZsRanks &zr) {
     memset(&zr, 0, sizeof zr);
     zr.nranks = (uint32_t) R;
+    // entries per workgroup of the two streaming merge kernels: the big block from ~1 M triangles on (option "zs_block": 256 / 1024 / 0 = by size)
+    uint64_t tsum = 0;
+    for (int r = 0; r < R; r++) tsum += cap_t[r];
+    zr.blk = h->zs_block ? (uint32_t) h->zs_block : (tsum >= 1000000ull ? 1024u : 256u);
     uint32_t vb = 0, tb = 0;
     const uint32_t F = MESH_GENERATION_INIT_FACTOR;
     for (int r = 0; r < R; r++) {
         zr.vbase[r] = vb; zr.tbase[r] = tb;
         vb += cap_v[r]; tb += cap_t[r];
-        zr.tblk[r + 1] = zr.tblk[r] + (cap_t[r] + 255u) / 256u;
+        zr.tblk[r + 1] = zr.tblk[r] + (cap_t[r] + zr.blk - 1u) / zr.blk;
         uint32_t lo = F * (uint32_t) r / (uint32_t) R, hi = F * (uint32_t) (r + 1) / (uint32_t) R;
         if (h->slab_nparts == R && h->slab_mode == SDMESH_PART_ZSLAB) { lo = h->slab_bounds[r]; hi = h->slab_bounds[r + 1]; }
         zr.zlo[r] = -MESH_GENERATION_BB_SIZE / 2.0f + MESH_GENERATION_BB_SIZE * (float) lo / (float) F;

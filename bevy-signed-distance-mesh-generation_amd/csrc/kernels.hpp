@@ -123,7 +123,8 @@ hipError_t launch_tile_tricount(hipStream_t st, int grid, const uint8_t *cubeidx
 struct ZsRanks {
     uint32_t nranks;
     uint32_t vbase[33], tbase[33];      // first vertex / triangle of rank r's slot; [nranks] = the slots' total
-    uint32_t tblk[33];                  // first 256-triangle block of rank r's slot in k_zs_index_out's grid; [nranks] = blocks in all
+    uint32_t blk;                       // slot entries per workgroup of k_zs_vertex_out / k_zs_index_out: 256 or 1024
+    uint32_t tblk[33];                  // first `blk`-triangle block of rank r's slot in k_zs_index_out's grid; [nranks] = blocks in all
     float zlo[32], zhi[32];             // the slabs' z extents
     float zbot, ztop, band;             // the domain's z extent (a face on it is no slab face), half-width of the face bands
 };
@@ -141,7 +142,7 @@ hipError_t launch_zs_local(hipStream_t st, uint32_t *row, uint32_t *next_row, co
 // then 4-byte minima) only with more than one rank; zctl = ZC_WORDS words; pub (pinned host, optional) receives zctl and the records
 hipError_t launch_zs_merge(hipStream_t st, int grid, const Vertex *v_all, const uint32_t *idx_all, const uint32_t *counts, uint32_t cstride,
                            const ZsRanks &zr, const ZsRanks *d_zr, uint32_t *tplan, uint32_t *vplan, uint32_t *vstart, uint32_t *newcnt,
-                           uint32_t *segof, uint32_t *redirect, uint32_t *map, uint32_t *blockdrop /* per 256 slot vertices */, uint32_t *thint /* per 256 slot triangles */,
+                           uint32_t *segof, uint32_t *redirect, uint32_t *map, uint32_t *blockdrop /* per zr.blk slot vertices */, uint32_t *thint /* per zr.blk slot triangles */,
                            uint64_t *hkeys, uint32_t hsize,
                            Vertex *v_out, uint32_t cap_verts, uint32_t *i_out, uint32_t cap_tris, uint32_t *zctl, uint32_t seq, uint32_t *pub);
 // peers: the records (and a zeroed control block) to pinned host memory

@@ -37,8 +37,10 @@ namespace sdm {
 
 static constexpr uint32_t NCOL = MESH_GENERATION_INIT_FACTOR * MESH_GENERATION_INIT_FACTOR;     // 1024 level-0 columns
 static constexpr uint32_t ZS_GAP = 0xfffffffeu;        // redirect[] of a slot entry behind the rank's last vertex
-static constexpr uint32_t ZS_VBLK = 256;               // slot vertices per workgroup of k_zs_vertex_out = per entry of blockdrop[]
-static constexpr uint32_t ZS_TBLK = 256;               // slot triangles per workgroup of k_zs_index_out (zr.tblk counts these)
+// k_zs_vertex_out / k_zs_index_out take 256 * IPT slot entries per workgroup (IPT = 1 or 4 items per thread, every load issued in front):
+// a workgroup's chain of dependent steps (hints, checks, segment starts, gathers, staging) is the same whatever it carries, so large
+// meshes want the big block (1024^3: 19 -> see MEASUREMENTS.md) and small ones the many small blocks.  zr.blk = 256 * IPT, chosen by the host;
+// blockdrop[] and the block hints are per that many entries.
 static constexpr uint32_t ZS_FCOLS = 4;                // columns per workgroup of k_zs_front's per-vertex pass
 static_assert(SHARD_REC == 2 * NCOL, "a row is 1024 triangle counts, 1024 vertex counts, the record");
 
@@ -78,7 +80,7 @@ __device__ __forceinline__ uint32_t zs_plan_body(const uint32_t *__restrict__ co
     return total;
 }
 
-// the triangle plan with the block hints of k_zs_index_out: thint[zr.tblk[r] + j] = the column that holds triangle j * ZS_TBLK of rank r
+// the triangle plan with the block hints of k_zs_index_out: thint[zr.tblk[r] + j] = the column that holds triangle j * zr.blk of rank r
 // (so a workgroup of that kernel stages only the few segment starts its 256 triangles can fall into, not the rank's 1024)
 __device__ __forceinline__ uint32_t zs_col_of(const uint32_t *__restrict__ s_start, uint32_t t);
 __device__ __forceinline__ uint32_t zs_tplan_with_hints(const uint32_t *__restrict__ counts, uint32_t cstride, const ZsRanks &zr, uint32_t *__restrict__ plan,
@@ -99,7 +101,7 @@ __device__ __forceinline__ uint32_t zs_tplan_with_hints(const uint32_t *__restri
         __syncthreads();
         s_src[c] = src;
         __syncthreads();
-        for (uint32_t j = c; j < zr.tblk[r + 1u] - zr.tblk[r]; j += 1024u) thint[zr.tblk[r] + j] = zs_col_of(s_src, j * ZS_TBLK);
+        for (uint32_t j = c; j < zr.tblk[r + 1u] - zr.tblk[r]; j += 1024u) thint[zr.tblk[r] + j] = zs_col_of(s_src, j * zr.blk);
     }
     return total;
 }
@@ -229,7 +231,7 @@ __global__ __launch_bounds__(1024) void k_zs_front(const uint32_t *__restrict__ 
     if (!ok) return;
     for (uint32_t i = blockIdx.x * 1024u + tid; i < hwords; i += groups * 1024u) hclear[i] = 0xffffffffu;      // (all-ones = empty key = no vertex yet)
     if (blockdrop)
-        for (uint32_t i = blockIdx.x * 1024u + tid; i < zr.vbase[R] / ZS_VBLK + 1u; i += groups * 1024u) blockdrop[i] = 0u;
+        for (uint32_t i = blockIdx.x * 1024u + tid; i < zr.vbase[R] / zr.blk + 1u; i += groups * 1024u) blockdrop[i] = 0u;
     const uint32_t r = blockIdx.x / (NCOL / ZS_FCOLS), c0 = (blockIdx.x % (NCOL / ZS_FCOLS)) * ZS_FCOLS;
     const uint32_t vc = counts[(size_t) r * cstride + NCOL + tid];
     uint32_t total;
@@ -319,7 +321,7 @@ __global__ __launch_bounds__(256) void k_zs_band_resolve(const Vertex *__restric
                     const uint32_t win = a_first ? a : i, lose = a_first ? i : a;
                     redirect[lose] = win;
                     atomicSub(&newcnt[a_first ? si : sa], 1u);
-                    atomicAdd(&blockdrop[lose / ZS_VBLK], 1u);       // (k_zs_vertex_out numbers the kept vertices of a segment from these)
+                    atomicAdd(&blockdrop[lose / zr.blk], 1u);        // (k_zs_vertex_out numbers the kept vertices of a segment from these)
                 }
                 break;
             }
@@ -342,77 +344,92 @@ __global__ __launch_bounds__(1024) void k_zs_vplan(const uint32_t *__restrict__ 
     }
 }
 
-// kept vertices to their merged places; map[i] = merged number.  Flat over the slot space, one entry per thread, every load that does not
-// depend on another one issued in front.  A kept vertex's place = its segment's merged start + its rank among the segment's kept vertices
-// = (i - first) - (dropped copies in [first, i)).  Only band vertices are ever dropped, and only with several ranks: the drops in front of i
-// are counted inside the workgroup's own ZS_VBLK entries by a block scan; a segment that began in an earlier block (only the block's
-// first segment can) adds the drops between its first vertex and the block -- the tail of the first vertex's block, read here, and
-// the whole blocks in between from blockdrop[] (k_zs_band_resolve).  No global scan.
+// kept vertices to their merged places; map[i] = merged number.  Flat over the slot space, 256 IPT entries per workgroup, IPT consecutive ones
+// per thread, every load that does not depend on another one issued in front.  A kept vertex's place = its segment's merged start + its rank
+// among the segment's kept vertices = (i - first) - (dropped copies in [first, i)).  Only band vertices are ever dropped, and only with
+// several ranks: the drops in front of i are counted inside the workgroup's own entries by a block scan; a segment that began in an earlier
+// block (only the block's first segment can) adds the drops between its first vertex and the block -- the tail of the first vertex's
+// block, read here, and the whole blocks in between from blockdrop[] (k_zs_band_resolve).  No global scan.  The vertices themselves move
+// as dwords through registers with their destinations staged in LDS: a 24-byte vertex per lane would touch every line six times.
+template <uint32_t IPT>
 __global__ __launch_bounds__(256) void k_zs_vertex_out(const Vertex *__restrict__ v, const uint32_t *__restrict__ counts, uint32_t cstride,
                                                         const ZsRanks *__restrict__ zrp, const uint32_t *__restrict__ redirect, const uint32_t *__restrict__ segof,
                                                         const uint32_t *__restrict__ vstart, const uint32_t *__restrict__ vplan, const uint32_t *__restrict__ blockdrop,
-                                                        Vertex *__restrict__ out, uint32_t cap, uint32_t *__restrict__ map, uint32_t dbg) {
+                                                        Vertex *__restrict__ out, uint32_t cap, uint32_t *__restrict__ map, uint32_t flags) {
+    constexpr uint32_t BLK = 256u * IPT;
     const ZsRanks &zr = *zrp;
     __shared__ uint32_t lds[17];
-    __shared__ uint32_t s_e[ZS_VBLK];
+    __shared__ uint32_t s_e[BLK];
     __shared__ uint32_t s_x;
-    const uint32_t tid = threadIdx.x, V = zr.vbase[zr.nranks], b0 = blockIdx.x * ZS_VBLK, i = b0 + tid;
+    const uint32_t tid = threadIdx.x, V = zr.vbase[zr.nranks], b0 = blockIdx.x * BLK;
     if (b0 >= V) return;
-    // (speculative loads: entries behind V or in a slot's tail read allocated memory, their values are not used.)  The block's vertices
-    // as six coalesced dword loads per thread: a 24-byte vertex per lane would touch every line six times.
-    const uint32_t red = i < V ? redirect[i] : ZS_GAP;
-    const uint32_t seg_i = i < V ? segof[i] : 0u;
-    const uint32_t nd = (V - b0 < ZS_VBLK ? V - b0 : ZS_VBLK) * 6u;
-    const uint32_t *__restrict__ v32 = reinterpret_cast<const uint32_t *>(v) + 6ull * b0;
-    uint32_t w[6];
+    // (speculative loads: entries behind V or in a slot's tail read allocated memory, their values are not used)
+    uint32_t red[IPT], seg_i[IPT];
 #pragma unroll
-    for (uint32_t j = 0; j < 6u; j++) w[j] = (tid + 256u * j < nd && !(dbg & 1u)) ? v32[tid + 256u * j] : 0u;
-    if (!(dbg & 8u) && !zs_rows_ok(counts, cstride, zr)) return;
+    for (uint32_t j = 0; j < IPT; j++) {
+        const uint32_t i = b0 + IPT * tid + j;
+        red[j] = i < V ? redirect[i] : ZS_GAP;
+        seg_i[j] = i < V ? segof[i] : 0u;
+    }
+    const uint32_t nd = (V - b0 < BLK ? V - b0 : BLK) * 6u;
+    const uint32_t *__restrict__ v32 = reinterpret_cast<const uint32_t *>(v) + 6ull * b0;
+    uint32_t w[6u * IPT];
+#pragma unroll
+    for (uint32_t j = 0; j < 6u * IPT; j++) w[j] = tid + 256u * j < nd ? v32[tid + 256u * j] : 0u;
+    if (!zs_rows_ok(counts, cstride, zr)) return;
     const bool drops = zr.nranks > 1u;
-    const bool kept = red == U32_NONE;
-    uint32_t first = 0, dstart = 0;
-    if (kept) { first = zr.vbase[seg_i / NCOL] + vstart[seg_i]; dstart = vplan[2u * seg_i + 1u]; }
-    uint32_t before = 0;
+    uint32_t first[IPT], dstart[IPT];
+#pragma unroll
+    for (uint32_t j = 0; j < IPT; j++) {
+        first[j] = 0; dstart[j] = 0;
+        if (red[j] == U32_NONE) { first[j] = zr.vbase[seg_i[j] / NCOL] + vstart[seg_i[j]]; dstart[j] = vplan[2u * seg_i[j] + 1u]; }
+    }
+    uint32_t ex = 0, xt = 0;
     if (drops) {
-        const uint32_t d = (red != U32_NONE && red != ZS_GAP) ? 1u : 0u;
+        uint32_t d = 0;
+#pragma unroll
+        for (uint32_t j = 0; j < IPT; j++) d += (red[j] != U32_NONE && red[j] != ZS_GAP) ? 1u : 0u;
         uint32_t total;
-        s_e[tid] = block_excl_scan(d, total, lds);
-        // drops of the block's first segment in front of the block
+        ex = block_excl_scan(d, total, lds);
+        uint32_t e = ex;
+#pragma unroll
+        for (uint32_t j = 0; j < IPT; j++) { s_e[IPT * tid + j] = e; e += (red[j] != U32_NONE && red[j] != ZS_GAP) ? 1u : 0u; }
+        // drops of the block's first segment in front of the block (thread 0 holds the block's first entry)
+        if (tid == 0) s_x = red[0] != ZS_GAP ? zr.vbase[seg_i[0] / NCOL] + vstart[seg_i[0]] : b0;
+        __syncthreads();
+        const uint32_t first0 = s_x;
         uint32_t x = 0;
-        const uint32_t r0 = (uint32_t) __builtin_amdgcn_readfirstlane((int) red), s0 = (uint32_t) __builtin_amdgcn_readfirstlane((int) seg_i);
-        uint32_t first0 = b0;
-        if (tid < 64u) {
-            // (wave 0 holds the block's first entry in its first lane)
-            if (r0 != ZS_GAP) first0 = zr.vbase[s0 / NCOL] + vstart[s0];
-        }
-        if (tid == 0) s_x = first0;
-        __syncthreads();
-        first0 = s_x;
-        __syncthreads();
         if (first0 < b0) {
-            const uint32_t fb = first0 / ZS_VBLK, fend = (fb + 1u) * ZS_VBLK;          // (fend <= b0)
+            const uint32_t fb = first0 / BLK, fend = (fb + 1u) * BLK;              // (fend <= b0)
             for (uint32_t j = first0 + tid; j < fend; j += 256u) { const uint32_t q = redirect[j]; x += (q != U32_NONE && q != ZS_GAP) ? 1u : 0u; }
             for (uint32_t bb = fb + 1u + tid; bb < blockIdx.x; bb += 256u) x += blockdrop[bb];
         }
-        uint32_t xt;
-        (void) block_excl_scan(x, xt, lds);
-        if (kept) before = first >= b0 ? s_e[tid] - s_e[first - b0] : s_e[tid] + xt;
+        (void) block_excl_scan(x, xt, lds);                                  // (synchronises: every reader of s_e below is behind it)
     }
-    uint32_t g = U32_NONE;
-    if (kept) {
-        g = dstart + (i - first) - before;
-        if (!(dbg & 4u)) map[i] = g;
-        if (g >= cap) g = U32_NONE;                                       // flagged by the plan
+    uint32_t g[IPT];
+#pragma unroll
+    for (uint32_t j = 0; j < IPT; j++) {
+        g[j] = U32_NONE;
+        if (red[j] == U32_NONE) {
+            const uint32_t i = b0 + IPT * tid + j;
+            uint32_t before = 0;
+            if (drops) before = first[j] >= b0 ? s_e[i - b0] - s_e[first[j] - b0] : s_e[i - b0] + xt;
+            g[j] = dstart[j] + (i - first[j]) - before;
+            map[i] = g[j];
+            if (g[j] >= cap) g[j] = U32_NONE;                              // flagged by the plan
+        }
     }
-    __syncthreads();
-    s_e[tid] = g;                                                         // (s_e: its last readers are behind the barrier above)
+    __syncthreads();                                                         // (s_e: its last readers are behind this barrier)
+#pragma unroll
+    for (uint32_t j = 0; j < IPT; j++) s_e[IPT * tid + j] = g[j];
     __syncthreads();
     uint32_t *__restrict__ out32 = reinterpret_cast<uint32_t *>(out);
 #pragma unroll
-    for (uint32_t j = 0; j < 6u; j++) {
+    for (uint32_t j = 0; j < 6u * IPT; j++) {
         const uint32_t k = tid + 256u * j;
-        if (k < nd && !(dbg & 2u)) { const uint32_t gg = s_e[k / 6u]; if (gg != U32_NONE) out32[6ull * gg + k % 6u] = w[j]; }
+        if (k < nd) { const uint32_t gg = s_e[k / 6u]; if (gg != U32_NONE) out32[6ull * gg + k % 6u] = w[j]; }
     }
+    (void) flags;
 }
 
 // a dropped copy takes its partner's number (the partner is kept: its number is final).  Its own pass over the vertices: folded into the
@@ -435,29 +452,33 @@ __device__ __forceinline__ void zs_publish_body(const uint32_t *__restrict__ cou
     if (tid < nranks * 8u) pub[ZC_WORDS + tid] = counts[(size_t) (tid >> 3) * cstride + SHARD_REC + (tid & 7u)];
 }
 
-// the index buffers into the merged triangle order with merged vertex numbers.  Flat over the triangle slots: workgroup = ZS_TBLK slot
-// triangles of one rank (blocks per rank from the slot capacities: zr.tblk), one triangle per thread; it finds its column segment by
-// bisection over the few segment starts the block can fall into (tplan's source offsets between the block's hint and the next one's).  Workgroup 0 also publishes the step's control block and
-// the ranks' records to pinned host memory: every word of them was final before this kernel started (no read-back copy behind the chain).
+// the index buffers into the merged triangle order with merged vertex numbers.  Flat over the triangle slots: workgroup = 256 IPT slot
+// triangles of one rank (blocks per rank from the slot capacities: zr.tblk), IPT triangles per thread; a triangle finds its column segment
+// by bisection over the few segment starts the block can fall into (tplan's source offsets between the block's hint and the next one's).
+// The indices move as dwords (three coalesced loads per triangle-slot of the thread, their destinations staged in LDS).  Workgroup 0 also
+// publishes the step's control block and the ranks' records to pinned host memory: every word of them was final before this kernel
+// started (no read-back copy behind the chain).
+template <uint32_t IPT>
 __global__ __launch_bounds__(256) void k_zs_index_out(const uint32_t *__restrict__ idx_all, const uint32_t *__restrict__ counts, uint32_t cstride,
                                                        const uint32_t *__restrict__ tplan, const uint32_t *__restrict__ thint, const ZsRanks *__restrict__ zrp,
                                                        const uint32_t *__restrict__ map, uint32_t *__restrict__ out, uint32_t cap_tris,
                                                        const uint32_t *__restrict__ zctl, uint32_t seq, uint32_t *__restrict__ pub) {
+    constexpr uint32_t BLK = 256u * IPT;
     const ZsRanks &zr = *zrp;
     __shared__ uint32_t s_start[NCOL + 1];
-    __shared__ uint32_t s_dst[ZS_TBLK];
+    __shared__ uint32_t s_dst[BLK];
     if (pub && blockIdx.x == 0) zs_publish_body(counts, cstride, zr.nranks, zctl, seq, pub);
     uint32_t r = 0;
     while (r + 1u < zr.nranks && blockIdx.x >= zr.tblk[r + 1u]) r++;
-    const uint32_t tid = threadIdx.x, t0 = (blockIdx.x - zr.tblk[r]) * ZS_TBLK, t = t0 + tid;
+    const uint32_t tid = threadIdx.x, t0 = (blockIdx.x - zr.tblk[r]) * BLK;
     const uint32_t slot = zr.tbase[r + 1u] - zr.tbase[r];
     if (t0 >= slot) return;
-    // the block's 768 indices as three coalesced dword loads per thread (speculative: in front of the hints and the checks)
-    const uint32_t ne_cap = (slot - t0 < ZS_TBLK ? slot - t0 : ZS_TBLK) * 3u;
+    // the block's indices as coalesced dword loads (speculative: in front of the hints and the checks)
+    const uint32_t ne_cap = (slot - t0 < BLK ? slot - t0 : BLK) * 3u;
     const uint32_t *__restrict__ s = idx_all + 3ull * (zr.tbase[r] + t0);
-    uint32_t e[3];
+    uint32_t e[3u * IPT];
 #pragma unroll
-    for (uint32_t j = 0; j < 3u; j++) e[j] = tid + 256u * j < ne_cap ? s[tid + 256u * j] : 0u;
+    for (uint32_t j = 0; j < 3u * IPT; j++) e[j] = tid + 256u * j < ne_cap ? s[tid + 256u * j] : 0u;
     // the columns this block's triangles can fall into: from its own first triangle's to the next block's (k_zs_front's hints)
     uint32_t c_lo = thint[blockIdx.x], c_hi = blockIdx.x + 1u < zr.tblk[r + 1u] ? thint[blockIdx.x + 1u] : NCOL - 1u;
     if (!zs_rows_ok(counts, cstride, zr)) return;
@@ -466,22 +487,26 @@ __global__ __launch_bounds__(256) void k_zs_index_out(const uint32_t *__restrict
     for (uint32_t k = tid; k < w; k += 256u) s_start[k] = tplan[2u * (r * NCOL + c_lo + k)];
     const uint32_t Tr = row_rec(counts, cstride, r, ZR_TRIS), Vr = row_rec(counts, cstride, r, ZR_VERTS), vb = zr.vbase[r];
     if (t0 >= Tr) return;
-    const uint32_t ne = (Tr - t0 < ZS_TBLK ? Tr - t0 : ZS_TBLK) * 3u;
-    uint32_t m[3];
+    const uint32_t ne = (Tr - t0 < BLK ? Tr - t0 : BLK) * 3u;
+    uint32_t m[3u * IPT];
 #pragma unroll
-    for (uint32_t j = 0; j < 3u; j++) m[j] = (tid + 256u * j < ne && e[j] < Vr) ? map[vb + e[j]] : 0u;
+    for (uint32_t j = 0; j < 3u * IPT; j++) m[j] = (tid + 256u * j < ne && e[j] < Vr) ? map[vb + e[j]] : 0u;
     __syncthreads();
-    uint32_t dst = U32_NONE;
-    if (t < Tr) {
-        uint32_t lo = 0, hi = w;                                        // the largest k with s_start[k] <= t
-        while (hi - lo > 1u) { const uint32_t mid = (lo + hi) >> 1; if (s_start[mid] <= t) lo = mid; else hi = mid; }
-        dst = tplan[2u * (r * NCOL + c_lo + lo) + 1u] + (t - s_start[lo]);
-        if (dst >= cap_tris) dst = U32_NONE;                            // flagged by k_zs_front
+#pragma unroll
+    for (uint32_t j = 0; j < IPT; j++) {
+        const uint32_t t = t0 + tid + 256u * j;
+        uint32_t dst = U32_NONE;
+        if (t < Tr) {
+            uint32_t lo = 0, hi = w;                                    // the largest k with s_start[k] <= t
+            while (hi - lo > 1u) { const uint32_t mid = (lo + hi) >> 1; if (s_start[mid] <= t) lo = mid; else hi = mid; }
+            dst = tplan[2u * (r * NCOL + c_lo + lo) + 1u] + (t - s_start[lo]);
+            if (dst >= cap_tris) dst = U32_NONE;                        // flagged by k_zs_front
+        }
+        s_dst[tid + 256u * j] = dst;
     }
-    s_dst[tid] = dst;
     __syncthreads();
 #pragma unroll
-    for (uint32_t j = 0; j < 3u; j++) {
+    for (uint32_t j = 0; j < 3u * IPT; j++) {
         const uint32_t k = tid + 256u * j;
         if (k < ne) { const uint32_t dd = s_dst[k / 3u]; if (dd != U32_NONE) out[3ull * dd + k % 3u] = m[j]; }
     }
@@ -516,11 +541,18 @@ hipError_t launch_zs_merge(hipStream_t st, int grid, const Vertex *v_all, const 
                            hsize, (const uint32_t *) segof, redirect, newcnt, blockdrop);
         hipLaunchKernelGGL(k_zs_vplan, dim3(1), dim3(1024), 0, st, counts, cstride, d_zr, (const uint32_t *) newcnt, vplan, cap_verts, zctl);
     }
-    hipLaunchKernelGGL(k_zs_vertex_out, dim3((zr.vbase[R] + ZS_VBLK - 1u) / ZS_VBLK + 1u), dim3(256), 0, st, v_all, counts, cstride, d_zr, (const uint32_t *) redirect,
-                       (const uint32_t *) segof, (const uint32_t *) vstart, (const uint32_t *) vplan, (const uint32_t *) blockdrop, v_out, cap_verts, map, 0u);
+    const bool big = zr.blk == 1024u;
+    const dim3 vgrid((zr.vbase[R] + zr.blk - 1u) / zr.blk + 1u);
+    if (big) hipLaunchKernelGGL(k_zs_vertex_out<4>, vgrid, dim3(256), 0, st, v_all, counts, cstride, d_zr, (const uint32_t *) redirect, (const uint32_t *) segof,
+                                (const uint32_t *) vstart, (const uint32_t *) vplan, (const uint32_t *) blockdrop, v_out, cap_verts, map, 0u);
+    else hipLaunchKernelGGL(k_zs_vertex_out<1>, vgrid, dim3(256), 0, st, v_all, counts, cstride, d_zr, (const uint32_t *) redirect, (const uint32_t *) segof,
+                            (const uint32_t *) vstart, (const uint32_t *) vplan, (const uint32_t *) blockdrop, v_out, cap_verts, map, 0u);
     if (band) hipLaunchKernelGGL(k_zs_loser_map, dim3(grid), dim3(256), 0, st, counts, cstride, d_zr, (const uint32_t *) redirect, map);
-    hipLaunchKernelGGL(k_zs_index_out, dim3(std::max<uint32_t>(1u, zr.tblk[R])), dim3(256), 0, st, idx_all, counts, cstride, (const uint32_t *) tplan, (const uint32_t *) thint, d_zr,
-                       (const uint32_t *) map, i_out, cap_tris, (const uint32_t *) zctl, seq, pub);
+    const dim3 tgrid(std::max<uint32_t>(1u, zr.tblk[R]));
+    if (big) hipLaunchKernelGGL(k_zs_index_out<4>, tgrid, dim3(256), 0, st, idx_all, counts, cstride, (const uint32_t *) tplan, (const uint32_t *) thint, d_zr,
+                                (const uint32_t *) map, i_out, cap_tris, (const uint32_t *) zctl, seq, pub);
+    else hipLaunchKernelGGL(k_zs_index_out<1>, tgrid, dim3(256), 0, st, idx_all, counts, cstride, (const uint32_t *) tplan, (const uint32_t *) thint, d_zr,
+                            (const uint32_t *) map, i_out, cap_tris, (const uint32_t *) zctl, seq, pub);
     return hipGetLastError();
 }
 
