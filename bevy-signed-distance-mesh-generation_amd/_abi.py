@@ -84,6 +84,16 @@ assert ctypes.sizeof(GlobalsBuffer) == 32 and ctypes.sizeof(CameraBuffer) == 52
 # every symbol include/sdmesh.h declares: name -> (restype, argtypes)
 _vp, _sz, _i, _u32 = ctypes.c_void_p, ctypes.c_size_t, ctypes.c_int, ctypes.c_uint32
 _psz = ctypes.POINTER(ctypes.c_size_t)
+class Transport(ctypes.Structure):
+    """sdmesh_transport (include/sdmesh.h): the caller's collectives, device pointers and the step's stream as plain addresses."""
+    AG = ctypes.CFUNCTYPE(ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p)
+    AR = ctypes.CFUNCTYPE(ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_int, ctypes.c_void_p)
+    SR = ctypes.CFUNCTYPE(ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_int, ctypes.c_void_p)
+    GR = ctypes.CFUNCTYPE(ctypes.c_int, ctypes.c_void_p)
+    _fields_ = [("user", ctypes.c_void_p), ("all_gather", AG), ("all_reduce_u32", AR), ("send", SR), ("recv", SR),
+                ("group_start", GR), ("group_end", GR)]
+
+
 SYMBOLS = {
     "sdmesh_create": (_i, [_i, ctypes.POINTER(_vp)]),
     "sdmesh_destroy": (None, [_vp]),
@@ -115,6 +125,7 @@ SYMBOLS = {
     "sdmesh_comm_init": (_i, [_vp, _vp, _i, _i]),
     "sdmesh_comm_destroy": (_i, [_vp]),
     "sdmesh_comm_ranks": (_i, [_vp, ctypes.POINTER(_i)]),
+    "sdmesh_comm_init_transport": (_i, [_vp, _i, _i, _vp]),
     "sdmesh_set_program_motion": (_i, [_vp, _vp, _i]),
     "sdmesh_set_program_time": (_i, [_vp, ctypes.c_float]),
     "sdmesh_sharded_regen": (_i, [_vp, _i, _i, ctypes.POINTER(RegenInfo)]),

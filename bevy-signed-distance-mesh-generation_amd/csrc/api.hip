@@ -193,7 +193,10 @@ struct sdmesh_handle {
     size_t prof_n = 0;
 
     // multi-GPU: communicator + the buffers of the z-slab gather / merge
-    ncclComm_t comm = nullptr;
+    ncclComm_t comm = nullptr;         // RCCL (sdmesh_comm_init) ...
+    sdmesh_transport ext{};            // ... or the caller's collectives (sdmesh_comm_init_transport)
+    bool comm_ext = false;
+    bool has_comm() const { return comm != nullptr || comm_ext; }
     int comm_rank = 0, comm_nranks = 1;
     DevBuf shard_mine, shard_counts, shard_recv, shard_lists, shard_plan, shard_merged;
     // z-slab INDEXED gather: the ranks' welded buffers in SLOTS of zs_verts / zs_idx (root), the merge's tables, its outputs
@@ -1969,6 +1972,37 @@ const char *load_rccl() {
             return fail(h, SDMESH_ERR_RCCL, "%s failed: %s (%s:%d)", #expr, g_rccl.GetErrorString(r_), __FILE__, __LINE__); \
     } while (0)
 
+// The handle's collectives: RCCL on its communicator, or the caller's transport.  Same semantics either way (ordered on `st` after the work
+// already enqueued there and in front of what follows; all-gather / all-reduce may be in place; send / recv between GroupStart and
+// GroupEnd progress together).  Counts are in elements of `type` (4- or 8-byte ones only).
+inline size_t tp_bytes(size_t count, ncclDataType_t type) { return count * (type == ncclUint64 ? 8u : 4u); }
+int tp_fail(sdmesh_handle *h, const char *what, int rc) { return fail(h, SDMESH_ERR_RCCL, "the caller's transport failed in %s (returned %d)", what, rc); }
+int tp_all_gather(sdmesh_handle *h, const void *send, void *recv, size_t count, ncclDataType_t type, hipStream_t st) {
+    if (h->comm_ext) { const int rc = h->ext.all_gather(h->ext.user, send, recv, tp_bytes(count, type), st); return rc ? tp_fail(h, "all_gather", rc) : SDMESH_OK; }
+    NCCLCHK(g_rccl.AllGather(send, recv, count, type, h->comm, st));
+    return SDMESH_OK;
+}
+int tp_all_reduce_u32(sdmesh_handle *h, const void *send, void *recv, size_t count, bool max_not_sum, hipStream_t st) {
+    if (h->comm_ext) { const int rc = h->ext.all_reduce_u32(h->ext.user, send, recv, count, max_not_sum ? SDMESH_REDUCE_MAX : SDMESH_REDUCE_SUM, st); return rc ? tp_fail(h, "all_reduce_u32", rc) : SDMESH_OK; }
+    NCCLCHK(g_rccl.AllReduce(send, recv, count, ncclUint32, max_not_sum ? ncclMax : ncclSum, h->comm, st));
+    return SDMESH_OK;
+}
+int tp_send(sdmesh_handle *h, const void *buf, size_t count, ncclDataType_t type, int peer, hipStream_t st) {
+    if (h->comm_ext) { const int rc = h->ext.send(h->ext.user, buf, tp_bytes(count, type), peer, st); return rc ? tp_fail(h, "send", rc) : SDMESH_OK; }
+    NCCLCHK(g_rccl.Send(buf, count, type, peer, h->comm, st));
+    return SDMESH_OK;
+}
+int tp_recv(sdmesh_handle *h, void *buf, size_t count, ncclDataType_t type, int peer, hipStream_t st) {
+    if (h->comm_ext) { const int rc = h->ext.recv(h->ext.user, buf, tp_bytes(count, type), peer, st); return rc ? tp_fail(h, "recv", rc) : SDMESH_OK; }
+    NCCLCHK(g_rccl.Recv(buf, count, type, peer, h->comm, st));
+    return SDMESH_OK;
+}
+int tp_group(sdmesh_handle *h, bool start) {
+    if (h->comm_ext) { const int rc = start ? h->ext.group_start(h->ext.user) : h->ext.group_end(h->ext.user); return rc ? tp_fail(h, start ? "group_start" : "group_end", rc) : SDMESH_OK; }
+    if (start) NCCLCHK(g_rccl.GroupStart()); else NCCLCHK(g_rccl.GroupEnd());
+    return SDMESH_OK;
+}
+
 int ensure_grow(sdmesh_handle *h, DevBuf &b, size_t bytes) {      // like ensure(), with 25 % head-room when it has to grow
     if (b.p && b.cap >= bytes) return SDMESH_OK;
     return ensure(h, b, bytes + bytes / 4 + 4096);
@@ -2013,7 +2047,7 @@ int sdmesh_comm_unique_id(sdmesh_unique_id *out) {
 
 int sdmesh_comm_init(sdmesh_handle *h, const sdmesh_unique_id *id, int nranks, int rank) {
     if (!h || !id || nranks < 1 || nranks > 32 || rank < 0 || rank >= nranks) return SDMESH_ERR_INVALID;
-    if (h->comm) return fail(h, SDMESH_ERR_INVALID, "the handle already has a communicator");
+    if (h->has_comm()) return fail(h, SDMESH_ERR_INVALID, "the handle already has a communicator");
     if (const char *why = load_rccl()) return fail(h, SDMESH_ERR_RCCL, "%s", why);
     HIPCHK(hipSetDevice(h->device));
     ncclUniqueId nid;
@@ -2024,8 +2058,25 @@ int sdmesh_comm_init(sdmesh_handle *h, const sdmesh_unique_id *id, int nranks, i
     return SDMESH_OK;
 }
 
+int sdmesh_comm_init_transport(sdmesh_handle *h, int nranks, int rank, const sdmesh_transport *t) {
+    if (!h || !t || nranks < 1 || nranks > 32 || rank < 0 || rank >= nranks) return SDMESH_ERR_INVALID;
+    if (h->has_comm()) return fail(h, SDMESH_ERR_INVALID, "the handle already has a communicator");
+    if (!t->all_gather || !t->all_reduce_u32 || !t->send || !t->recv || !t->group_start || !t->group_end)
+        return fail(h, SDMESH_ERR_INVALID, "sdmesh_comm_init_transport: every entry of the transport must be set");
+    h->ext = *t;
+    h->comm_ext = true;
+    h->comm_rank = rank;
+    h->comm_nranks = nranks;
+    return SDMESH_OK;
+}
+
 int sdmesh_comm_destroy(sdmesh_handle *h) {
     if (!h) return SDMESH_ERR_INVALID;
+    if (h->comm_ext) {
+        (void) hipStreamSynchronize(h->stream);
+        h->comm_ext = false;
+        h->ext = sdmesh_transport{};
+    }
     if (h->comm) {
         (void) hipStreamSynchronize(h->stream);
         (void) g_rccl.CommDestroy(h->comm);
@@ -2038,10 +2089,10 @@ int sdmesh_comm_destroy(sdmesh_handle *h) {
 
 int sdmesh_comm_ranks(sdmesh_handle *h, int *ranks_seen) {
     if (!h || !ranks_seen) return SDMESH_ERR_INVALID;
-    if (!h->comm) return fail(h, SDMESH_ERR_INVALID, "no communicator (sdmesh_comm_init)");
+    if (!h->has_comm()) return fail(h, SDMESH_ERR_INVALID, "no communicator (sdmesh_comm_init)");
     HIPCHK(hipSetDevice(h->device));
     HIPCHK(launch_set_u32(h->stream, h->d_ctr + CTR_SCRATCH, 1u));
-    NCCLCHK(g_rccl.AllReduce(h->d_ctr + CTR_SCRATCH, h->d_ctr + CTR_SCRATCH, 1, ncclUint32, ncclSum, h->comm, h->stream));
+    SDCHK(tp_all_reduce_u32(h, h->d_ctr + CTR_SCRATCH, h->d_ctr + CTR_SCRATCH, 1, false, h->stream));
     uint32_t v = 0;
     HIPCHK(hipMemcpyAsync(&v, h->d_ctr + CTR_SCRATCH, 4, hipMemcpyDeviceToHost, h->stream));
     HIPCHK(hipStreamSynchronize(h->stream));
@@ -2088,7 +2139,7 @@ int peer_failure(sdmesh_handle *h, int R, int me, const uint32_t *rec, uint32_t 
 int agree_flag(sdmesh_handle *h, uint32_t flag, uint32_t *out) {
     hipStream_t st = h->stream;
     HIPCHK(launch_set_u32(st, h->d_ctr + CTR_SCRATCH, flag));
-    NCCLCHK(g_rccl.AllReduce(h->d_ctr + CTR_SCRATCH, h->d_ctr + CTR_SCRATCH, 1, ncclUint32, ncclMax, h->comm, st));
+    SDCHK(tp_all_reduce_u32(h, h->d_ctr + CTR_SCRATCH, h->d_ctr + CTR_SCRATCH, 1, true, st));
     HIPCHK(hipMemcpyAsync(h->h_pinned + CTR_SCRATCH, h->d_ctr + CTR_SCRATCH, 4, hipMemcpyDeviceToHost, st));
     HIPCHK(hipStreamSynchronize(st));
     *out = h->h_pinned[CTR_SCRATCH];
@@ -2252,16 +2303,16 @@ int zs_merge_finish(sdmesh_handle *h, const ZsRanks &zr, const uint32_t *d_count
 struct ZsMsg { void *p; size_t count; ncclDataType_t type; int peer; bool send; };
 int zs_exchange(sdmesh_handle *h, const std::vector<ZsMsg> &msgs) {
     if (msgs.empty()) return SDMESH_OK;
-    ncclResult_t first = g_rccl.GroupStart();
-    if (first != ncclSuccess) return fail(h, SDMESH_ERR_RCCL, "ncclGroupStart failed: %s", g_rccl.GetErrorString(first));
+    SDCHK(tp_group(h, true));
+    int first = SDMESH_OK;
+    std::string why;
     for (const ZsMsg &m : msgs) {
-        const ncclResult_t r = m.send ? g_rccl.Send(m.p, m.count, m.type, m.peer, h->comm, h->stream) : g_rccl.Recv(m.p, m.count, m.type, m.peer, h->comm, h->stream);
-        if (r != ncclSuccess) { first = r; break; }
+        first = m.send ? tp_send(h, m.p, m.count, m.type, m.peer, h->stream) : tp_recv(h, m.p, m.count, m.type, m.peer, h->stream);
+        if (first != SDMESH_OK) { why = h->err; break; }
     }
-    const ncclResult_t end = g_rccl.GroupEnd();
-    if (first == ncclSuccess) first = end;
-    if (first != ncclSuccess) return fail(h, SDMESH_ERR_RCCL, "an RCCL message of the one-mesh exchange failed: %s", g_rccl.GetErrorString(first));
-    return SDMESH_OK;
+    const int end = tp_group(h, false);
+    if (first != SDMESH_OK) return fail(h, first, "%s", why.c_str());          // (the first failure is the one reported)
+    return end;
 }
 
 // this rank's slab, meshed AND welded with the ordinary synchronous regen; the column triangle counts land in `row` (pre-zeroed) on the way
@@ -2295,7 +2346,7 @@ int zs_step_sync(sdmesh_handle *h, int levels, int root, int inject, sdmesh_rege
     // 2. the row's vertex counts and record, then the all-gather -- ALWAYS entered
     HIPCHK(launch_zs_local(st, d_row, nullptr, h->d_ctr + CTR_NTRI, h->d_ctr + CTR_NVERT, h->d_status, (uint32_t) lrc, zs_root_capacity_v(h), zs_root_capacity_t(h),
                            (uint32_t) inject, 0u));
-    NCCLCHK(g_rccl.AllGather(d_row, d_counts, SHARD_ROW, ncclUint32, h->comm, st));                     // in place
+    SDCHK(tp_all_gather(h, d_row, d_counts, SHARD_ROW, ncclUint32, st));                     // in place
     HIPCHK(hipMemcpyAsync(h->h_counts, d_counts, 4ull * (size_t) R * SHARD_ROW, hipMemcpyDeviceToHost, st));
     HIPCHK(hipStreamSynchronize(st));
     // 3. every rank, on the same numbers
@@ -2426,7 +2477,7 @@ int zs_step_planned(sdmesh_handle *h, int levels, int root, int inject, sdmesh_r
                                      is_root ? (IndexTriangle *) h->zs_idx.p + zr.tbase[me] : nullptr, inject, d_row, d_next, &slab);
     if (lrc == SDMESH_ERR_HIP) return lrc;                                  // (the enqueue itself failed: nothing sane can follow)
     const uint32_t seq = ++h->zs_seq;
-    NCCLCHK(g_rccl.AllGather(d_row, d_counts, SHARD_ROW, ncclUint32, h->comm, st));                     // in place
+    SDCHK(tp_all_gather(h, d_row, d_counts, SHARD_ROW, ncclUint32, st));                     // in place
     std::vector<ZsMsg> msgs;
     if (!is_root) {
         msgs.push_back({h->vertices.p, (size_t) pl.cap_v[me] * 6, ncclFloat32, root, true});
@@ -2483,7 +2534,7 @@ int sdmesh_sharded_route(const sdmesh_handle *h) { return h ? (int) h->zs_last_r
 int sdmesh_sharded_regen(sdmesh_handle *h, int levels, int root, sdmesh_regen_info *info) {
     if (!h) return SDMESH_ERR_INVALID;
     // (argument errors are found before any communication: they must be the same on every rank, like the arguments)
-    if (!h->comm) return fail(h, SDMESH_ERR_INVALID, "no communicator (sdmesh_comm_init)");
+    if (!h->has_comm()) return fail(h, SDMESH_ERR_INVALID, "no communicator (sdmesh_comm_init)");
     const int R = h->comm_nranks, me = h->comm_rank;
     if (root < 0 || root >= R) return fail(h, SDMESH_ERR_INVALID, "root %d outside the communicator", root);
     if (h->shard_indexed) return sharded_regen_indexed(h, levels, root, info);
@@ -2528,7 +2579,7 @@ int sdmesh_sharded_regen(sdmesh_handle *h, int levels, int root, sdmesh_regen_in
                               cap_items(h->shard_merged, sizeof(Triangle))));
     // (k_pack_record writes {v0, v1 | status, v2, v3}: word 0 = status, word 1 = triangles here)
     HIPCHK(launch_pack_record(st, d_row + SHARD_REC + 4, nullptr, nullptr, 0u, 0u, (uint32_t) inject, 0u));     // {vertices: none, raw form, inject}
-    NCCLCHK(g_rccl.AllGather(d_row, d_counts, SHARD_ROW, ncclUint32, h->comm, st));                     // in place
+    SDCHK(tp_all_gather(h, d_row, d_counts, SHARD_ROW, ncclUint32, st));                     // in place
     HIPCHK(hipMemcpyAsync(h->h_counts, d_counts, 4ull * (size_t) R * SHARD_ROW, hipMemcpyDeviceToHost, st));
     HIPCHK(hipStreamSynchronize(st));
     // 3. every rank, on the same numbers: did anybody fail, do the counts add up, does the mesh fit one weld
@@ -2563,7 +2614,7 @@ int sdmesh_sharded_regen(sdmesh_handle *h, int levels, int root, sdmesh_regen_in
     }
     if (me != root) {
         // 5a. peers: the slab's triangles go straight to the root (each peer on its own xGMI link)
-        if (n_mine) NCCLCHK(g_rccl.Send(h->shard_mine.p, (size_t) n_mine * 18, ncclFloat32, root, h->comm, st));
+        if (n_mine) SDCHK(tp_send(h, h->shard_mine.p, (size_t) n_mine * 18, ncclFloat32, root, st));
         HIPCHK(hipStreamSynchronize(st));
         if (info) *info = slab;
         return SDMESH_OK;
@@ -2886,8 +2937,6 @@ int dist_phase_final(sdmesh_handle *h, int me, uint32_t cap_prev) {
                                 cap_items(h->indices, sizeof(IndexTriangle)), (const uint32_t *) h->dist_dupof.p, (const uint32_t *) h->dist_newidx.p,
                                 (const uint32_t *) h->dist_prevg.p, cap_prev, (const uint32_t *) h->dist_counts.p, (uint32_t) me, (uint32_t *) h->indices.p,
                                 (Vertex *) h->dist_verts.p));
-    h->res_v = (Vertex *) h->dist_verts.p;                 // the compacted list is the handle's vertex buffer now (the indices were rewritten in place)
-    h->res_i = nullptr;
     return SDMESH_OK;
 }
 
@@ -2897,6 +2946,10 @@ int dist_finish_host(sdmesh_handle *h, int R, int me, const uint32_t *counts /* 
     for (int r = 0; r < me; r++) off += counts[r];
     h->n_verts = counts[me];
     h->mesh_valid = true;
+    // the compacted list is the handle's vertex buffer now, the indices were rewritten in place (set HERE, behind the end of the slab's own
+    // regen, which clears the result pointers: found by the first run of the planned route between two real ranks)
+    h->res_v = (Vertex *) h->dist_verts.p;
+    h->res_i = nullptr;
     if (info) { *info = slab; info->vertices = counts[me]; }
     if (first_vertex) *first_vertex = off;
     (void) R;
@@ -2924,7 +2977,7 @@ int dist_step_sync(sdmesh_handle *h, int levels, sdmesh_regen_info *info, uint32
     //    lower neighbour without growing -- ALWAYS entered
     uint32_t *d_nups = (uint32_t *) h->dist_nups.p, *d_counts = (uint32_t *) h->dist_counts.p;
     HIPCHK(launch_dist_record(st, d_nups + (size_t) me * DIST_REC, h->d_ctr + CTR_DIST_NUP, nullptr, (uint32_t) lrc, dist_prev_capacity(h), (uint32_t) inject, 0u));
-    NCCLCHK(g_rccl.AllGather(d_nups + (size_t) me * DIST_REC, d_nups, DIST_REC, ncclUint32, h->comm, st));        // in place
+    SDCHK(tp_all_gather(h, d_nups + (size_t) me * DIST_REC, d_nups, DIST_REC, ncclUint32, st));        // in place
     uint32_t *rec = h->h_counts;
     HIPCHK(hipMemcpyAsync(rec, d_nups, 4ull * (size_t) R * DIST_REC, hipMemcpyDeviceToHost, st));
     HIPCHK(hipStreamSynchronize(st));
@@ -2963,7 +3016,7 @@ int dist_step_sync(sdmesh_handle *h, int levels, sdmesh_regen_info *info, uint32
     // 4. kept counts of every rank (stay on the device for the kernels) + each rank's device status: a vertex outside the
     //    packed key range on ONE rank fails the call on ALL of them
     HIPCHK(launch_dist_record(st, d_counts + (size_t) me * DIST_REC, h->d_ctr + CTR_DIST_NKEEP, h->d_status, 0u, 0u, 0u, 0u));
-    NCCLCHK(g_rccl.AllGather(d_counts + (size_t) me * DIST_REC, d_counts, DIST_REC, ncclUint32, h->comm, st));
+    SDCHK(tp_all_gather(h, d_counts + (size_t) me * DIST_REC, d_counts, DIST_REC, ncclUint32, st));
     SDCHK(dist_phase_pack(h, me, d_nups + (size_t) me * DIST_REC, n_up));
     {
         std::vector<ZsMsg> msgs;
@@ -3004,7 +3057,7 @@ int dist_step_planned(sdmesh_handle *h, int levels, sdmesh_regen_info *info, uin
     if (lrc == SDMESH_ERR_HIP) return lrc;
     const uint32_t seq = ++h->zs_seq;
     HIPCHK(launch_dist_record(st, d_nups + (size_t) me * DIST_REC, h->d_ctr + CTR_DIST_NUP, h->d_status, (uint32_t) lrc, dist_prev_capacity(h), (uint32_t) inject, pl.sig));
-    NCCLCHK(g_rccl.AllGather(d_nups + (size_t) me * DIST_REC, d_nups, DIST_REC, ncclUint32, h->comm, st));        // in place
+    SDCHK(tp_all_gather(h, d_nups + (size_t) me * DIST_REC, d_nups, DIST_REC, ncclUint32, st));        // in place
     {
         std::vector<ZsMsg> msgs;                               // plan-sized messages (the real counts are in the records)
         if (me + 1 < R && cap_up) msgs.push_back({h->dist_upkeys.p, cap_up, ncclUint64, me + 1, true});
@@ -3015,7 +3068,7 @@ int dist_step_planned(sdmesh_handle *h, int levels, sdmesh_regen_info *info, uin
         SDCHK(dist_phase_match(h, me > 0 ? d_nups + (size_t) (me - 1) * DIST_REC : d_nups, cap_prev));
     }
     HIPCHK(launch_dist_record(st, d_counts + (size_t) me * DIST_REC, h->d_ctr + CTR_DIST_NKEEP, h->d_status, (uint32_t) lrc, 0u, 0u, pl.sig));
-    NCCLCHK(g_rccl.AllGather(d_counts + (size_t) me * DIST_REC, d_counts, DIST_REC, ncclUint32, h->comm, st));
+    SDCHK(tp_all_gather(h, d_counts + (size_t) me * DIST_REC, d_counts, DIST_REC, ncclUint32, st));
     if (lrc == SDMESH_OK) SDCHK(dist_phase_pack(h, me, d_nups + (size_t) me * DIST_REC, me + 1 < R ? cap_up : 0u));
     {
         std::vector<ZsMsg> msgs;
@@ -3051,7 +3104,7 @@ extern "C" {
 
 int sdmesh_distributed_regen(sdmesh_handle *h, int levels, sdmesh_regen_info *info, uint32_t *first_vertex) {
     if (!h) return SDMESH_ERR_INVALID;
-    if (!h->comm) return fail(h, SDMESH_ERR_INVALID, "no communicator (sdmesh_comm_init)");
+    if (!h->has_comm()) return fail(h, SDMESH_ERR_INVALID, "no communicator (sdmesh_comm_init)");
     const int R = h->comm_nranks;
     SDCHK(dist_scratch(h));                                    // (before anything can fail on one rank only, see peer_failure)
     SDCHK(ensure_shard_host(h, R));                            // pinned landing zone of the records (>= 32 x DIST_REC words)

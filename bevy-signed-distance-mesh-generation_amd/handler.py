@@ -355,9 +355,33 @@ class CudaHandler:
         self._chk(self._lib.sdmesh_comm_init(self._h, buf, int(nranks), int(rank)))
         self.comm = (int(nranks), int(rank))
 
+    def comm_init_transport(self, nranks, rank, transport):
+        """The caller's collectives instead of RCCL (sdmesh_comm_init_transport): `transport` has all_gather(send, recv, nbytes, stream),
+        all_reduce_u32(send, recv, count, op, stream), send(buf, nbytes, peer, stream), recv(buf, nbytes, peer, stream), group_start(),
+        group_end() -- device addresses and the stream as ints.  An exception inside one of them fails the step (SDMESH_ERR_RCCL) and is
+        kept in `transport_error`."""
+        T = _abi.Transport
+        self.transport_error = None
+
+        def guarded(fn):
+            def call(_user, *args):
+                try:
+                    fn(*[0 if a is None else a for a in args])
+                    return 0
+                except BaseException as e:                  # (an exception cannot cross the C frames)
+                    self.transport_error = e
+                    return 1
+            return call
+        t = T(None, T.AG(guarded(transport.all_gather)), T.AR(guarded(transport.all_reduce_u32)), T.SR(guarded(transport.send)),
+              T.SR(guarded(transport.recv)), T.GR(guarded(transport.group_start)), T.GR(guarded(transport.group_end)))
+        self._chk(self._lib.sdmesh_comm_init_transport(self._h, int(nranks), int(rank), ctypes.byref(t)))
+        self._transport = (t, transport)                    # the callbacks live as long as the communicator
+        self.comm = (int(nranks), int(rank))
+
     def comm_destroy(self):
         self._chk(self._lib.sdmesh_comm_destroy(self._h))
         self.comm = None
+        self._transport = None
 
     def ensure_comm(self, dist, nranks, rank):
         """The handle's RCCL communicator over the ranks of the current torch.distributed job (made once per handle; the

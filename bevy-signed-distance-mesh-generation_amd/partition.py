@@ -396,3 +396,96 @@ class DistributedMesher:
             vs.append(self._recv(src, torch.float32).reshape(-1, 6))
             ts.append(self._recv(src, torch.int32).reshape(-1, 3))
         return torch.cat(vs), torch.cat(ts)
+
+
+class _RawDevice:
+    """`nbytes` of device memory at `ptr` for torch.as_tensor (no copy, no ownership)."""
+
+    def __init__(self, ptr, nbytes):
+        self.__cuda_array_interface__ = {"shape": (int(nbytes),), "typestr": "|u1", "data": (int(ptr), False), "version": 2}
+
+
+class StagedTransport:
+    """An sdmesh_transport (include/sdmesh.h, CudaHandler.comm_init_transport) over a torch.distributed group with HOST staging: every
+    operation synchronises the step's stream, moves the bytes through pageable host memory and the group's own backend (gloo), and copies
+    them back before it returns.  It is what lets sdmesh_sharded_regen / sdmesh_distributed_regen -- the very C++ steps that run over RCCL --
+    run between processes that share one GPU, where RCCL refuses duplicate devices: tests use it; a real job uses RCCL (comm_init)."""
+
+    def __init__(self, dist, device, group=None):
+        self.dist, self.device, self.group = dist, device, group
+        self.rank, self.world = dist.get_rank(group), dist.get_world_size(group)
+        self.queue = None
+        self.calls = {"all_gather": 0, "all_reduce_u32": 0, "send": 0, "recv": 0, "groups": 0, "bytes_sent": 0}
+
+    def _view(self, ptr, nbytes):
+        return torch.as_tensor(_RawDevice(ptr, nbytes), device=self.device)
+
+    def _stream(self, stream):
+        return torch.cuda.ExternalStream(stream, device=self.device) if stream else torch.cuda.default_stream(self.device)
+
+    def _down(self, ptr, nbytes, stream):
+        st = self._stream(stream)
+        with torch.cuda.stream(st):
+            host = self._view(ptr, nbytes).cpu()
+        st.synchronize()
+        return host
+
+    def _up(self, ptr, host, stream):
+        st = self._stream(stream)
+        with torch.cuda.stream(st):
+            self._view(ptr, host.numel()).copy_(host)
+        st.synchronize()
+
+    def all_gather(self, send, recv, nbytes, stream):
+        self.calls["all_gather"] += 1
+        mine = self._down(send, nbytes, stream)
+        parts = [torch.empty(nbytes, dtype=torch.uint8) for _ in range(self.world)]
+        self.dist.all_gather(parts, mine, group=self.group)
+        self._up(recv, torch.cat(parts), stream)
+
+    def all_reduce_u32(self, send, recv, count, op, stream):
+        self.calls["all_reduce_u32"] += 1
+        v = self._down(send, 4 * count, stream).view(torch.int32).to(torch.int64) & 0xFFFFFFFF
+        self.dist.all_reduce(v, op=self.dist.ReduceOp.MAX if op == 1 else self.dist.ReduceOp.SUM, group=self.group)
+        self._up(recv, (v & 0xFFFFFFFF).to(torch.int32).view(torch.uint8), stream)
+
+    def group_start(self):
+        if self.queue is not None:
+            raise RuntimeError("nested group")
+        self.queue = []
+
+    def group_end(self):
+        q, self.queue = self.queue, None
+        self.calls["groups"] += 1
+        self._run(q)
+
+    def send(self, buf, nbytes, peer, stream):
+        self.calls["send"] += 1
+        self.calls["bytes_sent"] += nbytes
+        op = ("send", buf, nbytes, peer, stream)
+        if self.queue is None:
+            self._run([op])
+        else:
+            self.queue.append(op)
+
+    def recv(self, buf, nbytes, peer, stream):
+        self.calls["recv"] += 1
+        op = ("recv", buf, nbytes, peer, stream)
+        if self.queue is None:
+            self._run([op])
+        else:
+            self.queue.append(op)
+
+    def _run(self, ops):
+        reqs, landed = [], []
+        for kind, buf, nbytes, peer, stream in ops:             # every message of a group is posted before any is waited for
+            if kind == "send":
+                reqs.append(self.dist.isend(self._down(buf, nbytes, stream), peer, group=self.group))
+            else:
+                host = torch.empty(nbytes, dtype=torch.uint8)
+                reqs.append(self.dist.irecv(host, peer, group=self.group))
+                landed.append((buf, host, stream))
+        for r in reqs:
+            r.wait()
+        for buf, host, stream in landed:
+            self._up(buf, host, stream)

@@ -265,6 +265,27 @@ int sdmesh_comm_destroy(sdmesh_handle *h);
 /* ncclAllReduce(sum) of 1 over the communicator: how many ranks really took part */
 int sdmesh_comm_ranks(sdmesh_handle *h, int *ranks_seen);
 
+/* The caller's own collectives instead of RCCL (MPI, UCX, a host-staged test transport ...): the six operations the one-mesh steps
+ * use, with RCCL's meaning.  Every buffer is a DEVICE pointer of this handle's GPU; `stream` is the hipStream_t the step runs on: an
+ * operation takes effect after the work already enqueued there and before the work enqueued afterwards (a host-staged transport
+ * synchronises the stream, moves the bytes and returns; a stream-aware one enqueues).  all_gather: `bytes` per rank, rank r's block at
+ * recv + r * bytes, and send may BE that block (in place).  all_reduce_u32: `count` 32-bit unsigned words, op = SDMESH_REDUCE_*; send may
+ * equal recv.  send / recv between group_start and group_end must make progress together (a root receives from every peer in one
+ * group; the x-slab weld's neighbours send up and receive from below in one).  Return 0, or non-zero: the step then fails with
+ * SDMESH_ERR_RCCL and the value in sdmesh_last_error.  sdmesh_sharded_regen and sdmesh_distributed_regen run unchanged over it, both
+ * routes.  The struct is copied; `user` must outlive the communicator (sdmesh_comm_destroy). */
+enum { SDMESH_REDUCE_SUM = 0, SDMESH_REDUCE_MAX = 1 };
+typedef struct sdmesh_transport {
+    void *user;
+    int (*all_gather)(void *user, const void *send, void *recv, size_t bytes, void *stream);
+    int (*all_reduce_u32)(void *user, const void *send, void *recv, size_t count, int op, void *stream);
+    int (*send)(void *user, const void *buf, size_t bytes, int peer, void *stream);
+    int (*recv)(void *user, void *buf, size_t bytes, int peer, void *stream);
+    int (*group_start)(void *user);
+    int (*group_end)(void *user);
+} sdmesh_transport;
+int sdmesh_comm_init_transport(sdmesh_handle *h, int nranks, int rank, const sdmesh_transport *transport);
+
 /* ONE regen of ONE mesh over all ranks of the communicator, entirely behind this call.
  * Indexed form (default): rank r meshes AND welds level-0 z-slab r, ncclAllGather of the 1024 per-column triangle counts, the 1024
  * per-column first-seen vertex counts, sizes and status (8 KB), grouped ncclSend / ncclRecv of the slab's vertex and index buffers (24 B per vertex + 12 B per triangle) straight to
