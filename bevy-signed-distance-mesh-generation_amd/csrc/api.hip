@@ -2946,8 +2946,8 @@ int dist_finish_host(sdmesh_handle *h, int R, int me, const uint32_t *counts /* 
     for (int r = 0; r < me; r++) off += counts[r];
     h->n_verts = counts[me];
     h->mesh_valid = true;
-    // the compacted list is the handle's vertex buffer now, the indices were rewritten in place (set HERE, behind the end of the slab's own
-    // regen, which clears the result pointers: found by the first run of the planned route between two real ranks)
+    // the compacted list is the handle's vertex buffer now, the indices were rewritten in place (set here, behind the end of the slab's own
+    // regen, which clears the result pointers)
     h->res_v = (Vertex *) h->dist_verts.p;
     h->res_i = nullptr;
     if (info) { *info = slab; info->vertices = counts[me]; }
