@@ -177,7 +177,7 @@ def single_gpu_step_times(pkg, local_rank, scene, params, levels_list, graph, re
     return out
 
 
-def one_mesh_legs(pkg, job, local_rank, scene, params, levels_list, base_levels, steps, warmup, graph):
+def one_mesh_legs(pkg, job, local_rank, scene, params, levels_list, base_levels, steps, warmup, graph, rehearse=False):
     """ONE mesh over all ranks, both forms, every size; plus the primary timing (the faster form at the workload size)."""
     from bevy_signed_distance_mesh_generation_amd import partition as P
     world, rank = job.world, job.rank
@@ -189,7 +189,7 @@ def one_mesh_legs(pkg, job, local_rank, scene, params, levels_list, base_levels,
         t1 = box[0]
     # --- z-slabs welded per rank, RCCL gather of the vertex / index buffers to rank 0, indexed merge there: all inside sdmesh_sharded_regen
     h = pkg.CudaHandler(local_rank, scene, params)
-    mesher = P.ShardedMesher(pkg, h, base_levels, rank, world, dev, transport="rccl")
+    mesher = P.ShardedMesher(pkg, h, base_levels, rank, world, dev, transport="collectives" if rehearse else "rccl")
     ranks_seen = mesher.ranks_seen
     zbounds, xbounds = mesher.bounds, None
     zslab, primary = {}, None
@@ -219,7 +219,7 @@ def one_mesh_legs(pkg, job, local_rank, scene, params, levels_list, base_levels,
     h = pkg.CudaHandler(local_rank, scene, params)
     xslab = {}
     for lv in levels_list:
-        dm = P.DistributedMesher(pkg, h, lv, rank, world, dev)
+        dm = P.DistributedMesher(pkg, h, lv, rank, world, dev, collectives=rehearse)
         xbounds = dm.bounds
         dm.step()
         k, w = (steps, warmup) if lv == base_levels else (max(3, min(20, steps // 4)), 2)
@@ -627,6 +627,9 @@ def main():
                          "other mode is reported beside it either way, and BASELINE configs[4] is reported with the graph)")
     ap.set_defaults(graph=False)
     ap.add_argument("--one-mesh-selftest", action="store_true", help="run the N > 1 one-mesh legs on 1 GPU (degenerate, for testing)")
+    ap.add_argument("--rehearse-on-one-gpu", action="store_true",
+                    help="N > 1 ranks that all use GPU 0 (process group gloo, the library's collectives host-staged instead of RCCL, which refuses "
+                         "duplicate devices): runs every line of the N > 1 path for testing; its timings mean nothing and the line says so")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -638,12 +641,17 @@ def main():
         args.gpus = world
     if not torch.cuda.is_available():
         sys.exit("bench.py: no GPU visible -- the product path has no CPU fallback")
+    if args.rehearse_on_one_gpu:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     job = Job(world, rank)
     if world > 1:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         job.arm_watchdog(180, "process group initialisation")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if args.rehearse_on_one_gpu:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
         job.disarm_watchdog()
 
     pkg = sdmesh_pkg.load()
@@ -657,7 +665,8 @@ def main():
         # 256^3 (one level below the workload) ... 4096^3: the sizes the north star names and the ones where one mesh can scale
         levels_list = [lv for lv in range(max(0, args.levels - 1), max(args.levels, args.max_levels) + 1)]
         job.arm_watchdog(900, "one-mesh legs (z-slab RCCL gather / x-slab distributed weld)")
-        primary, one_mesh = one_mesh_legs(pkg, job, local_rank, args.scene, params, levels_list, args.levels, args.steps, args.warmup, args.graph)
+        primary, one_mesh = one_mesh_legs(pkg, job, local_rank, args.scene, params, levels_list, args.levels, args.steps, args.warmup, args.graph,
+                                          rehearse=args.rehearse_on_one_gpu)
         job.disarm_watchdog()
         dt, k, tris, verts, form = primary
         out = {
@@ -674,6 +683,8 @@ def main():
             "mtris_per_s": round(tris * k / dt / 1e6, 2), "triangles": tris, "vertices": verts,
             "ranks_seen": one_mesh["ranks_seen"], "one_mesh": one_mesh,
         }
+        if args.rehearse_on_one_gpu:
+            out["rehearsal"] = "all ranks on ONE GPU over a host-staged transport: a test of the N > 1 code path, NOT a measurement"
         job.arm_watchdog(300, "sharded dense P1 leg")
         out["dense_p1_sharded"] = dense_p1_sharded_leg(pkg, job, local_rank, args.scene, params)
         job.disarm_watchdog()

@@ -383,13 +383,18 @@ class CudaHandler:
         self.comm = None
         self._transport = None
 
-    def ensure_comm(self, dist, nranks, rank):
+    def ensure_comm(self, dist, nranks, rank, staged_device=None):
         """The handle's RCCL communicator over the ranks of the current torch.distributed job (made once per handle; the
-        process group only carries the 128-byte unique id)."""
+        process group only carries the 128-byte unique id).  With `staged_device`: the caller's collectives instead, host-staged through
+        the process group itself (partition.StagedTransport)."""
         if getattr(self, "comm", None) == (int(nranks), int(rank)):
             return
         if getattr(self, "comm", None) is not None:
             self.comm_destroy()
+        if staged_device is not None:
+            from .partition import StagedTransport
+            self.comm_init_transport(nranks, rank, StagedTransport(dist, staged_device))
+            return
         uid = [CudaHandler.comm_unique_id() if rank == 0 else None]
         if nranks > 1:
             dist.broadcast_object_list(uid, src=0)

@@ -160,8 +160,11 @@ class ShardedMesher:
         if transport is None:
             transport = "staged" if (world > 1 and dist.get_backend() == "gloo") else "rccl"
         self.transport = transport
-        if transport == "rccl":
-            handler.ensure_comm(dist, world, rank)
+        # "rccl": sdmesh_sharded_regen over the library's RCCL communicator; "collectives": the same C++ step over the caller's collectives
+        # (StagedTransport: host staging through this process group -- several ranks on one GPU); "staged": the protocol in Python, below
+        self.in_library = transport in ("rccl", "collectives")
+        if self.in_library:
+            handler.ensure_comm(dist, world, rank, staged_device=device if transport == "collectives" else None)
             self.ranks_seen = handler.comm_ranks()
             if self.ranks_seen != world:
                 raise RuntimeError(f"RCCL communicator saw {self.ranks_seen} ranks, expected {world}")
@@ -175,12 +178,12 @@ class ShardedMesher:
             self.row = torch.zeros(handler.ZSLAB_ROW_WORDS, dtype=torch.int32, device=device)
 
     def close(self):
-        if self.transport == "rccl" and self.h.comm is not None:
+        if self.in_library and self.h.comm is not None:
             self.h.comm_destroy()
 
     def step(self):
         """One sharded regen.  Returns the root's sdmesh_regen_info of the welded mesh (None on the other ranks)."""
-        if self.transport == "rccl":
+        if self.in_library:
             info = self.h.sharded_regen(self.levels, 0)
             return info if self.rank == 0 else None
         return self._step_staged_indexed() if self.indexed else self._step_staged()
@@ -280,16 +283,17 @@ class DistributedMesher:
          concatenates the parts on the root -- no root-side weld, nothing proportional to the whole mesh is re-hashed.
     Transport as in ShardedMesher: the current process group ("nccl" direct, "gloo" staged through host memory)."""
 
-    def __init__(self, pkg, handler, levels, rank, world, device, balance=True, bounds=None):
+    def __init__(self, pkg, handler, levels, rank, world, device, balance=True, bounds=None, collectives=False):
         import torch.distributed as dist
         self.pkg, self.h, self.levels, self.rank, self.world, self.dev, self.dist = pkg, handler, levels, rank, world, device, dist
         self.staged = world > 1 and dist.get_backend() == "gloo"
+        self.collectives = collectives           # sdmesh_distributed_regen over StagedTransport instead of RCCL (several ranks on one GPU)
         size = torch.tensor(5.0, dtype=torch.float32) / torch.tensor(float(INIT_FACTOR << levels), dtype=torch.float32)
         if bounds is None and balance and handler is not None and world > 1:
             # slabs of equal surface content instead of equal thickness (every rank derives the same table from the scene)
             bounds = handler.balance_slabs(pkg.PART_XSLAB, world, min(levels, 3))
         self.bounds = bounds
-        self.native = handler is not None and (world == 1 or dist.get_backend() != "gloo")
+        self.native = handler is not None and (world == 1 or dist.get_backend() != "gloo" or collectives)
         lo, hi = (bounds[rank], bounds[rank + 1]) if bounds is not None else slab_bounds(rank, world)
         self.band = 2.5 * float(size)      # a projected vertex stays within ~a voxel diagonal of its lattice edge
         self.x_lo = -2.5 + 5.0 * lo / INIT_FACTOR
@@ -321,7 +325,7 @@ class DistributedMesher:
         rehearsed on one GPU) the same face exchange runs as torch index arithmetic with a host-staged transport
         (`exchange` below, also what the no-GPU tests drive with the oracle standing in for the kernels)."""
         if self.native:
-            self.h.ensure_comm(self.dist, self.world, self.rank)
+            self.h.ensure_comm(self.dist, self.world, self.rank, staged_device=self.dev if self.collectives else None)
             _, first = self.h.distributed_regen(self.levels)
             verts, tris = self.h.device_mesh_tensors(self.dev)
             return verts, tris, first

@@ -66,3 +66,28 @@ def test_one_mesh_line_keeps_the_contract_on_one_rank():
             row = d[size][sc]
             assert row["peak"] == 8000.0 and 0.0 < row["frac"] < 1.0 and row["t_1rank_ms"] > 0 and row["ms_per_pass"] > 0
     assert d["512^3"]["sphere"]["planes_of_rank0"] == [0, 513]
+
+
+@pytest.mark.gpu
+def test_the_multi_rank_bench_path_runs_as_the_driver_launches_it():
+    """`python -m torch.distributed.run --nproc-per-node 3 bench.py --gpus 3 ...` exactly as the driver starts it, except that all three ranks use
+    GPU 0 (`--rehearse-on-one-gpu`: process group gloo, the library's collectives host-staged instead of RCCL, which refuses duplicate
+    devices).  Every line of the N > 1 path runs -- slab balancing, sdmesh_sharded_regen and sdmesh_distributed_regen between real
+    processes, the count checks against the 1-GPU mesh, the dense P1 slabs, the replicas, the one JSON line on rank 0 -- and the line says
+    that its timings are not a measurement."""
+    port = 29800 + os.getpid() % 150
+    p = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "3", "--master-addr", "127.0.0.1",
+                        "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "3", "--steps", "6", "--warmup", "2",
+                        "--rehearse-on-one-gpu", "--max-levels", "4"], cwd=ROOT, capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0, p.stderr[-3000:]
+    lines = [l for l in p.stdout.splitlines() if l.strip().startswith("{")]
+    assert len(lines) == 1, p.stdout[-2000:]
+    j = json.loads(lines[0])
+    for k in REQUIRED:
+        assert k in j, k
+    assert j["n_gpus"] == 3 and j["ranks_seen"] == 3 and j["scaling"] == "strong" and "NOT a measurement" in j["rehearsal"]
+    assert j["config"]["one_mesh_form"] == "zslab_indexed_gather" and (j["triangles"], j["vertices"]) == (530536, 265262)
+    for form in ("zslab_indexed_gather", "xslab_distributed_weld"):
+        assert j["one_mesh"][form]["512^3"]["triangles"] == 530536 and j["one_mesh"][form]["256^3"]["route"].startswith("planned")
+    assert len(j["one_mesh"]["slab_bounds"]["z"]) == 4 and j["replicas"]["ms_per_step"] > 0
+    assert j["dense_p1_sharded"]["512^3"]["sphere"]["planes_of_rank0"] == [0, 171]
