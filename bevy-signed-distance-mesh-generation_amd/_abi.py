@@ -24,7 +24,7 @@ MESH_GENERATION_INIT_FACTOR = 32
 MESH_GENERATION_BB_SIZE = 5.0
 MAX_LEVELS = 15
 
-SCENES = {"sdobj": 0, "sphere": 1, "csg3": 2, "anim": 3}
+SCENES = {"sdobj": 0, "sphere": 1, "csg3": 2, "anim": 3, "bulb": 5}         # (4 is the runtime program: set_program)
 OPS = {"sphere": 1, "box": 2, "box_skeleton": 3, "capsule": 4, "torus_y": 5, "ray": 6, "simple_box": 7, "simple_bounding_box": 8, "wrap": 9}
 COMBINES = {"set": 0, "min": 1, "max": 2, "smooth_min": 3, "subtract": 4}
 INSTR = np.dtype([("op", "<u4"), ("combine", "<u4"), ("k", "<f4"), ("a", "<f4", (7,))])

@@ -655,7 +655,7 @@ int refine_level(sdmesh_handle *h, int L, uint32_t n_cap_in, uint32_t out_cap, P
     const uint32_t *n_in = h->d_ctr + CTR_LEVEL0 + L;
     uint32_t *n_out = h->d_ctr + CTR_LEVEL0 + L + 1;
     // 1 = one lane per parent (compiled scenes), else the 32-lane kernel with that parent chunk
-    const int mask_mode = (h->mask_lanes == 1 || (h->mask_lanes == 0 && h->scene != SCENE_PROGRAM)) ? 1 : h->mask_chunk;
+    const int mask_mode = (h->mask_lanes == 1 || (h->mask_lanes == 0 && h->scene != SCENE_PROGRAM && h->scene != SCENE_BULB)) ? 1 : h->mask_chunk;
     uint32_t *signs = nullptr;
     if (mesh_tilecnt) {                 // last level of a planned chain: emit the cube indices too (buffers presized)
         SDCHK(ensure(h, h->signs, 4ull * n_cap_in));
@@ -817,7 +817,17 @@ void drop_graph(sdmesh_handle *h) {
 
 // phase 0: whole regen; 1: begin (enqueue the planned chain and return without waiting; without a plan only the request
 // is recorded); 2: end (wait, validate, fall back to the synchronous path if a capacity was exceeded)
+// SDMESH_SCENE_MANDELBULB is a FIELD scene: dense sampling and the preview take it, the mesh path does not -- the reference's Newton
+// projection (signed_distance.cu:227-240: up to 10 000 steps of seven evaluations per vertex) does not converge on a distance ESTIMATE
+// (measured with the oracle: more than half of the 32^3 level's vertices run past 16 steps, thousands to the limit; minutes per level)
+int mesh_scene_ok(sdmesh_handle *h) {
+    if (h->scene != SCENE_BULB) return SDMESH_OK;
+    return fail(h, SDMESH_ERR_INVALID, "SDMESH_SCENE_MANDELBULB is a field scene (sdmesh_sample_dense*, sdmesh_render*): the reference's surface "
+                                       "projection does not converge on a distance estimate, so it is not meshed");
+}
+
 int regen_impl(sdmesh_handle *h, int levels, int mode, int part, int nparts, sdmesh_regen_info *info, int phase = 0) {
+    if (phase != 2) SDCHK(mesh_scene_ok(h));
     if (!h) return SDMESH_ERR_INVALID;
     if (phase == 2) {
         if (!h->pend_active) return fail(h, SDMESH_ERR_INVALID, "sdmesh_regen_end without sdmesh_regen_begin");
@@ -1187,11 +1197,15 @@ const char *sdmesh_last_error(const sdmesh_handle *h) { return h ? h->err : "nul
 
 int sdmesh_set_scene(sdmesh_handle *h, int scene, const float *params, int nparams) {
     if (!h) return SDMESH_ERR_INVALID;
-    if (scene < 0 || scene >= SCENE_PROGRAM) return fail(h, SDMESH_ERR_INVALID, "unknown scene %d (programs: sdmesh_set_program)", scene);
+    if (scene < 0 || scene >= SCENE_COUNT || scene == SCENE_PROGRAM) return fail(h, SDMESH_ERR_INVALID, "unknown scene %d (programs: sdmesh_set_program)", scene);
     if (nparams < 0 || nparams > 4 || (nparams > 0 && !params)) return fail(h, SDMESH_ERR_INVALID, "bad scene params");
     h->scene = scene;
     h->sp.ninstr = 0;
     for (int i = 0; i < 4; i++) h->sp.p[i] = i < nparams ? params[i] : 0.0f;
+    if (scene == SCENE_BULB) {
+        if (nparams < 1) h->sp.p[0] = 1.0f;                    // scale (sd_unit_mandelbulb's 0.4 is params = {0.4})
+        if (!(h->sp.p[0] > 0.0f)) return fail(h, SDMESH_ERR_INVALID, "SDMESH_SCENE_MANDELBULB: params[0] (scale) must be positive");
+    }
     h->sp_dirty = true;
     return SDMESH_OK;
 }
@@ -1377,6 +1391,7 @@ static int refine_host_common(sdmesh_handle *h, const Point *in, size_t n, Point
 int sdmesh_refine_voxel_field(sdmesh_handle *h, const struct Point *in, size_t n, struct Point voxel_size,
                               struct Point *out, size_t out_cap, size_t *n_out, struct Point *size_out) {
     if (!h || !n_out || !size_out || (n && (!in || !out))) return SDMESH_ERR_INVALID;
+    SDCHK(mesh_scene_ok(h));
     if (n == 0) {                      // src/cuda/mod.rs:137: nothing happens, not even the size halves
         *n_out = 0;
         *size_out = voxel_size;
@@ -1407,6 +1422,7 @@ int sdmesh_refine_voxel_field(sdmesh_handle *h, const struct Point *in, size_t n
 int sdmesh_refine_voxel_field_raw(sdmesh_handle *h, const struct Point *in, size_t n, struct Point voxel_size,
                                   struct Point *out8n) {
     if (!h || (n && (!in || !out8n))) return SDMESH_ERR_INVALID;
+    SDCHK(mesh_scene_ok(h));
     if (n == 0) return SDMESH_OK;
     if (n > 0x0FFFFFFFu) return fail(h, SDMESH_ERR_INVALID, "too many voxels");
     hipStream_t st = h->stream;
@@ -1422,6 +1438,7 @@ int sdmesh_refine_voxel_field_raw(sdmesh_handle *h, const struct Point *in, size
 int sdmesh_voxel_field_to_triangles_raw(sdmesh_handle *h, const struct Point *voxels, size_t n, struct Point voxel_size,
                                         struct Triangle *out5n) {
     if (!h || (n && (!voxels || !out5n))) return SDMESH_ERR_INVALID;
+    SDCHK(mesh_scene_ok(h));
     if (n == 0) return SDMESH_OK;
     if (n > 0x0FFFFFFFu) return fail(h, SDMESH_ERR_INVALID, "too many voxels");
     HIPCHK(hipSetDevice(h->device));
@@ -1442,6 +1459,7 @@ int sdmesh_voxel_field_to_mesh(sdmesh_handle *h, const struct Point *voxels, siz
                                struct Vertex *verts, size_t vert_cap, size_t *n_verts, struct IndexTriangle *tris,
                                size_t tri_cap, size_t *n_tris) {
     if (!h || !n_verts || !n_tris || (n && !voxels)) return SDMESH_ERR_INVALID;
+    SDCHK(mesh_scene_ok(h));
     *n_verts = *n_tris = 0;
     if (n == 0) {                                  // src/cuda/mod.rs:327-344: empty mesh
         h->n_tris = h->n_verts = 0;
@@ -1652,6 +1670,7 @@ static hipError_t launch_p1(sdmesh_handle *h, float *d_out, uint32_t N) { return
 int sdmesh_regen_dense(sdmesh_handle *h, int levels, sdmesh_regen_info *info) {
     if (!h) return SDMESH_ERR_INVALID;
     if (levels < 0 || levels > 5) return fail(h, SDMESH_ERR_INVALID, "dense mode supports levels 0..5 (N <= 1024)");
+    SDCHK(mesh_scene_ok(h));
     HIPCHK(hipSetDevice(h->device));
     SDCHK(sync_scene(h));
     hipStream_t st = h->stream;

@@ -2735,6 +2735,17 @@ __global__ __launch_bounds__(256) void k_sample_dense_rows_aligned(float *__rest
     case SCENE_PROGRAM: { constexpr int S = SCENE_PROGRAM; CALL; } break;                         \
     default: return hipErrorInvalidValue;                                                         \
     }
+// the field passes (dense sampling, the preview) also take SCENE_BULB, which the mesh path refuses (api.hip mesh_scene_ok)
+#define SDM_DISPATCH_FIELD(scene, CALL)                                                           \
+    switch (scene) {                                                                              \
+    case SCENE_SDOBJ: { constexpr int S = SCENE_SDOBJ; CALL; } break;                             \
+    case SCENE_SPHERE: { constexpr int S = SCENE_SPHERE; CALL; } break;                           \
+    case SCENE_CSG3: { constexpr int S = SCENE_CSG3; CALL; } break;                               \
+    case SCENE_ANIM: { constexpr int S = SCENE_ANIM; CALL; } break;                               \
+    case SCENE_PROGRAM: { constexpr int S = SCENE_PROGRAM; CALL; } break;                         \
+    case SCENE_BULB: { constexpr int S = SCENE_BULB; CALL; } break;                               \
+    default: return hipErrorInvalidValue;                                                         \
+    }
 
 hipError_t launch_refine_mask(hipStream_t st, int grid, int scene, const SceneParams *sp, const Point *vox,
                               const uint32_t *n_ptr, Point cs, uint8_t *mask, uint32_t *tilecnt, int chunk, uint32_t *signs) {
@@ -2893,7 +2904,7 @@ hipError_t launch_render(hipStream_t st, int scene, const SceneParams *sp, const
     r.fov_fac = fov_fac; r.screen_x = screen_x; r.screen_y = screen_y; r.gtex_x = gtex_x; r.gtex_y = gtex_y;
     r.width = width; r.height = height;
     const dim3 grid((width + 7) / 8, (height + 7) / 8);
-    SDM_DISPATCH(scene, hipLaunchKernelGGL(k_render<S>, grid, dim3(64), 0, st, r, sp, (uchar4 *) rgba));
+    SDM_DISPATCH_FIELD(scene, hipLaunchKernelGGL(k_render<S>, grid, dim3(64), 0, st, r, sp, (uchar4 *) rgba));
     return hipGetLastError();
 }
 
@@ -2999,8 +3010,8 @@ hipError_t launch_sample_dense_rows(hipStream_t st, int grid, int scene, const S
         const uint64_t ngroups = ((uint64_t) (N + 1) * (x1 - x0) + 15ull) / 16ull;
         grid = (int) std::min<uint64_t>((ngroups + 3ull) / 4ull, 0x7FFFFFFFull);
     }
-    if (nt) { SDM_DISPATCH(scene, hipLaunchKernelGGL((k_sample_dense_rows<S, true>), dim3(grid), dim3(256), 0, st, out, N, sp, x0, x1)); }
-    else { SDM_DISPATCH(scene, hipLaunchKernelGGL((k_sample_dense_rows<S, false>), dim3(grid), dim3(256), 0, st, out, N, sp, x0, x1)); }
+    if (nt) { SDM_DISPATCH_FIELD(scene, hipLaunchKernelGGL((k_sample_dense_rows<S, true>), dim3(grid), dim3(256), 0, st, out, N, sp, x0, x1)); }
+    else { SDM_DISPATCH_FIELD(scene, hipLaunchKernelGGL((k_sample_dense_rows<S, false>), dim3(grid), dim3(256), 0, st, out, N, sp, x0, x1)); }
     return hipGetLastError();
 }
 
@@ -3009,8 +3020,8 @@ hipError_t launch_sample_dense(hipStream_t st, int grid, int scene, const SceneP
     const uint64_t plane = (uint64_t) (N + 1) * (N + 1), total = plane * (x1 - x0), first = plane * x0;
     const uint32_t cg = contig ? 1u : 0u;
     if (total == 0) return hipSuccess;
-    if (nt) { SDM_DISPATCH(scene, hipLaunchKernelGGL((k_sample_dense<S, true>), dim3(grid), dim3(256), 0, st, out, N, total, sp, cg, first)); }
-    else { SDM_DISPATCH(scene, hipLaunchKernelGGL((k_sample_dense<S, false>), dim3(grid), dim3(256), 0, st, out, N, total, sp, cg, first)); }
+    if (nt) { SDM_DISPATCH_FIELD(scene, hipLaunchKernelGGL((k_sample_dense<S, true>), dim3(grid), dim3(256), 0, st, out, N, total, sp, cg, first)); }
+    else { SDM_DISPATCH_FIELD(scene, hipLaunchKernelGGL((k_sample_dense<S, false>), dim3(grid), dim3(256), 0, st, out, N, total, sp, cg, first)); }
     return hipGetLastError();
 }
 
@@ -3043,8 +3054,8 @@ hipError_t launch_sample_dense_q1(hipStream_t st, int scene, const SceneParams *
         const uint64_t total = plane * (xb - xa);
         float *o = out + plane * (xa - x0);
         const uint32_t grid = (uint32_t) (((total + 3ull) / 4ull + 255ull) / 256ull);
-        if (nt) { SDM_DISPATCH(scene, hipLaunchKernelGGL((k_sample_dense_q1<S, true>), dim3(grid), dim3(256), 0, st, o, N, (uint32_t) total, sp, dS, 5.0f / (float) N, xa)); }
-        else { SDM_DISPATCH(scene, hipLaunchKernelGGL((k_sample_dense_q1<S, false>), dim3(grid), dim3(256), 0, st, o, N, (uint32_t) total, sp, dS, 5.0f / (float) N, xa)); }
+        if (nt) { SDM_DISPATCH_FIELD(scene, hipLaunchKernelGGL((k_sample_dense_q1<S, true>), dim3(grid), dim3(256), 0, st, o, N, (uint32_t) total, sp, dS, 5.0f / (float) N, xa)); }
+        else { SDM_DISPATCH_FIELD(scene, hipLaunchKernelGGL((k_sample_dense_q1<S, false>), dim3(grid), dim3(256), 0, st, o, N, (uint32_t) total, sp, dS, 5.0f / (float) N, xa)); }
     }
     return hipGetLastError();
 }

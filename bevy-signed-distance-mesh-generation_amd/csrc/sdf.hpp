@@ -40,13 +40,13 @@
 
 namespace sdm {
 
-enum Scene : int { SCENE_SDOBJ = 0, SCENE_SPHERE = 1, SCENE_CSG3 = 2, SCENE_ANIM = 3, SCENE_PROGRAM = 4, SCENE_COUNT = 5 };
+enum Scene : int { SCENE_SDOBJ = 0, SCENE_SPHERE = 1, SCENE_CSG3 = 2, SCENE_ANIM = 3, SCENE_PROGRAM = 4, SCENE_BULB = 5, SCENE_COUNT = 6 };
 
 // Runtime SDF program: a linear CSG chain  acc = combine_i(acc, primitive_i(p)).
 // Primitives are the reference's (cuda/includes/signed_distance.cu:61-131: sd_ray in both forms, sd_line, sd_box, sd_box_skeleton,
 // sd_simple_box, sd_simple_bounding_box) plus a sphere with a radius and a torus; OP_WRAP is the reference's domain repetition
-// (signed_distance.cu:9-18) applied to the point every later instruction sees.  Layout == sdmesh_instr.  (sd_mandelbulb, :29-52, is
-// acos / atan2 / pow / sin / cos / log: not reproducible bit for bit between a CPU libm and the device, and the reference never calls it.)
+// (signed_distance.cu:9-18) applied to the point every later instruction sees.  Layout == sdmesh_instr.  (sd_mandelbulb, :29-52, is a
+// scene of its own, SCENE_BULB below: its acos / atan2 / pow / sin / cos / log are this file's own, see "elementary functions".)
 enum SdfOp : uint32_t { OP_SPHERE = 1, OP_BOX = 2, OP_BOX_SKELETON = 3, OP_CAPSULE = 4, OP_TORUS_Y = 5, OP_RAY = 6, OP_SIMPLE_BOX = 7,
                         OP_SIMPLE_BOUNDING_BOX = 8, OP_WRAP = 9, OP_LAST = 9 };
 enum SdfCombine : uint32_t { CB_SET = 0, CB_MIN = 1, CB_MAX = 2, CB_SMOOTH_MIN = 3, CB_SUBTRACT = 4 };
@@ -356,10 +356,150 @@ SDM_HD float sdf_program(f3 p, const SceneParams &sp) {
 }
 
 
+// ---------------------------------------------------------------------------------------------
+// Elementary functions for sd_mandelbulb (signed_distance.cu:29-53).  The reference takes acos / atan2 / pow / sin / cos / log from CUDA's
+// float library (fast-math variants in its build, build.rs:111-125): no two libraries agree on their last bits, so there is nothing to be
+// bit-identical WITH.  What this file fixes instead: each function is evaluated in f64 from +, -, *, /, sqrt and fma only (IEEE, the same
+// on the host and on the device), by the argument reductions and series written out below, and rounded ONCE to f32 -- the result is the
+// correctly rounded f32 value except within ~1e-7 ulp of a rounding boundary (tests/test_host_numerics.py measures <= 1 ulp against
+// f64 libm over each function's domain), and it is the same number on both sides, which is what the oracle comparison needs.
+// ---------------------------------------------------------------------------------------------
+SDM_HD double e_from_bits(uint64_t b) { double d; __builtin_memcpy(&d, &b, 8); return d; }
+SDM_HD uint64_t e_bits(double d) { uint64_t b; __builtin_memcpy(&b, &d, 8); return b; }
+SDM_HD double e_inf() { return e_from_bits(0x7FF0000000000000ull); }
+SDM_HD double e_nan() { return e_from_bits(0x7FF8000000000000ull); }
+#define SDM_FMA(a, b, c) __builtin_fma((a), (b), (c))
+
+// log(x), x = an f32 value (so never an f64 subnormal): x = m 2^e with m in (sqrt(1/2), sqrt(2)], log m = 2 atanh(s), s = (m - 1) / (m + 1),
+// |s| <= 0.1716: the series to s^19 leaves 2e-17.
+SDM_HD double e_log(double x) {
+    if (!(x > 0.0)) return x == 0.0 ? -e_inf() : e_nan();
+    if (x == e_inf()) return x;
+    const uint64_t b = e_bits(x);
+    int e = (int) (b >> 52) - 1023;
+    double m = e_from_bits((b & 0x000FFFFFFFFFFFFFull) | 0x3FF0000000000000ull);
+    if (m > 1.4142135623730951) { m *= 0.5; e += 1; }
+    const double s = (m - 1.0) / (m + 1.0), z = s * s;
+    double q = 1.0 / 19.0;
+    q = SDM_FMA(q, z, 1.0 / 17.0); q = SDM_FMA(q, z, 1.0 / 15.0); q = SDM_FMA(q, z, 1.0 / 13.0); q = SDM_FMA(q, z, 1.0 / 11.0);
+    q = SDM_FMA(q, z, 1.0 / 9.0); q = SDM_FMA(q, z, 1.0 / 7.0); q = SDM_FMA(q, z, 1.0 / 5.0); q = SDM_FMA(q, z, 1.0 / 3.0);
+    q = SDM_FMA(q, z, 1.0);
+    return SDM_FMA((double) e, 0.6931471805599453, 2.0 * s * q);
+}
+
+// exp(t): t = k ln2 + r, |r| <= 0.3466 (ln2 in two parts), Taylor to r^13 (r^14 / 14! = 4e-18), scaled by 2^k in two steps
+SDM_HD double e_exp(double t) {
+    if (t != t) return t;
+    if (t > 709.0) return e_inf();
+    if (t < -745.0) return 0.0;
+    const double k = __builtin_rint(t * 1.4426950408889634);
+    double r = SDM_FMA(-k, 6.93147180369123816490e-01, t);
+    r = SDM_FMA(-k, 1.90821492927058770002e-10, r);
+    double q = 1.0 / 6227020800.0;
+    q = SDM_FMA(q, r, 1.0 / 479001600.0); q = SDM_FMA(q, r, 1.0 / 39916800.0); q = SDM_FMA(q, r, 1.0 / 3628800.0); q = SDM_FMA(q, r, 1.0 / 362880.0);
+    q = SDM_FMA(q, r, 1.0 / 40320.0); q = SDM_FMA(q, r, 1.0 / 5040.0); q = SDM_FMA(q, r, 1.0 / 720.0); q = SDM_FMA(q, r, 1.0 / 120.0);
+    q = SDM_FMA(q, r, 1.0 / 24.0); q = SDM_FMA(q, r, 1.0 / 6.0); q = SDM_FMA(q, r, 0.5); q = SDM_FMA(q, r, 1.0); q = SDM_FMA(q, r, 1.0);
+    const int ki = (int) k, k1 = ki / 2, k2 = ki - k1;                    // |k1|, |k2| <= 538: both powers are normal
+    return q * e_from_bits((uint64_t) (k1 + 1023) << 52) * e_from_bits((uint64_t) (k2 + 1023) << 52);
+}
+
+// x^y for x >= 0 (x = a length), as exp(y log x) with `lx` = e_log(x) shared between the two powers of one iteration
+SDM_HD float e_powf_from_log(double lx, float x, float y) {
+    if (y == 0.0f) return 1.0f;
+    if (x != x || y != y) return x + y;
+    return (float) e_exp((double) y * lx);
+}
+
+// sin and cos of an f32 angle: k = rint(x 2/pi), r = x - k pi/2 in two parts (|k| < 2^20: the first product is exact), |r| <= pi/4,
+// Taylor to r^17 / r^16 (5e-17 left).  |x| >= 1e6 (never: angles here are below 2^10) and non-finite x give NaN.
+SDM_HD void e_sincosf(float xf, float *sn, float *cs) {
+    const double x = (double) xf;
+    if (!(__builtin_fabs(x) < 1.0e6)) { const float n = (float) e_nan(); *sn = n; *cs = n; return; }
+    const double k = __builtin_rint(x * 0.63661977236758134308);
+    double r = SDM_FMA(-k, 1.57079632673412561417e+00, x);
+    r = SDM_FMA(-k, 6.07710050650619224932e-11, r);
+    const double z = r * r;
+    double a = -1.0 / 355687428096000.0;                                  // sin: r (1 - z/3! + ... - z^8/17!)
+    a = SDM_FMA(a, z, 1.0 / 1307674368000.0); a = SDM_FMA(a, z, -1.0 / 6227020800.0); a = SDM_FMA(a, z, 1.0 / 39916800.0);
+    a = SDM_FMA(a, z, -1.0 / 362880.0); a = SDM_FMA(a, z, 1.0 / 5040.0); a = SDM_FMA(a, z, -1.0 / 120.0); a = SDM_FMA(a, z, 1.0 / 6.0);
+    const double s = SDM_FMA(-a * z, r, r);
+    double c = 1.0 / 20922789888000.0;                                    // cos: 1 - z/2! + ... + z^8/16!
+    c = SDM_FMA(c, z, -1.0 / 87178291200.0); c = SDM_FMA(c, z, 1.0 / 479001600.0); c = SDM_FMA(c, z, -1.0 / 3628800.0);
+    c = SDM_FMA(c, z, 1.0 / 40320.0); c = SDM_FMA(c, z, -1.0 / 720.0); c = SDM_FMA(c, z, 1.0 / 24.0); c = SDM_FMA(c, z, -0.5);
+    c = SDM_FMA(c, z, 1.0);
+    const int n = (int) k & 3;
+    const double sv = (n & 1) ? c : s, cv = (n & 1) ? s : c;
+    *sn = (float) ((n & 2) ? -sv : sv);
+    *cs = (float) (((n + 1) & 2) ? -cv : cv);
+}
+
+// atan(t), 0 <= t <= 1: above tan(pi/8) through atan t = pi/4 + atan((t - 1) / (t + 1)); |w| <= 0.41422: the series to w^37 leaves 2e-16 w
+SDM_HD double e_atan01(double t) {
+    const bool hi = t > 0.41421356237309503;
+    const double w = hi ? (t - 1.0) / (t + 1.0) : t, z = w * w;
+    double q = 1.0 / 37.0;
+    q = SDM_FMA(q, z, -1.0 / 35.0); q = SDM_FMA(q, z, 1.0 / 33.0); q = SDM_FMA(q, z, -1.0 / 31.0); q = SDM_FMA(q, z, 1.0 / 29.0);
+    q = SDM_FMA(q, z, -1.0 / 27.0); q = SDM_FMA(q, z, 1.0 / 25.0); q = SDM_FMA(q, z, -1.0 / 23.0); q = SDM_FMA(q, z, 1.0 / 21.0);
+    q = SDM_FMA(q, z, -1.0 / 19.0); q = SDM_FMA(q, z, 1.0 / 17.0); q = SDM_FMA(q, z, -1.0 / 15.0); q = SDM_FMA(q, z, 1.0 / 13.0);
+    q = SDM_FMA(q, z, -1.0 / 11.0); q = SDM_FMA(q, z, 1.0 / 9.0); q = SDM_FMA(q, z, -1.0 / 7.0); q = SDM_FMA(q, z, 1.0 / 5.0);
+    q = SDM_FMA(q, z, -1.0 / 3.0); q = SDM_FMA(q, z, 1.0);
+    const double a = w * q;
+    return hi ? 0.78539816339744830962 + a : a;
+}
+
+// atan2(y, x) in f64 with C's conventions for zeros and signs; an infinite operand gives NaN (never reached: the iteration has left by then)
+SDM_HD double e_atan2(double y, double x) {
+    if (x != x || y != y) return e_nan();
+    const double ax = __builtin_fabs(x), ay = __builtin_fabs(y);
+    const bool xneg = (e_bits(x) >> 63) != 0;
+    double a;
+    if (ax == 0.0 && ay == 0.0) a = xneg ? 3.14159265358979323846 : 0.0;
+    else {
+        const bool steep = ay > ax;
+        a = e_atan01(steep ? ax / ay : ay / ax);
+        if (steep) a = 1.57079632679489661923 - a;
+        if (xneg) a = 3.14159265358979323846 - a;
+    }
+    return __builtin_copysign(a, y);
+}
+SDM_HD float e_atan2f(float y, float x) { return (float) e_atan2((double) y, (double) x); }
+// acos(x) = 2 atan2(sqrt(1 - x), sqrt(1 + x)): NaN outside [-1, 1], as the library function
+SDM_HD float e_acosf(float xf) {
+    const double x = (double) xf;
+    return (float) (2.0 * e_atan2(__builtin_sqrt(1.0 - x), __builtin_sqrt(1.0 + x)));
+}
+SDM_HD float e_logf(float x) { return (float) e_log((double) x); }
+
+// signed_distance.cu:29-53, statement by statement in f32 (GLM: length = sqrt(dot), dot = (x x + y y) + z z; vec * float per component)
+SDM_HD float sd_mandelbulb(f3 p, float time) {
+    f3 z = p;
+    float dr = 1.0f;
+    float r = 0.0f;
+    const float power = 7.0f * (1.0f + time * 0.001f);
+    for (int i = 0; i < 25; i++) {
+        r = sqrt_rn(dot3(z, z));
+        if (r > 2.0f) break;
+        const float theta = e_acosf(z.z / r) * power;
+        const float phi = e_atan2f(z.y, z.x) * power;
+        const double lr = e_log((double) r);
+        const float zr = e_powf_from_log(lr, r, power);
+        dr = e_powf_from_log(lr, r, power - 1.0f) * power * dr + 1.0f;
+        float s_theta, c_theta, s_phi, c_phi;
+        e_sincosf(theta, &s_theta, &c_theta);
+        e_sincosf(phi, &s_phi, &c_phi);
+        z = mk(zr * (s_theta * c_phi), zr * (s_phi * s_theta), zr * c_theta);
+        z = add3(z, p);
+    }
+    return 0.5f * e_logf(r) * r / dr;
+}
+
 template <int SCENE>
 SDM_HD float sdf(float px, float py, float pz, const SceneParams &sp) {
     if (SCENE == SCENE_PROGRAM) {
         return sdf_program(mk(px, py, pz), sp);
+    } else if (SCENE == SCENE_BULB) {
+        // sd_unit_mandelbulb's form (signed_distance.cu:55-57) with the scale and the time as scene parameters: p[0] = scale, p[1] = time
+        return sd_mandelbulb(mk(px / sp.p[0], py / sp.p[0], pz / sp.p[0]), sp.p[1]) * sp.p[0];
     } else if (SCENE == SCENE_SPHERE) {
         return sqrt_rn_normal((px * px + py * py) + pz * pz) - 1.0f;
     } else if (SCENE == SCENE_CSG3) {

@@ -49,7 +49,14 @@ enum {
     SDMESH_SCENE_SDOBJ = 0,
     SDMESH_SCENE_SPHERE = 1,
     SDMESH_SCENE_CSG3 = 2,
-    SDMESH_SCENE_ANIM = 3        /* params[0] = y of the sphere centre (host passes 0.5*sin(t)) */
+    SDMESH_SCENE_ANIM = 3,       /* params[0] = y of the sphere centre (host passes 0.5*sin(t)) */
+    /* 4 is taken by the runtime program (sdmesh_set_program) */
+    SDMESH_SCENE_MANDELBULB = 5  /* the reference's sd_mandelbulb (cuda/includes/signed_distance.cu:29-53, never called there) in
+                                  * sd_unit_mandelbulb's form (:55-57): sd_mandelbulb(p / params[0], params[1]) * params[0];
+                                  * params[0] = scale (1 without params; the reference's unit bulb is 0.4), params[1] = time (the
+                                  * power is 7 (1 + 0.001 time)).  acos / atan2 / pow / sin / cos / log are the library's own f64
+                                  * evaluations rounded once to f32 (csrc/sdf.hpp): the same bits on host and device, within 1 ulp
+                                  * of a correctly rounded libm, NOT the bits of CUDA's fast-math functions. */
 };
 
 /* Multi-GPU partition of the level-0 field. */

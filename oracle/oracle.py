@@ -16,7 +16,7 @@ import numpy as np
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _LIB = None
 
-SCENES = {"sdobj": 0, "sphere": 1, "csg3": 2, "anim": 3, "program": 4}
+SCENES = {"sdobj": 0, "sphere": 1, "csg3": 2, "anim": 3, "program": 4, "bulb": 5}
 OPS = {"sphere": 1, "box": 2, "box_skeleton": 3, "capsule": 4, "torus_y": 5, "ray": 6, "simple_box": 7, "simple_bounding_box": 8, "wrap": 9}
 COMBINES = {"set": 0, "min": 1, "max": 2, "smooth_min": 3, "subtract": 4}
 INSTR = np.dtype([("op", "<u4"), ("combine", "<u4"), ("k", "<f4"), ("a", "<f4", (7,))])

@@ -63,8 +63,10 @@ _Static_assert(sizeof(Triangle) == 72, "Triangle");
  * 2 CSG3   : build-defined -- no reference counterpart
  * 3 ANIM   : build-defined: sd_obj with the sphere centre at
  *            (0, params[0], 0); the host passes params[0] = 0.5*sin(t)
+ * 5 BULB   : sd_mandelbulb (cuda/includes/signed_distance.cu:29-53) in sd_unit_mandelbulb's form (:55-57):
+ *            sd_mandelbulb(p / params[0], params[1]) * params[0]; the reference never calls it
  */
-enum { SCENE_SDOBJ = 0, SCENE_SPHERE = 1, SCENE_CSG3 = 2, SCENE_ANIM = 3, SCENE_PROGRAM = 4 };
+enum { SCENE_SDOBJ = 0, SCENE_SPHERE = 1, SCENE_CSG3 = 2, SCENE_ANIM = 3, SCENE_PROGRAM = 4, SCENE_BULB = 5 };
 
 /* 4 PROGRAM: build-defined runtime SDF program, a linear CSG chain of the reference's
  * primitives: acc = combine_i(acc, primitive_i(p)).  Same instruction layout as include/sdmesh.h sdmesh_instr. */
@@ -188,6 +190,132 @@ static float sd_torus_y(v3 p, float R, float r) {
     return sqrtf(qx * qx + p.y * p.y) - r;
 }
 
+/* ---- sd_mandelbulb (signed_distance.cu:29-53) ---------------------------------------------------
+ * The reference takes acos / atan2 / pow / sin / cos / log from CUDA's float library, built with --use_fast_math
+ * (build.rs:111-125): values no other library reproduces.  PARITY UNPINNED for this scene beyond "the same
+ * statements in the same order": the elementary functions below are this build's definition of them -- each
+ * evaluated in double from + - * / sqrt fma by a fixed reduction and a fixed series, rounded once to float --
+ * restated here from the description in csrc/sdf.hpp, coefficient tables and Horner loops instead of unrolled
+ * code.  tests/test_host_numerics.py bounds them against glibc's double functions (<= 1 ulp of float). */
+static double horner(const double *c, int n, double z) {
+    double q = c[0];
+    for (int i = 1; i < n; i++) q = fma(q, z, c[i]);
+    return q;
+}
+static double dbl_from_bits(uint64_t b) { double d; memcpy(&d, &b, 8); return d; }
+static uint64_t dbl_bits(double d) { uint64_t b; memcpy(&b, &d, 8); return b; }
+
+static double el_log(double x) {                 /* x: a float's value, so never a double subnormal */
+    static const double C[10] = {1.0 / 19.0, 1.0 / 17.0, 1.0 / 15.0, 1.0 / 13.0, 1.0 / 11.0, 1.0 / 9.0, 1.0 / 7.0, 1.0 / 5.0, 1.0 / 3.0, 1.0};
+    if (!(x > 0.0)) return x == 0.0 ? -INFINITY : NAN;
+    if (isinf(x)) return x;
+    uint64_t b = dbl_bits(x);
+    int e = (int) (b >> 52) - 1023;
+    double m = dbl_from_bits((b & 0x000FFFFFFFFFFFFFull) | 0x3FF0000000000000ull);
+    if (m > 1.4142135623730951) { m *= 0.5; e += 1; }
+    double s = (m - 1.0) / (m + 1.0);
+    return fma((double) e, 0.6931471805599453, 2.0 * s * horner(C, 10, s * s));
+}
+
+static double el_exp(double t) {
+    static const double C[14] = {1.0 / 6227020800.0, 1.0 / 479001600.0, 1.0 / 39916800.0, 1.0 / 3628800.0, 1.0 / 362880.0, 1.0 / 40320.0,
+                                 1.0 / 5040.0, 1.0 / 720.0, 1.0 / 120.0, 1.0 / 24.0, 1.0 / 6.0, 0.5, 1.0, 1.0};
+    if (t != t) return t;
+    if (t > 709.0) return INFINITY;
+    if (t < -745.0) return 0.0;
+    double k = rint(t * 1.4426950408889634);
+    double r = fma(-k, 6.93147180369123816490e-01, t);
+    r = fma(-k, 1.90821492927058770002e-10, r);
+    int ki = (int) k, k1 = ki / 2, k2 = ki - k1;
+    return horner(C, 14, r) * dbl_from_bits((uint64_t) (k1 + 1023) << 52) * dbl_from_bits((uint64_t) (k2 + 1023) << 52);
+}
+
+static float el_powf_from_log(double lx, float x, float y) {      /* x^y = exp(y log x), x >= 0 */
+    if (y == 0.0f) return 1.0f;
+    if (x != x || y != y) return x + y;
+    return (float) el_exp((double) y * lx);
+}
+
+static void el_sincosf(float xf, float *sn, float *cs) {
+    static const double S[8] = {-1.0 / 355687428096000.0, 1.0 / 1307674368000.0, -1.0 / 6227020800.0, 1.0 / 39916800.0, -1.0 / 362880.0,
+                                1.0 / 5040.0, -1.0 / 120.0, 1.0 / 6.0};
+    static const double Cc[9] = {1.0 / 20922789888000.0, -1.0 / 87178291200.0, 1.0 / 479001600.0, -1.0 / 3628800.0, 1.0 / 40320.0,
+                                 -1.0 / 720.0, 1.0 / 24.0, -0.5, 1.0};
+    double x = (double) xf;
+    if (!(fabs(x) < 1.0e6)) { *sn = NAN; *cs = NAN; return; }
+    double k = rint(x * 0.63661977236758134308);
+    double r = fma(-k, 1.57079632673412561417e+00, x);
+    r = fma(-k, 6.07710050650619224932e-11, r);
+    double z = r * r;
+    double s = fma(-horner(S, 8, z) * z, r, r), c = horner(Cc, 9, z);
+    int n = (int) k & 3;
+    double sv = (n & 1) ? c : s, cv = (n & 1) ? s : c;
+    *sn = (float) ((n & 2) ? -sv : sv);
+    *cs = (float) (((n + 1) & 2) ? -cv : cv);
+}
+
+static double el_atan01(double t) {               /* 0 <= t <= 1 */
+    static const double C[19] = {1.0 / 37.0, -1.0 / 35.0, 1.0 / 33.0, -1.0 / 31.0, 1.0 / 29.0, -1.0 / 27.0, 1.0 / 25.0, -1.0 / 23.0, 1.0 / 21.0,
+                                 -1.0 / 19.0, 1.0 / 17.0, -1.0 / 15.0, 1.0 / 13.0, -1.0 / 11.0, 1.0 / 9.0, -1.0 / 7.0, 1.0 / 5.0, -1.0 / 3.0, 1.0};
+    int hi = t > 0.41421356237309503;
+    double w = hi ? (t - 1.0) / (t + 1.0) : t;
+    double a = w * horner(C, 19, w * w);
+    return hi ? 0.78539816339744830962 + a : a;
+}
+
+static double el_atan2(double y, double x) {
+    if (x != x || y != y) return NAN;
+    double ax = fabs(x), ay = fabs(y), a;
+    int xneg = (int) (dbl_bits(x) >> 63);
+    if (ax == 0.0 && ay == 0.0) a = xneg ? 3.14159265358979323846 : 0.0;
+    else {
+        int steep = ay > ax;
+        a = el_atan01(steep ? ax / ay : ay / ax);
+        if (steep) a = 1.57079632679489661923 - a;
+        if (xneg) a = 3.14159265358979323846 - a;
+    }
+    return copysign(a, y);
+}
+static float el_atan2f(float y, float x) { return (float) el_atan2((double) y, (double) x); }
+static float el_acosf(float xf) { double x = (double) xf; return (float) (2.0 * el_atan2(sqrt(1.0 - x), sqrt(1.0 + x))); }
+static float el_logf(float x) { return (float) el_log((double) x); }
+
+/* the functions above, one by one, for the accuracy test: which = 0 log, 1 exp, 2 sin, 3 cos, 4 atan2(a, b), 5 acos, 6 pow(a, b) */
+float orc_elementary(int which, float a, float b) {
+    float s, c;
+    switch (which) {
+    case 0: return el_logf(a);
+    case 1: return (float) el_exp((double) a);
+    case 2: el_sincosf(a, &s, &c); return s;
+    case 3: el_sincosf(a, &s, &c); return c;
+    case 4: return el_atan2f(a, b);
+    case 5: return el_acosf(a);
+    default: return el_powf_from_log(el_log((double) a), a, b);
+    }
+}
+
+static float sd_mandelbulb(v3 p, float time) {     /* signed_distance.cu:29-53 */
+    v3 z = p;
+    float dr = 1.0f;
+    float r = 0.0f;
+    float power = 7.0f * (1.0f + time * 0.001f);   /* POWER * (1.0f + time * 0.001f), :27,34 */
+    for (int i = 0; i < 25; i++) {
+        r = length3(z);
+        if (r > 2.0f) break;
+        float theta = el_acosf(z.z / r) * power;
+        float phi = el_atan2f(z.y, z.x) * power;
+        double lr = el_log((double) r);
+        float zr = el_powf_from_log(lr, r, power);
+        dr = el_powf_from_log(lr, r, power - 1.0f) * power * dr + 1.0f;
+        float st, ct, sp, cp;
+        el_sincosf(theta, &st, &ct);
+        el_sincosf(phi, &sp, &cp);
+        z = V(zr * (st * cp), zr * (sp * st), zr * ct);      /* zr * vec3(s_theta * cos(phi), sin(phi) * s_theta, cos(theta)), :48 */
+        z = vadd(z, p);
+    }
+    return 0.5f * el_logf(r) * r / dr;
+}
+
 static float sdf_eval(int scene, const float *params, v3 p) {
     tl_evals++;
     switch (scene) {
@@ -231,6 +359,8 @@ static float sdf_eval(int scene, const float *params, v3 p) {
         }
         return acc;
     }
+    case SCENE_BULB:
+        return sd_mandelbulb(V(p.x / params[0], p.y / params[0], p.z / params[0]), params[1]) * params[0];
     case SCENE_ANIM: {
         float a1 = sd_box_skeleton(p, V(0.0f, 0.0f, 0.0f), V(3.0f, 1.0f, 0.5f), 0.1f);
         float a2 = length3(vsub(p, V(0.0f, params[0], 0.0f))) - 1.0f;

@@ -46,11 +46,26 @@ extern "C" int sdm_host_eval(int scene, const float *params, const float *pts, l
     case SCENE_SPHERE: eval_all<SCENE_SPHERE>(pts, n, sp, sd, nrm, proj, flip); return 0;
     case SCENE_CSG3: eval_all<SCENE_CSG3>(pts, n, sp, sd, nrm, proj, flip); return 0;
     case SCENE_ANIM: eval_all<SCENE_ANIM>(pts, n, sp, sd, nrm, proj, flip); return 0;
+    case SCENE_BULB: eval_all<SCENE_BULB>(pts, n, sp, sd, nrm, proj, flip); return 0;
     }
     return 1;
 }
 
 extern "C" long long sdm_host_weld_quant(float x) { return weld_quant(x); }
+
+// sdf.hpp's elementary functions one by one: which = 0 log, 1 exp, 2 sin, 3 cos, 4 atan2(a, b), 5 acos, 6 pow(a, b)
+extern "C" float sdm_host_elementary(int which, float a, float b) {
+    float s, c;
+    switch (which) {
+    case 0: return e_logf(a);
+    case 1: return (float) e_exp((double) a);
+    case 2: e_sincosf(a, &s, &c); return s;
+    case 3: e_sincosf(a, &s, &c); return c;
+    case 4: return e_atan2f(a, b);
+    case 5: return e_acosf(a);
+    default: return e_powf_from_log(e_log((double) a), a, b);
+    }
+}
 
 // the preview's bounding-cube wire frame as rewritten in sdf.hpp (axis-aligned, sqrt of the minimum)
 extern "C" void sdm_host_cube_frame(const float *pts, long n, float *out) {

@@ -10,7 +10,7 @@ import pytest
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 NATIVE = os.path.join(ROOT, "tests", "native")
-SCENES = {"sdobj": 0, "sphere": 1, "csg3": 2, "anim": 3, "program": 4}
+SCENES = {"sdobj": 0, "sphere": 1, "csg3": 2, "anim": 3, "program": 4, "bulb": 5}
 
 PROGRAMS = {
     # the reference scene and the build's csg3 as programs: must reproduce the AOT scenes bit for bit
@@ -223,3 +223,64 @@ def test_cube_frame_rewrite_bit_exact_on_host(oracle, hostnum):
     L.orc_cube_frame.restype = None
     L.orc_cube_frame(pts.ctypes.data, n, b.ctypes.data)
     assert np.array_equal(a.view(np.uint32), b.view(np.uint32))
+
+
+def _ulp_err(got, exact):
+    """|got - exact| in units of the f32 ulp at `exact` (exact: float64 reference values)."""
+    got = got.astype(np.float64)
+    ulp = np.spacing(np.abs(exact).astype(np.float32)).astype(np.float64)
+    return np.abs(got - exact) / np.maximum(ulp, 1e-300)
+
+
+def test_elementary_functions_of_the_mandelbulb_scene(oracle, hostnum):
+    """The product's own log / exp / sin / cos / atan2 / acos / pow (csrc/sdf.hpp, f64 evaluation rounded once to f32) and the oracle's
+    restatement of them: identical bits on every sample, and within 1 ulp (f32) of numpy's float64 functions over the domains
+    sd_mandelbulb feeds them (angles up to +-7 pi and beyond, lengths in (0, 2], cosines in [-1, 1]); the special values C defines."""
+    hostnum.sdm_host_elementary.restype = ctypes.c_float
+    hostnum.sdm_host_elementary.argtypes = [ctypes.c_int, ctypes.c_float, ctypes.c_float]
+    L = oracle.lib()
+    L.orc_elementary.restype = ctypes.c_float
+    L.orc_elementary.argtypes = [ctypes.c_int, ctypes.c_float, ctypes.c_float]
+    rng = np.random.default_rng(77)
+    n = 20000
+    f32 = lambda a: np.asarray(a, dtype=np.float32)                               # noqa: E731
+    cases = {
+        0: (f32(np.concatenate([rng.uniform(1e-6, 2.0, n), np.exp(rng.uniform(-80, 80, n // 4)), [1.0, 2.0, 0.5, 1e-45, 3e38]])), None, np.log),
+        1: (f32(np.concatenate([rng.uniform(-87, 88, n), [0.0, -0.0, 1e-10]])), None, np.exp),
+        2: (f32(np.concatenate([rng.uniform(-25, 25, n), rng.uniform(-3000, 3000, n // 4), [0.0, np.pi, 2 * np.pi, 11.0]])), None, np.sin),
+        3: (f32(np.concatenate([rng.uniform(-25, 25, n), rng.uniform(-3000, 3000, n // 4), [0.0, np.pi / 2, np.pi]])), None, np.cos),
+        4: (f32(rng.uniform(-130, 130, n)), f32(rng.uniform(-130, 130, n)), np.arctan2),
+        5: (f32(np.concatenate([rng.uniform(-1, 1, n), [1.0, -1.0, 0.0, 0.99999994, -0.99999994]])), None, np.arccos),
+        6: (f32(rng.uniform(1e-4, 2.0, n)), f32(rng.uniform(5.0, 9.0, n)), np.power),
+    }
+    worst = {}
+    for which, (a, b, fn) in cases.items():
+        bb = b if b is not None else np.zeros_like(a)
+        mine = f32([hostnum.sdm_host_elementary(which, float(x), float(y)) for x, y in zip(a, bb)])
+        orc = f32([L.orc_elementary(which, float(x), float(y)) for x, y in zip(a, bb)])
+        assert np.array_equal(mine.view(np.uint32), orc.view(np.uint32)), which
+        exact = fn(a.astype(np.float64), bb.astype(np.float64)) if b is not None else fn(a.astype(np.float64))
+        ok = np.isfinite(exact) & (np.abs(exact) > 1e-37)
+        worst[which] = float(_ulp_err(mine[ok], exact[ok]).max())
+        assert worst[which] <= 1.0, (which, worst[which])
+    E = lambda w, a, b=0.0: hostnum.sdm_host_elementary(w, a, b)                  # noqa: E731
+    assert E(0, 0.0) == -np.inf and np.isnan(E(0, -1.0)) and E(0, np.inf) == np.inf and E(0, 1.0) == 0.0
+    assert E(1, -1000.0) == 0.0 and E(1, 1000.0) == np.inf and E(1, 0.0) == 1.0
+    assert np.isnan(E(2, np.inf)) and np.isnan(E(3, np.nan)) and E(2, 0.0) == 0.0 and E(3, 0.0) == 1.0
+    assert E(4, 0.0, 1.0) == 0.0 and E(4, 0.0, -1.0) == np.float32(np.pi) and E(4, -0.0, -1.0) == -np.float32(np.pi)
+    assert E(4, 1.0, 0.0) == np.float32(np.pi / 2) and E(4, 0.0, 0.0) == 0.0 and E(4, 0.0, -0.0) == np.float32(np.pi) and np.isnan(E(4, np.nan, 1.0))
+    assert E(5, 1.0) == 0.0 and E(5, -1.0) == np.float32(np.pi) and np.isnan(E(5, 1.5)) and np.isnan(E(5, np.nan))
+    assert E(6, 0.0, 7.0) == 0.0 and E(6, 2.0, 0.0) == 1.0 and E(6, 1.0, 7.0) == 1.0 and E(6, 2.0, 7.0) == 128.0 and np.isnan(E(6, np.nan, 7.0))
+
+
+@pytest.mark.parametrize("params", [[1.0, 0.0], [0.4, 0.0], [1.7, 250.0]])
+def test_mandelbulb_scene_bit_exact_on_host(oracle, hostnum, params):
+    """SDMESH_SCENE_MANDELBULB (sd_mandelbulb, signed_distance.cu:29-53): the product's sdf.hpp compiled for the host against the oracle's
+    restatement -- distance and empirical normal on random points, lattice points (the origin is NaN: 0 / 0 inside acos) and points around
+    the bulb.  No projection: the reference's Newton iteration does not converge on this distance estimate (the product refuses to mesh it)."""
+    pts = _points(4321, 1200)
+    ref = oracle.eval_points("bulb", pts, params, project=False, flips=False)
+    sd, nrm, _, _ = _host(hostnum, "bulb", pts, params, project=False)
+    assert np.array_equal(sd.view(np.uint32), ref["sd"].view(np.uint32))
+    assert np.isnan(sd).sum() >= 1 and np.isfinite(sd).sum() > 0.9 * len(sd) and (sd < 0).any() and (sd > 0).any()
+    assert np.array_equal(np.isnan(nrm), np.isnan(ref["nrm"])) and np.array_equal(nrm[~np.isnan(nrm)].view(np.uint32), ref["nrm"][~np.isnan(nrm)].view(np.uint32))

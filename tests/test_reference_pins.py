@@ -139,7 +139,7 @@ def test_path_constants_of_oracle_and_product_equal_the_reference_text():
     assert "e2 = 2.0f * SDM_NORMAL_EPS" in sdf and re.search(r"8\.0f \* \w+\.x - 8\.0f \* \w+\.y", sdf)
     # Newton projection: threshold (inclusive), iteration cap
     thr, cap = f(ref["newton_threshold"]), int(ref["newton_iteration_cap"])
-    m = re.search(r"i < (\d+); i\+\+\) \{.*?collision = gabs\(sd\) <= ([0-9.]+)f;", oracle, flags=re.S)
+    m = re.search(r"!collision && i < (\d+); i\+\+\) \{.*?collision = gabs\(sd\) <= ([0-9.]+)f;", oracle, flags=re.S)
     assert int(m.group(1)) == cap and f(m.group(2)) == thr
     assert int(re.search(r"#define SDM_MAX_NEWTON (\d+)", sdf).group(1)) == cap
     got = {f(v) for v in re.findall(r"fabsf\(sd\) <= ([0-9.]+)f", sdf + kern)}
