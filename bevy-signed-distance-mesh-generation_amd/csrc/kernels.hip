@@ -2185,14 +2185,41 @@ __global__ __launch_bounds__(256) void k_dist_finalize(const Vertex *__restrict_
                                                         Vertex *__restrict__ out_v) {
     const uint32_t off = dist_offset(counts, me);
     const uint32_t V = *v_ptr < vcap ? *v_ptr : vcap, T = *t_ptr < tcap ? *t_ptr : tcap;
-    const uint32_t stride = gridDim.x * blockDim.x, t0 = blockIdx.x * blockDim.x + threadIdx.x;
-    for (uint32_t i = t0; i < V; i += stride)
-        if (dup_of[i] == U32_NONE) out_v[newidx[i]] = v[i];
-    for (uint32_t c = t0; c < 3u * T; c += stride) {
-        const uint32_t vi = indices[c];
-        if (vi >= V) continue;                                         // (never of a chain that kept to its plan)
-        const uint32_t d = dup_of[vi];
-        indices[c] = d == U32_NONE ? off + newidx[vi] : (d < pcap ? prev_g[d] : 0u);
+    // the kept vertices, 256 at a time: moved as dwords (coalesced both ways: almost every vertex is kept, so the destinations of a block are
+    // one run with a few gaps) with the destinations staged in LDS -- a 24-byte vertex per lane touches every line six times
+    __shared__ uint32_t s_dst[256];
+    const uint32_t *__restrict__ v32 = reinterpret_cast<const uint32_t *>(v);
+    uint32_t *__restrict__ o32 = reinterpret_cast<uint32_t *>(out_v);
+    for (uint32_t b0 = blockIdx.x * 256u; b0 < V; b0 += gridDim.x * 256u) {
+        const uint32_t i = b0 + threadIdx.x, nd = (V - b0 < 256u ? V - b0 : 256u) * 6u;
+        uint32_t w[6];
+#pragma unroll
+        for (uint32_t j = 0; j < 6u; j++) w[j] = threadIdx.x + 256u * j < nd ? v32[6ull * b0 + threadIdx.x + 256u * j] : 0u;
+        s_dst[threadIdx.x] = (i < V && dup_of[i] == U32_NONE) ? newidx[i] : U32_NONE;
+        __syncthreads();
+#pragma unroll
+        for (uint32_t j = 0; j < 6u; j++) {
+            const uint32_t k = threadIdx.x + 256u * j;
+            if (k < nd) { const uint32_t d = s_dst[k / 6u]; if (d != U32_NONE) o32[6ull * d + k % 6u] = w[j]; }
+        }
+        __syncthreads();
+    }
+    // the indices in place, four per thread and pass with every load in front: an index costs two gathers (is its vertex a copy? its new
+    // number) that do not depend on each other -- one after the other, one index at a time, the loop ran at a third of the copy rate
+    const uint32_t n3 = 3u * T;
+    for (uint32_t c0 = blockIdx.x * 1024u + threadIdx.x; c0 < n3; c0 += gridDim.x * 1024u) {
+        uint32_t vi[4], d[4], n[4];
+#pragma unroll
+        for (uint32_t j = 0; j < 4u; j++) vi[j] = c0 + 256u * j < n3 ? indices[c0 + 256u * j] : U32_NONE;
+#pragma unroll
+        for (uint32_t j = 0; j < 4u; j++) {
+            const bool ok = vi[j] < V;                                 // (always, of a chain that kept to its plan)
+            d[j] = ok ? dup_of[vi[j]] : 0u;
+            n[j] = ok ? newidx[vi[j]] : 0u;
+        }
+#pragma unroll
+        for (uint32_t j = 0; j < 4u; j++)
+            if (vi[j] < V) indices[c0 + 256u * j] = d[j] == U32_NONE ? off + n[j] : (d[j] < pcap ? prev_g[d[j]] : 0u);
     }
 }
 
