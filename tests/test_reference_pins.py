@@ -160,6 +160,15 @@ def test_path_constants_of_oracle_and_product_equal_the_reference_text():
     assert np.float32(float(re.search(r"#define SDM_SIXTH_HALF ([0-9.]+)f", sdf).group(1))) == np.float32(1.0) / np.float32(6.0) / np.float32(2.0)
     assert re.search(r"- 0\.1f", sdf) and re.search(r"\) - 1\.0f;", sdf)
     assert re.search(r"3\.0f,\s*1\.0f,\s*0\.5f", oracle) and re.search(r"0\.1f", oracle)
+    # sd_mandelbulb (the field scene): power, time factor, iteration count, escape radius, the estimate's factor -- in oracle and product
+    mb = ref["mandelbulb"]
+    assert (mb["power"], mb["time_factor"], mb["iterations"], mb["escape_radius"], mb["estimate_factor"], mb["unit_scale"]) == ("7.0", "0.001", "25", "2.0", "0.5", "0.4")
+    for txt, fn in ((oracle, "static float sd_mandelbulb("), (sdf, "SDM_HD float sd_mandelbulb(")):
+        body = txt[txt.index(fn):]
+        body = body[:body.index("\n}\n")]
+        assert re.search(r"power = %sf \* \(1\.0f \+ time \* %sf\)" % (re.escape(mb["power"]), re.escape(mb["time_factor"])), body), fn
+        assert re.search(r"i < %s; i\+\+" % mb["iterations"], body) and re.search(r"if \(r > %sf\) break;" % re.escape(mb["escape_radius"]), body), fn
+        assert re.search(r"return %sf \* \w+\(r\) \* r / dr;" % re.escape(mb["estimate_factor"]), body), fn
     # weld: key = round(x * 10e4) per coordinate, triangles dropped on a non-finite x of their first vertex
     q = f(ref["weld_quantum_factor"])
     assert q == 1e5 and ref["weld_finite_test"] == "x"

@@ -100,7 +100,7 @@ def pin_path_constants(ref):
     mc = text("cuda/includes/marching_cubes.cu")
     gen = text("cuda/modules/compute_mesh_generation.cu")
     host = open(os.path.join(ref, "src/cuda/mod.rs")).read()
-    out = {"source": "cuda/includes/signed_distance.cu:20-23,177-240; cuda/modules/common.cu:222-226; cuda/includes/marching_cubes.cu:13-21; "
+    out = {"source": "cuda/includes/signed_distance.cu:20-57,177-240; cuda/modules/common.cu:222-226; cuda/includes/marching_cubes.cu:13-21; "
                      "cuda/modules/compute_mesh_generation.cu:12-120; src/cuda/mod.rs:105-122,163-174,268"}
     out["normal_epsilon"] = one(r"#define\s+NORMAL_EPSILON\s+([0-9.eE+-]+)f", sd, "NORMAL_EPSILON")
     normal = sd[sd.index("empirical_normal("):sd.index("struct NormalPlane")]
@@ -116,6 +116,13 @@ def pin_path_constants(ref):
                      "skeleton_line_width": one(r"vec3\([0-9.f, ]+\),\s*([0-9.]+)f\)", obj, "line width"),
                      "sphere_radius": one(r"length\(p\)\s*-\s*([0-9.]+)f", obj, "sphere radius"),
                      "smooth_k": one(r"smooth_min\(a1,\s*a2,\s*([0-9.]+)f\)", obj, "smooth k")}
+    bulb = sd[sd.index("float sd_mandelbulb("):sd.index("float sd_unit_mandelbulb(")]
+    out["mandelbulb"] = {"power": one(r"#define\s+POWER\s+([0-9.]+)f", sd, "POWER"),
+                         "time_factor": one(r"time\s*\*\s*([0-9.]+)f", bulb, "time factor"),
+                         "iterations": one(r"i\s*<\s*(\d+)", bulb, "iterations"),
+                         "escape_radius": one(r"r\s*>\s*([0-9.]+)f", bulb, "escape radius"),
+                         "estimate_factor": one(r"return\s+([0-9.]+)f\s*\*\s*log\(r\)", bulb, "estimate factor"),
+                         "unit_scale": one(r"sd_mandelbulb\(p\s*/\s*([0-9.]+)f", sd, "unit scale")}
     out["mc_midpoint_factor"] = one(r"float v = ([0-9.]+)f;", mc, "midpoint factor")
     out["mc_inside_test"] = one(r"cube\.values\[i\]\s*(<=|<)\s*0\.0f", mc, "inside test")
     out["refine_inside_test"] = one(r"sd_obj\([^)]*\)\s*(<=|<)\s*0\.0f", gen, "refine inside test")
