@@ -46,6 +46,20 @@ def test_struct_layouts_match_survey_table(pkg):
                                os.path.join(ROOT, "include", "sdmesh.h")])
 
 
+def test_transport_table_matches_the_header(pkg):
+    """sdmesh_transport (the caller's collectives): the ctypes mirror has the header's entries in the header's order, and a call without a
+    handle or without a complete table is refused before anything touches a GPU."""
+    hdr = open(os.path.join(ROOT, "include", "sdmesh.h")).read()
+    body = hdr[hdr.index("typedef struct sdmesh_transport {"):hdr.index("} sdmesh_transport;")]
+    names = re.findall(r"\(\*(\w+)\)", body)
+    T = pkg._abi.Transport
+    assert ["user"] + names == [f[0] for f in T._fields_] and ctypes.sizeof(T) == 8 * (1 + len(names)) == 56
+    assert (re.search(r"SDMESH_REDUCE_SUM = (\d)", hdr).group(1), re.search(r"SDMESH_REDUCE_MAX = (\d)", hdr).group(1)) == ("0", "1")
+    lib = pkg._abi.load()
+    t = T()
+    assert lib.sdmesh_comm_init_transport(None, 2, 0, ctypes.byref(t)) == 1            # SDMESH_ERR_INVALID: no handle
+
+
 def test_create_voxel_field_needs_no_gpu(pkg, oracle):
     f = pkg.CudaHandler.create_cuda_voxel_field()
     v, s = oracle.create_voxel_field()
