@@ -2928,7 +2928,7 @@ int dist_grow_prev(sdmesh_handle *h, uint32_t n_prev) {
 
 // phase 2: match my lower band against the lower neighbour's upper-band keys (already in dist_prevkeys; their count at *n_prev_ptr, at most
 // cap_prev), number what I keep
-int dist_phase_match(sdmesh_handle *h, const uint32_t *n_prev_ptr, uint32_t cap_prev) {
+int dist_phase_match(sdmesh_handle *h, const uint32_t *n_prev_ptr, uint32_t cap_prev, const DistRecord &rec = DistRecord{}) {
     hipStream_t st = h->stream;
     if (cap_prev) {
         const uint32_t hsize = 2u * cap_prev + 64u;              // (dist_grow_prev made room)
@@ -2938,7 +2938,7 @@ int dist_phase_match(sdmesh_handle *h, const uint32_t *n_prev_ptr, uint32_t cap_
                                  (uint32_t *) h->dist_dupof.p, h->d_status));
     }
     HIPCHK(launch_dist_number(st, h->tgrid, (const uint32_t *) h->dist_dupof.p, h->d_ctr + CTR_NVERT, dist_local_capacity(h), (uint32_t *) h->dist_tilecnt.p,
-                              h->d_ctr + CTR_DIST_NKEEP, (uint32_t *) h->dist_newidx.p, h->d_status));
+                              h->d_ctr + CTR_DIST_NKEEP, (uint32_t *) h->dist_newidx.p, h->d_status, rec));
     return SDMESH_OK;
 }
 
@@ -2951,11 +2951,11 @@ int dist_phase_pack(sdmesh_handle *h, int me, const uint32_t *n_up_ptr, uint32_t
 }
 
 // phase 4: kept vertices compacted, indices global (dist_prevg holds the lower neighbour's numbers of its upper band)
-int dist_phase_final(sdmesh_handle *h, int me, uint32_t cap_prev) {
+int dist_phase_final(sdmesh_handle *h, int me, uint32_t cap_prev, const DistPublish &pb = DistPublish{}) {
     HIPCHK(launch_dist_finalize(h->stream, h->grid, (const Vertex *) h->vertices.p, h->d_ctr + CTR_NVERT, dist_local_capacity(h), h->d_ctr + CTR_NTRI,
                                 cap_items(h->indices, sizeof(IndexTriangle)), (const uint32_t *) h->dist_dupof.p, (const uint32_t *) h->dist_newidx.p,
                                 (const uint32_t *) h->dist_prevg.p, cap_prev, (const uint32_t *) h->dist_counts.p, (uint32_t) me, (uint32_t *) h->indices.p,
-                                (Vertex *) h->dist_verts.p));
+                                (Vertex *) h->dist_verts.p, pb));
     return SDMESH_OK;
 }
 
@@ -3083,10 +3083,14 @@ int dist_step_planned(sdmesh_handle *h, int levels, sdmesh_regen_info *info, uin
         if (me > 0 && cap_prev) msgs.push_back({h->dist_prevkeys.p, cap_prev, ncclUint64, me - 1, false});
         SDCHK(zs_exchange(h, msgs));
     }
+    // (this rank's record of the second all-gather and the publication of both tables ride in the numbering / finalize kernels; a rank whose
+    //  local phase failed runs neither and uses the two one-thread kernels instead)
     if (lrc == SDMESH_OK) {
-        SDCHK(dist_phase_match(h, me > 0 ? d_nups + (size_t) (me - 1) * DIST_REC : d_nups, cap_prev));
+        const DistRecord rec = {d_counts + (size_t) me * DIST_REC, h->d_ctr + CTR_DIST_NKEEP, h->d_status, 0u, 0u, 0u, pl.sig};
+        SDCHK(dist_phase_match(h, me > 0 ? d_nups + (size_t) (me - 1) * DIST_REC : d_nups, cap_prev, rec));
+    } else {
+        HIPCHK(launch_dist_record(st, d_counts + (size_t) me * DIST_REC, h->d_ctr + CTR_DIST_NKEEP, h->d_status, (uint32_t) lrc, 0u, 0u, pl.sig));
     }
-    HIPCHK(launch_dist_record(st, d_counts + (size_t) me * DIST_REC, h->d_ctr + CTR_DIST_NKEEP, h->d_status, (uint32_t) lrc, 0u, 0u, pl.sig));
     SDCHK(tp_all_gather(h, d_counts + (size_t) me * DIST_REC, d_counts, DIST_REC, ncclUint32, st));
     if (lrc == SDMESH_OK) SDCHK(dist_phase_pack(h, me, d_nups + (size_t) me * DIST_REC, me + 1 < R ? cap_up : 0u));
     {
@@ -3095,8 +3099,8 @@ int dist_step_planned(sdmesh_handle *h, int levels, sdmesh_regen_info *info, uin
         if (me > 0 && cap_prev) msgs.push_back({h->dist_prevg.p, cap_prev, ncclUint32, me - 1, false});
         SDCHK(zs_exchange(h, msgs));
     }
-    if (lrc == SDMESH_OK) SDCHK(dist_phase_final(h, me, cap_prev));
-    HIPCHK(launch_dist_publish(st, d_nups, d_counts, (uint32_t) R, seq, h->h_dist_pub));
+    if (lrc == SDMESH_OK) SDCHK(dist_phase_final(h, me, cap_prev, DistPublish{d_nups, d_counts, (uint32_t) R, seq, h->h_dist_pub}));
+    else HIPCHK(launch_dist_publish(st, d_nups, d_counts, (uint32_t) R, seq, h->h_dist_pub));
     // the step's one host synchronisation
     HIPCHK(hipStreamSynchronize(st));
     int erc = SDMESH_OK;

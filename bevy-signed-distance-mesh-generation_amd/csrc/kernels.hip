@@ -2124,9 +2124,17 @@ __global__ __launch_bounds__(256) void k_dist_keep_count(const uint32_t *__restr
     }
 }
 
+__device__ __forceinline__ void dist_record_body(uint32_t *__restrict__ dst, const uint32_t *__restrict__ count, const uint32_t *__restrict__ status, uint32_t host_status,
+                                                 uint32_t cap_prev, uint32_t inject, uint32_t sig);
+__device__ __forceinline__ void dist_publish_body(const uint32_t *__restrict__ nups, const uint32_t *__restrict__ counts, uint32_t nranks, uint32_t seq, uint32_t *__restrict__ pub);
+
+// rec.dst != nullptr: workgroup 0 also writes this rank's record of the kept-count all-gather that follows (the count is the scan kernel's
+// total in front of this launch, every status word is final): one launch less in the planned step.  (Prefixing the tile counts in every
+// workgroup instead of the scan launch in front was measured and is not faster: 0.158-0.160 against 0.157-0.158 ms per 512^3 step.)
 __global__ __launch_bounds__(256) void k_dist_newidx(const uint32_t *__restrict__ dup_of, const uint32_t *__restrict__ v_ptr, uint32_t vcap,
-                                                      const uint32_t *__restrict__ tileoff, uint32_t *__restrict__ newidx) {
+                                                      const uint32_t *__restrict__ tileoff, uint32_t *__restrict__ newidx, DistRecord rec) {
     __shared__ uint32_t lds[17];
+    if (rec.dst && blockIdx.x == 0 && threadIdx.x == 0) dist_record_body(rec.dst, rec.count, rec.status, rec.host_status, rec.cap_prev, rec.inject, rec.sig);
     const uint32_t V = *v_ptr < vcap ? *v_ptr : vcap;
     const uint32_t ntiles = (V + TILE - 1) / TILE;
     for (uint32_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
@@ -2159,8 +2167,8 @@ __global__ void k_pack_record(uint32_t *__restrict__ dst, const uint32_t *__rest
 
 // One DIST_REC-word record of the distributed weld's two all-gathers: {count, status, capacity for the lower neighbour's band, inject, sig, 0, 0, 0};
 // status = the host's code for a local phase that already failed, else the device flags that make the chain's result unusable
-__global__ void k_dist_record(uint32_t *__restrict__ dst, const uint32_t *__restrict__ count, const uint32_t *__restrict__ status, uint32_t host_status,
-                              uint32_t cap_prev, uint32_t inject, uint32_t sig) {
+__device__ __forceinline__ void dist_record_body(uint32_t *__restrict__ dst, const uint32_t *__restrict__ count, const uint32_t *__restrict__ status, uint32_t host_status,
+                                                 uint32_t cap_prev, uint32_t inject, uint32_t sig) {
     uint32_t st = host_status;
     if (!st && status) {
         const uint32_t dev = (status[ST_OVERFLOW] ? 1u : 0u) | (status[ST_NOT_LATTICE] ? 2u : 0u) | (status[ST_INTERNAL] ? 8u : 0u) |
@@ -2171,12 +2179,19 @@ __global__ void k_dist_record(uint32_t *__restrict__ dst, const uint32_t *__rest
     dst[0] = (count && !host_status) ? *count : 0u;
     dst[1] = st; dst[2] = cap_prev; dst[3] = inject; dst[4] = sig; dst[5] = 0u; dst[6] = 0u; dst[7] = 0u;
 }
+__global__ void k_dist_record(uint32_t *__restrict__ dst, const uint32_t *__restrict__ count, const uint32_t *__restrict__ status, uint32_t host_status,
+                              uint32_t cap_prev, uint32_t inject, uint32_t sig) {
+    dist_record_body(dst, count, status, host_status, cap_prev, inject, sig);
+}
 
 // both record tables of a distributed step and its sequence number to pinned host memory: [seq | R records of the band sizes | R of the kept counts]
-__global__ void k_dist_publish(const uint32_t *__restrict__ nups, const uint32_t *__restrict__ counts, uint32_t nranks, uint32_t seq, uint32_t *__restrict__ pub) {
-    const uint32_t t = threadIdx.x;
+__device__ __forceinline__ void dist_publish_body(const uint32_t *__restrict__ nups, const uint32_t *__restrict__ counts, uint32_t nranks, uint32_t seq, uint32_t *__restrict__ pub) {
+    const uint32_t t = threadIdx.x;                                  // (256 threads: 32 ranks x DIST_REC words)
     if (t == 0) pub[0] = seq;
     if (t < nranks * DIST_REC) { pub[8u + t] = nups[t]; pub[8u + nranks * DIST_REC + t] = counts[t]; }
+}
+__global__ void k_dist_publish(const uint32_t *__restrict__ nups, const uint32_t *__restrict__ counts, uint32_t nranks, uint32_t seq, uint32_t *__restrict__ pub) {
+    dist_publish_body(nups, counts, nranks, seq, pub);
 }
 
 __global__ __launch_bounds__(256) void k_dist_pack_up(const uint32_t *__restrict__ up_ids, const uint32_t *__restrict__ n_up_ptr, uint32_t ncap,
@@ -2191,7 +2206,10 @@ __global__ __launch_bounds__(256) void k_dist_finalize(const Vertex *__restrict_
                                                         const uint32_t *__restrict__ t_ptr, uint32_t tcap, const uint32_t *__restrict__ dup_of,
                                                         const uint32_t *__restrict__ newidx, const uint32_t *__restrict__ prev_g, uint32_t pcap,
                                                         const uint32_t *__restrict__ counts, uint32_t me, uint32_t *__restrict__ indices,
-                                                        Vertex *__restrict__ out_v) {
+                                                        Vertex *__restrict__ out_v, DistPublish pb) {
+    // (pb.pub != nullptr: workgroup 0 publishes both record tables and the step's sequence number to pinned host memory -- every word of them
+    //  was final before this kernel started)
+    if (pb.pub && blockIdx.x == 0) dist_publish_body(pb.nups, pb.counts, pb.nranks, pb.seq, pb.pub);
     const uint32_t off = dist_offset(counts, me);
     const uint32_t V = *v_ptr < vcap ? *v_ptr : vcap, T = *t_ptr < tcap ? *t_ptr : tcap;
     // the kept vertices, 256 at a time: moved as dwords (coalesced both ways: almost every vertex is kept, so the destinations of a block are
@@ -3143,10 +3161,10 @@ hipError_t launch_dist_match(hipStream_t st, int grid, const uint64_t *prev_keys
 }
 
 hipError_t launch_dist_number(hipStream_t st, int grid, const uint32_t *dup_of, const uint32_t *v_ptr, uint32_t vcap, uint32_t *tilecnt,
-                              uint32_t *n_keep_out, uint32_t *newidx, uint32_t *status) {
+                              uint32_t *n_keep_out, uint32_t *newidx, uint32_t *status, const DistRecord &rec) {
     hipLaunchKernelGGL(k_dist_keep_count, dim3(grid), dim3(256), 0, st, dup_of, v_ptr, vcap, tilecnt);
     hipLaunchKernelGGL(k_scan_tiles, dim3(1), dim3(1024), 0, st, tilecnt, v_ptr, 256u, n_keep_out, 0xFFFFFFFFu, status);
-    hipLaunchKernelGGL(k_dist_newidx, dim3(grid), dim3(256), 0, st, dup_of, v_ptr, vcap, (const uint32_t *) tilecnt, newidx);
+    hipLaunchKernelGGL(k_dist_newidx, dim3(std::max(grid, 1)), dim3(256), 0, st, dup_of, v_ptr, vcap, (const uint32_t *) tilecnt, newidx, rec);
     return hipGetLastError();
 }
 
@@ -3158,8 +3176,8 @@ hipError_t launch_dist_pack_up(hipStream_t st, int grid, const uint32_t *up_ids,
 
 hipError_t launch_dist_finalize(hipStream_t st, int grid, const Vertex *v, const uint32_t *v_ptr, uint32_t vcap, const uint32_t *t_ptr, uint32_t tcap,
                                 const uint32_t *dup_of, const uint32_t *newidx, const uint32_t *prev_g, uint32_t pcap, const uint32_t *counts, uint32_t me,
-                                uint32_t *indices, Vertex *out_v) {
-    hipLaunchKernelGGL(k_dist_finalize, dim3(grid), dim3(256), 0, st, v, v_ptr, vcap, t_ptr, tcap, dup_of, newidx, prev_g, pcap, counts, me, indices, out_v);
+                                uint32_t *indices, Vertex *out_v, const DistPublish &pb) {
+    hipLaunchKernelGGL(k_dist_finalize, dim3(std::max(grid, 1)), dim3(256), 0, st, v, v_ptr, vcap, t_ptr, tcap, dup_of, newidx, prev_g, pcap, counts, me, indices, out_v, pb);
     return hipGetLastError();
 }
 

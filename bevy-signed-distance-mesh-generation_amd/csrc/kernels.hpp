@@ -152,13 +152,17 @@ hipError_t launch_band_select(hipStream_t st, int grid, const Vertex *v, const u
                               uint32_t *up_ids, uint64_t *up_keys, uint32_t *lo_ids, uint32_t *ctr, uint32_t *dup_of, uint32_t *status);
 hipError_t launch_dist_match(hipStream_t st, int grid, const uint64_t *prev_keys, const uint32_t *n_prev_ptr, uint32_t ncap, uint64_t *hkeys, uint32_t *hpos, uint32_t hsize,
                              const Vertex *v, const uint32_t *lo_ids, const uint32_t *n_lo_ptr, uint32_t *dup_of, uint32_t *status);
+// what the planned step folds into the kernels that run anyway: this rank's record of the kept-count all-gather (written by the numbering
+// kernel's workgroup 0) and the publication of both record tables to pinned host memory (by the finalize kernel's); dst / pub == nullptr: not
+struct DistRecord { uint32_t *dst; const uint32_t *count; const uint32_t *status; uint32_t host_status, cap_prev, inject, sig; };
+struct DistPublish { const uint32_t *nups; const uint32_t *counts; uint32_t nranks, seq; uint32_t *pub; };
 hipError_t launch_dist_number(hipStream_t st, int grid, const uint32_t *dup_of, const uint32_t *v_ptr, uint32_t vcap, uint32_t *tilecnt,
-                              uint32_t *n_keep_out, uint32_t *newidx, uint32_t *status);
+                              uint32_t *n_keep_out, uint32_t *newidx, uint32_t *status, const DistRecord &rec);
 hipError_t launch_dist_pack_up(hipStream_t st, int grid, const uint32_t *up_ids, const uint32_t *n_up_ptr, uint32_t ncap, const uint32_t *newidx, const uint32_t *counts,
                                uint32_t me, uint32_t *up_g);
 hipError_t launch_dist_finalize(hipStream_t st, int grid, const Vertex *v, const uint32_t *v_ptr, uint32_t vcap, const uint32_t *t_ptr, uint32_t tcap,
                                 const uint32_t *dup_of, const uint32_t *newidx, const uint32_t *prev_g, uint32_t pcap, const uint32_t *counts, uint32_t me,
-                                uint32_t *indices, Vertex *out_v);
+                                uint32_t *indices, Vertex *out_v, const DistPublish &pb);
 hipError_t launch_dist_record(hipStream_t st, uint32_t *dst, const uint32_t *count, const uint32_t *status, uint32_t host_status, uint32_t cap_prev,
                               uint32_t inject, uint32_t sig);
 hipError_t launch_dist_publish(hipStream_t st, const uint32_t *nups, const uint32_t *counts, uint32_t nranks, uint32_t seq, uint32_t *pub /* 8 + 2 nranks DIST_REC words */);
