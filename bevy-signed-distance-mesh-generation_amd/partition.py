@@ -481,10 +481,11 @@ class StagedTransport:
             self.queue.append(op)
 
     def _run(self, ops):
-        reqs, landed = [], []
+        reqs, landed, sent = [], [], []
         for kind, buf, nbytes, peer, stream in ops:             # every message of a group is posted before any is waited for
             if kind == "send":
-                reqs.append(self.dist.isend(self._down(buf, nbytes, stream), peer, group=self.group))
+                sent.append(self._down(buf, nbytes, stream))    # (kept alive until the request has completed)
+                reqs.append(self.dist.isend(sent[-1], peer, group=self.group))
             else:
                 host = torch.empty(nbytes, dtype=torch.uint8)
                 reqs.append(self.dist.irecv(host, peer, group=self.group))
