@@ -17,9 +17,9 @@
 //     slot vertex id) and look themselves up; of a pair the copy whose first-seen segment comes first in the (column, rank) order
 //     is the single-GPU representative, the other one is dropped from its segment's count and redirected;
 //   * a kept vertex's merged place is its segment's merged start + its position in the segment - the dropped copies in front of it
-//     inside the segment (counted per 256-entry block: no global scan); the dropped ones inherit their partner's number; every
-//     triangle finds its segment by bisection over a few segment starts and is rewritten with the merged numbers.  All of it as flat,
-//     one-item-per-thread streaming kernels (k_zs_vertex_out, k_zs_loser_map, k_zs_index_out).
+//     inside the segment (counted per block of 256 or 1024 entries: no global scan); the dropped ones inherit their partner's number; every
+//     triangle finds its segment by bisection over a few segment starts and is rewritten with the merged numbers.  All of it as flat
+//     streaming kernels, one or four items per thread (k_zs_vertex_out, k_zs_loser_map, k_zs_index_out).
 //
 // Inputs lie in SLOTS (kernels.hpp, ZsRanks): slot capacities come from the host (exact counts on the synchronous path, planned
 // sizes on the planned one, where the host does not know the counts when it enqueues the kernels); the ACTUAL counts are read from
@@ -39,7 +39,7 @@ static constexpr uint32_t NCOL = MESH_GENERATION_INIT_FACTOR * MESH_GENERATION_I
 static constexpr uint32_t ZS_GAP = 0xfffffffeu;        // redirect[] of a slot entry behind the rank's last vertex
 // k_zs_vertex_out / k_zs_index_out take 256 * IPT slot entries per workgroup (IPT = 1 or 4 items per thread, every load issued in front):
 // a workgroup's chain of dependent steps (hints, checks, segment starts, gathers, staging) is the same whatever it carries, so large
-// meshes want the big block (1024^3: 19 -> see MEASUREMENTS.md) and small ones the many small blocks.  zr.blk = 256 * IPT, chosen by the host;
+// meshes want the big block (MEASUREMENTS.md) and small ones the many small blocks.  zr.blk = 256 * IPT, chosen by the host;
 // blockdrop[] and the block hints are per that many entries.
 static constexpr uint32_t ZS_FCOLS = 4;                // columns per workgroup of k_zs_front's per-vertex pass
 static_assert(SHARD_REC == 2 * NCOL, "a row is 1024 triangle counts, 1024 vertex counts, the record");
