@@ -126,6 +126,7 @@ SYMBOLS = {
     "sdmesh_comm_destroy": (_i, [_vp]),
     "sdmesh_comm_ranks": (_i, [_vp, ctypes.POINTER(_i)]),
     "sdmesh_comm_init_transport": (_i, [_vp, _i, _i, _vp]),
+    "sdmesh_comm_selftest": (_i, [_vp, ctypes.POINTER(ctypes.c_uint64)]),
     "sdmesh_set_program_motion": (_i, [_vp, _vp, _i]),
     "sdmesh_set_program_time": (_i, [_vp, ctypes.c_float]),
     "sdmesh_sharded_regen": (_i, [_vp, _i, _i, ctypes.POINTER(RegenInfo)]),

@@ -2550,6 +2550,57 @@ extern "C" {
 
 int sdmesh_sharded_route(const sdmesh_handle *h) { return h ? (int) h->zs_last_route : 0; }
 
+// Every operation of the handle's collective layer once, with this rank as its own peer where a peer is needed: grouped send / recv of the
+// three element types the steps use (odd counts, a megabyte), an out-of-place all-gather, both reductions.  *mismatches = words that did not
+// arrive as sent (0 = the layer moves bytes as the steps assume).  Collective: every rank calls it.
+int sdmesh_comm_selftest(sdmesh_handle *h, uint64_t *mismatches) {
+    if (!h || !mismatches) return SDMESH_ERR_INVALID;
+    if (!h->has_comm()) return fail(h, SDMESH_ERR_INVALID, "no communicator (sdmesh_comm_init)");
+    HIPCHK(hipSetDevice(h->device));
+    hipStream_t st = h->stream;
+    const int R = h->comm_nranks, me = h->comm_rank;
+    const size_t words = 1u << 18;                                          // 1 MiB of u32
+    std::vector<uint32_t> src(words), dst(words);
+    for (size_t i = 0; i < words; i++) src[i] = (uint32_t) (i * 2654435761u) ^ (uint32_t) (me + 1) * 0x9E3779B9u;
+    uint32_t *a = nullptr, *b = nullptr;
+    HIPCHK(hipMalloc((void **) &a, 4 * words));
+    if (hipMalloc((void **) &b, 4 * words * (size_t) std::max(R, 1)) != hipSuccess) { (void) hipFree(a); return fail(h, SDMESH_ERR_HIP, "hipMalloc failed in the collective self-test"); }
+    uint64_t bad = 0;
+    int rc = SDMESH_OK;
+    auto upload = [&]() { return hipMemcpyAsync(a, src.data(), 4 * words, hipMemcpyHostToDevice, st) == hipSuccess && hipMemsetAsync(b, 0xA5, 4 * words, st) == hipSuccess; };
+    auto compare = [&](size_t n_words, size_t offset_words) {
+        if (hipMemcpyAsync(dst.data(), b + offset_words, 4 * n_words, hipMemcpyDeviceToHost, st) != hipSuccess || hipStreamSynchronize(st) != hipSuccess) { rc = fail(h, SDMESH_ERR_HIP, "copy failed in the collective self-test"); return; }
+        for (size_t i = 0; i < n_words; i++) bad += dst[i] != src[i] ? 1u : 0u;
+    };
+    const struct { ncclDataType_t type; size_t count, words; } cases[] = {{ncclUint32, words, words}, {ncclFloat32, 12345, 12345}, {ncclUint64, 777, 1554}, {ncclUint32, 1, 1}};
+    for (const auto &c : cases) {
+        if (rc != SDMESH_OK) break;
+        if (!upload()) { rc = fail(h, SDMESH_ERR_HIP, "upload failed in the collective self-test"); break; }
+        std::vector<ZsMsg> msgs;
+        msgs.push_back({a, c.count, c.type, me, true});
+        msgs.push_back({b, c.count, c.type, me, false});
+        rc = zs_exchange(h, msgs);
+        if (rc == SDMESH_OK) compare(c.words, 0);
+    }
+    if (rc == SDMESH_OK && upload()) {                                      // out of place: this rank's 64 words land in block `me`
+        rc = tp_all_gather(h, a, b, 64, ncclUint32, st);
+        if (rc == SDMESH_OK) compare(64, 64u * (size_t) me);
+    }
+    for (int mx = 0; mx < 2 && rc == SDMESH_OK; mx++) {
+        const uint32_t mine = (uint32_t) me + 1u;
+        if (hipMemcpyAsync(a, &mine, 4, hipMemcpyHostToDevice, st) != hipSuccess) { rc = fail(h, SDMESH_ERR_HIP, "upload failed in the collective self-test"); break; }
+        rc = tp_all_reduce_u32(h, a, b, 1, mx != 0, st);
+        uint32_t got = 0;
+        if (rc == SDMESH_OK && (hipMemcpyAsync(&got, b, 4, hipMemcpyDeviceToHost, st) != hipSuccess || hipStreamSynchronize(st) != hipSuccess)) rc = fail(h, SDMESH_ERR_HIP, "copy failed in the collective self-test");
+        if (rc == SDMESH_OK) bad += got != (mx ? (uint32_t) R : (uint32_t) (R * (R + 1) / 2)) ? 1u : 0u;
+    }
+    (void) hipStreamSynchronize(st);
+    (void) hipFree(a); (void) hipFree(b);
+    *mismatches = bad;
+    return rc;
+}
+
+
 int sdmesh_sharded_regen(sdmesh_handle *h, int levels, int root, sdmesh_regen_info *info) {
     if (!h) return SDMESH_ERR_INVALID;
     // (argument errors are found before any communication: they must be the same on every rank, like the arguments)

@@ -400,6 +400,12 @@ class CudaHandler:
             dist.broadcast_object_list(uid, src=0)
         self.comm_init(uid[0], nranks, rank)
 
+    def comm_selftest(self):
+        """Every operation of the collective layer once with this rank as its own peer (sdmesh_comm_selftest): words that did not arrive."""
+        bad = ctypes.c_uint64(0)
+        self._chk(self._lib.sdmesh_comm_selftest(self._h, ctypes.byref(bad)))
+        return int(bad.value)
+
     def comm_ranks(self):
         n = ctypes.c_int(0)
         self._chk(self._lib.sdmesh_comm_ranks(self._h, ctypes.byref(n)))

@@ -482,7 +482,12 @@ class StagedTransport:
 
     def _run(self, ops):
         reqs, landed, sent = [], [], []
+        mine = [op for op in ops if op[3] == self.rank]         # a rank that is its own peer (sdmesh_comm_selftest): sends meet receives in order
+        for snd, rcv in zip([o for o in mine if o[0] == "send"], [o for o in mine if o[0] == "recv"]):
+            landed.append((rcv[1], self._down(snd[1], snd[2], snd[4]), rcv[4]))
         for kind, buf, nbytes, peer, stream in ops:             # every message of a group is posted before any is waited for
+            if peer == self.rank:
+                continue
             if kind == "send":
                 sent.append(self._down(buf, nbytes, stream))    # (kept alive until the request has completed)
                 reqs.append(self.dist.isend(sent[-1], peer, group=self.group))

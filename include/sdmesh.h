@@ -292,6 +292,10 @@ typedef struct sdmesh_transport {
     int (*group_end)(void *user);
 } sdmesh_transport;
 int sdmesh_comm_init_transport(sdmesh_handle *h, int nranks, int rank, const sdmesh_transport *transport);
+/* Every operation of the handle's collective layer once (RCCL's or the caller's), this rank being its own peer where one is needed: grouped
+ * send / recv of the element types and odd counts the steps use, an out-of-place all-gather, both reductions; *mismatches = words that did
+ * not arrive as sent.  Collective (every rank calls it); a diagnostic for a new node or a new transport, never called by the steps. */
+int sdmesh_comm_selftest(sdmesh_handle *h, uint64_t *mismatches);
 
 /* ONE regen of ONE mesh over all ranks of the communicator, entirely behind this call.
  * Indexed form (default): rank r meshes AND welds level-0 z-slab r, ncclAllGather of the 1024 per-column triangle counts, the 1024
