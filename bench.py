@@ -191,6 +191,10 @@ def one_mesh_legs(pkg, job, local_rank, scene, params, levels_list, base_levels,
     h = pkg.CudaHandler(local_rank, scene, params)
     mesher = P.ShardedMesher(pkg, h, base_levels, rank, world, dev, transport="collectives" if rehearse else "rccl")
     ranks_seen = mesher.ranks_seen
+    try:                                             # every kind of message the steps use, once, each rank its own peer (never fatal here)
+        selftest = h.comm_selftest()
+    except Exception as e:                           # noqa: BLE001
+        selftest = f"failed: {e}"
     zbounds, xbounds = mesher.bounds, None
     zslab, primary = {}, None
     for lv in levels_list:
@@ -237,7 +241,7 @@ def one_mesh_legs(pkg, job, local_rank, scene, params, levels_list, base_levels,
                            "triangles": int(cnt[1]), "vertices": int(cnt[0]), "steps": k,
                            "route": {1: "planned (one host synchronisation)", 2: "synchronous", 3: "planned, repeated synchronously"}.get(h.distributed_route())}
     h.close()
-    return primary, {"n_gpus": world, "ranks_seen": ranks_seen, "slab_bounds": {"z": zbounds, "x": xbounds},
+    return primary, {"n_gpus": world, "ranks_seen": ranks_seen, "comm_selftest_mismatches": selftest, "slab_bounds": {"z": zbounds, "x": xbounds},
                      "zslab_indexed_gather": {"what": "sdmesh_sharded_regen (indexed form): level-0 z-slab per rank, meshed AND welded there; ncclAllGather of "
                                                       "1024 column counts + sizes + status; ncclSend/ncclRecv of the slabs' vertex and index buffers "
                                                       "(24 B per vertex + 12 B per triangle) to rank 0; there the buffers are merged by (column, rank) "

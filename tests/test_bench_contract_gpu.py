@@ -53,7 +53,7 @@ def test_one_mesh_line_keeps_the_contract_on_one_rank():
     j = _run("--one-mesh-selftest", "--steps", "8", "--warmup", "2", "--max-levels", "5", "--no-replicas")
     for k in REQUIRED:
         assert k in j, k
-    assert j["n_gpus"] == 1 and j["scaling"] == "strong" and j["ranks_seen"] == 1
+    assert j["n_gpus"] == 1 and j["scaling"] == "strong" and j["ranks_seen"] == 1 and j["one_mesh"]["comm_selftest_mismatches"] == 0
     assert j["config"]["one_mesh_form"] in ("zslab_indexed_gather", "xslab_distributed_weld")
     for form in ("zslab_indexed_gather", "xslab_distributed_weld"):
         for size in ("256^3", "512^3", "1024^3"):
@@ -86,6 +86,7 @@ def test_the_multi_rank_bench_path_runs_as_the_driver_launches_it():
     for k in REQUIRED:
         assert k in j, k
     assert j["n_gpus"] == 3 and j["ranks_seen"] == 3 and j["scaling"] == "strong" and "NOT a measurement" in j["rehearsal"]
+    assert j["one_mesh"]["comm_selftest_mismatches"] == 0
     assert j["config"]["one_mesh_form"] == "zslab_indexed_gather" and (j["triangles"], j["vertices"]) == (530536, 265262)
     for form in ("zslab_indexed_gather", "xslab_distributed_weld"):
         assert j["one_mesh"][form]["512^3"]["triangles"] == 530536 and j["one_mesh"][form]["256^3"]["route"].startswith("planned")
