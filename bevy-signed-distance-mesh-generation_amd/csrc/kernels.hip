@@ -3047,13 +3047,14 @@ hipError_t launch_sample_dense_rows(hipStream_t st, int grid, int scene, const S
         // than the 64 extra registers cost occupancy; at 512^3, where a row is one 8 x 2 piece anyway, both shapes time the same).
         // (Balancing the chunks of a longer row instead -- 1449-sample rows as two chunks of 3 x 64 quads rather than 4 x 64 + a 41 % full one -- was
         // slower, 2.97 against 2.84 ms: as few pieces per row as possible is what counts.)
-        constexpr uint32_t R = 8;
-        const uint32_t nq = (N + 1) >> 2, Q = nq <= 128u ? 2u : 4u;
+        // Rows of at most 64 quads (256^3 and below): ONE quad per lane and sixteen rows per wave -- with two quads per lane half of them lie behind
+        // the row's end, and eight one-quad rows are too little work for the wave's 200-instruction prologue.
+        const uint32_t nq = (N + 1) >> 2, Q = nq <= 64u ? 1u : (nq <= 128u ? 2u : 4u), R = Q == 1u ? 16u : 8u;
         const uint64_t nrows = (uint64_t) (N + 1) * (x1 - x0), nchunks = ((uint64_t) nq + 64ull * Q - 1ull) / (64ull * Q);
         const uint64_t ngroups = nchunks * 4ull * ((((nrows + 3ull) >> 2) + R - 1ull) / R);
         const int g2 = (int) std::min<uint64_t>((ngroups + 3ull) / 4ull, 0x7FFFFFFFull);
-#define SDM_AL(SC, NTF, QQ) hipLaunchKernelGGL((k_sample_dense_rows_aligned<SC, NTF, R, QQ>), dim3(g2), dim3(256), 0, st, out, N, sp, x0, x1)
-#define SDM_ALQ(SC, NTF) { if (Q == 4) SDM_AL(SC, NTF, 4); else SDM_AL(SC, NTF, 2); }
+#define SDM_AL(SC, NTF, RR, QQ) hipLaunchKernelGGL((k_sample_dense_rows_aligned<SC, NTF, RR, QQ>), dim3(g2), dim3(256), 0, st, out, N, sp, x0, x1)
+#define SDM_ALQ(SC, NTF) { if (Q == 4) SDM_AL(SC, NTF, 8, 4); else if (Q == 2) SDM_AL(SC, NTF, 8, 2); else SDM_AL(SC, NTF, 16, 1); }
         if (scene == SCENE_SDOBJ) { if (nt_rows) SDM_ALQ(SCENE_SDOBJ, true) else SDM_ALQ(SCENE_SDOBJ, false) }
         else { if (nt_rows) SDM_ALQ(SCENE_ANIM, true) else SDM_ALQ(SCENE_ANIM, false) }
 #undef SDM_ALQ
