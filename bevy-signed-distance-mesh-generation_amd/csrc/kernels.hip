@@ -2752,27 +2752,28 @@ __global__ __launch_bounds__(256) void k_sample_dense_rows_aligned(float *__rest
             }
         }
     }
-    // ---- the rows' unaligned ends (ht <= 6 samples per row), by the wave of the first chunk: one lane per sample, two samples per
-    // packed evaluation, with the row contexts fetched from the lanes that hold them (ds_bpermute: no LDS memory involved)
-    if (chunk == 0) {
-        for (uint32_t u0 = 0; u0 < rows * ht; u0 += 128u) {
-            const uint32_t ua = u0 + lane, ub = ua + 64u;
-            const uint32_t ja = ua / ht, jb = ub / ht, ka = ua - ja * ht, kb = ub - jb * ht;
-            const uint32_t za = ka < head ? ka : tail0 + (ka - head), zb = kb < head ? kb : tail0 + (kb - head);
-            const int sa = (int) ((ja & (ROWS - 1u)) << 2), sb = (int) ((jb & (ROWS - 1u)) << 2);
+    // ---- the rows' unaligned ends (ht <= 6 samples per row), by the wave of the first chunk: lane = (row, end sample) with eight slots per
+    // row -- shifts instead of the two integer divisions a dense numbering costs (they were a tenth of the kernel at 512^3: one extra sample
+    // per 513-sample row, 0.577 against 0.621 of the HBM peak at N = 511) -- rows j and j + 8 in the two components of one packed
+    // evaluation (same slot, so the same z terms), the row contexts fetched from the lanes that hold them (ds_bpermute: no LDS memory)
+    static_assert(ROWS <= 16, "eight slots per row, two rows per lane");
+    if (chunk == 0 && ht) {
+        const uint32_t k = lane & 7u, ja = lane >> 3, jb = ROWS > 8u ? ja + 8u : ja;
+        const uint32_t z = k < head ? k : tail0 + (k - head);
+        const int sa = (int) (ja << 2), sb = (int) (jb << 2);
 #define SDM_ROWCTX2(v) mk2(__builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(sa, __builtin_bit_cast(int, v))), \
                            __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(sb, __builtin_bit_cast(int, v))))
-            const v2f a0 = SDM_ROWCTX2(ca0), a1 = SDM_ROWCTX2(ca1), a2 = SDM_ROWCTX2(ca2), cs = SDM_ROWCTX2(cc);
+        const v2f a0 = SDM_ROWCTX2(ca0), a1 = SDM_ROWCTX2(ca1), a2 = SDM_ROWCTX2(ca2), cs = SDM_ROWCTX2(cc);
 #undef SDM_ROWCTX2
-            const v2f pz = mk2((float) za * h - 2.5f, (float) zb * h - 2.5f);
-            const v2f eaz = along_sq2(pz, -0.25f, 0.5f), esz = sq2(abs2(pz) - 0.25f), emz = min2(sq2(pz - (-0.25f)), sq2(pz - 2.75f));
-            const v2f m = min2(min2(a0 + esz, a1 + emz), a2 + eaz);
-            const v2f d1 = sqrt_rn_normal2_nonudge(m) - 0.1f;
-            const v2f d2 = sqrt_rn_normal2_nonudge(cs + pz * pz) - 1.0f;
-            const v2f r = smooth_min_half2(d1, d2);
-            if (ua < rows * ht) out[(uint64_t) (c + 4u * (i0 + ja)) * S + za] = r.x;
-            if (ub < rows * ht) out[(uint64_t) (c + 4u * (i0 + jb)) * S + zb] = r.y;
-        }
+        const float pz1 = (float) z * h - 2.5f;
+        const v2f pz = mk2(pz1, pz1);
+        const v2f eaz = along_sq2(pz, -0.25f, 0.5f), esz = sq2(abs2(pz) - 0.25f), emz = min2(sq2(pz - (-0.25f)), sq2(pz - 2.75f));
+        const v2f m = min2(min2(a0 + esz, a1 + emz), a2 + eaz);
+        const v2f d1 = sqrt_rn_normal2_nonudge(m) - 0.1f;
+        const v2f d2 = sqrt_rn_normal2_nonudge(cs + pz * pz) - 1.0f;
+        const v2f r = smooth_min_half2(d1, d2);
+        if (k < ht && ja < rows) out[(uint64_t) (c + 4u * (i0 + ja)) * S + z] = r.x;
+        if (ROWS > 8u && k < ht && jb < rows) out[(uint64_t) (c + 4u * (i0 + jb)) * S + z] = r.y;
     }
 #endif
 }
