@@ -2687,7 +2687,9 @@ __global__ __launch_bounds__(256) void k_sample_dense_rows_aligned(float *__rest
     // wave -> (chunk of 64 QPL quads along z, phase class, group of ROWS rows of that class)
     const uint32_t per_class = (((nrows + 3u) >> 2) + ROWS - 1u) / ROWS;            // row groups per phase class
     const uint32_t nchunks = ((S >> 2) + 64u * QPL - 1u) / (64u * QPL);               // (S >> 2 = the most aligned quads a row can have)
-    uint32_t g = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    // (the wave's number through v_readfirstlane: chunk, class, group, the row loop's bound and every row's base address stay in
+    //  scalar registers, and the quad stores take the scalar base + a 32-bit lane offset)
+    uint32_t g = (uint32_t) __builtin_amdgcn_readfirstlane((int) (blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)));
     if (g >= nchunks * 4u * per_class) return;
     const uint32_t chunk = g % nchunks;
     g /= nchunks;
@@ -2733,7 +2735,7 @@ __global__ __launch_bounds__(256) void k_sample_dense_rows_aligned(float *__rest
             const float a1 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, ca1), j));
             const float a2 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, ca2), j));
             const float cs = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, cc), j));
-            float *__restrict__ o = out + (uint64_t) (c + 4u * (i0 + j)) * S;
+            char *__restrict__ o = reinterpret_cast<char *>(out + (uint64_t) (c + 4u * (i0 + j)) * S);
 #pragma unroll
             for (int u = 0; u < QPL; u++) {
                 if (on[u]) {
@@ -2746,8 +2748,10 @@ __global__ __launch_bounds__(256) void k_sample_dense_rows_aligned(float *__rest
                         r[p] = smooth_min_half2(d1, d2);
                     }
                     const v4f v = {r[0].x, r[0].y, r[1].x, r[1].y};
-                    if (NT) __builtin_nontemporal_store(v, reinterpret_cast<v4f *>(o + zq[u]));
-                    else *reinterpret_cast<v4f *>(o + zq[u]) = v;
+                    uint32_t off = zq[u] << 2;
+                    asm volatile("" : "+v"(off));          // (keeps the zero-extension in this block: scalar base + 32-bit lane offset)
+                    if (NT) __builtin_nontemporal_store(v, reinterpret_cast<v4f *>(o + off));
+                    else *reinterpret_cast<v4f *>(o + off) = v;
                 }
             }
         }
@@ -3032,7 +3036,7 @@ hipError_t launch_triangles_direct(hipStream_t st, int scene, const SceneParams 
 }
 
 hipError_t launch_sample_dense_rows(hipStream_t st, int grid, int scene, const SceneParams *sp, float *out, uint32_t N, bool nt,
-                                    uint32_t x0, uint32_t x1, bool aligned_rows, bool nt_rows) {
+                                    uint32_t x0, uint32_t x1, bool aligned_rows, bool nt_rows, int occ) {
     if (x1 <= x0) return hipSuccess;
 #if defined(SDM_NO_PAIRS)
     aligned_rows = false;                    // (the aligned kernel is written on the packed 2-vector helpers)
@@ -3054,8 +3058,15 @@ hipError_t launch_sample_dense_rows(hipStream_t st, int grid, int scene, const S
         const uint64_t nrows = (uint64_t) (N + 1) * (x1 - x0), nchunks = ((uint64_t) nq + 64ull * Q - 1ull) / (64ull * Q);
         const uint64_t ngroups = nchunks * 4ull * ((((nrows + 3ull) >> 2) + R - 1ull) / R);
         const int g2 = (int) std::min<uint64_t>((ngroups + 3ull) / 4ull, 0x7FFFFFFFull);
-#define SDM_AL(SC, NTF, RR, QQ) hipLaunchKernelGGL((k_sample_dense_rows_aligned<SC, NTF, RR, QQ>), dim3(g2), dim3(256), 0, st, out, N, sp, x0, x1)
-#define SDM_ALQ(SC, NTF) { if (Q == 4) SDM_AL(SC, NTF, 8, 4); else if (Q == 2) SDM_AL(SC, NTF, 8, 2); else SDM_AL(SC, NTF, 16, 1); }
+        // Workgroups per CU: measured on three boxes at 512^3 / 1024^3 / 1500^3, 2 or 3 resident workgroups (8-12 waves per CU) run this kernel
+        // 4-10 % faster than 4 and more (a sharp step between 3 and 4 at every size, also where the last round's tail is nothing: 0.124 ->
+        // 0.112-0.117 ms at 512^3, 3.08 -> 2.97 ms at 1500^3); rows of <= 64 quads (256^3) want all they can get.  The cap is an LDS allotment the
+        // kernel never touches (160 KiB / 3 per workgroup); `occ` > 0 = the caller's choice (option dense_occ), < 0 = no cap.
+        if (occ == 0) occ = Q == 1u ? -1 : 3;
+        const uint32_t lds = occ >= 1 && occ <= 8 ? (160u * 1024u / (uint32_t) occ) & ~1023u : 0u;
+#define SDM_AL(SC, NTF, RR, QQ) { if (lds > 65536u) (void) hipFuncSetAttribute(reinterpret_cast<const void *>(&k_sample_dense_rows_aligned<SC, NTF, RR, QQ>), hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds); \
+        hipLaunchKernelGGL((k_sample_dense_rows_aligned<SC, NTF, RR, QQ>), dim3(g2), dim3(256), lds, st, out, N, sp, x0, x1); }
+#define SDM_ALQ(SC, NTF) { if (Q == 4) SDM_AL(SC, NTF, 8, 4) else if (Q == 2) SDM_AL(SC, NTF, 8, 2) else SDM_AL(SC, NTF, 16, 1) }
         if (scene == SCENE_SDOBJ) { if (nt_rows) SDM_ALQ(SCENE_SDOBJ, true) else SDM_ALQ(SCENE_SDOBJ, false) }
         else { if (nt_rows) SDM_ALQ(SCENE_ANIM, true) else SDM_ALQ(SCENE_ANIM, false) }
 #undef SDM_ALQ

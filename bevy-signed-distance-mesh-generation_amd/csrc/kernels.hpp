@@ -104,7 +104,8 @@ hipError_t launch_sample_dense_q1(hipStream_t st, int scene, const SceneParams *
 hipError_t launch_stream_fill(hipStream_t st, int grid, float *out, uint64_t total, float value);
 hipError_t launch_sample_dense_rows(hipStream_t st, int grid, int scene, const SceneParams *sp, float *out, uint32_t N, bool nt, uint32_t x0, uint32_t x1,
                                     bool aligned_rows /* sd_obj family: whole-line stores + hoisted z terms (needs a 16-byte aligned out) */,
-                                    bool nt_rows /* nontemporal stores in that kernel too (measured slower) */);
+                                    bool nt_rows /* nontemporal stores in that kernel too (measured slower) */,
+                                    int occ = 0 /* aligned kernel: workgroups per CU capped through its LDS allotment (0 = by row length, < 0 = no cap) */);
 hipError_t launch_sample_dense(hipStream_t st, int grid, int scene, const SceneParams *sp, float *out, uint32_t N, bool nt,
                                bool contig, uint32_t x0, uint32_t x1);
 hipError_t launch_create_field(hipStream_t st, Point *vox, uint32_t x0, uint32_t x1, uint32_t z0, uint32_t z1, uint32_t *n_out,

@@ -179,8 +179,15 @@ SDM_HD float smooth_min(float a, float b, float k) {
 // 0 or >= 2^-24, so h^3 >= 2^-72 and nothing underflows), hence fl(fl(h^3 * 0.5) * c) = fl(h^3 * (c / 2)) with c = fl(1 / 6), c / 2 exact.
 // (The compiler may not reassociate this itself without fast-math; `/ 0.5f` it does turn into an exact doubling.)
 #define SDM_SIXTH_HALF 0.0833333358168601989746f          /* fl(1.0f / 6.0f) / 2, exactly */
+// On the device h = max(0.5 - |d|, 0) / 0.5 is taken as max(fma(|d|, -2, 1), 0): 2 |d| is exact, so the fma rounds 1 - 2 |d| once, which is
+// the doubling of fl(0.5 - |d|) bit for bit (doubling commutes with rounding; 0.5 - |d| is 0 or >= 2^-26, nothing underflows), and
+// max(2 t, 0) == 2 max(t, 0).  One v_fma_f32 with an |abs| source modifier instead of v_and + v_sub + v_add per component.
 SDM_HD float smooth_min_half(float a, float b) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    const float h = fmax1(__builtin_fmaf(fabsf(a - b), -2.0f, 1.0f), 0.0f);
+#else
     const float h = fmax1(0.5f - fabsf(a - b), 0.0f) / 0.5f;
+#endif
     return fmin1(a, b) - h * h * h * SDM_SIXTH_HALF;
 }
 
@@ -604,7 +611,8 @@ SDM_HD v2f sqrt_rn_normal2_nonudge(v2f xc) {
 #endif
 }
 SDM_HD v2f smooth_min_half2(v2f a, v2f b) {                        // smooth_min_half() on both components
-    const v2f h = max2s(0.5f - abs2(a - b), 0.0f) / 0.5f;
+    const v2f d = a - b;                                             // (h as in smooth_min_half: one fma per component)
+    const v2f h = mk2(fmax1(__builtin_fmaf(fabsf(d.x), -2.0f, 1.0f), 0.0f), fmax1(__builtin_fmaf(fabsf(d.y), -2.0f, 1.0f), 0.0f));
     return min2(a, b) - h * h * h * SDM_SIXTH_HALF;
 }
 SDM_HD v2f smooth_min2(v2f a, v2f b, float k) {
