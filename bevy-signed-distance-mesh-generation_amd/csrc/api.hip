@@ -123,6 +123,8 @@ struct sdmesh_handle {
     int dense_nt = 1;          // nontemporal stores in k_sample_dense
     int dense_contig = 1;      // flat P1 kernel: every workgroup writes one contiguous run (measured best)
     int dense_q1 = 1;          // flat P1 kernel: one quad per thread, one 4 KiB piece per workgroup (the shape the write stream is fastest in)
+    int dense_xcd = 1;         // option "dense_xcd": workgroups of one XCD write one contiguous eighth of the output: 1 = in the aligned row kernel (sd_obj
+                               // family: 512^3 0.110 -> 0.104 ms, 1024^3 0.861 -> 0.805), 2 = in every P1 kernel (sphere / write ceiling: no difference), 0 = nowhere
     int dense_occ = 0;         // option "dense_occ": workgroups per CU of the aligned row kernel (0 = the launcher's choice, < 0 = no cap)
     int dense_rows = 2;        // P1 kernel: 0 = flat 16-B aligned quads, 1 = one wave per z-row, 2 = auto
     char err[512] = {0};
@@ -1352,6 +1354,7 @@ int sdmesh_set_option(sdmesh_handle *h, const char *name, int value) {
     if (!strcmp(name, "dense_nt")) { h->dense_nt = value < 0 ? 0 : (value > 2 ? 2 : value); return SDMESH_OK; }    // 2: also in the aligned row kernel
     if (!strcmp(name, "dense_rows")) { h->dense_rows = value; return SDMESH_OK; }
     if (!strcmp(name, "dense_occ")) { h->dense_occ = value; return SDMESH_OK; }
+    if (!strcmp(name, "dense_xcd")) { h->dense_xcd = value < 0 ? 0 : (value > 2 ? 2 : value); return SDMESH_OK; }
     if (!strcmp(name, "dense_q1")) { h->dense_q1 = value ? 1 : 0; return SDMESH_OK; }
     if (!strcmp(name, "dense_contig")) { h->dense_contig = value ? 1 : 0; return SDMESH_OK; }
     if (!strcmp(name, "forget_plan")) { h->plan_valid = false; return SDMESH_OK; }
@@ -1663,8 +1666,8 @@ static hipError_t launch_p1(sdmesh_handle *h, float *d_out, uint32_t N, uint32_t
     // the flat kernels store 16-byte quads: a slab written into its place of a shared volume starts at x_begin (N + 1)^2 samples, which is
     // only dword-aligned when N + 1 is odd -> the row kernel there (4-byte aligned vector stores)
     if ((reinterpret_cast<uintptr_t>(d_out) & 15u) != 0) rows = true;
-    if (!rows && h->dense_q1 && N >= 1u) return launch_sample_dense_q1(h->stream, h->scene, h->d_sp, d_out, N, h->dense_nt != 0, x0, x1);
-    return rows ? launch_sample_dense_rows(h->stream, h->dense_grid, h->scene, h->d_sp, d_out, N, h->dense_nt != 0, x0, x1, h->dense_aligned != 0, h->dense_nt == 2, h->dense_occ)
+    if (!rows && h->dense_q1 && N >= 1u) return launch_sample_dense_q1(h->stream, h->scene, h->d_sp, d_out, N, h->dense_nt != 0, x0, x1, h->dense_xcd == 2);
+    return rows ? launch_sample_dense_rows(h->stream, h->dense_grid, h->scene, h->d_sp, d_out, N, h->dense_nt != 0, x0, x1, h->dense_aligned != 0, h->dense_nt == 2, h->dense_occ, h->dense_xcd != 0)
                          : launch_sample_dense(h->stream, grid, h->scene, h->d_sp, d_out, N, h->dense_nt != 0, h->dense_contig != 0, x0, x1);
 }
 static hipError_t launch_p1(sdmesh_handle *h, float *d_out, uint32_t N) { return launch_p1(h, d_out, N, 0u, N + 1u); }
@@ -1783,9 +1786,9 @@ int sdmesh_time_kernel(sdmesh_handle *h, int which, uint32_t N, float *d_buf, in
     if (which == 2) {     // write ceiling: P1's store stream without the arithmetic
         const uint64_t total = (uint64_t) (N + 1) * (N + 1) * (N + 1);
         const int grid = h->dense_q1 ? 0 : (h->dense_grid > 0 ? h->dense_grid : 8 * h->grid);       // 0 = one quad per thread
-        HIPCHK(launch_stream_fill(h->stream, grid, d_buf, total, 1.0f));
+        HIPCHK(launch_stream_fill(h->stream, grid, d_buf, total, 1.0f, h->dense_xcd == 2));
         HIPCHK(hipEventRecord(h->ev0, h->stream));
-        for (int i = 0; i < iters; i++) HIPCHK(launch_stream_fill(h->stream, grid, d_buf, total, 1.0f));
+        for (int i = 0; i < iters; i++) HIPCHK(launch_stream_fill(h->stream, grid, d_buf, total, 1.0f, h->dense_xcd == 2));
         HIPCHK(hipEventRecord(h->ev1, h->stream));
         HIPCHK(hipStreamSynchronize(h->stream));
         float ms2 = 0.0f;

@@ -2477,15 +2477,22 @@ __global__ __launch_bounds__(256) void k_sample_dense(float *__restrict__ out, u
     }
 }
 
+// Workgroup ids are dealt to the eight XCDs round robin; with `xcd` set, the workgroups of one XCD take one contiguous eighth of the
+// pieces instead of every eighth piece, so that an XCD's L2 writes ONE ascending stream (measured: launch_sample_dense_rows).
+__device__ __forceinline__ uint32_t xcd_contiguous(uint32_t wg, uint32_t nwg, uint32_t xcd) {
+    const uint32_t per = nwg >> 3;
+    return (xcd && wg < (per << 3)) ? (wg & 7u) * per + (wg >> 3) : wg;
+}
 // Write ceiling for P1: the same store stream (contiguous run of float4 per workgroup, nontemporal) with no
 // arithmetic in front of it.  bench.py times it beside P1 to show how much of the achievable write rate P1 reaches.
-__global__ __launch_bounds__(256) void k_stream_fill(float *__restrict__ out, uint64_t total, float value) {
+__global__ __launch_bounds__(256) void k_stream_fill(float *__restrict__ out, uint64_t total, float value, uint32_t xcd) {
     // (grid = ceil(quads / 256): every thread issues one store -- the shape the write stream is fastest in, see k_sample_dense_q1)
     typedef float v4f __attribute__((ext_vector_type(4)));
     const uint64_t nquads = total >> 2;
     const uint64_t per = ((nquads + gridDim.x - 1) / gridDim.x + blockDim.x - 1) / blockDim.x * blockDim.x;
-    uint64_t qd = (uint64_t) blockIdx.x * per + threadIdx.x;
-    const uint64_t qlim = (uint64_t) (blockIdx.x + 1) * per < nquads ? (uint64_t) (blockIdx.x + 1) * per : nquads;
+    const uint32_t wg = xcd_contiguous(blockIdx.x, gridDim.x, xcd);
+    uint64_t qd = (uint64_t) wg * per + threadIdx.x;
+    const uint64_t qlim = (uint64_t) (wg + 1) * per < nquads ? (uint64_t) (wg + 1) * per : nquads;
     const v4f q = {value, value, value, value};
     for (; qd < qlim; qd += blockDim.x) __builtin_nontemporal_store(q, reinterpret_cast<v4f *>(out) + qd);
     if (blockIdx.x == 0 && threadIdx.x < (total & 3ull)) out[(nquads << 2) + threadIdx.x] = value;
@@ -2513,16 +2520,18 @@ __device__ __forceinline__ uint32_t div_magic(uint32_t n, DivMagic d) {
 template <int SCENE, bool NT>
 __global__ __launch_bounds__(256) void k_sample_dense_q1(float *__restrict__ out, uint32_t N, uint32_t total, const SceneParams *__restrict__ spp,
                                                           DivMagic dS, float h /* = 5.0f / (float) N, computed on the host: the same IEEE quotient */,
-                                                          uint32_t xplane0 /* out[0] is sample (xplane0, 0, 0): x-slabs, and volumes of >= 2^32 samples in batches of planes */) {
+                                                          uint32_t xplane0 /* out[0] is sample (xplane0, 0, 0): x-slabs, and volumes of >= 2^32 samples in batches of planes */,
+                                                          uint32_t xcd) {
     typedef float v4f __attribute__((ext_vector_type(4)));
     const SceneParams &sp = *spp;
     const uint32_t S = N + 1u;
-    const uint32_t i0 = (blockIdx.x * 256u + threadIdx.x) << 2;
+    const uint32_t wg = xcd_contiguous(blockIdx.x, gridDim.x, xcd);
+    const uint32_t i0 = (wg * 256u + threadIdx.x) << 2;
     if (i0 >= total) return;
     // (x, y, z) of the WAVE's first sample on the scalar unit: two magic divisions of the workgroup's first index, then the wave's
     // offset and at most two row steps (a piece is 1 024 consecutive samples, a row has S >= 512 of them), all on uniform values.
     // A wave's 256 samples touch at most two rows, so a lane needs one compare and three selects.
-    const uint32_t iw = blockIdx.x << 10;                      // (indices relative to the slab: it starts on a plane, so x = xplane0 + the quotient)
+    const uint32_t iw = wg << 10;                              // (indices relative to the slab: it starts on a plane, so x = xplane0 + the quotient)
     const uint32_t r0 = div_magic(iw, dS), x0 = xplane0 + div_magic(r0, dS);
     uint32_t x, y, z;
     if (S >= 512u) {                                         // (the usual case: no loop)
@@ -2671,7 +2680,7 @@ __global__ __launch_bounds__(256) void k_sample_dense_rows(float *__restrict__ o
 // (tests: test_dense_sample_matches_oracle, ..._at_full_size_..., test_dense_slabs_concatenate_to_the_whole_volume).
 template <int SCENE, bool NT, uint32_t ROWS, int QPL /* aligned quads per lane: a wave covers 64 QPL quads of each of its rows */>
 __global__ __launch_bounds__(256) void k_sample_dense_rows_aligned(float *__restrict__ out /* 16-byte aligned */, uint32_t N,
-                                                                    const SceneParams *__restrict__ spp, uint32_t xb, uint32_t xe) {
+                                                                    const SceneParams *__restrict__ spp, uint32_t xb, uint32_t xe, uint32_t flags) {
     static_assert(SCENE == SCENE_SDOBJ || SCENE == SCENE_ANIM, "sd_obj family only");
     static_assert(ROWS <= 64 && (ROWS & (ROWS - 1u)) == 0, "one lane per row context");
 #if defined(SDM_HAVE_PAIRS)                      // (device pass only: the packed 2-vector helpers of sdf.hpp)
@@ -2689,7 +2698,8 @@ __global__ __launch_bounds__(256) void k_sample_dense_rows_aligned(float *__rest
     const uint32_t nchunks = ((S >> 2) + 64u * QPL - 1u) / (64u * QPL);               // (S >> 2 = the most aligned quads a row can have)
     // (the wave's number through v_readfirstlane: chunk, class, group, the row loop's bound and every row's base address stay in
     //  scalar registers, and the quad stores take the scalar base + a 32-bit lane offset)
-    uint32_t g = (uint32_t) __builtin_amdgcn_readfirstlane((int) (blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)));
+    const uint32_t wg = xcd_contiguous(blockIdx.x, gridDim.x, flags & 1u);
+    uint32_t g = (uint32_t) __builtin_amdgcn_readfirstlane((int) (wg * (blockDim.x >> 6) + (threadIdx.x >> 6)));
     if (g >= nchunks * 4u * per_class) return;
     const uint32_t chunk = g % nchunks;
     g /= nchunks;
@@ -3036,7 +3046,7 @@ hipError_t launch_triangles_direct(hipStream_t st, int scene, const SceneParams 
 }
 
 hipError_t launch_sample_dense_rows(hipStream_t st, int grid, int scene, const SceneParams *sp, float *out, uint32_t N, bool nt,
-                                    uint32_t x0, uint32_t x1, bool aligned_rows, bool nt_rows, int occ) {
+                                    uint32_t x0, uint32_t x1, bool aligned_rows, bool nt_rows, int occ, bool xcd) {
     if (x1 <= x0) return hipSuccess;
 #if defined(SDM_NO_PAIRS)
     aligned_rows = false;                    // (the aligned kernel is written on the packed 2-vector helpers)
@@ -3058,14 +3068,19 @@ hipError_t launch_sample_dense_rows(hipStream_t st, int grid, int scene, const S
         const uint64_t nrows = (uint64_t) (N + 1) * (x1 - x0), nchunks = ((uint64_t) nq + 64ull * Q - 1ull) / (64ull * Q);
         const uint64_t ngroups = nchunks * 4ull * ((((nrows + 3ull) >> 2) + R - 1ull) / R);
         const int g2 = (int) std::min<uint64_t>((ngroups + 3ull) / 4ull, 0x7FFFFFFFull);
-        // Workgroups per CU: measured on three boxes at 512^3 / 1024^3 / 1500^3, 2 or 3 resident workgroups (8-12 waves per CU) run this kernel
-        // 4-10 % faster than 4 and more (a sharp step between 3 and 4 at every size, also where the last round's tail is nothing: 0.124 ->
-        // 0.112-0.117 ms at 512^3, 3.08 -> 2.97 ms at 1500^3); rows of <= 64 quads (256^3) want all they can get.  The cap is an LDS allotment the
-        // kernel never touches (160 KiB / 3 per workgroup); `occ` > 0 = the caller's choice (option dense_occ), < 0 = no cap.
-        if (occ == 0) occ = Q == 1u ? -1 : 3;
+        // Workgroups per CU and their order (MEASUREMENTS.md "Round 4, last"; same boxes, ms at 512^3 / 1024^3):
+        //   ids dealt round robin to the XCDs as the hardware does, no cap (8 / 5 workgroups per CU by registers)   0.124 / 0.903
+        //   the same, capped at 3 per CU through an LDS allotment the kernel never touches                          0.111 / 0.861
+        //   an XCD's workgroups on one contiguous eighth of the row groups (`xcd`), no cap                           0.104 / 0.873
+        //   `xcd`, capped at 3                                                                                       0.110 / 0.805
+        // The write stream wants few rows in flight per L2 and ascending addresses from each; the arithmetic wants waves: two quads per
+        // lane (rows of <= 512 samples) keep every wave, four quads per lane run best with three workgroups per CU.  Rows of <= 64 quads
+        // (256^3): no difference either way.  `occ` > 0 = the caller's cap (option dense_occ), < 0 = none.
+        const uint32_t flags = xcd && Q > 1u ? 1u : 0u;
+        if (occ == 0) occ = Q == 4u ? 3 : (Q == 2u && !flags ? 3 : -1);
         const uint32_t lds = occ >= 1 && occ <= 8 ? (160u * 1024u / (uint32_t) occ) & ~1023u : 0u;
 #define SDM_AL(SC, NTF, RR, QQ) { if (lds > 65536u) (void) hipFuncSetAttribute(reinterpret_cast<const void *>(&k_sample_dense_rows_aligned<SC, NTF, RR, QQ>), hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds); \
-        hipLaunchKernelGGL((k_sample_dense_rows_aligned<SC, NTF, RR, QQ>), dim3(g2), dim3(256), lds, st, out, N, sp, x0, x1); }
+        hipLaunchKernelGGL((k_sample_dense_rows_aligned<SC, NTF, RR, QQ>), dim3(g2), dim3(256), lds, st, out, N, sp, x0, x1, flags); }
 #define SDM_ALQ(SC, NTF) { if (Q == 4) SDM_AL(SC, NTF, 8, 4) else if (Q == 2) SDM_AL(SC, NTF, 8, 2) else SDM_AL(SC, NTF, 16, 1) }
         if (scene == SCENE_SDOBJ) { if (nt_rows) SDM_ALQ(SCENE_SDOBJ, true) else SDM_ALQ(SCENE_SDOBJ, false) }
         else { if (nt_rows) SDM_ALQ(SCENE_ANIM, true) else SDM_ALQ(SCENE_ANIM, false) }
@@ -3092,9 +3107,9 @@ hipError_t launch_sample_dense(hipStream_t st, int grid, int scene, const SceneP
     return hipGetLastError();
 }
 
-hipError_t launch_stream_fill(hipStream_t st, int grid, float *out, uint64_t total, float value) {
+hipError_t launch_stream_fill(hipStream_t st, int grid, float *out, uint64_t total, float value, bool xcd) {
     if (grid <= 0) grid = (int) std::min<uint64_t>(((total >> 2) + 255ull) / 256ull, 0x7FFFFFFFull);      // one quad per thread
-    hipLaunchKernelGGL(k_stream_fill, dim3(grid), dim3(256), 0, st, out, total, value);
+    hipLaunchKernelGGL(k_stream_fill, dim3(grid), dim3(256), 0, st, out, total, value, xcd ? 1u : 0u);
     return hipGetLastError();
 }
 
@@ -3108,7 +3123,7 @@ static DivMagic make_div_magic(uint32_t d) {
     return r;
 }
 
-hipError_t launch_sample_dense_q1(hipStream_t st, int scene, const SceneParams *sp, float *out, uint32_t N, bool nt, uint32_t x0, uint32_t x1) {
+hipError_t launch_sample_dense_q1(hipStream_t st, int scene, const SceneParams *sp, float *out, uint32_t N, bool nt, uint32_t x0, uint32_t x1, bool xcd) {
     // planes x0 .. x1 - 1 of the volume into out[0 ..).  The kernel indexes relative to its launch's first plane in 32 bits: a range of
     // 2^32 samples or more goes out as several launches of whole planes (2048^3: three) -- every one in the shape the store stream likes.
     if (N < 1u || x1 < x0 || x1 > N + 1u) return hipErrorInvalidValue;
@@ -3121,8 +3136,8 @@ hipError_t launch_sample_dense_q1(hipStream_t st, int scene, const SceneParams *
         const uint64_t total = plane * (xb - xa);
         float *o = out + plane * (xa - x0);
         const uint32_t grid = (uint32_t) (((total + 3ull) / 4ull + 255ull) / 256ull);
-        if (nt) { SDM_DISPATCH_FIELD(scene, hipLaunchKernelGGL((k_sample_dense_q1<S, true>), dim3(grid), dim3(256), 0, st, o, N, (uint32_t) total, sp, dS, 5.0f / (float) N, xa)); }
-        else { SDM_DISPATCH_FIELD(scene, hipLaunchKernelGGL((k_sample_dense_q1<S, false>), dim3(grid), dim3(256), 0, st, o, N, (uint32_t) total, sp, dS, 5.0f / (float) N, xa)); }
+        if (nt) { SDM_DISPATCH_FIELD(scene, hipLaunchKernelGGL((k_sample_dense_q1<S, true>), dim3(grid), dim3(256), 0, st, o, N, (uint32_t) total, sp, dS, 5.0f / (float) N, xa, xcd ? 1u : 0u)); }
+        else { SDM_DISPATCH_FIELD(scene, hipLaunchKernelGGL((k_sample_dense_q1<S, false>), dim3(grid), dim3(256), 0, st, o, N, (uint32_t) total, sp, dS, 5.0f / (float) N, xa, xcd ? 1u : 0u)); }
     }
     return hipGetLastError();
 }

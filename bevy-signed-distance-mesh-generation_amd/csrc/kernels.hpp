@@ -100,12 +100,14 @@ hipError_t launch_expand_raw(hipStream_t st, int grid, const Vertex *uverts, con
 hipError_t launch_triangles_direct(hipStream_t st, int scene, const SceneParams *sp, const Point *vox, uint32_t n, Point vs,
                                    Triangle *out);
 // (x0, x1: the x planes [x0, x1) of the volume, written to out[0 ..) -- the whole volume is (0, N + 1))
-hipError_t launch_sample_dense_q1(hipStream_t st, int scene, const SceneParams *sp, float *out, uint32_t N, bool nt, uint32_t x0, uint32_t x1);   // one quad per thread (< 2^32 samples in the volume)
-hipError_t launch_stream_fill(hipStream_t st, int grid, float *out, uint64_t total, float value);
+hipError_t launch_sample_dense_q1(hipStream_t st, int scene, const SceneParams *sp, float *out, uint32_t N, bool nt, uint32_t x0, uint32_t x1,
+                                  bool xcd = false /* an XCD's workgroups write one contiguous eighth */);   // one quad per thread (< 2^32 samples in the volume)
+hipError_t launch_stream_fill(hipStream_t st, int grid, float *out, uint64_t total, float value, bool xcd = false);
 hipError_t launch_sample_dense_rows(hipStream_t st, int grid, int scene, const SceneParams *sp, float *out, uint32_t N, bool nt, uint32_t x0, uint32_t x1,
                                     bool aligned_rows /* sd_obj family: whole-line stores + hoisted z terms (needs a 16-byte aligned out) */,
                                     bool nt_rows /* nontemporal stores in that kernel too (measured slower) */,
-                                    int occ = 0 /* aligned kernel: workgroups per CU capped through its LDS allotment (0 = by row length, < 0 = no cap) */);
+                                    int occ = 0 /* aligned kernel: workgroups per CU capped through its LDS allotment (0 = by row length, < 0 = no cap) */,
+                                    bool xcd = false /* an XCD's workgroups take one contiguous eighth of the row groups */);
 hipError_t launch_sample_dense(hipStream_t st, int grid, int scene, const SceneParams *sp, float *out, uint32_t N, bool nt,
                                bool contig, uint32_t x0, uint32_t x1);
 hipError_t launch_create_field(hipStream_t st, Point *vox, uint32_t x0, uint32_t x1, uint32_t z0, uint32_t z1, uint32_t *n_out,

@@ -18,6 +18,9 @@ for sc in scenes:
     h.set_scene(sc)
     for g in grids:
       for combo in combos:
-        for name, val in combo: h.set_option(name, val)
-        ms, ws = bench.steady_ms(h, 0, g, big.data_ptr(), 600 if g <= 256 else 50 if g <= 512 else 20)
+        which = 0                                  # ("which=2": the write-ceiling kernel k_stream_fill instead of P1, "which=1": k_sign_bits)
+        for name, val in combo:
+            if name == "which": which = val
+            else: h.set_option(name, val)
+        ms, ws = bench.steady_ms(h, which, g, big.data_ptr(), 600 if g <= 256 else 50 if g <= 512 else 20)
         print(json.dumps({"scene": sc, "grid": g, "opt": "+".join(f"{k}={v}" for k, v in combo), "ms": round(ms, 5), "frac": round(4.0 * (g + 1) ** 3 / (ms * 1e-3) / 8e12, 4), "windows_ms": [round(w, 5) for w in ws]}), flush=True)
