@@ -152,6 +152,10 @@ int sdmesh_use_own_stream(sdmesh_handle *h);
  *                       nontemporal stores never / in the flat kernels and the plain row kernel (default) / in the aligned row kernel too
  *   "dense_aligned" = 0 sd_obj family rows through the plain row kernel (default 1: k_sample_dense_rows_aligned -- four same-phase
  *                       rows per wave, z terms hoisted, 16-byte aligned stores; needs a 16-byte aligned output, else falls back)
+ *   "dense_xcd" = 0|1|2 an XCD's workgroups write one contiguous eighth of the output instead of every eighth piece: never / in the aligned row
+ *                       kernel (default; 6-17 % there) / in every P1 kernel (no difference in the others)
+ *   "dense_occ" = n     resident workgroups per CU of the aligned row kernel: 0 = by its shape (default), 1..8 = capped at n through an LDS
+ *                       allotment the kernel never touches, < 0 = not capped
  *   "forget_plan" = 1   drop the capacity plan (the next regen discovers sizes again)
  *   "fast_math" = 0|1   confirms the numeric mode of the loaded library: libsdmesh.so is strict IEEE (bit-exact against the
  *                       CPU oracle), libsdmesh_fast.so is the same code built like the reference's `nvcc --use_fast_math`

@@ -35,7 +35,9 @@ def test_single_gpu_line_keeps_the_contract():
     assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-3 and 0.3 < r["frac"] < 1.0
     assert abs(r["achieved"] - 4 * 513 ** 3 / (r["avg_launch_ms"] * 1e-3) / 1e9) / r["achieved"] < 1e-3
     assert r["traffic"] is None or abs(r["traffic"] - 4 * 513 ** 3) / (4 * 513 ** 3) < 0.05
-    assert r["write_ceiling"]["achieved"] > r["achieved"]            # the bare store stream is faster than the pass that computes
+    # the bare store stream beside the pass that computes: within a tenth of it either way (by box the fill is 4 % faster or 3 % slower than
+    # the sphere pass, whose arithmetic paces its stores: MEASUREMENTS.md "Round 4, last")
+    assert r["write_ceiling"]["achieved"] > 0.9 * r["achieved"]
     c = j["cpu_baseline"]
     assert c["kind"] == "port" and c["cores"] >= 1 and c["value"] > 0 and "sample" in c
     s = j["roofline_step"]
